@@ -1,0 +1,418 @@
+"""numpy restatement of the reference's per-item scoring formulas (TEST ORACLE).
+
+Each function cites the reference lines it follows (paths relative to
+/root/reference).  Everything is per item (one person crop) unless the name
+says ``_batch``; heat-maps are float32 ``(J, H, W)`` arrays.
+
+Pinned by tests/golden/scorers.npz (outputs of the reference itself, see
+tools/make_golden.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# a8  hard arg-max decode                      alphapose/utils/transforms.py
+# --------------------------------------------------------------------------
+
+def argmax_peaks(hm: np.ndarray):
+    """Flat first-max per joint.  Follows get_max_pred (transforms.py:710-727).
+
+    Returns (idx int64 (J,), xy float32 (J,2), maxval float32 (J,1)).  ``xy`` is
+    zeroed where ``maxval <= 0`` exactly as the reference's ``pred_mask`` does.
+    """
+    J, H, W = hm.shape
+    flat = hm.reshape(J, H * W)
+    idx = flat.argmax(axis=1)                       # first maximum, row-major
+    maxval = flat[np.arange(J), idx].astype(np.float32).reshape(J, 1)
+    xy = np.empty((J, 2), np.float32)
+    xy[:, 0] = (idx % W).astype(np.float32)
+    xy[:, 1] = (idx // W).astype(np.float32)
+    xy *= (maxval > 0.0).astype(np.float32)
+    return idx.astype(np.int64), xy, maxval
+
+
+def quarter_pixel_shift(hm: np.ndarray, xy: np.ndarray) -> np.ndarray:
+    """+-0.25 px refinement toward the larger neighbour (transforms.py:558-568).
+
+    Applied only when ``1 < px < W-1`` and ``1 < py < H-1`` (strict), using the
+    coordinates *after* the ``maxval <= 0`` zeroing.  Returns int8 (J,2) signs.
+    """
+    J, H, W = hm.shape
+    sgn = np.zeros((J, 2), np.int8)
+    for p in range(J):
+        px = int(round(float(xy[p, 0])))
+        py = int(round(float(xy[p, 1])))
+        if 1 < px < W - 1 and 1 < py < H - 1:
+            dx = hm[p, py, px + 1] - hm[p, py, px - 1]
+            dy = hm[p, py + 1, px] - hm[p, py - 1, px]
+            sgn[p, 0] = np.sign(dx)
+            sgn[p, 1] = np.sign(dy)
+    return sgn
+
+
+def crop_to_image_affine(bbox, hm_w: int, hm_h: int) -> np.ndarray:
+    """2x3 float64 map heat-map px -> image px for an un-rotated crop.
+
+    Follows transform_preds -> get_affine_transform(inv=1) (transforms.py:
+    704-708, 753-786): three point pairs are built in *float32* (centre,
+    centre shifted up by half the box WIDTH, and their perpendicular third
+    point), then the 2x3 transform is the exact solution of the 3-point system
+    in float64 (cv2.getAffineTransform in the reference).  Only the box width
+    enters the scale (transforms.py:763-769).
+    """
+    xmin, ymin, xmax, ymax = [float(v) for v in bbox]
+    w = xmax - xmin
+    h = ymax - ymin
+    cx = xmin + w * 0.5
+    cy = ymin + h * 0.5
+    img = np.zeros((3, 2), np.float32)          # points in image space
+    hmp = np.zeros((3, 2), np.float32)          # points in heat-map space
+    img[0] = (cx, cy)
+    img[1] = (cx + 0.0, cy + w * -0.5)
+    hmp[0] = (hm_w * 0.5, hm_h * 0.5)
+    hmp[1] = (hm_w * 0.5, hm_h * 0.5 + hm_w * -0.5)
+    for pts in (img, hmp):                       # third point: rotate (p0-p1) by 90 deg about p1
+        d = pts[0] - pts[1]
+        pts[2] = pts[1] + np.array([-d[1], d[0]], np.float32)
+    lhs = np.concatenate([hmp.astype(np.float64), np.ones((3, 1))], axis=1)
+    return np.linalg.solve(lhs, img.astype(np.float64)).T      # (2,3)
+
+
+def decode_heatmaps(hm: np.ndarray, bbox):
+    """heatmap_to_coord_simple (transforms.py:550-583) for one item.
+
+    Returns dict(idx int64 (J,), sign int8 (J,2), coords float32 (J,2) in image
+    space, maxvals float32 (J,1)).
+    """
+    J, H, W = hm.shape
+    idx, xy, maxval = argmax_peaks(hm)
+    sgn = quarter_pixel_shift(hm, xy)
+    xy = xy + sgn.astype(np.float32) * np.float32(0.25)
+    T = crop_to_image_affine(bbox, W, H)
+    out = np.zeros((J, 2), np.float32)
+    for p in range(J):
+        v = T @ np.array([float(xy[p, 0]), float(xy[p, 1]), 1.0])
+        out[p] = v                                # float64 -> float32 store
+    return dict(idx=idx, sign=sgn, coords=out, maxvals=maxval)
+
+
+def decode_closed_form(hm: np.ndarray, bbox):
+    """Same result as decode_heatmaps via the closed form used by the HIP kernel.
+
+    X = cx32 + (u - W/2) * d / (W/2),  Y = cy32 + (v - H/2) * d / (W/2) with
+    cx32/cy32 the float32-rounded box centre and d = cy32 - fl32(cy - w/2)
+    (float32 subtraction), everything else float64.
+    """
+    J, H, W = hm.shape
+    idx, xy, maxval = argmax_peaks(hm)
+    sgn = quarter_pixel_shift(hm, xy)
+    xy = xy + sgn.astype(np.float32) * np.float32(0.25)
+    xmin, ymin, xmax, ymax = [float(v) for v in bbox]
+    w = xmax - xmin
+    h = ymax - ymin
+    cx32 = np.float32(xmin + w * 0.5)
+    cy32 = np.float32(ymin + h * 0.5)
+    top32 = np.float32((ymin + h * 0.5) + w * -0.5)
+    d = float(np.float32(cy32 - top32))
+    g = d / (W * 0.5)
+    out = np.zeros((J, 2), np.float32)
+    out[:, 0] = (float(cx32) + (xy[:, 0].astype(np.float64) - W * 0.5) * g)
+    out[:, 1] = (float(cy32) + (xy[:, 1].astype(np.float64) - H * 0.5) * g)
+    return dict(idx=idx, sign=sgn, coords=out, maxvals=maxval)
+
+
+def keypoints_51(coords: np.ndarray, maxvals: np.ndarray) -> np.ndarray:
+    """(x, y, score) interleaved, ActiveLearning.py:305-306."""
+    return np.concatenate([coords, maxvals], axis=1).reshape(-1)
+
+
+def pose_score(maxvals: np.ndarray) -> float:
+    """mean + 1.25 max of joint scores, ActiveLearning.py:314."""
+    return float(np.mean(maxvals) + 1.25 * np.max(maxvals))
+
+
+# --------------------------------------------------------------------------
+# a8' soft-arg-max decode (L1JointRegression configs only)
+# --------------------------------------------------------------------------
+
+def softargmax_decode(hm: np.ndarray, bbox, norm_type: str = "softmax"):
+    """heatmap_to_coord_simple_regress (transforms.py:586-642) for one item.
+
+    Computed in float32 like the reference's torch path, affine in float64.
+    """
+    J, H, W = hm.shape
+    x = hm.reshape(J, -1).astype(np.float32)
+    if norm_type == "softmax":
+        e = np.exp(x - x.max(axis=1, keepdims=True))
+        p = e / e.sum(axis=1, keepdims=True)
+        score = np.ones((J, 1), np.float32)
+    elif norm_type == "sigmoid":
+        p = (1.0 / (1.0 + np.exp(-x))).astype(np.float32)
+        score = p.max(axis=1, keepdims=True)
+    elif norm_type == "divide_sum":
+        p = x / x.sum(axis=1, keepdims=True)
+        score = np.ones((J, 1), np.float32)
+    else:
+        raise NotImplementedError(norm_type)
+    p = (p / p.sum(axis=1, keepdims=True)).reshape(J, H, W)
+    ex = (p.sum(axis=1) * np.arange(W, dtype=np.float32)).sum(axis=1)
+    ey = (p.sum(axis=2) * np.arange(H, dtype=np.float32)).sum(axis=1)
+    u = ((ex / np.float32(W) - np.float32(0.5)) + np.float32(0.5)) * np.float32(W)
+    v = ((ey / np.float32(H) - np.float32(0.5)) + np.float32(0.5)) * np.float32(H)
+    T = crop_to_image_affine(bbox, W, H)
+    out = np.zeros((J, 2), np.float32)
+    for j in range(J):
+        out[j] = T @ np.array([float(u[j]), float(v[j]), 1.0])
+    return dict(coords=out, maxvals=score.astype(np.float32))
+
+
+# --------------------------------------------------------------------------
+# a9 / a10  temporal heat-map / pose continuity      ActiveLearning.py
+# --------------------------------------------------------------------------
+
+def thc_pair(a: np.ndarray, b: np.ndarray, norm_type: str = "L1") -> np.float32:
+    """compute_thc (ActiveLearning.py:747-760): sum|a-b| / J or sum (a-b)^2 / J."""
+    J = a.shape[0]
+    if norm_type == "L1":
+        return np.sum(np.abs(a - b)) / J
+    if norm_type == "L2":
+        return np.sum(np.square(a - b)) / J
+    raise ValueError(norm_type)
+
+
+def combine_neighbours(v_prev, v_next, is_prev: bool, is_next: bool):
+    """The isPrev/isNext rule shared by THC and TPC (ActiveLearning.py:333-363):
+    sum over existing neighbours, doubled when exactly one exists, 0 when none."""
+    t = 0
+    if is_prev:
+        t = t + v_prev
+    if is_next:
+        t = t + v_next
+        if not is_prev:
+            t = t * 2
+    elif is_prev:
+        t = t * 2
+    return t
+
+
+def thc_item(cur, prev, nxt, is_prev, is_next, norm_type="L1") -> float:
+    vp = thc_pair(cur, prev, norm_type) if is_prev else 0
+    vn = thc_pair(cur, nxt, norm_type) if is_next else 0
+    return float(combine_neighbours(vp, vn, bool(is_prev), bool(is_next)))
+
+
+def tpc_pair(cur_coords: np.ndarray, adj_hm: np.ndarray, bbox, thresh: float) -> int:
+    """compute_tpc (ActiveLearning.py:736-745): decode the neighbour with the
+    CURRENT box, count joints displaced by more than ``thresh``."""
+    adj = decode_heatmaps(adj_hm, bbox)["coords"]
+    dist = np.linalg.norm(cur_coords - adj, axis=1)
+    return int(np.count_nonzero(dist > thresh))
+
+
+def tpc_item(cur_hm, prev_hm, next_hm, bbox, is_prev, is_next) -> float:
+    """TPC branch of eval_and_query (ActiveLearning.py:333-344)."""
+    thresh = 0.01 * np.sqrt((bbox[2] - bbox[0]) * (bbox[3] - bbox[1]))
+    cur = decode_heatmaps(cur_hm, bbox)["coords"]
+    vp = tpc_pair(cur, prev_hm, bbox, thresh) if is_prev else 0
+    vn = tpc_pair(cur, next_hm, bbox, thresh) if is_next else 0
+    return float(combine_neighbours(vp, vn, bool(is_prev), bool(is_next)))
+
+
+# --------------------------------------------------------------------------
+# a11 local-peak mean                               active_learning/local_peak.py
+# --------------------------------------------------------------------------
+
+def _maxfilter3x3_zero(img: np.ndarray) -> np.ndarray:
+    """3x3 maximum filter with constant-0 border (scipy maximum_filter,
+    footprint ones(3,3), mode='constant', cval=0; local_peak.py:6)."""
+    H, W = img.shape
+    pad = np.zeros((H + 2, W + 2), img.dtype)
+    pad[1:-1, 1:-1] = img
+    out = pad[1:-1, 1:-1].copy()
+    for dy in (0, 1, 2):
+        for dx in (0, 1, 2):
+            np.maximum(out, pad[dy:dy + H, dx:dx + W], out=out)
+    return out
+
+
+def localpeak_values(img: np.ndarray, order: float = 0.5) -> np.ndarray:
+    """local_peak.py:5-10.  Peaks = pixels equal to their zero-padded 3x3 max;
+    kept = peaks >= order * (largest peak).  Row-major order."""
+    is_peak = img == _maxfilter3x3_zero(img)
+    if not is_peak.any():
+        return img[is_peak]                        # empty
+    top = img[is_peak].max()
+    keep = is_peak & (img >= top * order)
+    return img[keep]
+
+
+def localpeak_stats(hm: np.ndarray, order: float = 0.5):
+    """Per-joint kept-peak count (int64 (J,)) and float64 sum, plus the mean."""
+    cnt = np.zeros(hm.shape[0], np.int64)
+    vals = []
+    for j, img in enumerate(hm):
+        v = localpeak_values(img, order)
+        cnt[j] = v.size
+        vals.append(v)
+    allv = np.hstack(vals)
+    with np.errstate(invalid="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            mean = allv.mean() if allv.size else np.float32(np.nan)
+    return cnt, allv, mean
+
+
+def localpeak_mean(hm: np.ndarray, order: float = 0.5):
+    """local_peak.py:12-22: mean over the concatenated kept peaks of all joints
+    (nan when there is none)."""
+    return localpeak_stats(hm, order)[2]
+
+
+# --------------------------------------------------------------------------
+# a12 whole-body pose unnaturalness     active_learning/Whole_body_AE/*
+# --------------------------------------------------------------------------
+
+_TRIANGLES = np.array([[8, 6, 12], [6, 8, 10], [5, 7, 9], [7, 5, 11],
+                       [11, 12, 14], [12, 11, 13], [12, 14, 16], [11, 13, 15]])
+
+
+def xyxy_to_xywh(b):
+    """alphapose/utils/bbox.py:91-97 (inclusive-pixel convention: +1)."""
+    return (b[0], b[1], b[2] - b[0] + 1, b[3] - b[1] + 1)
+
+
+def hybrid_feature(bbox_xywh, kpts51) -> np.ndarray:
+    """compute_hybrid (hybrid_feature.py:14-59): 17 + 17 + 8 = 42 float64."""
+    k = np.asarray(kpts51, np.float64)
+    x, y, s = k[0::3], k[1::3], k[2::3]
+    height = float(bbox_xywh[3])
+    assert height > 0, "height of human body must be positive!"
+    assert s.sum() > 0, "at least one visible keypoint is required!"
+    gx = (x * s).sum() / s.sum()
+    gy = (y * s).sum() / s.sum()
+    eps = 1e-6
+    a, b, c = _TRIANGLES[:, 0], _TRIANGLES[:, 1], _TRIANGLES[:, 2]
+    m1 = (y[b] - y[a]) / (x[b] - x[a] + eps)
+    m2 = (y[c] - y[b]) / (x[c] - x[b] + eps)
+    ang = np.arctan(np.abs((m1 - m2) / (1 + m1 * m2 + eps)))
+    return np.hstack(((x - gx) / height, (y - gy) / height, ang))
+
+
+def ae_forward(feat32: np.ndarray, weights: dict) -> np.ndarray:
+    """WholeBodyAE.forward (AutoEncoder.py:13-39) in float32 numpy.
+
+    ``weights``: state-dict style ``encoder.{0,2,4,6}.{weight,bias}``,
+    ``decoder.{0,2,4,6}.{weight,bias}``.  ReLU between layers, none after the
+    bottleneck Linear, Sigmoid after the last.
+    """
+    h = feat32.astype(np.float32)
+    for i in (0, 2, 4, 6):
+        h = weights[f"encoder.{i}.weight"].astype(np.float32) @ h + weights[f"encoder.{i}.bias"].astype(np.float32)
+        if i != 6:
+            h = np.maximum(h, 0)
+    for i in (0, 2, 4, 6):
+        h = weights[f"decoder.{i}.weight"].astype(np.float32) @ h + weights[f"decoder.{i}.bias"].astype(np.float32)
+        if i != 6:
+            h = np.maximum(h, 0)
+    return (1.0 / (1.0 + np.exp(-h.astype(np.float32)))).astype(np.float32)
+
+
+_WPU38 = np.r_[0:3, 5:20, 22:42]
+
+
+def wpu_item(bbox_crop_xyxy, kpts51, weights, only38: bool = False) -> float:
+    """WPU of one item.  THC+WPU branch (ActiveLearning.py:364-370) uses all 42
+    values; the WPU-only branch (:371-386) drops indices 3,4,20,21 from both
+    the input and the reconstruction before the MSE."""
+    f = hybrid_feature(xyxy_to_xywh(bbox_crop_xyxy), kpts51).astype(np.float32)
+    r = ae_forward(f, weights)
+    if only38:
+        f, r = f[_WPU38], r[_WPU38]
+    return float(np.mean((r - f) ** 2, dtype=np.float32))
+
+
+# --------------------------------------------------------------------------
+# a6 masked MSE, a7 AdamW                       ActiveLearning.py:669, :224-231
+# --------------------------------------------------------------------------
+
+def masked_mse(out: np.ndarray, tgt: np.ndarray, mask: np.ndarray):
+    """loss = 0.5 * mean((out*m - tgt*m)^2), grad wrt out (ActiveLearning.py:669).
+    ``mask`` broadcasts as (B,J,1,1).  float64 accumulation for the scalar."""
+    m = mask.reshape(mask.shape[0], mask.shape[1], 1, 1).astype(np.float32)
+    d = out * m - tgt * m
+    loss = 0.5 * float(np.mean(d.astype(np.float64) ** 2))
+    grad = (d * m / np.float32(d.size)).astype(np.float32)
+    return loss, grad
+
+
+def adamw_step(p, g, m, v, step: int, lr: float, wd: float,
+               beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.AdamW single-tensor update (decoupled decay), float32 state.
+    Returns new (p, m, v).  ``step`` is the 1-based step count."""
+    f = np.float32
+    p = p * f(1.0 - lr * wd)
+    m = m + (g - m) * f(1.0 - beta1)
+    v = v * f(beta2) + g * g * f(1.0 - beta2)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    denom = np.sqrt(v) / f(np.sqrt(bc2)) + f(eps)
+    p = p - f(lr / bc1) * (m / denom)
+    return p.astype(f), m.astype(f), v.astype(f)
+
+
+# --------------------------------------------------------------------------
+# §8f rank 1: OKS and heat-map accuracy         al_metric.py:42-69, metrics.py:118-245
+# --------------------------------------------------------------------------
+
+_OKS_SIG = np.array([.26, .25, .25, .35, .35, .79, .79, .72, .72, .62, .62,
+                     1.07, 1.07, .87, .87, .89, .89]) / 10.0
+_OKS_VAR = (_OKS_SIG * 2) ** 2
+
+
+def oks(bbox_xywh, pred51, gt51) -> float:
+    """compute_OKS (al_metric.py:42-69) with the box area as the scale."""
+    d = np.asarray(pred51, np.float64)
+    g = np.asarray(gt51, np.float64)
+    xg, yg, vg = g[0::3], g[1::3], g[2::3]
+    xd, yd = d[0::3], d[1::3]
+    bx, by, bw, bh = [float(t) for t in bbox_xywh]
+    vis = vg > 0
+    if vis.any():
+        dx, dy = xd - xg, yd - yg
+    else:
+        z = np.zeros(17)
+        dx = np.maximum(z, (bx - bw) - xd) + np.maximum(z, xd - (bx + 2 * bw))
+        dy = np.maximum(z, (by - bh) - yd) + np.maximum(z, yd - (by + 2 * bh))
+    e = (dx ** 2 + dy ** 2) / _OKS_VAR / (bw * bh + np.spacing(1)) * 0.5
+    if vis.any():
+        e = e[vis]
+    return float(np.sum(np.exp(-e)) / e.shape[0])
+
+
+def heatmap_accuracy(pred: np.ndarray, label: np.ndarray, thr: float = 0.5) -> float:
+    """calc_accuracy (metrics.py:118-147) for (B,J,H,W) float32 arrays."""
+    B, J, H, W = pred.shape
+
+    def peaks(a):
+        flat = a.reshape(B, J, -1)
+        idx = flat.argmax(axis=2)
+        mv = np.take_along_axis(flat, idx[..., None], axis=2)[..., 0]
+        xy = np.stack([(idx % W), (idx // W)], axis=2).astype(np.float32)
+        return xy * (mv > 0)[..., None].astype(np.float32)
+
+    p, t = peaks(pred), peaks(label)
+    norm = np.array([W, H], np.float64) / 10
+    dist = np.zeros((J, B))
+    for n in range(B):
+        for c in range(J):
+            if t[n, c, 0] > 1 and t[n, c, 1] > 1:
+                dist[c, n] = np.linalg.norm(p[n, c] / norm - t[n, c] / norm)
+    total, cnt = 0.0, 0
+    for c in range(J):
+        used = dist[c] != 0
+        if used.sum() > 0:
+            total += float((dist[c][used] < thr).sum()) / used.sum()
+            cnt += 1
+    return total / cnt if cnt else 0

@@ -1,0 +1,118 @@
+"""Seeded, platform-stable synthetic weights and inputs (TEST ORACLE support).
+
+Everything is drawn from ``numpy.random.RandomState`` (legacy generator, frozen
+bit-stream) so that the golden fixtures, the CPU tests and the GPU-box tests
+regenerate identical tensors from a seed instead of shipping 136 MB state
+dicts.  Shapes follow SURVEY.md §8(d): crops ``rand - (0.406, 0.457, 0.480)``
+(simple_transform.py:246-249), boxes ``[100, 50, 100+w, 50+4w/3]``.
+"""
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+
+SEED = 166          # the reference's own seed (scripts/Run_active_learning.py:113)
+PIXEL_MEAN = (0.406, 0.457, 0.480)
+
+
+def _rs(seed: int, key: str) -> np.random.RandomState:
+    return np.random.RandomState((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+
+
+def tensor_for(key: str, shape, seed: int = SEED) -> np.ndarray:
+    """One state-dict entry, chosen by key suffix / rank (float32, or int64 for
+    ``num_batches_tracked``)."""
+    r = _rs(seed, key)
+    shape = tuple(shape)
+    if key.endswith("num_batches_tracked"):
+        return np.zeros(shape, np.int64)
+    if key.endswith("running_var"):
+        return r.uniform(0.5, 1.5, shape).astype(np.float32)
+    if key.endswith("running_mean"):
+        return (0.1 * r.standard_normal(shape)).astype(np.float32)
+    if len(shape) == 1 and key.endswith("bn3.weight"):        # last BN of a residual branch: keep the
+        return r.uniform(0.2, 0.4, shape).astype(np.float32)  # un-normalised (eval-mode) trunk from blowing up
+    if len(shape) == 1 and key.endswith("weight"):            # BN gamma
+        return r.uniform(0.5, 1.5, shape).astype(np.float32)
+    if len(shape) == 1:                                        # any bias / BN beta
+        return (0.1 * r.standard_normal(shape)).astype(np.float32)
+    if len(shape) == 4:                                        # conv OIHW or deconv IOHW
+        if "deconv" in key:
+            fan_in = shape[0] * shape[2] * shape[3] / 4.0      # 2x2 taps reach each output
+        else:
+            fan_in = shape[1] * shape[2] * shape[3]
+        return (np.sqrt(2.0 / fan_in) * r.standard_normal(shape)).astype(np.float32)
+    if len(shape) == 2:                                        # Linear (out, in)
+        return (np.sqrt(1.0 / shape[1]) * r.standard_normal(shape)).astype(np.float32)
+    return r.standard_normal(shape).astype(np.float32)
+
+
+def state_dict_for(module, seed: int = SEED) -> dict:
+    """Synthetic state dict for any torch module (keys/shapes from the module)."""
+    import torch
+    return {k: torch.from_numpy(tensor_for(k, v.shape, seed)) for k, v in module.state_dict().items()}
+
+
+def crops(n: int, seed: int = SEED, hw=(256, 192)) -> np.ndarray:
+    r = _rs(seed, f"crops{n}x{hw}")
+    x = r.random_sample((n, 3, hw[0], hw[1])).astype(np.float32)
+    x -= np.asarray(PIXEL_MEAN, np.float32).reshape(1, 3, 1, 1)
+    return x
+
+
+def bboxes(n: int, seed: int = SEED) -> np.ndarray:
+    r = _rs(seed, f"bboxes{n}")
+    w = r.uniform(60, 240, n)
+    return np.stack([np.full(n, 100.0), np.full(n, 50.0), 100.0 + w, 50.0 + w * 4.0 / 3.0], 1).astype(np.float32)
+
+
+def video_flags(n: int, tracks: int):
+    """isPrev / isNext for ``tracks`` equal-length tracks laid out contiguously
+    in id order (posetrack21.py:148-178 semantics: neighbour has same track)."""
+    per = n // tracks
+    pos = np.arange(n) % per
+    return (pos != 0), (pos != per - 1)
+
+
+def blob_heatmaps(n: int, seed: int = SEED, J: int = 17, hw=(64, 48), noise: float = 0.02) -> np.ndarray:
+    """Heat-maps that look like a pose network's: 1-3 Gaussian bumps per joint
+    (sigma 2, main amplitude 0.3..1) over low-amplitude noise; consecutive
+    items drift slowly so THC/TPC see realistic neighbour differences."""
+    r = _rs(seed, f"blobs{n}x{J}x{hw}")
+    H, W = hw
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    out = np.empty((n, J, H, W), np.float32)
+    cx = r.uniform(4, W - 4, J)
+    cy = r.uniform(4, H - 4, J)
+    for i in range(n):
+        cx = np.clip(cx + r.normal(0, 0.7, J), 1, W - 2)
+        cy = np.clip(cy + r.normal(0, 0.7, J), 1, H - 2)
+        for j in range(J):
+            amp = r.uniform(0.3, 1.0)
+            m = amp * np.exp(-((xx - cx[j]) ** 2 + (yy - cy[j]) ** 2) / 8.0)
+            for _ in range(r.randint(0, 3)):
+                m += r.uniform(0.1, 0.8) * amp * np.exp(
+                    -((xx - r.uniform(0, W)) ** 2 + (yy - r.uniform(0, H)) ** 2) / 8.0)
+            out[i, j] = m + noise * r.standard_normal((H, W))
+    return out
+
+
+def gaussian_targets(n: int, seed: int = SEED, J: int = 17, hw=(64, 48), sigma: float = 2.0, p_zero: float = 0.2):
+    """Labels like SimpleTransform._target_generator (simple_transform.py:
+    122-158): a (6*sigma+3)^2 Gaussian patch at an integer joint position;
+    ``mask`` (n,J,1,1) with about ``p_zero`` zeros."""
+    r = _rs(seed, f"targets{n}x{J}x{hw}")
+    H, W = hw
+    t = np.zeros((n, J, H, W), np.float32)
+    rad = int(3 * sigma)
+    g = np.arange(-rad, rad + 1, dtype=np.float32)
+    patch = np.exp(-(g[None, :] ** 2 + g[:, None] ** 2) / (2 * sigma ** 2))
+    for i in range(n):
+        for j in range(J):
+            mx, my = r.randint(0, W), r.randint(0, H)
+            x0, x1 = max(0, mx - rad), min(W, mx + rad + 1)
+            y0, y1 = max(0, my - rad), min(H, my + rad + 1)
+            t[i, j, y0:y1, x0:x1] = patch[y0 - (my - rad):y1 - (my - rad), x0 - (mx - rad):x1 - (mx - rad)]
+    mask = (r.random_sample((n, J, 1, 1)) >= p_zero).astype(np.float32)
+    return t, mask

@@ -1,0 +1,140 @@
+"""The oracle (oracle/*.py) against outputs of the reference itself
+(tests/golden/*.npz, produced by tools/make_golden.py).  CPU only."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets, scorers, synth
+
+
+def test_decode_matches_reference(golden_scorers):
+    g = golden_scorers
+    for i in range(g["hm"].shape[0]):
+        for fn in (scorers.decode_heatmaps, scorers.decode_closed_form):
+            d = fn(g["hm"][i], g["bbox"][i])
+            assert np.array_equal(d["idx"], g["idx"][i])                      # integer: bit-exact
+            assert np.array_equal(d["maxvals"], g["maxvals"][i])              # copied values: bit-exact
+            np.testing.assert_allclose(d["coords"], g["coords"][i], rtol=1e-6, atol=1e-4)
+    # the 3-point-solve route must be bit-identical to the reference's float32 result
+    for i in range(g["hm"].shape[0]):
+        assert np.array_equal(scorers.decode_heatmaps(g["hm"][i], g["bbox"][i])["coords"], g["coords"][i])
+
+
+def test_decode_appendix_b_known_answers(golden_scorers):
+    """SURVEY.md Appendix B, box [100,50,196,178] (item 5 of the fixture)."""
+    g = golden_scorers
+    d = scorers.decode_heatmaps(g["hm"][5], g["bbox"][5])
+    expect = {0: (140.0, 70.0), 1: (100.0, 50.0), 2: (102.0, 52.0), 3: (104.5, 53.5), 4: (191.5, 174.0), 5: (194.0, 176.0)}
+    for j, xy in expect.items():
+        assert tuple(d["coords"][j]) == xy, j
+    assert d["idx"][0] == 10 * 48 + 20
+
+
+@pytest.mark.parametrize("nt", ["softmax", "sigmoid", "divide_sum"])
+def test_softargmax_decode(golden_scorers, nt):
+    g = golden_scorers
+    for i in range(5):
+        src = g["hm"][i] if nt != "divide_sum" else np.abs(g["hm"][i]) + 1e-3
+        d = scorers.softargmax_decode(src, g["bbox"][i], nt)
+        np.testing.assert_allclose(d["coords"], g[f"soft_{nt}_coords"][i], rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(d["maxvals"], g[f"soft_{nt}_scores"][i], rtol=1e-5)
+
+
+def test_localpeak(golden_scorers):
+    g = golden_scorers
+    assert np.array_equal(scorers.localpeak_values(g["toy"]), g["toy_vals"])        # [4 3]
+    assert scorers.localpeak_mean(np.stack([g["toy"]] * 3)) == g["toy_mean"] == 3.5
+    for i in range(g["hm"].shape[0]):
+        cnt, _, mean = scorers.localpeak_stats(g["hm"][i])
+        assert np.array_equal(cnt, g["lp_cnt"][i])                                 # integer: bit-exact
+        if np.isnan(g["lp_mean"][i]):
+            assert np.isnan(mean)
+        else:
+            np.testing.assert_allclose(mean, g["lp_mean"][i], rtol=1e-6)
+    assert np.isnan(g["lp_mean"][6])            # all-negative item -> nan (Appendix B)
+
+
+def test_thc_tpc(golden_scorers):
+    g = golden_scorers
+    hm, bb = g["hm"], g["bbox"]
+    for i in range(hm.shape[0] - 1):
+        np.testing.assert_allclose(scorers.thc_pair(hm[i], hm[i + 1], "L1"), g["thc_l1"][i], rtol=1e-6)
+        np.testing.assert_allclose(scorers.thc_pair(hm[i], hm[i + 1], "L2"), g["thc_l2"][i], rtol=1e-6)
+        thr = 0.01 * np.sqrt((bb[i][2] - bb[i][0]) * (bb[i][3] - bb[i][1]))
+        cur = scorers.decode_heatmaps(hm[i], bb[i])["coords"]
+        assert scorers.tpc_pair(cur, hm[i + 1], bb[i], thr) == g["tpc"][i]
+    # neighbour rule: doubled with exactly one neighbour
+    assert scorers.combine_neighbours(3, 5, True, True) == 8
+    assert scorers.combine_neighbours(3, 5, True, False) == 6
+    assert scorers.combine_neighbours(3, 5, False, True) == 10
+    assert scorers.combine_neighbours(3, 5, False, False) == 0
+
+
+def test_hybrid_and_wpu(golden_scorers):
+    g = golden_scorers
+    np.testing.assert_allclose(scorers.hybrid_feature(g["lit_bbox"], g["lit_kp"]), g["lit_feat"], rtol=1e-12, atol=1e-12)
+    w42 = {k[5:]: g[k] for k in g.files if k.startswith("ae42.")}
+    w38 = {k[5:]: g[k] for k in g.files if k.startswith("ae38.")}
+    for i in range(g["hm"].shape[0]):
+        if not g["kp_ok"][i]:
+            with pytest.raises(AssertionError):
+                scorers.hybrid_feature(scorers.xyxy_to_xywh(g["bbox"][i]), g["kp"][i])
+            continue
+        f = scorers.hybrid_feature(scorers.xyxy_to_xywh(g["bbox"][i].tolist()), g["kp"][i])
+        np.testing.assert_allclose(f, g["hybrid"][i], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(scorers.wpu_item(g["bbox"][i].tolist(), g["kp"][i], w42), g["wpu42"][i], rtol=2e-5)
+        np.testing.assert_allclose(scorers.wpu_item(g["bbox"][i].tolist(), g["kp"][i], w42, only38=True), g["wpu38"][i], rtol=2e-5)
+        f38 = f[np.r_[0:3, 5:20, 22:42]].astype(np.float32)
+        r38 = scorers.ae_forward(f38, w38)
+        np.testing.assert_allclose(float(np.mean((r38 - f38) ** 2)), g["wpu38cls"][i], rtol=2e-5)
+
+
+def test_oks_and_accuracy(golden_scorers):
+    g = golden_scorers
+    for i in range(g["hm"].shape[0]):
+        np.testing.assert_allclose(scorers.oks(g["bb_ann"][i], g["kp"][i], g["gt"][i]), g["oks"][i], rtol=1e-12)
+    tgt, mask = synth.gaussian_targets(g["hm"].shape[0], seed=int(g["acc_targets_seed"]))
+    np.testing.assert_allclose(scorers.heatmap_accuracy(g["hm"] * mask, tgt * mask), g["acc"], rtol=1e-12)
+
+
+def test_simplepose_restatement_matches_reference(golden_simplepose):
+    g = golden_simplepose
+    torch.manual_seed(0)
+    m = nets.SimplePoseRef(50)
+    keys = list(m.state_dict().keys())
+    assert keys == list(g["keys"])                                               # drop-in: same keys, same order
+    assert [str(tuple(v.shape)) for v in m.state_dict().values()] == list(g["shapes"])
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    m.eval()
+    x = torch.from_numpy(synth.crops(int(g["batch"])))
+    with torch.no_grad():
+        hm = m(x).numpy()
+        emb = m.get_embedding(x).numpy()
+    scale = np.abs(g["heatmaps"]).max()
+    assert np.abs(hm - g["heatmaps"]).max() <= 1e-5 * scale
+    np.testing.assert_allclose(emb, g["embedding"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(hm.reshape(2, 17, -1).argmax(2), g["heatmaps"].reshape(2, 17, -1).argmax(2))
+
+
+def test_masked_mse_and_adamw_against_torch():
+    r = np.random.RandomState(0)
+    out = r.standard_normal((3, 17, 64, 48)).astype(np.float32)
+    tgt, mask = synth.gaussian_targets(3, seed=2)
+    loss, grad = scorers.masked_mse(out, tgt, mask)
+    o = torch.from_numpy(out).requires_grad_()
+    l = 0.5 * torch.nn.MSELoss()(o.mul(torch.from_numpy(mask)), torch.from_numpy(tgt).mul(torch.from_numpy(mask)))
+    l.backward()
+    np.testing.assert_allclose(loss, l.item(), rtol=1e-5)
+    np.testing.assert_allclose(grad, o.grad.numpy(), rtol=1e-5, atol=1e-12)
+
+    p = torch.from_numpy(r.standard_normal(1000).astype(np.float32)).requires_grad_()
+    opt = torch.optim.AdamW([p], lr=2.5e-3, weight_decay=0.7)
+    pn, m, v = p.detach().numpy().copy(), np.zeros(1000, np.float32), np.zeros(1000, np.float32)
+    for step in range(1, 4):
+        gnp = r.standard_normal(1000).astype(np.float32)
+        p.grad = torch.from_numpy(gnp.copy())
+        opt.step()
+        pn, m, v = scorers.adamw_step(pn, gnp, m, v, step, 2.5e-3, 0.7)
+        np.testing.assert_allclose(pn, p.detach().numpy(), rtol=2e-5, atol=1e-6)

@@ -1,0 +1,389 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+Usage:  python tools/make_golden.py [--ref /root/reference] [--out tests/golden]
+
+The reference (Python, CPU) is imported from ``--ref`` with three import shims
+injected into ``sys.modules``: ``cv2`` (only getAffineTransform,
+solved exactly in float64), ``torchvision.models.resnet*`` (returns an object
+with an empty state dict so the ImageNet overwrite is a no-op) and
+``easydict``.  Leaf modules of ``active_learning`` are loaded by file path
+because the package ``__init__`` needs many absent third-party packages.
+
+Nothing from the reference is copied: the fixtures hold seeded inputs (or the
+seed that regenerates them through ``oracle/synth.py``) and the outputs the
+reference produced for them.  This script never runs on the GPU box.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import synth  # noqa: E402
+
+
+# ----------------------------------------------------------------------------
+# import shims
+# ----------------------------------------------------------------------------
+
+def install_shims():
+    cv2 = types.ModuleType("cv2")
+
+    def getAffineTransform(src, dst):
+        a = np.concatenate([np.asarray(src, np.float64), np.ones((3, 1))], axis=1)
+        return np.linalg.solve(a, np.asarray(dst, np.float64)).T
+
+    cv2.getAffineTransform = getAffineTransform
+    cv2.INTER_LINEAR = 1
+    cv2.BORDER_CONSTANT = 0
+    sys.modules["cv2"] = cv2
+
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+
+    class _Empty:
+        def state_dict(self):
+            return {}
+
+    for n in (18, 34, 50, 101, 152):
+        setattr(tvm, f"resnet{n}", lambda *a, **k: _Empty())
+    tv.models = tvm
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tvm
+
+    ed = types.ModuleType("easydict")
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in {**(d or {}), **kw}.items():
+                self[k] = v
+
+        def __setitem__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            super().__setitem__(k, v)
+
+        __setattr__ = __setitem__
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError as e:
+                raise AttributeError(k) from e
+
+    ed.EasyDict = EasyDict
+    sys.modules["easydict"] = ed
+    return EasyDict
+
+
+def load_by_path(name: str, path: str):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# ----------------------------------------------------------------------------
+# edge-case heat-maps
+# ----------------------------------------------------------------------------
+
+def edge_case_item(H=64, W=48) -> np.ndarray:
+    m = np.zeros((17, H, W), np.float32)
+    m[0, 10, 20] = 1.0; m[0, 40, 5] = 1.0                       # tie -> first in row-major
+    m[1] = -1.0                                                 # all negative
+    m[2, 1, 1] = 1.0; m[2, 1, 2] = 0.5                          # px == 1 -> no shift
+    m[3, 2, 2] = 1.0; m[3, 2, 3] = 0.5; m[3, 3, 2] = 0.2; m[3, 1, 2] = 0.4   # (+.25,-.25)
+    m[4, 62, 46] = 1.0; m[4, 62, 45] = 0.5                      # (-.25, 0)
+    m[5, 63, 47] = 1.0                                          # corner
+    m[6] = 0.3                                                  # constant plateau
+    m[7, 0, 0] = 1.0; m[7, 10, 10] = 0.5; m[7, 20, 20] = 0.49; m[7, 63, 47] = 0.7
+    m[8] = -1.0; m[8, 5, 5] = 2.0; m[8, 30, 30] = -0.5
+    m[9, 30:33, 20:23] = 0.8                                    # 3x3 plateau
+    m[10, 31, 23] = 0.9; m[10, 31, 24] = 0.9                    # equal neighbours -> sign 0
+    m[11, 0, 30] = 0.6; m[11, 63, 3] = 0.6                      # border peaks
+    m[12] = 0.0                                                 # all zero -> maxval 0 -> coords zeroed
+    m[13, 32, 24] = 1e-30                                       # tiny positive
+    m[14, 5, 46] = 1.0; m[14, 5, 47] = 0.3                      # px == W-2
+    m[15, 62, 10] = 1.0; m[15, 63, 10] = 0.3                    # py == H-2
+    m[16, 17, 17] = 0.7; m[16, 17, 16] = 0.2; m[16, 16, 17] = 0.6; m[16, 18, 17] = 0.1
+    return m
+
+
+# ----------------------------------------------------------------------------
+# scorers
+# ----------------------------------------------------------------------------
+
+def gen_scorers(ref: str, out: str):
+    from alphapose.utils import transforms as T                # the reference's
+    pkg = types.ModuleType("active_learning"); pkg.__path__ = [os.path.join(ref, "active_learning")]
+    sub = types.ModuleType("active_learning.Whole_body_AE"); sub.__path__ = [os.path.join(ref, "active_learning", "Whole_body_AE")]
+    sys.modules["active_learning"] = pkg
+    sys.modules["active_learning.Whole_body_AE"] = sub
+    lp = load_by_path("active_learning.local_peak", os.path.join(ref, "active_learning/local_peak.py"))
+    hf = load_by_path("active_learning.Whole_body_AE.hybrid_feature", os.path.join(ref, "active_learning/Whole_body_AE/hybrid_feature.py"))
+    ae = load_by_path("active_learning.Whole_body_AE.AutoEncoder", os.path.join(ref, "active_learning/Whole_body_AE/AutoEncoder.py"))
+    alm = load_by_path("active_learning.al_metric", os.path.join(ref, "active_learning/al_metric.py"))
+    from alphapose.utils.bbox import bbox_xyxy_to_xywh
+    from alphapose.utils.metrics import calc_accuracy
+
+    N = 8
+    hm = np.empty((N, 17, 64, 48), np.float32)
+    hm[:5] = synth.blob_heatmaps(5, seed=synth.SEED)
+    hm[5] = edge_case_item()
+    hm[6] = -np.abs(synth.blob_heatmaps(1, seed=7)[0]) - 0.1     # everything negative
+    hm[7] = synth.blob_heatmaps(1, seed=9, noise=0.0)[0]         # noise-free (flat zero background)
+    bbox = synth.bboxes(N)
+    bbox[5] = [100, 50, 196, 178]                                # Appendix-B box (w 96 -> scale 2)
+
+    f = T.heatmap_to_coord_simple
+    coords = np.zeros((N, 17, 2), np.float32)
+    maxvals = np.zeros((N, 17, 1), np.float32)
+    idx = np.zeros((N, 17), np.int64)
+    for i in range(N):
+        c, m = f(torch.from_numpy(hm[i]), bbox[i].tolist(), hm_shape=(64, 48), norm_type=None)
+        coords[i], maxvals[i] = c, m
+        idx[i] = np.argmax(hm[i].reshape(17, -1), 1)             # what get_max_pred does internally
+
+    # soft-arg-max decode (a8')
+    soft = {}
+    for nt in ("softmax", "sigmoid", "divide_sum"):
+        sc = np.zeros((5, 17, 2), np.float32); ss = np.zeros((5, 17, 1), np.float32)
+        for i in range(5):
+            src = hm[i] if nt != "divide_sum" else np.abs(hm[i]) + 1e-3
+            c, s = T.heatmap_to_coord_simple_regress(torch.from_numpy(src), bbox[i].tolist(), hm_shape=(64, 48), norm_type=nt)
+            sc[i], ss[i] = c, s
+        soft[f"soft_{nt}_coords"] = sc
+        soft[f"soft_{nt}_scores"] = ss
+
+    # local peaks
+    import warnings
+    lp_mean = np.zeros(N, np.float32)
+    lp_cnt = np.zeros((N, 17), np.int64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(N):
+            lp_mean[i] = lp.localpeak_mean(hm[i])
+            for j in range(17):
+                lp_cnt[i, j] = lp.localpeak_values(hm[i, j]).size
+    toy = np.array([[0, 0, 0, 0, 0, 0, 0, 4, 0, 0], [0, 0, 0, 1, 1, 0, 0, 0, 0, 0],
+                    [0, 0, 0, 0, 3, 2, 0, 0, 0, 0], [0, 0, 0, 0, 2, 2, 0, 0, 0, 0]])   # data literal of local_peak.py:26-29
+    toy_vals = lp.localpeak_values(toy)
+    toy_mean = lp.localpeak_mean(np.array([toy, toy, toy]))
+
+    # THC / TPC through the reference's own (unbound) methods
+    almod_src = os.path.join(ref, "active_learning/ActiveLearning.py")
+    ns = _extract_methods(almod_src, ("compute_thc", "compute_tpc"))
+
+    class Dummy:
+        eval_joints = list(range(17)); hm_size = (64, 48); norm_type = None
+        heatmap_to_coord = staticmethod(f)
+    d = Dummy()
+    thc_l1 = np.array([ns["compute_thc"](d, hm[i], hm[i + 1], "L1") for i in range(N - 1)], np.float64)
+    thc_l2 = np.array([ns["compute_thc"](d, hm[i], hm[i + 1], "L2") for i in range(N - 1)], np.float64)
+    tpc = np.zeros(N - 1, np.int64)
+    for i in range(N - 1):
+        bb = bbox[i].tolist()
+        thr = 0.01 * np.sqrt((bb[2] - bb[0]) * (bb[3] - bb[1]))
+        tpc[i] = ns["compute_tpc"](d, coords[i], torch.from_numpy(hm[i + 1]), bb, thr)
+
+    # hybrid feature + AE (items with positive score sums only)
+    kp = np.concatenate([coords, maxvals], 2).reshape(N, 51)
+    ok = np.array([kp[i, 2::3].sum() > 0 for i in range(N)])
+    hyb = np.full((N, 42), np.nan)
+    for i in range(N):
+        if ok[i]:
+            hyb[i] = hf.compute_hybrid(bbox_xyxy_to_xywh(bbox[i].tolist()), kp[i].tolist())
+    lit_bbox = [10, 20, 30, 40]
+    lit_kp = [411.0, 296.0, 0.0, 397.7706599832915, 324.5295867768595, 1.0, 394.74, 280.64, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
+              405.0146198830409, 339.11983471074376, 0.0, 377.37593984962405, 339.11983471074376, 1.0,
+              403.73708461707747, 377.9917443864447, 0.0, 378.0, 385.0, 1.0, 431.68074658890845, 361.15543076883813, 0.0,
+              390.0, 427.0, 1.0, 388.0, 437.5, 0.0, 368.0, 438.0, 1.0, 404.0, 517.5, 1.0, 384.0, 518.0, 1.0,
+              396.0, 582.0, 1.0, 372.0, 581.5, 1.0]                # data literal of hybrid_feature.py:65-84
+    lit_feat = hf.compute_hybrid(lit_bbox, lit_kp)
+
+    torch.manual_seed(synth.SEED)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        ae38 = ae.WholeBodyAE(z_dim=4)                            # the reference class (D = 38)
+    sd38 = {k: synth.tensor_for("ae38." + k, v.shape) for k, v in ae38.state_dict().items()}
+    ae38.load_state_dict({k: torch.from_numpy(v) for k, v in sd38.items()})
+    ae38.eval()
+    ae42 = torch.nn.Sequential()                                  # same topology, D = 42
+    from oracle.nets import WholeBodyAERef
+    ae42 = WholeBodyAERef(4, 42)
+    sd42 = {k: synth.tensor_for("ae42." + k, v.shape) for k, v in ae42.state_dict().items()}
+    ae42.load_state_dict({k: torch.from_numpy(v) for k, v in sd42.items()})
+    crit = torch.nn.MSELoss()
+    keep38 = np.r_[0:3, 5:20, 22:42]
+    wpu42 = np.full(N, np.nan); wpu38 = np.full(N, np.nan); wpu38cls = np.full(N, np.nan)
+    with torch.no_grad():
+        for i in range(N):
+            if not ok[i]:
+                continue
+            x = torch.tensor(hyb[i]).float()
+            y = ae42(x)
+            wpu42[i] = float(crit(y, x))                          # THC+WPU branch, ActiveLearning.py:364-370
+            xi, yo = x.numpy(), y.numpy()
+            xi = np.concatenate([xi[:3], xi[5:20], xi[22:]]); yo = np.concatenate([yo[:3], yo[5:20], yo[22:]])
+            wpu38[i] = float(crit(torch.tensor(yo).float(), torch.tensor(xi).float()))   # WPU-only branch :371-386
+            x38 = torch.tensor(hyb[i][keep38]).float()
+            wpu38cls[i] = float(crit(ae38(x38), x38))             # reference class fed its declared width
+
+    # OKS + heat-map accuracy (§8f rank 1)
+    gt = kp.copy()
+    r = np.random.RandomState(5)
+    gt[:, 0::3] += r.normal(0, 3, (N, 17)); gt[:, 1::3] += r.normal(0, 3, (N, 17))
+    gt[:, 2::3] = (r.random_sample((N, 17)) > 0.3).astype(np.float64)
+    gt[6, 2::3] = 0                                               # no visible GT joint -> box-distance branch
+    bb_ann = np.stack([bbox[:, 0], bbox[:, 1], bbox[:, 2] - bbox[:, 0] + 1, bbox[:, 3] - bbox[:, 1] + 1], 1)
+    oks = np.array([alm.compute_OKS(bb_ann[i].tolist(), kp[i].tolist(), gt[i].tolist()) for i in range(N)])
+    tgt, mask = synth.gaussian_targets(N, seed=3)
+    acc = calc_accuracy(torch.from_numpy(hm * mask), torch.from_numpy(tgt * mask))
+
+    np.savez_compressed(
+        os.path.join(out, "scorers.npz"),
+        hm=hm, bbox=bbox, idx=idx, coords=coords, maxvals=maxvals, **soft,
+        lp_mean=lp_mean, lp_cnt=lp_cnt, toy=toy, toy_vals=np.asarray(toy_vals), toy_mean=np.float64(toy_mean),
+        thc_l1=thc_l1, thc_l2=thc_l2, tpc=tpc,
+        kp=kp, kp_ok=ok, hybrid=hyb, lit_bbox=np.array(lit_bbox, np.float64), lit_kp=np.array(lit_kp), lit_feat=lit_feat,
+        wpu42=wpu42, wpu38=wpu38, wpu38cls=wpu38cls,
+        **{"ae38." + k: v for k, v in sd38.items()}, **{"ae42." + k: v for k, v in sd42.items()},
+        gt=gt, bb_ann=bb_ann, oks=oks, acc_targets_seed=np.int64(3), acc=np.float64(acc))
+    print("scorers.npz written")
+
+
+def _extract_methods(path: str, names):
+    """Compile selected ``def``s of class ActiveLearning out of the reference file
+    *in memory* (the class itself cannot be imported here: skimage/seaborn/umap/...
+    are absent).  Nothing is written to disk."""
+    import ast
+    src = open(path, encoding="utf-8").read()
+    tree = ast.parse(src)
+    ns = {"np": np, "torch": torch}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ClassDef) and node.name == "ActiveLearning":
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name in names:
+                    mod = ast.Module(body=[item], type_ignores=[])
+                    exec(compile(mod, path, "exec"), ns)
+    return ns
+
+
+# ----------------------------------------------------------------------------
+# SimplePose-R50 forward, embedding, and one fine-tune step
+# ----------------------------------------------------------------------------
+
+def _sample_idx(numel: int, key: str, k: int = 256) -> np.ndarray:
+    r = np.random.RandomState(abs(hash_str(key)) % (2 ** 31))
+    return np.sort(r.randint(0, numel, size=min(k, numel)))
+
+
+def hash_str(s: str) -> int:
+    import zlib
+    return zlib.crc32(s.encode())
+
+
+def gen_simplepose(EasyDict, out: str):
+    from alphapose.models import builder                         # the reference's
+    cfg = EasyDict({"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "",
+                    "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50})
+    preset = EasyDict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    torch.manual_seed(synth.SEED)
+    m = builder.build_sppe(cfg, preset_cfg=preset)
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    keys = list(m.state_dict().keys())
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+
+    B = 2
+    x = torch.from_numpy(synth.crops(B))
+    m.eval()
+    stage = {}
+    hooks = []
+
+    def tap(name):
+        def fn(_m, _i, o):
+            stage[name] = o.detach().numpy().copy()
+        return fn
+    for name, mod in (("stem_pool", m.preact.maxpool), ("layer1", m.preact.layer1), ("layer2", m.preact.layer2),
+                      ("layer3", m.preact.layer3), ("layer4", m.preact.layer4), ("deconv1", m.deconv_layers[2]),
+                      ("deconv2", m.deconv_layers[5]), ("deconv3", m.deconv_layers[8])):
+        hooks.append(mod.register_forward_hook(tap(name)))
+    with torch.no_grad():
+        hm = m(x).numpy()
+        for h in hooks:
+            h.remove()
+        emb = m.get_embedding(x).numpy()
+    taps = {}
+    for k, v in stage.items():
+        ii = _sample_idx(v.size, k)
+        taps[f"tap_{k}_idx"] = ii
+        taps[f"tap_{k}_val"] = v.reshape(-1)[ii]
+        taps[f"tap_{k}_absmean"] = np.float64(np.abs(v).mean())
+
+    # one fine-tune step exactly as retrain_model does it (ActiveLearning.py:662-677)
+    torch.manual_seed(synth.SEED)
+    mt = builder.build_sppe(cfg, preset_cfg=preset)
+    mt.load_state_dict(synth.state_dict_for(mt), strict=True)
+    lr, wd = 2.5e-4, 0.7
+    opt = torch.optim.AdamW(params=[{"params": mt.final_layer.parameters(), "lr": lr * 10},
+                                    {"params": mt.preact.parameters(), "lr": lr},
+                                    {"params": mt.deconv_layers.parameters(), "lr": lr * 5}], weight_decay=wd)
+    crit = builder.build_loss(EasyDict({"TYPE": "MSELoss"}))
+    labels, masks = synth.gaussian_targets(B, seed=11)
+    labels, masks = torch.from_numpy(labels), torch.from_numpy(masks)
+    mt.train()
+    outp = mt(x.clone().requires_grad_())
+    loss = 0.5 * crit(outp.mul(masks), labels.mul(masks))
+    opt.zero_grad(); loss.backward(); opt.step()
+    train = {"train_loss": np.float64(loss.item()), "train_out_absmean": np.float64(outp.detach().abs().mean().item())}
+    sd = mt.state_dict()
+    watch = ["final_layer.weight", "final_layer.bias", "deconv_layers.6.weight", "deconv_layers.7.weight", "deconv_layers.0.weight",
+             "preact.layer4.2.conv3.weight", "preact.layer4.0.downsample.0.weight", "preact.layer3.0.conv2.weight",
+             "preact.layer1.0.conv1.weight", "preact.layer1.0.bn1.weight", "preact.layer1.0.bn1.bias", "preact.conv1.weight", "preact.bn1.weight"]
+    named = dict(mt.named_parameters())
+    for k in watch:
+        ii = _sample_idx(named[k].numel(), "g" + k, 512)
+        train[f"grad_idx::{k}"] = ii
+        train[f"grad_val::{k}"] = named[k].grad.reshape(-1)[ii].numpy()
+        train[f"grad_norm::{k}"] = np.float64(named[k].grad.double().norm().item())
+        train[f"new_val::{k}"] = sd[k].reshape(-1)[ii].numpy()
+    for k in ("preact.bn1.running_mean", "preact.bn1.running_var", "preact.layer4.2.bn3.running_mean",
+              "preact.layer4.2.bn3.running_var", "deconv_layers.7.running_mean", "deconv_layers.7.running_var"):
+        train[f"bnstat::{k}"] = sd[k].numpy()
+    train["bn_tracked"] = np.int64(sd["preact.bn1.num_batches_tracked"].item())
+
+    np.savez_compressed(os.path.join(out, "simplepose_r50.npz"), batch=np.int64(B), seed=np.int64(synth.SEED),
+                        heatmaps=hm, embedding=emb, keys=np.array(keys),
+                        shapes=np.array([str(shapes[k]) for k in keys]), **taps, **train)
+    print("simplepose_r50.npz written", hm.shape, float(np.abs(hm).mean()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    EasyDict = install_shims()
+    sys.path.insert(0, a.ref)
+    os.makedirs(a.out, exist_ok=True)
+    torch.set_num_threads(8)
+    if a.only in ("", "scorers"):
+        gen_scorers(a.ref, a.out)
+    if a.only in ("", "simplepose"):
+        gen_simplepose(EasyDict, a.out)
+
+
+if __name__ == "__main__":
+    main()
