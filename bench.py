@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of pose inference + uncertainty scoring.
+
+Workload (BASELINE.json configs[1]): SimpleBaseline
+ResNet-50, 256x192 crops, 17 key-points, a 1024-frame synthetic video per GPU
+(4 tracks x 256 consecutive frames, id-sorted), batches of 256:
+    one "step" = backbone forward (one per frame, de-duplicated neighbours)
+               + arg-max decode + local-peak mean + THC-L1 over the whole video.
+Inputs are resident in HBM before the timed region.  Random-init weights of the
+named architecture, synthetic crops (no dataset / checkpoint on the box).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL); frames shard
+across ranks (weak scaling: 1024 frames per rank), per-item results are
+all-gathered; there is no other exchange on this path.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying
+`roofline` (conv implicit-GEMM launches timed with HIP events) and, at N = 1,
+`cpu_baseline` (the oracle restatement timed on the host cores, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "vatl4pose-wacv2024_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+FRAMES = 1024
+TRACKS = 4
+BATCH = 256
+GFLOP_PER_CROP = 10.853          # SimplePose-R50 256x192 forward, conv+deconv MACs x 2
+PEAK_FP32_MFMA = 157.3           # TFLOP/s, v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
+
+
+def build_model(dev):
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    cfg = edict({"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50})
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    torch.manual_seed(166)
+    m = builder.build_sppe(cfg, preset_cfg=preset)
+    with torch.no_grad():                              # random running stats so BN folding is exercised
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+    return m.to(dev).eval()
+
+
+def make_video(dev, seed):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    x = torch.rand((FRAMES, 3, 256, 192), device=dev, generator=g)
+    x -= torch.tensor([0.406, 0.457, 0.480], device=dev).view(1, 3, 1, 1)
+    w = 60 + 180 * torch.rand(FRAMES, device=dev, generator=g)
+    bbox = torch.stack([torch.full_like(w, 100.0), torch.full_like(w, 50.0), 100 + w, 50 + w * 4 / 3], 1).contiguous()
+    pos = torch.arange(FRAMES, device=dev) % (FRAMES // TRACKS)
+    return x, bbox, (pos != 0).to(torch.uint8), (pos != FRAMES // TRACKS - 1).to(torch.uint8)
+
+
+def one_step(model, x, bbox, is_prev, is_next, hm_buf):
+    from active_learning.scoring import score_batch
+    from alphapose.models import hip_engine
+    with torch.no_grad():
+        for i in range(0, FRAMES, BATCH):
+            hip_engine.forward_into(model, x[i:i + BATCH], hm_buf[i:i + BATCH])
+        return score_batch(hm_buf, bbox, is_prev, is_next, thc_norm="L1")
+
+
+def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
+    """Time every conv/deconv implicit-GEMM launch of one step with HIP events on the
+    launch stream (torch's current stream) and relate the sum to the algorithmic FLOPs."""
+    import vatl_hip as vh
+    events = []
+    orig_c, orig_d = vh.conv2d_fwd, vh.deconv4x4s2_fwd
+
+    def wrap(fn):
+        def inner(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            events.append((e0, e1))
+            return r
+        return inner
+    vh.conv2d_fwd, vh.deconv4x4s2_fwd = wrap(orig_c), wrap(orig_d)
+    try:
+        one_step(model, x, bbox, is_prev, is_next, hm_buf)
+        torch.cuda.synchronize()
+    finally:
+        vh.conv2d_fwd, vh.deconv4x4s2_fwd = orig_c, orig_d
+    ms = sum(a.elapsed_time(b) for a, b in events)
+    flops = GFLOP_PER_CROP * 1e9 * FRAMES
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": None,
+            "kernel": "conv_igemm_kernel (all conv/deconv launches of one step)", "launches": len(events),
+            "avg_launch_us": round(ms * 1e3 / len(events), 2), "flops_per_step": flops}
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference graph + scorers) on the host cores,
+    bounded sample: 32 crops forward x 3 (median) + decode/local-peak/THC of 32 items."""
+    import numpy as np
+    from oracle import nets, scorers, synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = nets.SimplePoseRef(50).eval()
+    n = 32
+    x = torch.from_numpy(synth.crops(n, seed=1))
+    ts = []
+    with torch.no_grad():
+        m(x[:4])
+        for _ in range(3):
+            t0 = time.perf_counter()
+            hm = m(x).numpy()
+            ts.append(time.perf_counter() - t0)
+    fwd = sorted(ts)[1]
+    bb = synth.bboxes(n)
+    t0 = time.perf_counter()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(n):
+            scorers.decode_heatmaps(hm[i], bb[i])
+            scorers.localpeak_mean(hm[i])
+            if i:
+                scorers.thc_pair(hm[i], hm[i - 1])
+    post = time.perf_counter() - t0
+    return {"value": round(n / (fwd + post), 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} crops: SimplePose-R50 forward (torch CPU fp32, {cores} threads, median of 3) + numpy decode/local-peak/THC",
+            "forward_s": round(fwd, 3), "scoring_s": round(post, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = world > 1
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=dev)
+
+    model = build_model(dev)
+    x, bbox, is_prev, is_next = make_video(dev, 166 + rank)
+    hm_buf = torch.empty((FRAMES, 17, 64, 48), device=dev)
+
+    def step():
+        s = one_step(model, x, bbox, is_prev, is_next, hm_buf)
+        if dist:                                        # the only exchange: ~290 B of results per item
+            row = torch.cat([s.keypoints.reshape(FRAMES, -1), s.argmax.float(), s.hp[:, None], s.thc[:, None], s.localpeak[:, None]], 1)
+            out = torch.empty((world * FRAMES, row.shape[1]), device=dev)
+            td.all_gather_into_tensor(out, row.contiguous())
+        return s
+
+    for _ in range(a.warmup):
+        step()
+    if dist:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roof = conv_roofline(model, x, bbox, is_prev, is_next, hm_buf) if rank == 0 else None
+    if rank == 0:
+        line = {
+            "metric": "frames/sec pose-infer+uncertainty, 256x192 17-kp", "value": round(a.steps * FRAMES * world / dt, 1),
+            "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SimpleBaseline-R50 256x192 inference + decode + local-peak + THC-L1, 1024-frame synthetic video per GPU",
+                       "frames_per_gpu": FRAMES, "batch": BATCH, "tracks": TRACKS, "parallelism": f"frame-sharded x{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

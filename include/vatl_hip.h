@@ -1,0 +1,146 @@
+/*
+ * vatl_hip.h — C ABI of libvatl_hip.so, the MI355X (gfx950) implementation of
+ * the VATL4Pose pose-inference + uncertainty-scoring hot path.
+ *
+ * The reference (ImIntheMiddle/VATL4Pose-WACV2024) is pure Python; it has no FFI
+ * of its own for this path.  Each entry point below therefore names the
+ * reference Python call site whose arithmetic it replaces (paths relative to the
+ * reference root); INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocator);
+ *     the library never allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return 0 on success, a negative VATL_E* code on failure; the message of
+ *     the last failure on the calling thread is vatl_last_error();
+ *   - activations between conv entry points are NHWC fp32 ("channels-last"),
+ *     the network input and the heat-maps are NCHW fp32 like the reference's;
+ *   - re-entrant, no global mutable state except the thread-local error string.
+ */
+#ifndef VATL_HIP_H
+#define VATL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VATL_VERSION 100          /* 0.1.0 */
+#define VATL_EINVAL  (-1)         /* bad argument / unsupported shape */
+#define VATL_ELAUNCH (-2)         /* hipLaunch / hipFuncSetAttribute failed */
+
+int         vatl_version(void);
+const char* vatl_last_error(void);
+
+/* ------------------------------------------------------------------------ *
+ * Layout and parameter preparation (done once per weight version)
+ * ------------------------------------------------------------------------ */
+
+/* (N,C,H,W) -> (N,H,W,Cpad), channels C..Cpad-1 zero.  Network input:
+ * ActiveLearning.py:277 `m(inps[:,0].cuda())` hands over NCHW crops. */
+int vatl_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int Cpad, void* stream);
+/* (N,H,W,C) -> (N,C,H,W). */
+int vatl_nhwc_to_nchw(const float* src, float* dst, int N, int C, int H, int W, void* stream);
+
+/* nn.Conv2d weight (Cout,Cin,R,S) -> [CoutPad][R][Spad][CinPad] (zeros in the
+ * padding), the K-contiguous layout the implicit-GEMM kernel reads.
+ * Resnet.py:63,72,97 / simplepose.py:33 weights. */
+int vatl_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int Cin, int R, int S,
+                          int CoutPad, int Spad, int CinPad, void* stream);
+/* nn.ConvTranspose2d(k=4,s=2,p=1) weight (Cin,Cout,4,4) -> four sub-pixel 2x2
+ * filters [phase=py*2+px][CoutPad][ty][tx][Cin] with ky = 3-py-2*ty, kx = 3-px-2*tx.
+ * simplepose.py:39-46. */
+int vatl_pack_deconv4x4s2_weight(const float* w_iohw, float* w_packed, int Cin, int Cout, int CoutPad, void* stream);
+/* Eval-mode BatchNorm2d as a per-channel affine: scale = gamma/sqrt(var+eps),
+ * bias = beta - mean*scale (Resnet.py:67,98,100,155; simplepose.py:41,44,47).
+ * gamma/beta may be NULL (then 1 / 0); conv_bias (may be NULL) is folded in:
+ * bias += conv_bias*scale. */
+int vatl_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* conv_bias,
+                 float eps, float* scale, float* bias, int C, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Backbone forward (inference): implicit-GEMM on fp32 MFMA
+ * ------------------------------------------------------------------------ */
+
+/* y = act( conv(x, w) * scale + bias (+ residual) ).
+ * x (N,H,W,Cin) NHWC; w packed by vatl_pack_conv_weight with CinPad == Cin
+ * (Cin % 32 == 0) or, for the 3-channel stem, Cin = 4 / Spad = 8;
+ * y NHWC (N,Ho,Wo,Cout) or, when out_nchw != 0, NCHW (N,Cout,Ho,Wo);
+ * scale/bias (Cout) may be NULL (1 / 0); residual (same layout as y) may be NULL.
+ * Replaces Conv2d+BatchNorm2d(+add)(+ReLU) chains of Bottleneck.forward
+ * (Resnet.py:104-128), ResNet.forward stem (Resnet.py:171-172) and
+ * SimplePose.final_layer (simplepose.py:85). */
+/* CoutPad the packer must use for a given Cout (multiple of the kernel's N tile). */
+int vatl_conv_cout_pad(int Cout);
+int vatl_conv2d_fwd(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
+                    float* y, int N, int H, int W, int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad,
+                    int relu, int out_nchw, void* stream);
+
+/* ConvTranspose2d(4,2,1,bias=False)+BatchNorm2d+ReLU as four 2x2 sub-pixel
+ * convolutions (no zero stuffing).  x (N,H,W,Cin) -> y (N,2H,2W,Cout) NHWC.
+ * simplepose.py:37-59, :84. */
+int vatl_deconv4x4s2_fwd(const float* x, const float* w, const float* scale, const float* bias, float* y,
+                         int N, int H, int W, int Cin, int Cout, int CoutPad, int relu, void* stream);
+
+/* MaxPool2d(3,2,1) on NHWC (Resnet.py:158,172).  C % 4 == 0. */
+int vatl_maxpool3x3s2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* AdaptiveAvgPool2d(1)+flatten on NHWC -> (N,C)  (simplepose.py:88-91). */
+int vatl_gap_fwd(const float* x, float* y, int N, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Scorers on heat-maps (N,J,H,W) fp32 NCHW, one pass over HBM each
+ * ------------------------------------------------------------------------ */
+
+/* heatmap_to_coord_simple (transforms.py:550-583): first-max arg-max, +-0.25 px
+ * shift, inverse crop affine (float64, float32-rounded control points).
+ * bbox (N,4) xyxy fp32; coords (N,J,2) fp32 image px; maxvals (N,J) fp32;
+ * idx (N,J) int32 flat arg-max (may be NULL). */
+int vatl_decode_argmax_affine(const float* hm, const float* bbox, float* coords, float* maxvals, int32_t* idx,
+                              int N, int J, int H, int W, void* stream);
+
+/* compute_thc (ActiveLearning.py:747-760) for P pairs: out[i] = sum|a_i-b_i|/J
+ * (norm 1) or sum (a_i-b_i)^2/J (norm 2); a_i = a + i*stride_a, b likewise
+ * (strides in floats; stride J*H*W and b = a + J*H*W gives consecutive frames). */
+int vatl_thc_pairs(const float* a, const float* b, int64_t stride_a, int64_t stride_b, float* out,
+                   int P, int J, int HW, int norm, void* stream);
+/* The isPrev/isNext rule of eval_and_query (ActiveLearning.py:345-363) on a
+ * de-duplicated id-sorted stream: thc[i] = [prev]*pair[i-1] + [next]*pair[i],
+ * doubled when exactly one neighbour exists.  pair has N-1 entries. */
+int vatl_thc_combine(const float* pair, const uint8_t* is_prev, const uint8_t* is_next, float* thc, int N, void* stream);
+
+/* localpeak_mean (local_peak.py:5-22): per item the mean of 3x3 zero-padded
+ * local maxima >= order * largest local maximum, pooled over joints (nan when
+ * none).  count (N,J) int32 kept peaks per joint (may be NULL). */
+int vatl_localpeak_mean(const float* hm, float* mean, int32_t* count, int N, int J, int H, int W, float order, void* stream);
+
+/* compute_hybrid + WholeBodyAE + MSELoss (hybrid_feature.py:14-59,
+ * AutoEncoder.py:13-39, ActiveLearning.py:364-386).  kpts (N,17,3) (x,y,score)
+ * fp32, bbox (N,4) crop box xyxy; ae = 8 (weight,bias) pairs concatenated in
+ * state-dict order (encoder.0,2,4,6, decoder.0,2,4,6), D in {38,42}, z = code
+ * width; only38 != 0 drops feature indices 3,4,20,21 before the MSE (D must be
+ * 42).  wpu (N) fp32; status (N) int32: 0 ok, 1 bbox height <= 0, 2 score sum
+ * <= 0 (the reference's two asserts). */
+int vatl_hybrid_ae_wpu(const float* kpts, const float* bbox, const float* ae, int D, int z, int only38,
+                       float* wpu, int32_t* status, int N, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Fine-tune step pieces (ActiveLearning.py:662-677)
+ * ------------------------------------------------------------------------ */
+
+/* loss = 0.5*mean((o*m - t*m)^2) and dL/do; mask (N,J).  partial: workspace of
+ * vatl_masked_mse_workspace_floats(N*J*HW) floats; loss: 1 float on device. */
+int64_t vatl_masked_mse_workspace_floats(int64_t numel);
+int vatl_masked_mse_fwd_bwd(const float* out, const float* target, const float* mask, float* grad, float* loss,
+                            float* partial, int N, int J, int HW, void* stream);
+
+/* torch.optim.AdamW step on one flat fp32 span (decoupled weight decay);
+ * hyper-parameters are doubles like the Python floats torch derives its
+ * per-step scalars from; `step` is the 1-based step count. */
+int vatl_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                    double eps, double weight_decay, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VATL_HIP_H */

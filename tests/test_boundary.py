@@ -1,0 +1,69 @@
+"""Host-side mirror of the reference's plugin surface, CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+
+
+def _cfgs():
+    from alphapose.utils.config import edict
+    cfg = edict({"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50})
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    return cfg, preset
+
+
+def test_registry_behaviour():
+    from alphapose.models import builder
+    from alphapose.utils import Registry, build_from_cfg
+    assert builder.SPPE.get("SimplePose") is not None
+    assert builder.LOSS.get("MSELoss") is torch.nn.MSELoss
+    with pytest.raises(KeyError):
+        build_from_cfg({"TYPE": "Nope"}, builder.SPPE)
+    r = Registry("x")
+
+    @r.register_module
+    class A:
+        def __init__(self, P=1, Q=2):
+            self.P, self.Q = P, Q
+    with pytest.raises(KeyError):
+        r.register_module(A)
+    with pytest.raises(TypeError):
+        r.register_module(3)
+    a = build_from_cfg({"TYPE": "A", "P": 5}, r, {"Q": 7, "P": 9})
+    assert (a.P, a.Q) == (5, 7)                     # explicit keys win over defaults
+    assert isinstance(builder.build_loss({"TYPE": "MSELoss"}), torch.nn.MSELoss)
+
+
+def test_simplepose_state_dict_is_checkpoint_compatible(golden_simplepose):
+    from alphapose.models import builder
+    cfg, preset = _cfgs()
+    m = builder.build_sppe(cfg, preset_cfg=preset)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(golden_simplepose["keys"])                     # the reference module's keys, in order
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(golden_simplepose["shapes"])
+    assert len(sd) == 338
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    for attr in ("preact", "deconv_layers", "final_layer", "_initialize", "get_embedding"):
+        assert hasattr(m, attr)
+    groups = [list(m.final_layer.parameters()), list(m.preact.parameters()), list(m.deconv_layers.parameters())]
+    assert sum(len(g) for g in groups) == len(list(m.parameters()))                 # optimizer param groups cover the model
+    m._initialize()
+    assert float(m.final_layer.bias.abs().sum()) == 0.0
+
+
+def test_forward_without_gpu_fails_loudly():
+    from alphapose.models import builder
+    cfg, preset = _cfgs()
+    m = builder.build_sppe(cfg, preset_cfg=preset).eval()
+    with pytest.raises(Exception) as e:
+        m(torch.zeros(1, 3, 256, 192))
+    assert "fallback" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_config_loader(tmp_path):
+    from alphapose.utils.config import update_config
+    p = tmp_path / "c.yaml"
+    p.write_text("MODEL:\n  TYPE: 'SimplePose'\n  NUM_LAYERS: 50\nVAL:\n  QUERY_RATIO: [0.05, 0.1]\n")
+    cfg = update_config(str(p))
+    assert cfg.MODEL.TYPE == "SimplePose" and cfg["MODEL"]["NUM_LAYERS"] == 50 and cfg.VAL.QUERY_RATIO[1] == 0.1

@@ -1,0 +1,174 @@
+"""Implicit-GEMM conv / deconv / pooling kernels vs a float64 torch-CPU reference,
+and the whole SimplePose-R50 forward vs the reference-generated golden heat-maps."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import synth
+from tests.gpu_util import dev, record, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5      # max|err| / max|ref| per layer (fp32 accumulate, K <= 4608); network-level bar is 1e-4
+
+
+@pytest.fixture(scope="module")
+def vh():
+    import vatl_hip
+    vatl_hip.lib()
+    return vatl_hip
+
+
+def _nhwc(x):
+    return np.ascontiguousarray(np.transpose(x, (0, 2, 3, 1)))
+
+
+def test_layout_roundtrip(vh):
+    r = np.random.RandomState(0)
+    x = r.standard_normal((3, 3, 10, 7)).astype(np.float32)
+    y = vh.nchw_to_nhwc(to_dev(x), 4).cpu().numpy()
+    assert np.array_equal(y[..., :3], _nhwc(x)) and (y[..., 3] == 0).all()
+    x = r.standard_normal((2, 8, 5, 6)).astype(np.float32)
+    y = vh.nchw_to_nhwc(to_dev(x))
+    assert np.array_equal(y.cpu().numpy(), _nhwc(x))
+    assert np.array_equal(vh.nhwc_to_nchw(y).cpu().numpy(), x)
+
+
+CONV_CASES = [
+    # name, N, H, W, Cin, Cout, k, stride, pad, relu, residual, bias, nchw
+    ("1x1_64_256_res", 2, 64, 48, 64, 256, 1, 1, 0, True, True, False, False),
+    ("1x1_256_64", 1, 64, 48, 256, 64, 1, 1, 0, True, False, False, False),
+    ("3x3_64_64", 2, 64, 48, 64, 64, 3, 1, 1, True, False, False, False),
+    ("3x3s2_128_128", 2, 64, 48, 128, 128, 3, 2, 1, True, False, False, False),
+    ("1x1s2_256_512", 2, 64, 48, 256, 512, 1, 2, 0, False, False, False, False),
+    ("3x3_512_512_tiny", 3, 8, 6, 512, 512, 3, 1, 1, True, False, False, False),
+    ("1x1_2048_512_oddM", 1, 8, 6, 2048, 512, 1, 1, 0, True, False, False, False),
+    ("1x1_cout96", 1, 9, 7, 64, 96, 1, 1, 0, False, True, True, False),
+    ("3x3_oddHW", 1, 13, 11, 32, 40, 3, 1, 1, True, True, False, False),
+    ("3x3s2_oddHW", 2, 13, 11, 32, 64, 3, 2, 1, False, False, True, False),
+    ("head_256_17_nchw", 2, 64, 48, 256, 17, 1, 1, 0, False, False, True, True),
+    ("stem_7x7", 2, 256, 192, 3, 64, 7, 2, 3, True, False, False, False),
+    ("stem_7x7_odd", 1, 37, 29, 3, 64, 7, 2, 3, True, False, False, False),
+    ("3x3_32_17_nchw", 1, 16, 12, 128, 17, 3, 1, 1, False, False, True, True),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_fwd(vh, case):
+    name, n, h, w, cin, cout, k, stride, pad, relu, use_res, use_bias, nchw = case
+    import zlib; r = np.random.RandomState(zlib.crc32(name.encode()) % 2 ** 31)
+    x = r.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (r.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    gamma, beta = r.uniform(0.5, 1.5, cout).astype(np.float32), r.standard_normal(cout).astype(np.float32) * 0.1
+    mean, var = r.standard_normal(cout).astype(np.float32) * 0.1, r.uniform(0.5, 1.5, cout).astype(np.float32)
+    cb = r.standard_normal(cout).astype(np.float32) if use_bias else None
+    ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None if cb is None else torch.from_numpy(cb).double(),
+                   stride, pad)
+    ref = F.batch_norm(ref, torch.from_numpy(mean).double(), torch.from_numpy(var).double(), torch.from_numpy(gamma).double(),
+                       torch.from_numpy(beta).double(), False, 0.0, 1e-5)
+    res = None
+    if use_res:
+        res = r.standard_normal(tuple(ref.shape)).astype(np.float32)
+        ref = ref + torch.from_numpy(res).double()
+    if relu:
+        ref = ref.relu()
+    ref = ref.numpy()
+
+    xd = vh.nchw_to_nhwc(to_dev(x), 4 if cin == 3 else cin)
+    wp = vh.pack_conv_weight(to_dev(wt))
+    scale, bias = vh.bn_fold(to_dev(gamma), to_dev(beta), to_dev(mean), to_dev(var), 1e-5, None if cb is None else to_dev(cb))
+    resd = None
+    if use_res:
+        resd = to_dev(res) if nchw else to_dev(_nhwc(res))
+    y = vh.conv2d_fwd(xd, wp, scale, bias, cout, k, k, stride, pad, relu, residual=resd, out_nchw=nchw)
+    torch.cuda.synchronize()
+    got = y.cpu().numpy() if nchw else np.transpose(y.cpu().numpy(), (0, 3, 1, 2))
+    assert got.shape == ref.shape
+    e = rel_err(got, ref)
+    record("conv2d_" + name, rel=e)
+    assert e < TOL, (name, e)
+
+
+DECONV_CASES = [("2048_256", 2, 8, 6, 2048, 256), ("256_256", 1, 16, 12, 256, 256), ("odd", 1, 5, 3, 64, 48), ("256_256_big", 1, 32, 24, 256, 256)]
+
+
+@pytest.mark.parametrize("case", DECONV_CASES, ids=[c[0] for c in DECONV_CASES])
+def test_deconv4x4s2_fwd(vh, case):
+    name, n, h, w, cin, cout = case
+    r = np.random.RandomState(len(name) + cin)
+    x = r.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (r.standard_normal((cin, cout, 4, 4)) / np.sqrt(cin * 4)).astype(np.float32)
+    gamma, beta = r.uniform(0.5, 1.5, cout).astype(np.float32), r.standard_normal(cout).astype(np.float32) * 0.1
+    mean, var = r.standard_normal(cout).astype(np.float32) * 0.1, r.uniform(0.5, 1.5, cout).astype(np.float32)
+    ref = F.conv_transpose2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, 2, 1)
+    ref = F.batch_norm(ref, torch.from_numpy(mean).double(), torch.from_numpy(var).double(), torch.from_numpy(gamma).double(),
+                       torch.from_numpy(beta).double(), False, 0.0, 1e-5).relu().numpy()
+    scale, bias = vh.bn_fold(to_dev(gamma), to_dev(beta), to_dev(mean), to_dev(var), 1e-5)
+    y = vh.deconv4x4s2_fwd(vh.nchw_to_nhwc(to_dev(x)), vh.pack_deconv_weight(to_dev(wt)), scale, bias, cout, True)
+    got = np.transpose(y.cpu().numpy(), (0, 3, 1, 2))
+    e = rel_err(got, ref)
+    record("deconv_" + name, rel=e)
+    assert got.shape == ref.shape and e < TOL, (name, e)
+
+
+def test_maxpool_and_gap(vh):
+    r = np.random.RandomState(3)
+    for (n, c, h, w) in ((2, 64, 128, 96), (1, 8, 7, 5)):
+        x = r.standard_normal((n, c, h, w)).astype(np.float32)
+        ref = F.max_pool2d(torch.from_numpy(x), 3, 2, 1).numpy()
+        got = np.transpose(vh.maxpool3x3s2_fwd(vh.nchw_to_nhwc(to_dev(x))).cpu().numpy(), (0, 3, 1, 2))
+        assert np.array_equal(got, ref)                                                   # max is exact
+    x = r.standard_normal((3, 2048, 8, 6)).astype(np.float32)
+    got = vh.gap_fwd(vh.nchw_to_nhwc(to_dev(x))).cpu().numpy()
+    np.testing.assert_allclose(got, x.reshape(3, 2048, -1).mean(2), rtol=1e-5, atol=1e-6)
+
+
+def _build_simplepose():
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    cfg = edict({"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50})
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    m = builder.build_sppe(cfg, preset_cfg=preset)
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    return m.to(dev()).eval()
+
+
+def test_simplepose_forward_vs_reference_golden(vh, golden_simplepose):
+    g = golden_simplepose
+    m = _build_simplepose()
+    x = to_dev(synth.crops(int(g["batch"])))
+    with torch.no_grad():
+        hm = m(x)
+        emb = m.get_embedding(x)
+    torch.cuda.synchronize()
+    hm, emb = hm.cpu().numpy(), emb.cpu().numpy()
+    e = rel_err(hm, g["heatmaps"])
+    record("simplepose_r50_heatmaps", rel=e, emb_rel=rel_err(emb, g["embedding"]))
+    assert hm.shape == (2, 17, 64, 48)
+    assert e < 1e-4                                                                       # north_star: heat-maps within 1e-4 rel fp32
+    assert np.array_equal(hm.reshape(2, 17, -1).argmax(2), g["heatmaps"].reshape(2, 17, -1).argmax(2))   # integer peaks bit-exact
+    assert rel_err(emb, g["embedding"]) < 1e-4
+    # staged taps (debug aid: which stage diverges first)
+    from alphapose.models import hip_engine
+    plan = hip_engine._plan_for(m, dev())
+    with torch.no_grad():
+        feat = plan.features(x)
+    v = np.transpose(feat.cpu().numpy(), (0, 3, 1, 2)).reshape(-1)[g["tap_layer4_idx"]]
+    assert rel_err(v, g["tap_layer4_val"]) < 1e-4
+
+
+def test_simplepose_batch_invariance(vh):
+    """A crop's heat-map must not depend on its batch position (THC de-duplication)."""
+    m = _build_simplepose()
+    x = to_dev(synth.crops(3, seed=5))
+    with torch.no_grad():
+        full = m(x)
+        solo = torch.cat([m(x[i:i + 1]) for i in range(3)], 0)
+    assert torch.equal(full, solo)
+
+
+def test_cpu_input_fails_loudly(vh):
+    m = _build_simplepose()
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 3, 256, 192))

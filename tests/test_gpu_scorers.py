@@ -1,0 +1,147 @@
+"""HIP scorers (through the C ABI) vs the golden vectors and the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scorers, synth
+from tests.gpu_util import dev, record, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vh():
+    import vatl_hip
+    vatl_hip.lib()
+    return vatl_hip
+
+
+def test_library_loaded(vh):
+    assert vh.lib().vatl_version() == 100
+
+
+def test_decode_golden(vh, golden_scorers):
+    g = golden_scorers
+    coords, maxv, idx = vh.decode(to_dev(g["hm"]), to_dev(g["bbox"]))
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), g["idx"].astype(np.int32))                   # bit-exact integers
+    assert np.array_equal(maxv.cpu().numpy(), g["maxvals"][..., 0])                      # copied values: bit-exact
+    c = coords.cpu().numpy()
+    exact = float((c == g["coords"]).mean())
+    record("decode_golden", coords_bit_exact_fraction=exact, max_abs=float(np.abs(c - g["coords"]).max()))
+    np.testing.assert_allclose(c, g["coords"], rtol=1e-4, atol=1e-4)                      # north_star: key-points 1e-4 rel
+    assert exact == 1.0                                                                   # and in fact bit-identical here
+
+
+def test_decode_random_vs_oracle(vh):
+    r = np.random.RandomState(1)
+    hm = r.standard_normal((32, 17, 64, 48)).astype(np.float32)
+    hm[3] = np.round(hm[3] * 2) / 2                                                       # many exact ties
+    hm[4] = -np.abs(hm[4])                                                                # all non-positive
+    bb = synth.bboxes(32, seed=4)
+    coords, maxv, idx = vh.decode(to_dev(hm), to_dev(bb))
+    for i in range(32):
+        d = scorers.decode_heatmaps(hm[i], bb[i])
+        assert np.array_equal(idx[i].cpu().numpy(), d["idx"]), i
+        assert np.array_equal(maxv[i].cpu().numpy(), d["maxvals"][:, 0])
+        np.testing.assert_allclose(coords[i].cpu().numpy(), d["coords"], rtol=1e-4, atol=1e-4)
+
+
+def test_decode_other_heatmap_sizes(vh):
+    r = np.random.RandomState(2)
+    for (h, w) in ((96, 72), (5, 7), (1, 1)):
+        hm = r.standard_normal((3, 17, h, w)).astype(np.float32)
+        bb = synth.bboxes(3, seed=h)
+        coords, maxv, idx = vh.decode(to_dev(hm), to_dev(bb))
+        for i in range(3):
+            d = scorers.decode_heatmaps(hm[i], bb[i])
+            assert np.array_equal(idx[i].cpu().numpy(), d["idx"])
+            np.testing.assert_allclose(coords[i].cpu().numpy(), d["coords"], rtol=1e-4, atol=1e-4)
+    c, m, i = vh.decode(torch.empty((0, 17, 64, 48), device=dev()), torch.empty((0, 4), device=dev()))   # empty batch
+    assert c.shape == (0, 17, 2)
+
+
+def test_thc_golden_and_stream_rule(vh, golden_scorers):
+    g = golden_scorers
+    hm = to_dev(g["hm"])
+    for norm, key in (("L1", "thc_l1"), ("L2", "thc_l2")):
+        got = vh.thc_pairs(hm[:-1], hm[1:], norm).cpu().numpy()
+        record("thc_" + norm, rel=rel_err(got, g[key]))
+        np.testing.assert_allclose(got, g[key], rtol=1e-5)
+    n = hm.shape[0]
+    is_prev = np.array([0, 1, 1, 0, 1, 0, 0, 1], np.uint8)
+    is_next = np.array([1, 1, 0, 1, 0, 0, 1, 0], np.uint8)
+    got = vh.thc_stream(hm, to_dev(is_prev, torch.uint8), to_dev(is_next, torch.uint8)).cpu().numpy()
+    for i in range(n):
+        want = scorers.thc_item(g["hm"][i], g["hm"][i - 1] if i else None, g["hm"][i + 1] if i + 1 < n else None,
+                                is_prev[i], is_next[i])
+        np.testing.assert_allclose(got[i], want, rtol=1e-5)
+    one = vh.thc_stream(hm[:1], to_dev([0], torch.uint8), to_dev([0], torch.uint8))       # single item: no pairs
+    assert float(one[0]) == 0.0
+
+
+def test_localpeak_golden(vh, golden_scorers):
+    g = golden_scorers
+    mean, cnt = vh.localpeak_mean(to_dev(g["hm"]))
+    assert np.array_equal(cnt.cpu().numpy(), g["lp_cnt"].astype(np.int32))               # integer peak counts: bit-exact
+    m = mean.cpu().numpy()
+    assert np.isnan(m[6]) and np.isnan(g["lp_mean"][6])
+    ok = ~np.isnan(g["lp_mean"])
+    record("localpeak", rel=rel_err(m[ok], g["lp_mean"][ok]))
+    np.testing.assert_allclose(m[ok], g["lp_mean"][ok], rtol=1e-5)
+    toy = np.zeros((1, 3, 4, 10), np.float32) + g["toy"].astype(np.float32)
+    mean, cnt = vh.localpeak_mean(to_dev(toy))
+    assert float(mean[0]) == 3.5 and cnt.cpu().tolist() == [[2, 2, 2]]
+
+
+def test_localpeak_random_vs_oracle(vh):
+    hm = synth.blob_heatmaps(24, seed=21)
+    hm[5] = np.round(hm[5] * 8) / 8                                                       # plateaus
+    mean, cnt = vh.localpeak_mean(to_dev(hm))
+    for i in range(24):
+        c, _, m = scorers.localpeak_stats(hm[i])
+        assert np.array_equal(cnt[i].cpu().numpy(), c), i
+        np.testing.assert_allclose(float(mean[i]), m, rtol=1e-5)
+
+
+def test_wpu_golden(vh, golden_scorers):
+    g = golden_scorers
+    kp = to_dev(g["kp"].reshape(-1, 17, 3))
+    bb = to_dev(g["bbox"])
+    sd42 = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("ae42.")}
+    sd38 = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("ae38.")}
+    ok = g["kp_ok"]
+    for flat, d, only38, key in ((vh.pack_ae(sd42, dev()), 42, False, "wpu42"), (vh.pack_ae(sd42, dev()), 42, True, "wpu38"),
+                                 (vh.pack_ae(sd38, dev()), 38, False, "wpu38cls")):
+        wpu, status = vh.hybrid_ae_wpu(kp, bb, flat, d, 4, only38)
+        w, s = wpu.cpu().numpy(), status.cpu().numpy()
+        assert np.array_equal(s == 0, ok)
+        assert (s[~ok] == 2).all() and np.isnan(w[~ok]).all()                              # "at least one visible keypoint"
+        record(key, rel=rel_err(w[ok], g[key][ok]))
+        np.testing.assert_allclose(w[ok], g[key][ok], rtol=1e-4)
+    bad = bb.clone(); bad[:, 3] = bad[:, 1] - 5                                           # height <= 0 -> status 1
+    _, status = vh.hybrid_ae_wpu(kp, bad, vh.pack_ae(sd42, dev()), 42, 4)
+    assert (status.cpu().numpy()[ok] == 1).all()
+
+
+def test_masked_mse_and_adamw(vh):
+    r = np.random.RandomState(0)
+    out = r.standard_normal((5, 17, 64, 48)).astype(np.float32)
+    tgt, mask = synth.gaussian_targets(5, seed=2)
+    loss, grad = vh.masked_mse_fwd_bwd(to_dev(out), to_dev(tgt), to_dev(mask))
+    want_l, want_g = scorers.masked_mse(out, tgt, mask)
+    np.testing.assert_allclose(float(loss), want_l, rtol=1e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), want_g, rtol=1e-5, atol=1e-12)
+
+    n = 100003                                                                             # odd tail
+    p = r.standard_normal(n).astype(np.float32); m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    tp = torch.from_numpy(p.copy()).requires_grad_()
+    opt = torch.optim.AdamW([tp], lr=2.5e-3, weight_decay=0.7)
+    dp, dm, dv = to_dev(p), to_dev(m), to_dev(v)
+    for step in range(1, 4):
+        g_ = r.standard_normal(n).astype(np.float32)
+        tp.grad = torch.from_numpy(g_.copy()); opt.step()
+        vh.adamw_step(dp, to_dev(g_), dm, dv, step, 2.5e-3, 0.7)
+        p, m, v = scorers.adamw_step(p, g_, m, v, step, 2.5e-3, 0.7)
+    np.testing.assert_allclose(dp.cpu().numpy(), tp.detach().numpy(), rtol=2e-5, atol=1e-6)   # vs torch.optim.AdamW
+    np.testing.assert_allclose(dp.cpu().numpy(), p, rtol=2e-5, atol=1e-6)                      # vs the numpy oracle

@@ -1,0 +1,189 @@
+"""Inference plans: torch module tree -> sequence of libvatl_hip.so launches.
+
+A plan is built once per (module, parameter version, device): conv weights are
+re-packed K-contiguous ([Cout][R][S][Cin]), eval-mode BatchNorm is folded into a
+per-channel scale/bias consumed by the conv epilogue (with residual add and ReLU),
+ConvTranspose2d(4,2,1) becomes four sub-pixel 2x2 filters.  Activations stay NHWC
+between launches; only the network input (NCHW crops) and the heat-maps (NCHW,
+what the scorers and the reference's callers expect) are converted.
+
+Dataflow of SimplePose (reference: simplepose.py:82-86, Resnet.py:171-177):
+  NCHW crops -> NHWC(4ch) -> stem 7x7/2 (+BN+ReLU) -> maxpool 3x3/2
+  -> 16 bottlenecks {1x1, 3x3(stride), 1x1 (+proj) + add + ReLU}
+  -> 3 x deconv4x4/2 (+BN+ReLU) -> 1x1 head (+bias) written NCHW.
+
+There is no fallback: without the library or on CPU tensors this raises.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+import vatl_hip as vh
+
+# items per launch sequence; bounds workspace (stem output = 3.1 MB/crop) and
+# keeps every tensor far below the kernels' 2^31-element guard
+MAX_CHUNK = int(os.environ.get("VATL_MAX_CHUNK", "256"))
+
+
+class _Conv:
+    __slots__ = ("w", "scale", "bias", "cout", "r", "s", "stride", "pad")
+
+    def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d | None):
+        assert conv.groups == 1 and conv.dilation == (1, 1)
+        assert conv.stride[0] == conv.stride[1] and conv.padding[0] == conv.padding[1]
+        self.w = vh.pack_conv_weight(conv.weight.detach())
+        self.cout, _, self.r, self.s = conv.weight.shape
+        self.stride, self.pad = conv.stride[0], conv.padding[0]
+        cb = conv.bias.detach() if conv.bias is not None else None
+        if bn is not None:
+            self.scale, self.bias = vh.bn_fold(_d(bn.weight), _d(bn.bias), bn.running_mean, bn.running_var, bn.eps, cb)
+        elif cb is not None:
+            self.scale, self.bias = vh.bn_fold(None, None, None, None, 0.0, cb, channels=self.cout)
+        else:
+            self.scale = self.bias = None
+
+    def __call__(self, x, relu, residual=None, out_nchw=False, out=None):
+        return vh.conv2d_fwd(x, self.w, self.scale, self.bias, self.cout, self.r, self.s, self.stride, self.pad, relu,
+                             residual=residual, out_nchw=out_nchw, out=out)
+
+
+class _Deconv:
+    __slots__ = ("w", "scale", "bias", "cout")
+
+    def __init__(self, dc: nn.ConvTranspose2d, bn: nn.BatchNorm2d):
+        assert dc.kernel_size == (4, 4) and dc.stride == (2, 2) and dc.padding == (1, 1) and dc.bias is None
+        self.w = vh.pack_deconv_weight(dc.weight.detach())
+        self.cout = dc.weight.shape[1]
+        self.scale, self.bias = vh.bn_fold(_d(bn.weight), _d(bn.bias), bn.running_mean, bn.running_var, bn.eps)
+
+    def __call__(self, x, relu=True):
+        return vh.deconv4x4s2_fwd(x, self.w, self.scale, self.bias, self.cout, relu)
+
+
+def _d(p):
+    return None if p is None else p.detach()
+
+
+class _BottleneckPlan:
+    def __init__(self, blk):
+        self.c1 = _Conv(blk.conv1, blk.bn1)
+        self.c2 = _Conv(blk.conv2, blk.bn2)
+        self.c3 = _Conv(blk.conv3, blk.bn3)
+        self.proj = _Conv(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+
+    def __call__(self, x):
+        y = self.c1(x, relu=True)
+        y = self.c2(y, relu=True)
+        skip = x if self.proj is None else self.proj(x, relu=False)
+        return self.c3(y, relu=True, residual=skip)                 # relu(bn3(conv3) + skip)
+
+
+class _TrunkPlan:
+    def __init__(self, net):
+        self.stem = _Conv(net.conv1, net.bn1)
+        self.blocks = [_BottleneckPlan(b) for stage in net.stages() for b in stage]
+
+    def __call__(self, x_nchw):
+        x = vh.nchw_to_nhwc(x_nchw, 4)                              # 3 -> 4 channels (zero), 16-byte pixels
+        x = self.stem(x, relu=True)
+        x = vh.maxpool3x3s2_fwd(x)
+        for b in self.blocks:
+            x = b(x)
+        return x
+
+
+class _SimplePosePlan:
+    def __init__(self, m):
+        self.trunk = _TrunkPlan(m.preact)
+        d = m.deconv_layers
+        self.deconvs = [_Deconv(d[0], d[1]), _Deconv(d[3], d[4]), _Deconv(d[6], d[7])]
+        self.head = _Conv(m.final_layer, None)
+
+    def features(self, x_nchw):
+        return self.trunk(x_nchw)
+
+    def __call__(self, x_nchw, out=None):
+        x = self.trunk(x_nchw)
+        for dc in self.deconvs:
+            x = dc(x)
+        return self.head(x, relu=False, out_nchw=True, out=out)
+
+
+class _NchwAdapter:
+    """Stand-alone use of a sub-module (ResNet / Bottleneck) on NCHW tensors."""
+
+    def __init__(self, inner, cin_pad=None):
+        self.inner, self.cin_pad = inner, cin_pad
+
+    def __call__(self, x_nchw):
+        if isinstance(self.inner, _TrunkPlan):
+            return vh.nhwc_to_nchw(self.inner(x_nchw))
+        return vh.nhwc_to_nchw(self.inner(vh.nchw_to_nhwc(x_nchw)))
+
+
+def _version_key(m: nn.Module, device):
+    v = 0
+    for t in list(m.parameters()) + list(m.buffers()):
+        v = v * 1000003 + t._version + (t.data_ptr() & 0xFFFF)
+    return (str(device), v & 0xFFFFFFFFFFFF)
+
+
+def _plan_for(m: nn.Module, device):
+    key = _version_key(m, device)
+    cached = m.__dict__.get("_vatl_plan")
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    from .simplepose import SimplePose
+    from .layers.Resnet import Bottleneck, ResNet
+    with torch.no_grad():
+        if isinstance(m, SimplePose):
+            plan = _SimplePosePlan(m)
+        elif isinstance(m, ResNet):
+            plan = _NchwAdapter(_TrunkPlan(m))
+        elif isinstance(m, Bottleneck):
+            plan = _NchwAdapter(_BottleneckPlan(m))
+        else:
+            raise TypeError(f"no HIP plan for {type(m).__name__}")
+    m.__dict__["_vatl_plan"] = (key, plan)
+    return plan
+
+
+def _prepare_input(m: nn.Module, x: torch.Tensor):
+    if not x.is_cuda:
+        raise vh.VatlError("the pose network runs on MI355X only: move the model and inputs to a HIP device "
+                           "(there is deliberately no CPU fallback)")
+    if m.training:
+        raise NotImplementedError("training-mode forward (batch-stat BN + autograd) is not part of this build yet; "
+                                  "call .eval() for inference")
+    p = next(m.parameters())
+    if p.device != x.device:
+        raise vh.VatlError(f"model on {p.device}, input on {x.device}")
+    return x.detach().float().contiguous()
+
+
+def run_module_nchw(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    x = _prepare_input(m, x)
+    plan = _plan_for(m, x.device)
+    if x.shape[0] <= MAX_CHUNK:
+        return plan(x)
+    return torch.cat([plan(c) for c in x.split(MAX_CHUNK)], 0)
+
+
+def forward_into(m: nn.Module, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """Heat-maps of ``x`` written straight into ``out`` (N,J,H/4,W/4), a contiguous fp32
+    device tensor (e.g. a slice of a whole-video buffer): no concat / copy kernels."""
+    x = _prepare_input(m, x)
+    plan = _plan_for(m, x.device)
+    for i in range(0, x.shape[0], MAX_CHUNK):
+        plan(x[i:i + MAX_CHUNK], out=out[i:i + MAX_CHUNK])
+    return out
+
+
+def embedding(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """trunk -> global average pool -> (B, 2048)   (simplepose.py:88-91)."""
+    x = _prepare_input(m, x)
+    plan = _plan_for(m, x.device)
+    return torch.cat([vh.gap_fwd(plan.features(c)) for c in x.split(MAX_CHUNK)], 0)

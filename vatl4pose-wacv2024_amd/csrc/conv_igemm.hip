@@ -1,0 +1,320 @@
+// Implicit-GEMM convolution forward on the gfx950 fp32 matrix cores.
+//
+//   Y[m][n] = act( (sum_k A[m][k] * Wt[n][k]) * scale[n] + bias[n] (+ R[m][n]) )
+//   m = (image b, out row oy, out col ox)   M = N*Ho*Wo      (GEMM rows = pixels)
+//   n = output channel                                        (GEMM cols)
+//   k = (r, s, c) filter tap x input channel, c fastest       K = R*S*Cin
+//
+// Activations are NHWC, so for a fixed tap (r,s) a 32-wide k-tile is 128
+// contiguous bytes of one input pixel: the A operand is gathered on the fly
+// (zero-filled outside the image), never materialised (no im2col buffer).
+// Weights are pre-packed [CoutPad][K] (vatl_pack_conv_weight) so both operands
+// are K-contiguous and staged with 16-byte loads.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate) —
+// the reference path is fp32 and parity is 1e-4 relative through 50+ layers,
+// which bf16 inputs do not hold (SURVEY.md §7 hard part 1).  Peak for this
+// instruction is 157.3 TFLOP/s (MI355X_MICROARCH.md).
+//
+// Block = 256 threads = 4 waves, tile BM x BN x 32, wave tile WM x WN made of
+// 32x32 MFMA tiles.  K-loop: LDS double buffer, one barrier per k-tile; the next
+// tile's global loads are issued before the current tile's 16 k-steps of MFMAs
+// and written to the other LDS buffer after them (register staging), so HBM/L2
+// latency hides under >= 2048 cycles of matrix work per wave.
+// LDS rows are padded 32 -> 36 floats: ds_read_b128 fragment reads (16 rows at
+// one k offset per lane group) and ds_write_b128 staging writes are both
+// conflict-free (bank = (row*36 + k) mod 64).
+//
+// One ds_read_b128 feeds four MFMA k-steps: lanes 0-31 hold k = 8g+t, lanes
+// 32-63 hold k = 8g+4+t at step t (same permutation for A and B, so the sum
+// over the 8 k's of group g is complete after t = 0..3).  The per-output
+// reduction order is fixed and independent of the batch position (needed for
+// the THC de-duplication, SURVEY.md §7 hard part 3).
+//
+// The same kernel runs ConvTranspose2d(4,2,1) as four 2x2 sub-pixel phases
+// (blockIdx.y = py*2+px): pad = (1-py, 1-px), output scattered to (2y+py, 2x+px).
+#include "common.h"
+
+#include <atomic>
+
+namespace vatl {
+
+struct ConvParams {
+    const float* x;
+    const float* w;
+    const float* scale;
+    const float* bias;
+    const float* res;
+    float* y;
+    int N, H, W, Cin;
+    int Cout, CoutPad;
+    int R, S, stride, pad_y, pad_x;
+    int Ho, Wo, M;
+    int OH, OW, osy, osx, ooy, oox;   // output pixel = (oy*osy+ooy, ox*osx+oox) in an OH x OW image
+    int relu, out_nchw, deconv;
+    int kpr;                          // k-tiles per filter tap  (Cin/32; 1 for the stem)
+    int ktiles;                       // total k-tiles
+    int n_tiles;
+    long long K;                      // packed K per output channel
+};
+
+constexpr int BK = 32;
+constexpr int LDK = 36;               // padded LDS row (floats)
+
+template <int BM, int BN, int WM, int WN, bool STEM>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                          // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;           // [2][BN][LDK]
+
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int LA = BM / 32, LB = BN / 32;  // 16-byte loads per thread per k-tile
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous
+    // run of tiles with the n-tile fastest so the blocks sharing an A panel hit
+    // the same L2 (bijective for any grid size).
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3, q = nblk >> 3, r8 = nblk & 7;
+    const int t = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+    const int m_tile = t / p.n_tiles;
+    const int n_tile = t - m_tile * p.n_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    int pad_y = p.pad_y, pad_x = p.pad_x, ooy = p.ooy, oox = p.oox;
+    const float* wbase = p.w;
+    if (p.deconv) {
+        const int py = blockIdx.y >> 1, px = blockIdx.y & 1;
+        pad_y = 1 - py; pad_x = 1 - px; ooy = py; oox = px;
+        wbase += (long long)blockIdx.y * p.CoutPad * p.K;
+    }
+
+    // ---- per-thread gather state --------------------------------------------
+    const int lrow = tid >> 3;        // 0..31
+    const int kq = tid & 7;           // which float4 of the 32-wide k-tile
+    const float* arow[LA];
+    int iy0[LA], ix0[LA];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < p.M) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            iy0[i] = oy * p.stride - pad_y;
+            ix0[i] = ox * p.stride - pad_x;
+            arow[i] = p.x + ((long long)(b * p.H + iy0[i]) * p.W + ix0[i]) * p.Cin + kq * 4;
+        } else {
+            iy0[i] = -(1 << 20); ix0[i] = -(1 << 20);
+            arow[i] = p.x;
+        }
+    }
+    const float* brow[LB];
+#pragma unroll
+    for (int j = 0; j < LB; ++j) brow[j] = wbase + (long long)(n0 + lrow + 32 * j) * p.K + kq * 4;
+
+    f32x4 ra[LA], rb[LB];
+    auto gload = [&](int kt) {
+        int r, s, off;
+        if (STEM) {                    // k-tile = one filter row: 8 taps x 4 channels
+            r = kt; s = kq; off = r * p.W * p.Cin;
+        } else {
+            const int rs = kt / p.kpr;
+            const int c0 = (kt - rs * p.kpr) * BK;
+            r = rs / p.S; s = rs - r * p.S;
+            off = (r * p.W + s) * p.Cin + c0;
+        }
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const bool ok = (unsigned)(iy0[i] + r) < (unsigned)p.H && (unsigned)(ix0[i] + s) < (unsigned)p.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(arow[i] + off);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(brow[j] + (long long)kt * BK);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + 32 * i) * LDK + kq * 4]) = ra[i];
+#pragma unroll
+        for (int j = 0; j < LB; ++j)
+            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + 32 * j) * LDK + kq * 4]) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frow = lane & 31;
+    const int fk = (lane >> 5) * 4;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < p.ktiles; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < p.ktiles;
+        if (more) gload(kt + 1);
+        const float* Ab = As + (buf * BM + wm * WM + frow) * LDK + fk;
+        const float* Bb = Bs + (buf * BN + wn * WN + frow) * LDK + fk;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + g * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + g * 8);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31] -----
+    const int OHW = p.OH * p.OW;
+    const bool plain = !p.out_nchw && !p.deconv;        // output row index == m
+    int ncol[TN];
+    float sc[TN], bi[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+        const bool nv = n < p.Cout;
+        ncol[j] = nv ? n : -1;
+        sc[j] = (nv && p.scale) ? p.scale[n] : 1.f;
+        bi[j] = (nv && p.bias) ? p.bias[n] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            if (m >= p.M) continue;
+            long long obase, ostride;                    // element (m, n) lives at obase + n*ostride
+            if (plain) {
+                obase = (long long)m * p.Cout; ostride = 1;
+            } else {
+                const int b = m / HoWo;
+                const int rem = m - b * HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                const long long opix = (long long)(oy * p.osy + ooy) * p.OW + (ox * p.osx + oox);
+                if (p.out_nchw) { obase = (long long)b * p.Cout * OHW + opix; ostride = OHW; }
+                else            { obase = ((long long)b * OHW + opix) * p.Cout; ostride = 1; }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (ncol[j] < 0) continue;
+                const long long o = obase + (long long)ncol[j] * ostride;
+                float v = acc[i][j][e] * sc[j] + bi[j];
+                if (p.res) v += p.res[o];
+                if (p.relu) v = fmaxf(v, 0.f);
+                p.y[o] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool STEM>
+static int launch(const ConvParams& p, int phases, hipStream_t st) {
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM>;
+    constexpr int smem = 2 * (BM + BN) * LDK * (int)sizeof(float);
+    static std::atomic<int> configured{0};
+    if (!configured.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return fail(VATL_ELAUNCH, "hipFuncSetAttribute(conv_igemm): %s", hipGetErrorString(e));
+        configured.store(1, std::memory_order_release);
+    }
+    ConvParams q = p;
+    q.n_tiles = p.CoutPad / BN;
+    const int m_tiles = cdiv(p.M, BM);
+    dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
+    return check_launch("conv_igemm");
+}
+
+// CoutPad granularity the packer must honour for a given Cout.
+static int tile_n_for(int Cout) { return Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128); }
+
+static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st) {
+    const int bn = tile_n_for(p.Cout);
+    if (p.CoutPad % bn != 0) return fail(VATL_EINVAL, "CoutPad %d must be a multiple of %d for Cout %d", p.CoutPad, bn, p.Cout);
+    if (stem) {
+        if (bn == 64) return launch<128, 64, 64, 32, true>(p, phases, st);
+        if (bn == 128) return launch<128, 128, 64, 64, true>(p, phases, st);
+        return launch<128, 32, 32, 32, true>(p, phases, st);
+    }
+    if (bn == 128) return launch<128, 128, 64, 64, false>(p, phases, st);
+    if (bn == 64) return launch<128, 64, 64, 32, false>(p, phases, st);
+    return launch<128, 32, 32, 32, false>(p, phases, st);
+}
+
+}  // namespace vatl
+
+using namespace vatl;
+
+extern "C" int vatl_conv_cout_pad(int Cout) {
+    const int bn = tile_n_for(Cout);
+    return (Cout + bn - 1) / bn * bn;
+}
+
+extern "C" int vatl_conv2d_fwd(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
+                               float* y, int N, int H, int W, int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad,
+                               int relu, int out_nchw, void* stream) {
+    if (!x || !w || !y || N <= 0) return fail(VATL_EINVAL, "conv2d_fwd: null pointer or empty batch");
+    const bool stem = (Cin == 4);
+    if (!stem && Cin % 32 != 0) return fail(VATL_EINVAL, "conv2d_fwd: Cin %d must be a multiple of 32 (or 4 for the stem)", Cin);
+    if (stem && S > 8) return fail(VATL_EINVAL, "conv2d_fwd: stem filter width %d > 8", S);
+    ConvParams p{};
+    p.x = x; p.w = w; p.scale = scale; p.bias = bias; p.res = residual; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.CoutPad = CoutPad;
+    p.R = R; p.S = S; p.stride = stride; p.pad_y = pad; p.pad_x = pad;
+    p.Ho = (H + 2 * pad - R) / stride + 1;
+    p.Wo = (W + 2 * pad - S) / stride + 1;
+    p.M = N * p.Ho * p.Wo;
+    p.OH = p.Ho; p.OW = p.Wo; p.osy = 1; p.osx = 1; p.ooy = 0; p.oox = 0;
+    p.relu = relu; p.out_nchw = out_nchw; p.deconv = 0;
+    if (stem) { p.kpr = 1; p.ktiles = R; p.K = (long long)R * 8 * 4; }
+    else      { p.kpr = Cin / BK; p.ktiles = R * S * p.kpr; p.K = (long long)R * S * Cin; }
+    if ((long long)N * H * W * Cin >= (1LL << 31) || (long long)p.M * Cout >= (1LL << 31))
+        return fail(VATL_EINVAL, "conv2d_fwd: tensor exceeds 2^31 elements; split the batch");
+    return dispatch(p, 1, stem, (hipStream_t)stream);
+}
+
+extern "C" int vatl_deconv4x4s2_fwd(const float* x, const float* w, const float* scale, const float* bias, float* y,
+                                    int N, int H, int W, int Cin, int Cout, int CoutPad, int relu, void* stream) {
+    if (!x || !w || !y || N <= 0) return fail(VATL_EINVAL, "deconv4x4s2_fwd: null pointer or empty batch");
+    if (Cin % 32 != 0) return fail(VATL_EINVAL, "deconv4x4s2_fwd: Cin %d must be a multiple of 32", Cin);
+    ConvParams p{};
+    p.x = x; p.w = w; p.scale = scale; p.bias = bias; p.res = nullptr; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.CoutPad = CoutPad;
+    p.R = 2; p.S = 2; p.stride = 1; p.pad_y = 0; p.pad_x = 0;
+    p.Ho = H; p.Wo = W; p.M = N * H * W;
+    p.OH = 2 * H; p.OW = 2 * W; p.osy = 2; p.osx = 2; p.ooy = 0; p.oox = 0;
+    p.relu = relu; p.out_nchw = 0; p.deconv = 1;
+    p.kpr = Cin / BK; p.ktiles = 4 * p.kpr; p.K = 4LL * Cin;
+    if ((long long)N * 4 * H * W * Cout >= (1LL << 31) || (long long)N * H * W * Cin >= (1LL << 31))
+        return fail(VATL_EINVAL, "deconv4x4s2_fwd: tensor exceeds 2^31 elements; split the batch");
+    return dispatch(p, 4, false, (hipStream_t)stream);
+}

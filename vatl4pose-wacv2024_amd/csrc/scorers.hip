@@ -1,0 +1,322 @@
+// Heat-map scorers: each reads the (N,J,H,W) fp32 heat-maps once (HBM-bound).
+//   decode      heatmap_to_coord_simple        alphapose/utils/transforms.py:550-583
+//   thc         compute_thc + neighbour rule   active_learning/ActiveLearning.py:345-363, 747-760
+//   local-peak  localpeak_mean                 active_learning/local_peak.py:5-22
+//   wpu         compute_hybrid + AE + MSE      active_learning/Whole_body_AE/*, ActiveLearning.py:364-386
+#include "common.h"
+
+namespace vatl {
+
+// --------------------------------------------------------------------------
+// decode: one 256-thread block per (item, joint)
+// --------------------------------------------------------------------------
+__device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+__global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ hm, const float* __restrict__ bbox,
+                                                     float* __restrict__ coords, float* __restrict__ maxvals,
+                                                     int32_t* __restrict__ idx_out, int J, int H, int W) {
+    const int item = blockIdx.x / J;
+    const int HW = H * W;
+    const float* src = hm + (long long)blockIdx.x * HW;
+    const int tid = threadIdx.x;
+
+    // first maximum in row-major order: strict '>' inside a thread (indices ascend),
+    // (value, lower index) ordering between threads
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    if ((HW & 3) == 0) {
+        const int n4 = HW >> 2;
+        for (int q = tid; q < n4; q += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (v[e] > best || bidx == 0x7fffffff) { best = v[e]; bidx = 4 * q + e; }
+        }
+    } else {
+        for (int q = tid; q < HW; q += 256) {
+            const float v = src[q];
+            if (v > best || bidx == 0x7fffffff) { best = v; bidx = q; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        argmax_merge(best, bidx, ov, oi);
+    }
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bidx; }
+    __syncthreads();
+    if (tid != 0) return;
+    for (int w = 1; w < 4; ++w) argmax_merge(best, bidx, sv[w], si[w]);
+
+    int px = bidx % W, py = bidx / W;
+    if (!(best > 0.f)) { px = 0; py = 0; }                      // pred_mask: maxval <= 0 zeroes the coords
+    float u = (float)px, v = (float)py;
+    if (1 < px && px < W - 1 && 1 < py && py < H - 1) {
+        const float dx = src[py * W + px + 1] - src[py * W + px - 1];
+        const float dy = src[(py + 1) * W + px] - src[(py - 1) * W + px];
+        u += (dx > 0.f ? 0.25f : (dx < 0.f ? -0.25f : 0.f));
+        v += (dy > 0.f ? 0.25f : (dy < 0.f ? -0.25f : 0.f));
+    }
+    // inverse crop affine: control points rounded to float32 like the reference's
+    // np.float32 src/dst arrays, transform itself in float64 (cv2.getAffineTransform)
+    const double xmin = bbox[item * 4 + 0], ymin = bbox[item * 4 + 1];
+    const double xmax = bbox[item * 4 + 2], ymax = bbox[item * 4 + 3];
+    const double bw = xmax - xmin, bh = ymax - ymin;
+    const double cx = xmin + bw * 0.5, cy = ymin + bh * 0.5;
+    const float cx32 = (float)cx, cy32 = (float)cy;
+    const float top32 = (float)(cy + bw * -0.5);
+    const float d32 = cy32 - top32;
+    const double g = (double)d32 / (W * 0.5);
+    coords[(long long)blockIdx.x * 2 + 0] = (float)((double)cx32 + ((double)u - W * 0.5) * g);
+    coords[(long long)blockIdx.x * 2 + 1] = (float)((double)cy32 + ((double)v - H * 0.5) * g);
+    maxvals[blockIdx.x] = best;
+    if (idx_out) idx_out[blockIdx.x] = bidx;
+}
+
+// --------------------------------------------------------------------------
+// THC: one block per pair of heat-map stacks (J*H*W floats each)
+// --------------------------------------------------------------------------
+template <int NORM>
+__global__ __launch_bounds__(256) void thc_pairs_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        long long sa, long long sb, float* __restrict__ out, int J, int n) {
+    const float* pa = a + (long long)blockIdx.x * sa;
+    const float* pb = b + (long long)blockIdx.x * sb;
+    const int tid = threadIdx.x;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    const int n4 = n >> 2;
+    for (int q = tid; q < n4; q += 256) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(pa + 4 * q);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(pb + 4 * q);
+        const float d0 = x[0] - y[0], d1 = x[1] - y[1], d2 = x[2] - y[2], d3 = x[3] - y[3];
+        if (NORM == 1) { acc0 += fabsf(d0); acc1 += fabsf(d1); acc2 += fabsf(d2); acc3 += fabsf(d3); }
+        else           { acc0 += d0 * d0;   acc1 += d1 * d1;   acc2 += d2 * d2;   acc3 += d3 * d3; }
+    }
+    for (int q = 4 * n4 + tid; q < n; q += 256) {
+        const float d = pa[q] - pb[q];
+        acc0 += NORM == 1 ? fabsf(d) : d * d;
+    }
+    double s = wave_sum((double)acc0 + (double)acc1 + (double)acc2 + (double)acc3);
+    __shared__ double part[4];
+    if ((tid & 63) == 0) part[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) out[blockIdx.x] = (float)((part[0] + part[1] + part[2] + part[3]) / (double)J);
+}
+
+__global__ void thc_combine_kernel(const float* __restrict__ pair, const uint8_t* __restrict__ is_prev,
+                                   const uint8_t* __restrict__ is_next, float* __restrict__ thc, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const bool hp = is_prev[i] != 0 && i > 0, hn = is_next[i] != 0 && i < N - 1;
+    float t = 0.f;
+    if (hp) t += pair[i - 1];
+    if (hn) t += pair[i];
+    if (hp != hn) t *= 2.f;                                     // exactly one neighbour: doubled
+    thc[i] = t;
+}
+
+// --------------------------------------------------------------------------
+// local peaks: one block per item, joints in sequence, map staged in LDS with a zero halo
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void localpeak_kernel(const float* __restrict__ hm, float* __restrict__ mean_out,
+                                                        int32_t* __restrict__ count_out, int J, int H, int W, float order) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];        // (H+2) x (W+2)
+    __shared__ float wmax[4];
+    __shared__ int wcnt[4];
+    __shared__ double wsum[4];
+    const int tid = threadIdx.x;
+    const int HW = H * W, PW = W + 2, PN = (H + 2) * PW;
+    const float* item = hm + (long long)blockIdx.x * J * HW;
+    double tot = 0.0;
+    int totc = 0;
+    for (int j = 0; j < J; ++j) {
+        const float* src = item + (long long)j * HW;
+        for (int q = tid; q < PN; q += 256) {
+            const int y = q / PW - 1, x = q % PW - 1;
+            tile[q] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? src[y * W + x] : 0.f;   // mode='constant', cval=0
+        }
+        __syncthreads();
+        // pass 1: largest local maximum (pixel equal to its 3x3 zero-padded max)
+        float pmax = -INFINITY;
+        for (int q = tid; q < HW; q += 256) {
+            const int y = q / W, x = q - y * W;
+            const float* c = tile + (y + 1) * PW + (x + 1);
+            const float v = c[0];
+            float m = fmaxf(fmaxf(c[-PW - 1], c[-PW]), c[-PW + 1]);
+            m = fmaxf(m, fmaxf(c[-1], c[1]));
+            m = fmaxf(m, fmaxf(fmaxf(c[PW - 1], c[PW]), c[PW + 1]));
+            if (v >= m) pmax = fmaxf(pmax, v);
+        }
+        pmax = wave_max(pmax);
+        if ((tid & 63) == 0) wmax[tid >> 6] = pmax;
+        __syncthreads();
+        pmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        // pass 2: keep peaks >= order * largest peak
+        const float thr = pmax * order;
+        float s = 0.f;
+        int cnt = 0;
+        if (pmax > -INFINITY) {
+            for (int q = tid; q < HW; q += 256) {
+                const int y = q / W, x = q - y * W;
+                const float* c = tile + (y + 1) * PW + (x + 1);
+                const float v = c[0];
+                float m = fmaxf(fmaxf(c[-PW - 1], c[-PW]), c[-PW + 1]);
+                m = fmaxf(m, fmaxf(c[-1], c[1]));
+                m = fmaxf(m, fmaxf(fmaxf(c[PW - 1], c[PW]), c[PW + 1]));
+                if (v >= m && v >= thr) { s += v; ++cnt; }
+            }
+        }
+        const double ds = wave_sum((double)s);
+        cnt = wave_sum(cnt);
+        if ((tid & 63) == 0) { wsum[tid >> 6] = ds; wcnt[tid >> 6] = cnt; }
+        __syncthreads();
+        if (tid == 0) {
+            const int c = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            tot += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            totc += c;
+            if (count_out) count_out[(long long)blockIdx.x * J + j] = c;
+        }
+        __syncthreads();                                       // tile / w* reused by the next joint
+    }
+    if (tid == 0) mean_out[blockIdx.x] = totc > 0 ? (float)(tot / (double)totc) : __builtin_nanf("");
+}
+
+// --------------------------------------------------------------------------
+// WPU: one wave per item; lane l owns feature / neuron l
+// --------------------------------------------------------------------------
+__device__ __forceinline__ float dense_lane(const float* __restrict__ Wt, const float* __restrict__ bias, int n_out, int n_in,
+                                            float h, int lane) {
+    // out[lane] = bias[lane] + sum_k W[lane][k] * h_k, h_k broadcast from lane k
+    float acc = lane < n_out ? bias[lane] : 0.f;
+    for (int k = 0; k < n_in; ++k) {
+        const float hk = __shfl(h, k, 64);
+        if (lane < n_out) acc = fmaf(Wt[lane * n_in + k], hk, acc);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void wpu_kernel(const float* __restrict__ kpts, const float* __restrict__ bbox,
+                                                  const float* __restrict__ ae, int D, int z, int only38,
+                                                  float* __restrict__ wpu, int32_t* __restrict__ status, int N) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= N) return;
+    const float* kp = kpts + (long long)item * 51;
+    // bbox_xyxy_to_xywh: h = ymax - ymin + 1 (alphapose/utils/bbox.py:96)
+    const double height = (double)bbox[item * 4 + 3] - (double)bbox[item * 4 + 1] + 1.0;
+    double sw = 0.0, sx = 0.0, sy = 0.0;
+    for (int j = 0; j < 17; ++j) {
+        const double s = kp[3 * j + 2];
+        sw += s; sx += (double)kp[3 * j] * s; sy += (double)kp[3 * j + 1] * s;
+    }
+    int st = 0;
+    if (!(height > 0.0)) st = 1;
+    else if (!(sw > 0.0)) st = 2;
+    if (st) {
+        if (lane == 0) { wpu[item] = __builtin_nanf(""); if (status) status[item] = st; }
+        return;
+    }
+    const double gx = sx / sw, gy = sy / sw;
+    // 42-d feature: (x-gx)/h [17], (y-gy)/h [17], 8 joint-triangle angles
+    double f = 0.0;
+    if (lane < 17) f = ((double)kp[3 * lane] - gx) / height;
+    else if (lane < 34) f = ((double)kp[3 * (lane - 17) + 1] - gy) / height;
+    else if (lane < 42) {
+        const int tri[8][3] = {{8, 6, 12}, {6, 8, 10}, {5, 7, 9}, {7, 5, 11}, {11, 12, 14}, {12, 11, 13}, {12, 14, 16}, {11, 13, 15}};
+        const int t = lane - 34;
+        const double x0 = kp[3 * tri[t][0]], y0 = kp[3 * tri[t][0] + 1];
+        const double x1 = kp[3 * tri[t][1]], y1 = kp[3 * tri[t][1] + 1];
+        const double x2 = kp[3 * tri[t][2]], y2 = kp[3 * tri[t][2] + 1];
+        const double eps = 1e-6;
+        const double m1 = (y1 - y0) / (x1 - x0 + eps);
+        const double m2 = (y2 - y1) / (x2 - x1 + eps);
+        f = atan(fabs((m1 - m2) / (1.0 + m1 * m2 + eps)));
+    }
+    // D == 38: the auto-encoder's declared width takes the 38-value subset (drop 3,4,20,21)
+    float x0f = (float)f;
+    if (D == 38) {
+        const int srcl = lane < 3 ? lane : (lane < 18 ? lane + 2 : lane + 4);
+        x0f = __shfl(x0f, srcl & 63, 64);
+        if (lane >= 38) x0f = 0.f;
+    }
+    const int dims[5] = {D, 24, 12, 7, z};
+    const float* w = ae;
+    float h = x0f;
+    for (int i = 0; i < 4; ++i) {                               // encoder: ReLU after all but the code layer
+        const int ni = dims[i], no = dims[i + 1];
+        h = dense_lane(w, w + no * ni, no, ni, h, lane);
+        if (i < 3) h = fmaxf(h, 0.f);
+        w += no * ni + no;
+    }
+    for (int i = 4; i > 0; --i) {                               // decoder: ReLU, Sigmoid on the last
+        const int ni = dims[i], no = dims[i - 1];
+        h = dense_lane(w, w + no * ni, no, ni, h, lane);
+        h = i > 1 ? fmaxf(h, 0.f) : 1.f / (1.f + expf(-h));
+        w += no * ni + no;
+    }
+    float d = 0.f;
+    int cnt = D;
+    if (lane < D) {
+        bool use = true;
+        if (only38) use = !(lane == 3 || lane == 4 || lane == 20 || lane == 21);
+        d = use ? (h - x0f) * (h - x0f) : 0.f;
+    }
+    if (only38) cnt = D - 4;
+    const float s = wave_sum(d);
+    if (lane == 0) { wpu[item] = s / (float)cnt; if (status) status[item] = 0; }
+}
+
+}  // namespace vatl
+
+using namespace vatl;
+
+extern "C" int vatl_decode_argmax_affine(const float* hm, const float* bbox, float* coords, float* maxvals, int32_t* idx,
+                                         int N, int J, int H, int W, void* stream) {
+    if (!hm || !bbox || !coords || !maxvals) return fail(VATL_EINVAL, "decode_argmax_affine: null pointer");
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(decode_kernel, dim3(N * J), dim3(256), 0, (hipStream_t)stream, hm, bbox, coords, maxvals, idx, J, H, W);
+    return check_launch("decode_argmax_affine");
+}
+
+extern "C" int vatl_thc_pairs(const float* a, const float* b, int64_t stride_a, int64_t stride_b, float* out,
+                              int P, int J, int HW, int norm, void* stream) {
+    if (!a || !b || !out) return fail(VATL_EINVAL, "thc_pairs: null pointer");
+    if (norm != 1 && norm != 2) return fail(VATL_EINVAL, "thc_pairs: norm must be 1 (L1) or 2 (L2)");
+    if (P <= 0) return 0;
+    if (((uintptr_t)a | (uintptr_t)b) & 15 || (stride_a & 3) || (stride_b & 3))
+        return fail(VATL_EINVAL, "thc_pairs: operands must be 16-byte aligned");
+    if (norm == 1) hipLaunchKernelGGL(thc_pairs_kernel<1>, dim3(P), dim3(256), 0, (hipStream_t)stream, a, b, (long long)stride_a, (long long)stride_b, out, J, J * HW);
+    else           hipLaunchKernelGGL(thc_pairs_kernel<2>, dim3(P), dim3(256), 0, (hipStream_t)stream, a, b, (long long)stride_a, (long long)stride_b, out, J, J * HW);
+    return check_launch("thc_pairs");
+}
+
+extern "C" int vatl_thc_combine(const float* pair, const uint8_t* is_prev, const uint8_t* is_next, float* thc, int N, void* stream) {
+    if (!is_prev || !is_next || !thc || (N > 1 && !pair)) return fail(VATL_EINVAL, "thc_combine: null pointer");
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(thc_combine_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, pair, is_prev, is_next, thc, N);
+    return check_launch("thc_combine");
+}
+
+extern "C" int vatl_localpeak_mean(const float* hm, float* mean, int32_t* count, int N, int J, int H, int W, float order, void* stream) {
+    if (!hm || !mean) return fail(VATL_EINVAL, "localpeak_mean: null pointer");
+    if (N <= 0) return 0;
+    const size_t smem = (size_t)(H + 2) * (W + 2) * sizeof(float);
+    if (smem > 60 * 1024) return fail(VATL_EINVAL, "localpeak_mean: heat-map %dx%d too large for the LDS tile", H, W);
+    hipLaunchKernelGGL(localpeak_kernel, dim3(N), dim3(256), smem, (hipStream_t)stream, hm, mean, count, J, H, W, order);
+    return check_launch("localpeak_mean");
+}
+
+extern "C" int vatl_hybrid_ae_wpu(const float* kpts, const float* bbox, const float* ae, int D, int z, int only38,
+                                  float* wpu, int32_t* status, int N, void* stream) {
+    if (!kpts || !bbox || !ae || !wpu) return fail(VATL_EINVAL, "hybrid_ae_wpu: null pointer");
+    if (D != 38 && D != 42) return fail(VATL_EINVAL, "hybrid_ae_wpu: D must be 38 or 42, got %d", D);
+    if (z < 1 || z > 64) return fail(VATL_EINVAL, "hybrid_ae_wpu: code width %d out of range", z);
+    if (only38 && D != 42) return fail(VATL_EINVAL, "hybrid_ae_wpu: only38 needs D == 42");
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(wpu_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, kpts, bbox, ae, D, z, only38, wpu, status, N);
+    return check_launch("hybrid_ae_wpu");
+}

@@ -1,0 +1,114 @@
+// Fine-tune step pieces that are pure HBM streams:
+//   masked MSE forward+backward   ActiveLearning.py:669  (0.5 * MSELoss(out*m, tgt*m))
+//   AdamW update                  ActiveLearning.py:224-228, :673
+#include "common.h"
+
+namespace vatl {
+
+constexpr int MSE_MAX_BLOCKS = 1024;
+
+// grad = (o*m - t*m) * m / numel ; partial[block] = sum (o*m - t*m)^2 (double)
+__global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict__ o, const float* __restrict__ t,
+                                                         const float* __restrict__ mask, float* __restrict__ grad,
+                                                         double* __restrict__ partial, long long n4, int HW4, float inv_numel) {
+    float acc = 0.f;
+    for (long long q = blockIdx.x * 256LL + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        const float m = mask[q / HW4];                     // one mask value per (item, joint) plane
+        const f32x4 a = *reinterpret_cast<const f32x4*>(o + 4 * q);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(t + 4 * q);
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = a[e] * m - b[e] * m;
+            acc += d * d;
+            g[e] = d * m * inv_numel;
+        }
+        *reinterpret_cast<f32x4*>(grad + 4 * q) = g;
+    }
+    const double s = wave_sum((double)acc);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void mse_finish_kernel(const double* __restrict__ partial, int nblk, float* __restrict__ loss, double half_inv_numel) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += partial[i];
+    s = wave_sum(s);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = (float)((part[0] + part[1] + part[2] + part[3]) * half_inv_numel);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n, float decay, float omb1, float b2, float omb2,
+                                                    float bc2s, float eps, float step_size) {
+    const long long n4 = n >> 2;
+    for (long long q = blockIdx.x * 256LL + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        f32x4 P = *reinterpret_cast<f32x4*>(p + 4 * q);
+        const f32x4 G = *reinterpret_cast<const f32x4*>(g + 4 * q);
+        f32x4 M = *reinterpret_cast<f32x4*>(m + 4 * q);
+        f32x4 V = *reinterpret_cast<f32x4*>(v + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            P[e] = P[e] * decay;
+            M[e] = M[e] + (G[e] - M[e]) * omb1;
+            V[e] = V[e] * b2 + G[e] * G[e] * omb2;
+            P[e] = P[e] - step_size * (M[e] / (sqrtf(V[e]) / bc2s + eps));
+        }
+        *reinterpret_cast<f32x4*>(p + 4 * q) = P;
+        *reinterpret_cast<f32x4*>(m + 4 * q) = M;
+        *reinterpret_cast<f32x4*>(v + 4 * q) = V;
+    }
+    if (blockIdx.x == 0) {
+        for (long long i = 4 * n4 + threadIdx.x; i < n; i += 256) {
+            float P = p[i] * decay;
+            const float G = g[i];
+            const float M = m[i] + (G - m[i]) * omb1;
+            const float V = v[i] * b2 + G * G * omb2;
+            P = P - step_size * (M / (sqrtf(V) / bc2s + eps));
+            p[i] = P; m[i] = M; v[i] = V;
+        }
+    }
+}
+
+}  // namespace vatl
+
+using namespace vatl;
+
+extern "C" int64_t vatl_masked_mse_workspace_floats(int64_t numel) { (void)numel; return 2 * MSE_MAX_BLOCKS; }
+
+extern "C" int vatl_masked_mse_fwd_bwd(const float* out, const float* target, const float* mask, float* grad, float* loss,
+                                       float* partial, int N, int J, int HW, void* stream) {
+    if (!out || !target || !mask || !grad || !loss || !partial) return fail(VATL_EINVAL, "masked_mse_fwd_bwd: null pointer");
+    if (HW & 3) return fail(VATL_EINVAL, "masked_mse_fwd_bwd: H*W %d must be a multiple of 4", HW);
+    if ((uintptr_t)partial & 7) return fail(VATL_EINVAL, "masked_mse_fwd_bwd: workspace must be 8-byte aligned");
+    const long long numel = (long long)N * J * HW;
+    if (numel <= 0) return fail(VATL_EINVAL, "masked_mse_fwd_bwd: empty batch");
+    const long long n4 = numel / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > MSE_MAX_BLOCKS) blocks = MSE_MAX_BLOCKS;
+    hipLaunchKernelGGL(masked_mse_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, target, mask, grad,
+                       reinterpret_cast<double*>(partial), n4, HW / 4, (float)(1.0 / (double)numel));
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const double*>(partial), blocks, loss,
+                       0.5 / (double)numel);
+    return check_launch("masked_mse_fwd_bwd");
+}
+
+extern "C" int vatl_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                               double eps, double weight_decay, int step, void* stream) {
+    if (!p || !g || !m || !v) return fail(VATL_EINVAL, "adamw_step: null pointer");
+    if (step < 1) return fail(VATL_EINVAL, "adamw_step: step is 1-based");
+    if (n <= 0) return 0;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return fail(VATL_EINVAL, "adamw_step: spans must be 16-byte aligned");
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
+                       (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                       (float)sqrt(bc2), (float)eps, (float)(lr / bc1));
+    return check_launch("adamw_step");
+}

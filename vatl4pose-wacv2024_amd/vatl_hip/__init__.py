@@ -1,0 +1,265 @@
+"""ctypes binding of libvatl_hip.so (include/vatl_hip.h) + thin torch-tensor wrappers.
+
+PyTorch is plumbing only: it owns device memory and the HIP stream; every
+wrapper passes ``tensor.data_ptr()`` and the current stream to the C ABI.
+There is NO fallback: a missing library or a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvatl_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_d = C.c_double
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); mirrors include/vatl_hip.h one to one
+# (tests/test_cabi.py parses the header and checks this table against it)
+SIGNATURES = {
+    "vatl_version": (_i, []),
+    "vatl_last_error": (C.c_char_p, []),
+    "vatl_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "vatl_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "vatl_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vatl_pack_deconv4x4s2_weight": (_i, [_p, _p, _i, _i, _i, _p]),
+    "vatl_bn_fold": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _i, _p]),
+    "vatl_conv_cout_pad": (_i, [_i]),
+    "vatl_conv2d_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vatl_deconv4x4s2_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vatl_maxpool3x3s2_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "vatl_gap_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
+    "vatl_decode_argmax_affine": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vatl_thc_pairs": (_i, [_p, _p, _i64, _i64, _p, _i, _i, _i, _i, _p]),
+    "vatl_thc_combine": (_i, [_p, _p, _p, _p, _i, _p]),
+    "vatl_localpeak_mean": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "vatl_hybrid_ae_wpu": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i, _p]),
+    "vatl_masked_mse_workspace_floats": (_i64, [_i64]),
+    "vatl_masked_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "vatl_adamw_step": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _p]),
+}
+
+_lib = None
+
+
+class VatlError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VatlError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(or vatl4pose-wacv2024_amd/build.py). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise VatlError(f"{what} failed ({rc}): {lib().vatl_last_error().decode()}")
+
+
+def _ptr(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VatlError("vatl_hip needs device (HIP) tensors; there is no CPU path")
+    if t.dtype != dtype:
+        raise VatlError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise VatlError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ----------------------------------------------------------------------------
+# layout / parameter packing
+# ----------------------------------------------------------------------------
+
+def nchw_to_nhwc(x: torch.Tensor, cpad: int | None = None) -> torch.Tensor:
+    n, c, h, w = x.shape
+    cpad = cpad or c
+    y = torch.empty((n, h, w, cpad), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_nchw_to_nhwc(_ptr(x), _ptr(y), n, c, h, w, cpad, _stream()), "vatl_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    n, h, w, c = x.shape
+    y = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_nhwc_to_nchw(_ptr(x), _ptr(y), n, c, h, w, _stream()), "vatl_nhwc_to_nchw")
+    return y
+
+
+def conv_cout_pad(cout: int) -> int:
+    return lib().vatl_conv_cout_pad(cout)
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """(Cout,Cin,R,S) -> [CoutPad][R][Spad][CinPad]; the 3-channel stem is padded to 4 channels x 8 taps."""
+    cout, cin, r, s = w.shape
+    cpad = conv_cout_pad(cout)
+    spad, cinpad = (8, 4) if cin == 3 else (s, cin)
+    out = torch.empty((cpad, r, spad, cinpad), device=w.device, dtype=torch.float32)
+    _check(lib().vatl_pack_conv_weight(_ptr(w.contiguous()), _ptr(out), cout, cin, r, s, cpad, spad, cinpad, _stream()), "vatl_pack_conv_weight")
+    return out
+
+
+def pack_deconv_weight(w: torch.Tensor) -> torch.Tensor:
+    cin, cout, kh, kw = w.shape
+    if (kh, kw) != (4, 4):
+        raise VatlError("only ConvTranspose2d(4, 2, 1) is supported")
+    cpad = conv_cout_pad(cout)
+    out = torch.empty((4, cpad, 2, 2, cin), device=w.device, dtype=torch.float32)
+    _check(lib().vatl_pack_deconv4x4s2_weight(_ptr(w.contiguous()), _ptr(out), cin, cout, cpad, _stream()), "vatl_pack_deconv4x4s2_weight")
+    return out
+
+
+def bn_fold(gamma, beta, mean, var, eps: float, conv_bias=None, channels: int | None = None):
+    c = channels if channels is not None else (var.numel() if var is not None else conv_bias.numel())
+    dev = (var if var is not None else conv_bias).device
+    scale = torch.empty(c, device=dev, dtype=torch.float32)
+    bias = torch.empty(c, device=dev, dtype=torch.float32)
+    _check(lib().vatl_bn_fold(_ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), _ptr(conv_bias), eps, _ptr(scale), _ptr(bias), c, _stream()), "vatl_bn_fold")
+    return scale, bias
+
+
+# ----------------------------------------------------------------------------
+# backbone ops (NHWC)
+# ----------------------------------------------------------------------------
+
+def conv2d_fwd(x, w_packed, scale, bias, cout: int, r: int, s: int, stride: int, pad: int, relu: bool,
+               residual=None, out_nchw: bool = False, out=None):
+    n, h, w, cin = x.shape
+    ho = (h + 2 * pad - r) // stride + 1
+    wo = (w + 2 * pad - s) // stride + 1
+    shape = (n, cout, ho, wo) if out_nchw else (n, ho, wo, cout)
+    y = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
+    _check(lib().vatl_conv2d_fwd(_ptr(x), _ptr(w_packed), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(y), n, h, w, cin, cout,
+                                 w_packed.shape[0], r, s, stride, pad, int(relu), int(out_nchw), _stream()), "vatl_conv2d_fwd")
+    return y
+
+
+def deconv4x4s2_fwd(x, w_packed, scale, bias, cout: int, relu: bool):
+    n, h, w, cin = x.shape
+    y = torch.empty((n, 2 * h, 2 * w, cout), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_deconv4x4s2_fwd(_ptr(x), _ptr(w_packed), _ptr(scale), _ptr(bias), _ptr(y), n, h, w, cin, cout,
+                                      w_packed.shape[1], int(relu), _stream()), "vatl_deconv4x4s2_fwd")
+    return y
+
+
+def maxpool3x3s2_fwd(x):
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_maxpool3x3s2_fwd(_ptr(x), _ptr(y), n, h, w, c, _stream()), "vatl_maxpool3x3s2_fwd")
+    return y
+
+
+def gap_fwd(x):
+    n, h, w, c = x.shape
+    y = torch.empty((n, c), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_gap_fwd(_ptr(x), _ptr(y), n, h * w, c, _stream()), "vatl_gap_fwd")
+    return y
+
+
+# ----------------------------------------------------------------------------
+# scorers on (N,J,H,W) heat-maps
+# ----------------------------------------------------------------------------
+
+def decode(hm: torch.Tensor, bbox: torch.Tensor):
+    """-> coords (N,J,2) f32, maxvals (N,J) f32, idx (N,J) i32."""
+    n, j, h, w = hm.shape
+    coords = torch.empty((n, j, 2), device=hm.device, dtype=torch.float32)
+    maxv = torch.empty((n, j), device=hm.device, dtype=torch.float32)
+    idx = torch.empty((n, j), device=hm.device, dtype=torch.int32)
+    _check(lib().vatl_decode_argmax_affine(_ptr(hm), _ptr(bbox), _ptr(coords), _ptr(maxv), _ptr(idx, torch.int32), n, j, h, w, _stream()),
+           "vatl_decode_argmax_affine")
+    return coords, maxv, idx
+
+
+def thc_pairs(a: torch.Tensor, b: torch.Tensor, norm: str = "L1") -> torch.Tensor:
+    """a, b (P,J,H,W) (views with a uniform item stride are fine) -> (P,) f32."""
+    p, j, h, w = a.shape
+    for t in (a, b):
+        if not t.is_cuda or t.dtype != torch.float32 or t[0].is_contiguous() is False:
+            raise VatlError("thc_pairs: fp32 device tensors with contiguous items required")
+    out = torch.empty(p, device=a.device, dtype=torch.float32)
+    sa = a.stride(0) if p > 1 else j * h * w
+    sb = b.stride(0) if p > 1 else j * h * w
+    _check(lib().vatl_thc_pairs(a.data_ptr(), b.data_ptr(), sa, sb, _ptr(out), p, j, h * w, {"L1": 1, "L2": 2}[norm], _stream()), "vatl_thc_pairs")
+    return out
+
+
+def thc_stream(hm: torch.Tensor, is_prev: torch.Tensor, is_next: torch.Tensor, norm: str = "L1") -> torch.Tensor:
+    """THC of an id-sorted, de-duplicated stream: neighbours are items i-1 / i+1."""
+    n = hm.shape[0]
+    thc = torch.empty(n, device=hm.device, dtype=torch.float32)
+    pair = thc_pairs(hm[:-1], hm[1:], norm) if n > 1 else None
+    _check(lib().vatl_thc_combine(_ptr(pair), _ptr(is_prev, torch.uint8), _ptr(is_next, torch.uint8), _ptr(thc), n, _stream()), "vatl_thc_combine")
+    return thc
+
+
+def localpeak_mean(hm: torch.Tensor, order: float = 0.5):
+    """-> mean (N,) f32 (nan when no peak is kept), count (N,J) i32."""
+    n, j, h, w = hm.shape
+    mean = torch.empty(n, device=hm.device, dtype=torch.float32)
+    cnt = torch.empty((n, j), device=hm.device, dtype=torch.int32)
+    _check(lib().vatl_localpeak_mean(_ptr(hm), _ptr(mean), _ptr(cnt, torch.int32), n, j, h, w, order, _stream()), "vatl_localpeak_mean")
+    return mean, cnt
+
+
+def pack_ae(state_dict, device) -> torch.Tensor:
+    parts = []
+    for half in ("encoder", "decoder"):
+        for i in (0, 2, 4, 6):
+            parts.append(state_dict[f"{half}.{i}.weight"].detach().reshape(-1).float())
+            parts.append(state_dict[f"{half}.{i}.bias"].detach().reshape(-1).float())
+    return torch.cat([p.to(device) for p in parts]).contiguous()
+
+
+def hybrid_ae_wpu(kpts: torch.Tensor, bbox: torch.Tensor, ae_flat: torch.Tensor, d: int, z: int, only38: bool = False):
+    """kpts (N,17,3), bbox (N,4) crop xyxy -> wpu (N,) f32, status (N,) i32."""
+    n = kpts.shape[0]
+    wpu = torch.empty(n, device=kpts.device, dtype=torch.float32)
+    status = torch.empty(n, device=kpts.device, dtype=torch.int32)
+    _check(lib().vatl_hybrid_ae_wpu(_ptr(kpts), _ptr(bbox), _ptr(ae_flat), d, z, int(only38), _ptr(wpu), _ptr(status, torch.int32), n, _stream()),
+           "vatl_hybrid_ae_wpu")
+    return wpu, status
+
+
+# ----------------------------------------------------------------------------
+# fine-tune step pieces
+# ----------------------------------------------------------------------------
+
+def masked_mse_fwd_bwd(out: torch.Tensor, target: torch.Tensor, mask: torch.Tensor):
+    """-> loss (1,) f32 on device, grad like ``out``."""
+    n, j, h, w = out.shape
+    grad = torch.empty_like(out)
+    loss = torch.empty(1, device=out.device, dtype=torch.float32)
+    ws = torch.empty(int(lib().vatl_masked_mse_workspace_floats(out.numel())), device=out.device, dtype=torch.float32)
+    m = mask.reshape(n, j).contiguous()
+    _check(lib().vatl_masked_mse_fwd_bwd(_ptr(out), _ptr(target), _ptr(m), _ptr(grad), _ptr(loss), _ptr(ws), n, j, h * w, _stream()),
+           "vatl_masked_mse_fwd_bwd")
+    return loss, grad
+
+
+def adamw_step(p, g, m, v, step: int, lr: float, weight_decay: float, betas=(0.9, 0.999), eps: float = 1e-8):
+    _check(lib().vatl_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step, _stream()),
+           "vatl_adamw_step")
