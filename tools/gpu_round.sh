@@ -10,9 +10,9 @@ echo "== smoke" ; timeout 300 python -c "import __graft_entry__ as g; g.smoke()"
 echo "== bench" ; timeout 900 python bench.py --steps 5 --warmup 2 2>&1 | tail -5 | tee gpurun_out/bench.log
 if [ "${1:-}" = "prof" ]; then
   echo "== rocprofv3 kernel stats"
-  timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o r1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof.log 2>&1
   tail -3 gpurun_out/prof.log
   find gpurun_out/prof -name "*kernel_stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
   # keep only the small summaries
-  find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete
+  find gpurun_out/prof -name "*kernel_trace*" -size +30M -delete
 fi

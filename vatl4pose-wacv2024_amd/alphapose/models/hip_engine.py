@@ -23,9 +23,10 @@ import torch.nn as nn
 
 import vatl_hip as vh
 
-# items per launch sequence; bounds workspace (stem output = 3.1 MB/crop) and
-# keeps every tensor far below the kernels' 2^31-element guard
-MAX_CHUNK = int(os.environ.get("VATL_MAX_CHUNK", "256"))
+# items per launch sequence; bounds workspace (stem output = 3.1 MB/crop) and keeps
+# every tensor below the kernels' 2^30-element guard (32-bit buffer byte offsets);
+# large chunks keep every layer's tile grid a multiple of the 512 resident blocks
+MAX_CHUNK = int(os.environ.get("VATL_MAX_CHUNK", "1024"))
 
 
 class _Conv:

@@ -55,11 +55,28 @@ struct ConvParams {
     int kpr;                          // k-tiles per filter tap  (Cin/32; 1 for the stem)
     int ktiles;                       // total k-tiles
     int n_tiles;
-    long long K;                      // packed K per output channel
+    int K;                            // packed K per output channel
+    unsigned x_bytes, w_bytes, y_bytes;   // buffer extents (hardware bounds checks: OOB loads read 0, OOB stores drop)
 };
 
 constexpr int BK = 32;
 constexpr int LDK = 36;               // padded LDS row (floats)
+constexpr unsigned OOB = 0xFFFFFFFFu; // byte offset guaranteed outside any descriptor below
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);
+}
 
 template <int BM, int BN, int WM, int WN, bool STEM>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
@@ -94,12 +111,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
         pad_y = 1 - py; pad_x = 1 - px; ooy = py; oox = px;
         wbase += (long long)blockIdx.y * p.CoutPad * p.K;
     }
+    // All global traffic goes through buffer descriptors: 32-bit byte offsets, and an
+    // out-of-range offset (OOB) reads zeros / drops the store, so image borders, M
+    // tails and the optional residual need no branches (branches made hipcc drain
+    // vmcnt before the MFMAs in the first version of this kernel).
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase), 0, p.w_bytes, 0x00020000);
 
     // ---- per-thread gather state --------------------------------------------
     const int lrow = tid >> 3;        // 0..31
     const int kq = tid & 7;           // which float4 of the 32-wide k-tile
-    const float* arow[LA];
-    int iy0[LA], ix0[LA];
+    int abase[LA], iy0[LA], ix0[LA];  // element offset of (b, iy0, ix0, kq*4); may be negative
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
@@ -111,15 +133,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
             const int ox = rem - oy * p.Wo;
             iy0[i] = oy * p.stride - pad_y;
             ix0[i] = ox * p.stride - pad_x;
-            arow[i] = p.x + ((long long)(b * p.H + iy0[i]) * p.W + ix0[i]) * p.Cin + kq * 4;
+            abase[i] = ((b * p.H + iy0[i]) * p.W + ix0[i]) * p.Cin + kq * 4;
         } else {
-            iy0[i] = -(1 << 20); ix0[i] = -(1 << 20);
-            arow[i] = p.x;
+            iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); abase[i] = 0;
         }
     }
-    const float* brow[LB];
+    unsigned boff[LB];
 #pragma unroll
-    for (int j = 0; j < LB; ++j) brow[j] = wbase + (long long)(n0 + lrow + 32 * j) * p.K + kq * 4;
+    for (int j = 0; j < LB; ++j) boff[j] = (unsigned)(((n0 + lrow + 32 * j) * p.K + kq * 4) * 4);
 
     f32x4 ra[LA], rb[LB];
     auto gload = [&](int kt) {
@@ -135,12 +156,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const bool ok = (unsigned)(iy0[i] + r) < (unsigned)p.H && (unsigned)(ix0[i] + s) < (unsigned)p.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(arow[i] + off);
-            ra[i] = v;
+            ra[i] = buf_load4(xr, ok ? (unsigned)(abase[i] + off) << 2 : OOB);
         }
 #pragma unroll
-        for (int j = 0; j < LB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(brow[j] + (long long)kt * BK);
+        for (int j = 0; j < LB; ++j) rb[j] = buf_load4(wr, boff[j] + (unsigned)kt * (BK * 4));
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -191,45 +210,98 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31] -----
-    const int OHW = p.OH * p.OW;
-    const bool plain = !p.out_nchw && !p.deconv;        // output row index == m
-    int ncol[TN];
-    float sc[TN], bi[TN];
+    // ---- epilogue -------------------------------------------------------------
+    // 1. scale/bias in registers, tile -> LDS (the staging buffers are free after the
+    //    loop's last barrier).  D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31].
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+        const int cl = wn * WN + j * 32 + (lane & 31);
+        const int n = n0 + cl;
         const bool nv = n < p.Cout;
-        ncol[j] = nv ? n : -1;
-        sc[j] = (nv && p.scale) ? p.scale[n] : 1.f;
-        bi[j] = (nv && p.bias) ? p.bias[n] : 0.f;
+        const float sc = (nv && p.scale) ? p.scale[n] : 1.f;
+        const float bi = (nv && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                Cs[row * LDC + cl] = acc[i][j][e] * sc + bi;
+            }
     }
+    __syncthreads();
+
+    // 2. LDS -> HBM with full rows: (+ residual) (ReLU), branch-free through descriptors
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? p.y_bytes : 0u, 0x00020000);
+    const float lo = p.relu ? 0.f : -INFINITY;
+    const int OHW = p.OH * p.OW;
+    const bool plain = !p.deconv;                      // NHWC output row index == m
+    if (!p.out_nchw && (p.Cout & 3) == 0) {
+        constexpr int C4 = BN / 4;                     // float4 columns per tile row
+        constexpr int RPP = 256 / C4;                  // tile rows per pass
+        const int c4 = tid % C4, r0 = tid / C4;
+        const int n = n0 + c4 * 4;
+        const bool nv = n < p.Cout;
+        constexpr int UNR = 4;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int ps = 0; ps < BM / RPP; ps += UNR) {
+            unsigned off[UNR];
+            f32x4 v[UNR], rs[UNR];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            if (m >= p.M) continue;
-            long long obase, ostride;                    // element (m, n) lives at obase + n*ostride
-            if (plain) {
-                obase = (long long)m * p.Cout; ostride = 1;
-            } else {
-                const int b = m / HoWo;
-                const int rem = m - b * HoWo;
-                const int oy = rem / p.Wo;
-                const int ox = rem - oy * p.Wo;
-                const long long opix = (long long)(oy * p.osy + ooy) * p.OW + (ox * p.osx + oox);
-                if (p.out_nchw) { obase = (long long)b * p.Cout * OHW + opix; ostride = OHW; }
-                else            { obase = ((long long)b * OHW + opix) * p.Cout; ostride = 1; }
+            for (int u = 0; u < UNR; ++u) {
+                const int row = r0 + (ps + u) * RPP;
+                const int m = m0 + row;
+                int orow = m;
+                if (!plain) {
+                    const int b = m / HoWo;
+                    const int rem = m - b * HoWo;
+                    const int oy = rem / p.Wo;
+                    const int ox = rem - oy * p.Wo;
+                    orow = b * OHW + (oy * p.osy + ooy) * p.OW + (ox * p.osx + oox);
+                }
+                off[u] = (nv && m < p.M) ? (unsigned)(orow * p.Cout + n) << 2 : OOB;
+                rs[u] = buf_load4(rr, off[u]);
+                v[u] = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4 * 4]);
             }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (ncol[j] < 0) continue;
-                const long long o = obase + (long long)ncol[j] * ostride;
-                float v = acc[i][j][e] * sc[j] + bi[j];
-                if (p.res) v += p.res[o];
-                if (p.relu) v = fmaxf(v, 0.f);
-                p.y[o] = v;
+            for (int u = 0; u < UNR; ++u) {
+                f32x4 o;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = fmaxf(v[u][c] + rs[u][c], lo);
+                buf_store4(yr, off[u], o);
+            }
+        }
+    } else {
+        // NCHW output (heat-map head) or a channel count that is not a multiple of 4:
+        // one tile row per thread, lanes run along pixels (contiguous in NCHW)
+        constexpr int CPP = 256 / BM;                  // tile columns per pass
+        const int row = tid % BM, cl0 = tid / BM;
+        const int m = m0 + row;
+        const bool mv = m < p.M;
+        const int b = m / HoWo;
+        const int rem = m - b * HoWo;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        const int opix = (oy * p.osy + ooy) * p.OW + (ox * p.osx + oox);
+        const int nstride = p.out_nchw ? OHW : 1;
+        const int obase = p.out_nchw ? b * p.Cout * OHW + opix : (b * OHW + opix) * p.Cout;
+        if (p.res) {
+#pragma unroll 4
+            for (int ps = 0; ps < BN / CPP; ++ps) {
+                const int cl = cl0 + ps * CPP;
+                const int n = n0 + cl;
+                const unsigned off = (mv && n < p.Cout) ? (unsigned)(obase + n * nstride) << 2 : OOB;
+                buf_store1(yr, off, fmaxf(Cs[row * LDC + cl] + buf_load1(rr, off), lo));
+            }
+        } else {
+#pragma unroll 8
+            for (int ps = 0; ps < BN / CPP; ++ps) {
+                const int cl = cl0 + ps * CPP;
+                const int n = n0 + cl;
+                const unsigned off = (mv && n < p.Cout) ? (unsigned)(obase + n * nstride) << 2 : OOB;
+                buf_store1(yr, off, fmaxf(Cs[row * LDC + cl], lo));
             }
         }
     }
@@ -248,6 +320,7 @@ static int launch(const ConvParams& p, int phases, hipStream_t st) {
     }
     ConvParams q = p;
     q.n_tiles = p.CoutPad / BN;
+    static_assert(2 * (BM + BN) * LDK >= BM * (BN + 4), "epilogue tile must fit in the staging buffers");
     const int m_tiles = cdiv(p.M, BM);
     dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
@@ -295,10 +368,12 @@ extern "C" int vatl_conv2d_fwd(const float* x, const float* w, const float* scal
     p.M = N * p.Ho * p.Wo;
     p.OH = p.Ho; p.OW = p.Wo; p.osy = 1; p.osx = 1; p.ooy = 0; p.oox = 0;
     p.relu = relu; p.out_nchw = out_nchw; p.deconv = 0;
-    if (stem) { p.kpr = 1; p.ktiles = R; p.K = (long long)R * 8 * 4; }
-    else      { p.kpr = Cin / BK; p.ktiles = R * S * p.kpr; p.K = (long long)R * S * Cin; }
-    if ((long long)N * H * W * Cin >= (1LL << 31) || (long long)p.M * Cout >= (1LL << 31))
-        return fail(VATL_EINVAL, "conv2d_fwd: tensor exceeds 2^31 elements; split the batch");
+    if (stem) { p.kpr = 1; p.ktiles = R; p.K = R * 8 * 4; }
+    else      { p.kpr = Cin / BK; p.ktiles = R * S * p.kpr; p.K = R * S * Cin; }
+    const long long xe = (long long)N * H * W * Cin, ye = (long long)p.M * Cout, we = (long long)CoutPad * p.K;
+    if (xe >= (1LL << 30) || ye >= (1LL << 30) || we >= (1LL << 30))
+        return fail(VATL_EINVAL, "conv2d_fwd: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
+    p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.w_bytes = (unsigned)(we * 4);
     return dispatch(p, 1, stem, (hipStream_t)stream);
 }
 
@@ -313,8 +388,10 @@ extern "C" int vatl_deconv4x4s2_fwd(const float* x, const float* w, const float*
     p.Ho = H; p.Wo = W; p.M = N * H * W;
     p.OH = 2 * H; p.OW = 2 * W; p.osy = 2; p.osx = 2; p.ooy = 0; p.oox = 0;
     p.relu = relu; p.out_nchw = 0; p.deconv = 1;
-    p.kpr = Cin / BK; p.ktiles = 4 * p.kpr; p.K = 4LL * Cin;
-    if ((long long)N * 4 * H * W * Cout >= (1LL << 31) || (long long)N * H * W * Cin >= (1LL << 31))
-        return fail(VATL_EINVAL, "deconv4x4s2_fwd: tensor exceeds 2^31 elements; split the batch");
+    p.kpr = Cin / BK; p.ktiles = 4 * p.kpr; p.K = 4 * Cin;
+    const long long xe = (long long)N * H * W * Cin, ye = 4LL * p.M * Cout, we = (long long)CoutPad * p.K;
+    if (xe >= (1LL << 30) || ye >= (1LL << 30) || 4 * we >= (1LL << 30))
+        return fail(VATL_EINVAL, "deconv4x4s2_fwd: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
+    p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.w_bytes = (unsigned)(we * 4);   // w: one phase
     return dispatch(p, 4, false, (hipStream_t)stream);
 }

@@ -276,8 +276,8 @@ using namespace vatl;
 
 extern "C" int vatl_decode_argmax_affine(const float* hm, const float* bbox, float* coords, float* maxvals, int32_t* idx,
                                          int N, int J, int H, int W, void* stream) {
-    if (!hm || !bbox || !coords || !maxvals) return fail(VATL_EINVAL, "decode_argmax_affine: null pointer");
     if (N <= 0) return 0;
+    if (!hm || !bbox || !coords || !maxvals) return fail(VATL_EINVAL, "decode_argmax_affine: null pointer");
     hipLaunchKernelGGL(decode_kernel, dim3(N * J), dim3(256), 0, (hipStream_t)stream, hm, bbox, coords, maxvals, idx, J, H, W);
     return check_launch("decode_argmax_affine");
 }
