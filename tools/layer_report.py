@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Per-layer TFLOP/s of the SimplePose-R50 conv launches from a rocprofv3 kernel trace.
+
+    python tools/layer_report.py gpurun_out/prof/r1_kernel_trace.csv [batch]
+
+Takes the LAST 57 conv_igemm dispatches (one forward) and pairs them, in launch
+order, with the layer list of the network.
+"""
+import csv
+import sys
+
+
+def layers(B):
+    L = []
+
+    def conv(name, H, W, cin, cout, k, s):
+        Ho, Wo = H // s, W // s
+        L.append((name, 2 * B * Ho * Wo * cin * cout * k * k, B * Ho * Wo, cout, cin * k * k))
+    conv("stem", 256, 192, 3, 64, 7, 2)
+    H, W, cin = 64, 48, 64
+    for si, (n, wd) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512))):
+        for b in range(n):
+            s = 2 if (b == 0 and si > 0) else 1
+            tag = f"l{si + 1}.{'0' if b == 0 else 'n'}"
+            conv(tag + ".c1", H, W, cin, wd, 1, 1)
+            conv(tag + ".c2", H, W, wd, wd, 3, s)
+            if b == 0:
+                conv(tag + ".proj", H, W, cin, 4 * wd, 1, s)
+            H, W = H // s, W // s
+            conv(tag + ".c3", H, W, wd, 4 * wd, 1, 1)
+            cin = 4 * wd
+    for i, (ci, co) in enumerate(((2048, 256), (256, 256), (256, 256))):
+        L.append((f"deconv{i + 1}", 2 * B * H * W * 16 * ci * co, B * H * W, co, 4 * ci))
+        H, W = 2 * H, 2 * W
+    conv("head", H, W, 256, 17, 1, 1)
+    return L
+
+
+def main():
+    path = sys.argv[1]
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    L = layers(B)
+    last = rows[-len(L):]
+    agg = {}
+    for (name, fl, M, N, K), r in zip(L, last):
+        du = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        a = agg.setdefault((name, M, N, K), [0, 0, 0])
+        a[0] += fl; a[1] += du; a[2] += 1
+    tot = sum(a[1] for a in agg.values())
+    totf = sum(a[0] for a in agg.values())
+    print(f"{'layer':12s} {'M':>8s} {'N':>5s} {'K':>5s}  cnt   us/launch   TF/s   share%  ideal_ms")
+    for (name, M, N, K), (fl, du, c) in agg.items():
+        print(f"{name:12s} {M:8d} {N:5d} {K:5d}  x{c:<2d} {du / c / 1e3:10.1f} {fl / du / 1e3:7.1f} {100 * du / tot:7.2f} {fl / 157.3e12 * 1e3:8.3f}")
+    print(f"total {tot / 1e6:.2f} ms for {B} frames -> {totf / tot / 1e3:.1f} TF/s, {B / (tot / 1e9):.0f} frames/s (conv only)")
+
+
+if __name__ == "__main__":
+    main()
