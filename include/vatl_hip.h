@@ -124,6 +124,33 @@ int vatl_localpeak_mean(const float* hm, float* mean, int32_t* count, int N, int
 int vatl_hybrid_ae_wpu(const float* kpts, const float* bbox, const float* ae, int D, int z, int only38,
                        float* wpu, int32_t* status, int N, void* stream);
 
+/* TPC (ActiveLearning.py:333-344, compute_tpc :736-745) on a de-duplicated id-sorted
+ * stream: cur (N,J,2) decoded key-points; adj_prev[i] / adj_next[i] (N,J,2) = heat-maps
+ * of items i-1 / i+1 decoded with item i's box (vatl_decode_argmax_affine on shifted
+ * views); counts joints displaced by more than 0.01*sqrt(box area), summed over the
+ * existing neighbours, doubled when exactly one exists.  tpc (N) fp32 (integer valued). */
+int vatl_tpc_stream(const float* cur, const float* adj_prev, const float* adj_next, const float* bbox,
+                    const uint8_t* is_prev, const uint8_t* is_next, float* tpc, int N, int J, void* stream);
+
+/* heatmap_to_coord_simple_regress (transforms.py:586-702; LOSS.TYPE L1JointRegression):
+ * soft-arg-max expectation + the same inverse crop affine.  norm_type 0 softmax,
+ * 1 sigmoid, 2 divide_sum.  coords (N,J,2), scores (N,J) (1, max sigmoid, 1). */
+int vatl_decode_softargmax(const float* hm, const float* bbox, float* coords, float* scores,
+                           int N, int J, int H, int W, int norm_type, void* stream);
+
+/* WholeBodyAE.forward on given features (AutoEncoder.py:36-39): feat (N,D) -> recon
+ * (N,D) (may be NULL) and per-item mean squared reconstruction error mse (N) (may be
+ * NULL); ae packed as for vatl_hybrid_ae_wpu; D, z in 1..64. */
+int vatl_ae_forward(const float* feat, const float* ae, int D, int z, float* recon, float* mse, int N, void* stream);
+
+/* compute_hybrid (hybrid_feature.py:14-59) on float64 inputs: kpts (N,51), bbox (N,4)
+ * as (x,y,w,h) -> feat (N,42) float64; status (N) as in vatl_hybrid_ae_wpu (may be NULL). */
+int vatl_hybrid_feature_f64(const double* kpts, const double* bbox_xywh, double* feat, int32_t* status, int N, void* stream);
+
+/* localpeak_values (local_peak.py:5-10) as a mask: mask[p][y][x] = 1 where the pixel is a
+ * kept local peak of plane p (planes = N*J maps of H x W). */
+int vatl_localpeak_mask(const float* hm, uint8_t* mask, int planes, int H, int W, float order, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * Fine-tune step pieces (ActiveLearning.py:662-677)
  * ------------------------------------------------------------------------ */

@@ -1,0 +1,122 @@
+"""The reference-named Python surface (alphapose.utils.*, active_learning.*) on MI355X
+vs the golden vectors / oracle: same signatures, same results."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import scorers, synth
+from tests.gpu_util import dev, record, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def test_heatmap_to_coord_simple_per_item(golden_scorers):
+    from alphapose.utils.config import edict
+    from alphapose.utils.transforms import get_func_heatmap_to_coord, get_max_pred
+    g = golden_scorers
+    f = get_func_heatmap_to_coord(edict({"DATA_PRESET": {"TYPE": "simple"}, "LOSS": {"TYPE": "MSELoss"}}))
+    for i in range(g["hm"].shape[0]):
+        for src in (g["hm"][i], torch.from_numpy(g["hm"][i]), to_dev(g["hm"][i])):        # ndarray / cpu tensor / device tensor
+            c, m = f(src, g["bbox"][i].tolist(), hm_shape=(64, 48), norm_type=None)
+            assert c.shape == (17, 2) and m.shape == (17, 1) and c.dtype == np.float32
+            assert np.array_equal(c, g["coords"][i]) and np.array_equal(m, g["maxvals"][i])
+    p, m = get_max_pred(g["hm"][5])
+    want = scorers.argmax_peaks(g["hm"][5])
+    assert np.array_equal(p, want[1]) and np.array_equal(m, want[2])
+
+
+@pytest.mark.parametrize("nt", ["softmax", "sigmoid", "divide_sum"])
+def test_softargmax_decode(golden_scorers, nt):
+    from alphapose.utils.transforms import heatmap_to_coord_simple_regress
+    g = golden_scorers
+    for i in range(5):
+        src = g["hm"][i] if nt != "divide_sum" else np.abs(g["hm"][i]) + 1e-3
+        c, s = heatmap_to_coord_simple_regress(torch.from_numpy(src), g["bbox"][i].tolist(), (64, 48), nt)
+        record("softargmax_" + nt, max_abs=float(np.abs(c - g[f"soft_{nt}_coords"][i]).max()))
+        np.testing.assert_allclose(c, g[f"soft_{nt}_coords"][i], rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(s, g[f"soft_{nt}_scores"][i], rtol=1e-5)
+
+
+def test_tpc_stream(golden_scorers):
+    import vatl_hip as vh
+    g = golden_scorers
+    hm, bb = to_dev(g["hm"]), to_dev(g["bbox"])
+    n = hm.shape[0]
+    coords, _, _ = vh.decode(hm, bb)
+    is_prev = np.array([0, 1, 1, 0, 1, 0, 1, 1], np.uint8)
+    is_next = np.array([1, 1, 0, 1, 0, 1, 1, 0], np.uint8)
+    got = vh.tpc_stream(hm, bb, coords, to_dev(is_prev, torch.uint8), to_dev(is_next, torch.uint8)).cpu().numpy()
+    for i in range(n):
+        want = scorers.tpc_item(g["hm"][i], g["hm"][i - 1] if i else None, g["hm"][i + 1] if i + 1 < n else None,
+                                g["bbox"][i].tolist(), is_prev[i], is_next[i])
+        assert got[i] == want, (i, got[i], want)                                           # integer counts: exact
+    # the reference's own pair counts (golden): item i vs i+1 with item i's box
+    only_next = vh.tpc_stream(hm, bb, coords, to_dev(np.zeros(n, np.uint8), torch.uint8), to_dev(np.r_[np.ones(n - 1), 0].astype(np.uint8), torch.uint8))
+    assert np.array_equal(only_next.cpu().numpy()[:-1], 2 * g["tpc"])
+
+
+def test_local_peak_api(golden_scorers):
+    from active_learning.local_peak import localpeak_mean, localpeak_values
+    g = golden_scorers
+    assert np.array_equal(localpeak_values(g["toy"].astype(np.float32)), g["toy_vals"])   # [4 3]
+    assert localpeak_mean(np.stack([g["toy"]] * 3).astype(np.float32)) == 3.5
+    for i in (0, 5, 7):
+        np.testing.assert_allclose(localpeak_mean(g["hm"][i]), g["lp_mean"][i], rtol=1e-5)
+        for j in (0, 6, 7, 9):
+            assert np.array_equal(localpeak_values(g["hm"][i, j]), scorers.localpeak_values(g["hm"][i, j]))
+    assert np.isnan(localpeak_mean(g["hm"][6]))
+
+
+def test_hybrid_feature_and_autoencoder_api(golden_scorers):
+    from active_learning.Whole_body_AE.AutoEncoder import WholeBodyAE
+    from active_learning.Whole_body_AE.hybrid_feature import compute_hybrid
+    g = golden_scorers
+    f = compute_hybrid(g["lit_bbox"].tolist(), g["lit_kp"].tolist())                        # the reference's literal fixture
+    assert f.shape == (42,) and f.dtype == np.float64
+    np.testing.assert_allclose(f, g["lit_feat"], rtol=1e-12, atol=1e-13)
+    with pytest.raises(AssertionError):
+        compute_hybrid([0, 0, 10, 0], g["lit_kp"].tolist())
+    with pytest.raises(AssertionError):
+        compute_hybrid([0, 0, 10, 10], [0.0] * 51)
+    for d, pre in ((42, "ae42."), (38, "ae38.")):
+        ae = WholeBodyAE(z_dim=4, input_dim=d)
+        sd = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+        assert list(ae.state_dict().keys()) == list(sd.keys())
+        ae.load_state_dict(sd, strict=True)
+        ae = ae.to(dev()).eval()
+        i = int(np.flatnonzero(g["kp_ok"])[0])
+        x = g["hybrid"][i].astype(np.float32)
+        x = x if d == 42 else x[np.r_[0:3, 5:20, 22:42]]
+        y = ae(to_dev(x)).cpu().numpy()
+        np.testing.assert_allclose(y, scorers.ae_forward(x, {k: v.numpy() for k, v in sd.items()}), rtol=1e-5, atol=1e-6)
+    assert WholeBodyAE(z_dim=2).input_dim == 38 and WholeBodyAE(z_dim=2, kp_direct=True).input_dim == 51
+
+
+def test_calc_accuracy(golden_scorers):
+    from alphapose.utils.metrics import DataLogger, calc_accuracy
+    g = golden_scorers
+    tgt, mask = synth.gaussian_targets(g["hm"].shape[0], seed=int(g["acc_targets_seed"]))
+    acc = calc_accuracy(to_dev(g["hm"] * mask), to_dev(tgt * mask))
+    np.testing.assert_allclose(acc, g["acc"], rtol=1e-12)
+    lg = DataLogger(); lg.update(2.0, 3); lg.update(4.0, 1)
+    assert lg.avg == 2.5 and lg.cnt == 4
+
+
+def test_score_batch_all_scores(golden_scorers):
+    import vatl_hip as vh
+    from active_learning.scoring import score_batch
+    g = golden_scorers
+    sd42 = {k[5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("ae42.")}
+    n = g["hm"].shape[0]
+    is_prev, is_next = synth.video_flags(n, 2)
+    s = score_batch(to_dev(g["hm"]), to_dev(g["bbox"]), to_dev(is_prev, torch.uint8), to_dev(is_next, torch.uint8),
+                    ae_flat=vh.pack_ae(sd42, dev()), ae_dims=(42, 4))
+    kp = s.keypoints.cpu().numpy().reshape(n, 51)
+    assert np.array_equal(kp, g["kp"].astype(np.float32))
+    np.testing.assert_allclose(s.hp.cpu().numpy(), -g["maxvals"].sum(axis=(1, 2)), rtol=1e-5)
+    for i in range(n):
+        np.testing.assert_allclose(float(s.pose_score[i]), scorers.pose_score(g["maxvals"][i]), rtol=1e-5)
+        want = scorers.thc_item(g["hm"][i], g["hm"][i - 1] if i else None, g["hm"][i + 1] if i + 1 < n else None, is_prev[i], is_next[i])
+        np.testing.assert_allclose(float(s.thc[i]), want, rtol=1e-5)
+    ok = g["kp_ok"]
+    np.testing.assert_allclose(s.wpu.cpu().numpy()[ok], g["wpu42"][ok], rtol=1e-4)

@@ -1,0 +1,60 @@
+"""Running averages and heat-map accuracy (reference: alphapose/utils/metrics.py).
+
+``DataLogger`` :14-32 and ``calc_accuracy`` :118-147 (+ calc_dist :221-236, dist_acc
+:239-245) run inside the fine-tune loop (ActiveLearning.py:670-676).  The arg-max of
+predictions and labels comes from the same HIP kernel as the decoder, so only
+(B,J) indices cross to the host instead of two (B,J,H,W) tensors.
+``evaluate_mAP`` (:65-115, pycocotools) is offline evaluation and out of scope.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .transforms import get_max_pred_batch
+
+
+class DataLogger:
+    """Average data logger."""
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        self.value = 0
+        self.sum = 0
+        self.cnt = 0
+        self.avg = 0
+
+    def update(self, value, n=1):
+        self.value = value
+        self.sum += value * n
+        self.cnt += n
+        self._cal_avg()
+
+    def _cal_avg(self):
+        self.avg = self.sum / self.cnt
+
+
+def calc_accuracy(preds, labels, thr=0.5):
+    """Fraction of joints whose heat-map arg-max lies within ``thr`` of the label's
+    arg-max, distances normalised by (W,H)/10, averaged over joints that have at
+    least one labelled item (label arg-max > 1 in both axes)."""
+    hm_h, hm_w = preds.shape[2], preds.shape[3]
+    p, _ = get_max_pred_batch(preds)
+    t, _ = get_max_pred_batch(labels)
+    norm = np.array([hm_w, hm_h], np.float64) / 10
+    valid = (t[..., 0] > 1) & (t[..., 1] > 1)                       # (B,J)
+    d = np.linalg.norm(p.astype(np.float32) / norm - t.astype(np.float32) / norm, axis=2)
+    d = np.where(valid, d, 0.0).T                                   # (J,B); 0 marks "not counted" like the reference
+    total, cnt = 0.0, 0
+    for row in d:
+        used = row != 0
+        if used.sum() > 0:
+            total += float((row[used] < thr).sum()) / used.sum()
+            cnt += 1
+    return total / cnt if cnt > 0 else 0
+
+
+def evaluate_mAP(*args, **kwargs):
+    raise NotImplementedError("COCO mAP evaluation (pycocotools) is offline evaluation outside the MI355X hot path "
+                              "(SURVEY.md §2.1 row 5); run the reference's evaluate_mAP on the produced json files")

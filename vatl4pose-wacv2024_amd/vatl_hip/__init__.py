@@ -40,6 +40,11 @@ SIGNATURES = {
     "vatl_thc_combine": (_i, [_p, _p, _p, _p, _i, _p]),
     "vatl_localpeak_mean": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "vatl_hybrid_ae_wpu": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i, _p]),
+    "vatl_tpc_stream": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "vatl_decode_softargmax": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vatl_ae_forward": (_i, [_p, _p, _i, _i, _p, _p, _i, _p]),
+    "vatl_hybrid_feature_f64": (_i, [_p, _p, _p, _p, _i, _p]),
+    "vatl_localpeak_mask": (_i, [_p, _p, _i, _i, _i, _f, _p]),
     "vatl_masked_mse_workspace_floats": (_i64, [_i64]),
     "vatl_masked_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vatl_adamw_step": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _p]),
@@ -242,6 +247,63 @@ def hybrid_ae_wpu(kpts: torch.Tensor, bbox: torch.Tensor, ae_flat: torch.Tensor,
     _check(lib().vatl_hybrid_ae_wpu(_ptr(kpts), _ptr(bbox), _ptr(ae_flat), d, z, int(only38), _ptr(wpu), _ptr(status, torch.int32), n, _stream()),
            "vatl_hybrid_ae_wpu")
     return wpu, status
+
+
+def tpc_stream(hm: torch.Tensor, bbox: torch.Tensor, cur_coords: torch.Tensor, is_prev: torch.Tensor, is_next: torch.Tensor) -> torch.Tensor:
+    """TPC of an id-sorted de-duplicated stream (neighbours = items i-1 / i+1, decoded with item i's box)."""
+    n, j = hm.shape[:2]
+    adj_prev = torch.zeros((n, j, 2), device=hm.device, dtype=torch.float32)
+    adj_next = torch.zeros((n, j, 2), device=hm.device, dtype=torch.float32)
+    if n > 1:
+        h, w = hm.shape[2:]
+        scratch = torch.empty((n - 1, j), device=hm.device, dtype=torch.float32)
+        _check(lib().vatl_decode_argmax_affine(hm[:-1].data_ptr(), bbox[1:].data_ptr(), adj_prev[1:].data_ptr(), _ptr(scratch), None,
+                                               n - 1, j, h, w, _stream()), "vatl_decode_argmax_affine")
+        _check(lib().vatl_decode_argmax_affine(hm[1:].data_ptr(), bbox[:-1].data_ptr(), adj_next[:-1].data_ptr(), _ptr(scratch), None,
+                                               n - 1, j, h, w, _stream()), "vatl_decode_argmax_affine")
+    out = torch.empty(n, device=hm.device, dtype=torch.float32)
+    _check(lib().vatl_tpc_stream(_ptr(cur_coords), _ptr(adj_prev), _ptr(adj_next), _ptr(bbox), _ptr(is_prev, torch.uint8),
+                                 _ptr(is_next, torch.uint8), _ptr(out), n, j, _stream()), "vatl_tpc_stream")
+    return out
+
+
+def decode_softargmax(hm: torch.Tensor, bbox: torch.Tensor, norm_type: str = "softmax"):
+    n, j, h, w = hm.shape
+    coords = torch.empty((n, j, 2), device=hm.device, dtype=torch.float32)
+    scores = torch.empty((n, j), device=hm.device, dtype=torch.float32)
+    code = {"softmax": 0, "sigmoid": 1, "divide_sum": 2}.get(norm_type)
+    if code is None:
+        raise NotImplementedError(norm_type)
+    _check(lib().vatl_decode_softargmax(_ptr(hm), _ptr(bbox), _ptr(coords), _ptr(scores), n, j, h, w, code, _stream()), "vatl_decode_softargmax")
+    return coords, scores
+
+
+def ae_forward(feat: torch.Tensor, ae_flat: torch.Tensor, d: int, z: int):
+    """feat (N,D) -> recon (N,D), mse (N,)."""
+    n = feat.shape[0]
+    recon = torch.empty((n, d), device=feat.device, dtype=torch.float32)
+    mse = torch.empty(n, device=feat.device, dtype=torch.float32)
+    _check(lib().vatl_ae_forward(_ptr(feat), _ptr(ae_flat), d, z, _ptr(recon), _ptr(mse), n, _stream()), "vatl_ae_forward")
+    return recon, mse
+
+
+def hybrid_feature_f64(kpts: torch.Tensor, bbox_xywh: torch.Tensor):
+    """kpts (N,51) f64, bbox (N,4) f64 xywh -> feat (N,42) f64, status (N,) i32."""
+    n = kpts.shape[0]
+    feat = torch.empty((n, 42), device=kpts.device, dtype=torch.float64)
+    status = torch.empty(n, device=kpts.device, dtype=torch.int32)
+    _check(lib().vatl_hybrid_feature_f64(_ptr(kpts, torch.float64), _ptr(bbox_xywh, torch.float64), _ptr(feat, torch.float64),
+                                         _ptr(status, torch.int32), n, _stream()), "vatl_hybrid_feature_f64")
+    return feat, status
+
+
+def localpeak_mask(hm: torch.Tensor, order: float = 0.5) -> torch.Tensor:
+    """hm (..., H, W) -> uint8 mask of kept local peaks, same shape."""
+    h, w = hm.shape[-2:]
+    planes = hm.numel() // (h * w)
+    mask = torch.empty(hm.shape, device=hm.device, dtype=torch.uint8)
+    _check(lib().vatl_localpeak_mask(_ptr(hm), _ptr(mask, torch.uint8), planes, h, w, order, _stream()), "vatl_localpeak_mask")
+    return mask
 
 
 # ----------------------------------------------------------------------------
