@@ -88,6 +88,17 @@ int vatl_maxpool3x3s2_fwd(const float* x, float* y, int N, int H, int W, int C, 
 /* AdaptiveAvgPool2d(1)+flatten on NHWC -> (N,C)  (simplepose.py:88-91). */
 int vatl_gap_fwd(const float* x, float* y, int N, int HW, int C, void* stream);
 
+/* nn.PixelShuffle(2) on NHWC: (N,H,W,C) -> (N,2H,2W,C/4), out[2y+i][2x+j][c] = in[y][x][4c+2i+j]
+ * (fastpose.py:42,56; DUC.py:23,28).  C % 16 == 0. */
+int vatl_pixelshuffle2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* SE gate + residual + ReLU, NHWC: y = relu(x * sigmoid(gate[n][c]) + residual)
+ * (SE_module.py:20-24 with the second Linear's pre-sigmoid output as `gate`; SE_Resnet.py:125-135). */
+int vatl_se_scale_add_relu(const float* x, const float* gate, const float* residual, float* y, int N, int HW, int C, void* stream);
+/* HRNet branch fusion, NHWC: y = act(base + sum_k nearest_upsample(z_k, 2^shift_k)); z_k is
+ * (N, H>>shift_k, W>>shift_k, C) or NULL (hrnet.py:199-203 Upsample(nearest), :242-260 sum + ReLU). */
+int vatl_fuse_upsample_add(const float* base, const float* z0, int shift0, const float* z1, int shift1, const float* z2, int shift2,
+                           float* y, int N, int H, int W, int C, int relu, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * Scorers on heat-maps (N,J,H,W) fp32 NCHW, one pass over HBM each
  * ------------------------------------------------------------------------ */

@@ -31,8 +31,10 @@ def tensor_for(key: str, shape, seed: int = SEED) -> np.ndarray:
         return r.uniform(0.5, 1.5, shape).astype(np.float32)
     if key.endswith("running_mean"):
         return (0.1 * r.standard_normal(shape)).astype(np.float32)
-    if len(shape) == 1 and key.endswith("bn3.weight"):        # last BN of a residual branch: keep the
-        return r.uniform(0.2, 0.4, shape).astype(np.float32)  # un-normalised (eval-mode) trunk from blowing up
+    if len(shape) == 1 and (key.endswith("bn3.weight") or (".branches." in key and key.endswith("bn2.weight"))
+                            or (".fuse_layers." in key and key.endswith(".weight"))):
+        # last BN of a residual / fusion branch: keep the un-normalised (eval-mode) network from blowing up
+        return r.uniform(0.2, 0.4, shape).astype(np.float32)
     if len(shape) == 1 and key.endswith("weight"):            # BN gamma
         return r.uniform(0.5, 1.5, shape).astype(np.float32)
     if len(shape) == 1:                                        # any bias / BN beta

@@ -172,3 +172,54 @@ def test_cpu_input_fails_loudly(vh):
     m = _build_simplepose()
     with pytest.raises(Exception):
         m(torch.zeros(1, 3, 256, 192))
+
+
+HRNET_CFG = {"TYPE": "PoseHighResolutionNet", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50, "FINAL_CONV_KERNEL": 1, "PRETRAINED_LAYERS": ["*"],
+             "STAGE2": {"NUM_MODULES": 1, "NUM_BRANCHES": 2, "NUM_BLOCKS": [4, 4], "NUM_CHANNELS": [32, 64], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"},
+             "STAGE3": {"NUM_MODULES": 4, "NUM_BRANCHES": 3, "NUM_BLOCKS": [4, 4, 4], "NUM_CHANNELS": [32, 64, 128], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"},
+             "STAGE4": {"NUM_MODULES": 3, "NUM_BRANCHES": 4, "NUM_BLOCKS": [4, 4, 4, 4], "NUM_CHANNELS": [32, 64, 128, 256], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"}}
+
+
+def _build(cfg):
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    m = builder.build_sppe(edict(cfg), preset_cfg=preset)
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    return m.to(dev()).eval()
+
+
+def test_pixelshuffle_se_fuse_kernels(vh):
+    r = np.random.RandomState(7)
+    x = r.standard_normal((2, 64, 5, 3)).astype(np.float32)
+    got = np.transpose(vh.pixelshuffle2_fwd(vh.nchw_to_nhwc(to_dev(x))).cpu().numpy(), (0, 3, 1, 2))
+    assert np.array_equal(got, F.pixel_shuffle(torch.from_numpy(x), 2).numpy())
+    x = r.standard_normal((2, 32, 4, 6)).astype(np.float32); res = r.standard_normal((2, 32, 4, 6)).astype(np.float32)
+    g = r.standard_normal((2, 32)).astype(np.float32)
+    got = np.transpose(vh.se_scale_add_relu(vh.nchw_to_nhwc(to_dev(x)), to_dev(g), vh.nchw_to_nhwc(to_dev(res))).cpu().numpy(), (0, 3, 1, 2))
+    want = np.maximum(x * (1 / (1 + np.exp(-g)))[:, :, None, None] + res, 0)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    base = r.standard_normal((2, 8, 8, 16)).astype(np.float32)
+    z1 = r.standard_normal((2, 8, 4, 8)).astype(np.float32); z2 = r.standard_normal((2, 8, 2, 4)).astype(np.float32)
+    got = np.transpose(vh.fuse_upsample_add(vh.nchw_to_nhwc(to_dev(base)), [(vh.nchw_to_nhwc(to_dev(z1)), 1), (vh.nchw_to_nhwc(to_dev(z2)), 2)], True).cpu().numpy(), (0, 3, 1, 2))
+    want = np.maximum(base + np.repeat(np.repeat(z1, 2, 2), 2, 3) + np.repeat(np.repeat(z2, 4, 2), 4, 3), 0)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["fastpose", "hrnet"])
+def test_fastpose_hrnet_forward_vs_reference_golden(vh, name):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fastpose_hrnet.npz"))
+    m = _build({"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50} if name == "fastpose" else HRNET_CFG)
+    x = to_dev(synth.crops(int(g["batch"])))
+    with torch.no_grad():
+        hm = m(x).cpu().numpy()
+    ref = g[f"{name}_heatmaps"]
+    e = rel_err(hm, ref)
+    record(f"{name}_heatmaps", rel=e)
+    assert hm.shape == ref.shape and e < 1e-4
+    assert np.array_equal(hm.reshape(2, 17, -1).argmax(2), ref.reshape(2, 17, -1).argmax(2))
+    if name == "fastpose":
+        with torch.no_grad():
+            emb = m.get_embedding(x).cpu().numpy()
+        assert rel_err(emb, g["fastpose_embedding"]) < 1e-4

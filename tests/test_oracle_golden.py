@@ -138,3 +138,28 @@ def test_masked_mse_and_adamw_against_torch():
         opt.step()
         pn, m, v = scorers.adamw_step(pn, gnp, m, v, step, 2.5e-3, 0.7)
         np.testing.assert_allclose(pn, p.detach().numpy(), rtol=2e-5, atol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def golden_nets2():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "fastpose_hrnet.npz"))
+
+
+@pytest.mark.parametrize("name,ctor", [("fastpose", nets.FastPoseRef), ("hrnet", nets.HRNetRef)])
+def test_fastpose_hrnet_restatements_match_reference(golden_nets2, name, ctor):
+    g = golden_nets2
+    m = ctor()
+    assert list(m.state_dict().keys()) == list(g[f"{name}_keys"])
+    assert [str(tuple(v.shape)) for v in m.state_dict().values()] == list(g[f"{name}_shapes"])
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    m.eval()
+    x = torch.from_numpy(synth.crops(int(g["batch"])))
+    with torch.no_grad():
+        hm = m(x).numpy()
+    ref = g[f"{name}_heatmaps"]
+    assert np.abs(hm - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert np.array_equal(hm.reshape(2, 17, -1).argmax(2), ref.reshape(2, 17, -1).argmax(2))
+    if name == "fastpose":
+        with torch.no_grad():
+            np.testing.assert_allclose(m.get_embedding(x).numpy(), g["fastpose_embedding"], rtol=1e-4, atol=1e-5)

@@ -369,6 +369,38 @@ def gen_simplepose(EasyDict, out: str):
     print("simplepose_r50.npz written", hm.shape, float(np.abs(hm).mean()))
 
 
+
+def gen_fastpose_hrnet(EasyDict, out: str):
+    """FastPose-R50 and HRNet-W32 forward on the seeded crops (B = 2)."""
+    from alphapose.models import builder                         # the reference's
+    preset = EasyDict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    x = torch.from_numpy(synth.crops(2))
+    res = {}
+    cfgs = {
+        "fastpose": {"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50},
+        "hrnet": {"TYPE": "PoseHighResolutionNet", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50, "FINAL_CONV_KERNEL": 1,
+                  "PRETRAINED_LAYERS": ["*"],
+                  "STAGE2": {"NUM_MODULES": 1, "NUM_BRANCHES": 2, "NUM_BLOCKS": [4, 4], "NUM_CHANNELS": [32, 64], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"},
+                  "STAGE3": {"NUM_MODULES": 4, "NUM_BRANCHES": 3, "NUM_BLOCKS": [4, 4, 4], "NUM_CHANNELS": [32, 64, 128], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"},
+                  "STAGE4": {"NUM_MODULES": 3, "NUM_BRANCHES": 4, "NUM_BLOCKS": [4, 4, 4, 4], "NUM_CHANNELS": [32, 64, 128, 256], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"}},
+    }
+    for name, c in cfgs.items():
+        torch.manual_seed(synth.SEED)
+        m = builder.build_sppe(EasyDict(c), preset_cfg=preset)
+        m.load_state_dict(synth.state_dict_for(m), strict=True)
+        m.eval()
+        with torch.no_grad():
+            hm = m(x).numpy()
+            res[f"{name}_heatmaps"] = hm
+            if hasattr(m, "get_embedding"):
+                res[f"{name}_embedding"] = m.get_embedding(x).numpy()
+        sd = m.state_dict()
+        res[f"{name}_keys"] = np.array(list(sd.keys()))
+        res[f"{name}_shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+        print(name, hm.shape, float(np.abs(hm).mean()), len(sd))
+    np.savez_compressed(os.path.join(out, "fastpose_hrnet.npz"), batch=np.int64(2), seed=np.int64(synth.SEED), **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -383,6 +415,8 @@ def main():
         gen_scorers(a.ref, a.out)
     if a.only in ("", "simplepose"):
         gen_simplepose(EasyDict, a.out)
+    if a.only in ("", "nets2"):
+        gen_fastpose_hrnet(EasyDict, a.out)
 
 
 if __name__ == "__main__":

@@ -7,6 +7,9 @@ ConvTranspose2d(4,2,1) becomes four sub-pixel 2x2 filters.  Activations stay NHW
 between launches; only the network input (NCHW crops) and the heat-maps (NCHW,
 what the scorers and the reference's callers expect) are converted.
 
+FastPose (fastpose.py:52-59) and HRNet (hrnet.py:421-456) plans reuse the same conv
+launches plus vatl_pixelshuffle2_fwd / vatl_se_scale_add_relu / vatl_fuse_upsample_add.
+
 Dataflow of SimplePose (reference: simplepose.py:82-86, Resnet.py:171-177):
   NCHW crops -> NHWC(4ch) -> stem 7x7/2 (+BN+ReLU) -> maxpool 3x3/2
   -> 16 bottlenecks {1x1, 3x3(stride), 1x1 (+proj) + add + ReLU}
@@ -113,6 +116,146 @@ class _SimplePosePlan:
         return self.head(x, relu=False, out_nchw=True, out=out)
 
 
+class _Linear:
+    """nn.Linear as a 1x1 convolution over a (B,1,1,C) NHWC tensor (same MFMA kernel)."""
+    __slots__ = ("w", "scale", "bias", "cout")
+
+    def __init__(self, lin: nn.Linear):
+        self.cout, cin = lin.weight.shape
+        self.w = vh.pack_conv_weight(lin.weight.detach().reshape(self.cout, cin, 1, 1))
+        self.scale, self.bias = vh.bn_fold(None, None, None, None, 0.0, lin.bias.detach(), channels=self.cout)
+
+    def __call__(self, x2d, relu):
+        b, c = x2d.shape
+        return vh.conv2d_fwd(x2d.reshape(b, 1, 1, c), self.w, self.scale, self.bias, self.cout, 1, 1, 1, 0, relu).reshape(b, self.cout)
+
+
+class _SEBottleneckPlan(_BottleneckPlan):
+    """First block of a FastPose stage: conv3+BN output is gated by sigmoid(fc(avgpool)) before
+    the projection shortcut is added (SE_Resnet.py:110-137, SE_module.py:20-24)."""
+
+    def __init__(self, blk):
+        super().__init__(blk)
+        self.fc1, self.fc2 = _Linear(blk.se.fc[0]), _Linear(blk.se.fc[2])
+
+    def __call__(self, x):
+        y = self.c1(x, relu=True)
+        y = self.c2(y, relu=True)
+        y = self.c3(y, relu=False)
+        gate = self.fc2(self.fc1(vh.gap_fwd(y), relu=True), relu=False)     # pre-sigmoid
+        return vh.se_scale_add_relu(y, gate, self.proj(x, relu=False))
+
+
+class _SETrunkPlan(_TrunkPlan):
+    def __init__(self, net):
+        self.stem = _Conv(net.conv1, net.bn1)
+        self.blocks = [(_SEBottleneckPlan(b) if getattr(b, "reduc", False) else _BottleneckPlan(b))
+                       for stage in net.stages() for b in stage]
+
+
+class _FastPosePlan:
+    def __init__(self, m):
+        self.trunk = _SETrunkPlan(m.preact)
+        self.duc1 = _Conv(m.duc1.conv, m.duc1.bn)
+        self.duc2 = _Conv(m.duc2.conv, m.duc2.bn)
+        self.head = _Conv(m.conv_out, None)
+
+    def features(self, x_nchw):
+        return self.trunk(x_nchw)
+
+    def __call__(self, x_nchw, out=None):
+        x = vh.pixelshuffle2_fwd(self.trunk(x_nchw))
+        x = vh.pixelshuffle2_fwd(self.duc1(x, relu=True))
+        x = vh.pixelshuffle2_fwd(self.duc2(x, relu=True))
+        return self.head(x, relu=False, out_nchw=True, out=out)
+
+
+class _BasicBlockPlan:
+    def __init__(self, blk):
+        self.c1 = _Conv(blk.conv1, blk.bn1)
+        self.c2 = _Conv(blk.conv2, blk.bn2)
+        self.proj = _Conv(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+
+    def __call__(self, x):
+        skip = x if self.proj is None else self.proj(x, relu=False)
+        return self.c2(self.c1(x, relu=True), relu=True, residual=skip)
+
+
+def _block_plan(blk):
+    return _BottleneckPlan(blk) if hasattr(blk, "conv3") else _BasicBlockPlan(blk)
+
+
+class _ConvChain:
+    """Sequential of Conv-BN(-ReLU) groups (HRNet transitions and strided fusion paths)."""
+
+    def __init__(self, seq):
+        groups = [seq] if isinstance(seq[0], nn.Conv2d) else list(seq)
+        self.steps = [(_Conv(g[0], g[1]), len(g) > 2 and isinstance(g[2], nn.ReLU)) for g in groups]
+
+    def __call__(self, x, residual=None, final_relu=None):
+        for k, (conv, relu) in enumerate(self.steps):
+            last = k == len(self.steps) - 1
+            x = conv(x, relu=(final_relu if (last and final_relu is not None) else relu), residual=residual if last else None)
+        return x
+
+
+class _HRModulePlan:
+    """Branches of BasicBlocks, then per output resolution i:
+    y_i = relu( x_i + sum_{j<i} down_ij(x_j) + sum_{j>i} up(conv1x1_ij(x_j)) )   (hrnet.py:242-260).
+    Strided paths accumulate through the conv epilogue's residual input; the up-sampled
+    terms are added (and the ReLU applied) by one vatl_fuse_upsample_add launch."""
+
+    def __init__(self, mod):
+        self.branches = [[_block_plan(b) for b in br] for br in mod.branches]
+        self.rows = []
+        if mod.fuse_layers is not None:
+            for i, row in enumerate(mod.fuse_layers):
+                downs = [(j, _ConvChain(row[j])) for j in range(i)]
+                ups = [(j, _Conv(row[j][0], row[j][1])) for j in range(i + 1, len(row))]
+                self.rows.append((i, downs, ups))
+
+    def __call__(self, xs):
+        xs = list(xs)
+        for i, br in enumerate(self.branches):
+            for blk in br:
+                xs[i] = blk(xs[i])
+        if not self.rows:
+            return xs
+        out = []
+        for i, downs, ups in self.rows:
+            acc = xs[i]
+            for k, (j, chain) in enumerate(downs):
+                acc = chain(xs[j], residual=acc, final_relu=(not ups and k == len(downs) - 1))
+            if ups:
+                acc = vh.fuse_upsample_add(acc, [(conv(xs[j], relu=False), j - i) for j, conv in ups], relu=True)
+            out.append(acc)
+        return out
+
+
+class _HRNetPlan:
+    def __init__(self, m):
+        self.stem1, self.stem2 = _Conv(m.conv1, m.bn1), _Conv(m.conv2, m.bn2)
+        self.layer1 = [_block_plan(b) for b in m.layer1]
+        self.stages = []
+        for s in (2, 3, 4):
+            trans = [None if t is None else _ConvChain(t) for t in getattr(m, f"transition{s - 1}")]
+            self.stages.append((trans, [_HRModulePlan(mod) for mod in getattr(m, f"stage{s}")]))
+        self.head = _Conv(m.final_layer, None)
+
+    def __call__(self, x_nchw, out=None):
+        x = vh.nchw_to_nhwc(x_nchw, 4)
+        x = self.stem2(self.stem1(x, relu=True), relu=True)
+        for b in self.layer1:
+            x = b(x)
+        ys = [x]
+        for trans, mods in self.stages:
+            xs = [ys[i] if t is None else t(ys[-1]) for i, t in enumerate(trans)]
+            for mod in mods:
+                xs = mod(xs)
+            ys = xs
+        return self.head(ys[0], relu=False, out_nchw=True, out=out)
+
+
 class _NchwAdapter:
     """Stand-alone use of a sub-module (ResNet / Bottleneck) on NCHW tensors."""
 
@@ -137,11 +280,20 @@ def _plan_for(m: nn.Module, device):
     cached = m.__dict__.get("_vatl_plan")
     if cached is not None and cached[0] == key:
         return cached[1]
+    from .fastpose import FastPose
+    from .hrnet import PoseHighResolutionNet
     from .simplepose import SimplePose
     from .layers.Resnet import Bottleneck, ResNet
+    from .layers.SE_Resnet import SEResnet
     with torch.no_grad():
         if isinstance(m, SimplePose):
             plan = _SimplePosePlan(m)
+        elif isinstance(m, FastPose):
+            plan = _FastPosePlan(m)
+        elif isinstance(m, PoseHighResolutionNet):
+            plan = _HRNetPlan(m)
+        elif isinstance(m, SEResnet):
+            plan = _NchwAdapter(_SETrunkPlan(m))
         elif isinstance(m, ResNet):
             plan = _NchwAdapter(_TrunkPlan(m))
         elif isinstance(m, Bottleneck):

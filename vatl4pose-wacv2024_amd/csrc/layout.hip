@@ -129,6 +129,68 @@ __global__ void gap_kernel(const float* __restrict__ x, float* __restrict__ y, i
     }
 }
 
+
+// PixelShuffle(2) on NHWC: out[b][2y+i][2x+j][c] = in[b][y][x][4c + 2i + j]
+// thread per (input pixel, 4 input channels = one output channel c at the 4 sub-positions)
+__global__ void pixelshuffle2_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+    const int C4 = C >> 2;
+    const long long total = (long long)N * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long t = i / C4;
+        const int px = (int)(t % W); t /= W;
+        const int py = (int)(t % H);
+        const long long n = t / H;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        float* o = y + ((n * 2 * H + 2 * py) * 2 * W + 2 * px) * C4 + c;
+        o[0] = v[0];
+        o[C4] = v[1];
+        o[(long long)2 * W * C4] = v[2];
+        o[(long long)2 * W * C4 + C4] = v[3];
+    }
+}
+
+// SE gate + residual + ReLU: y = relu(x * sigmoid(g[b][c]) + res)   (SE_module.py:20-24, SE_Resnet.py:125-135)
+__global__ void se_scale_add_relu_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ res,
+                                         float* __restrict__ y, int N, int HW, int C) {
+    const int C4 = C >> 2;
+    const long long total = (long long)N * HW * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long long n = i / ((long long)HW * C4);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + n * C + c4 * 4);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(res + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(xv[e] * (1.f / (1.f + expf(-gv[e]))) + rv[e], 0.f);
+        *reinterpret_cast<f32x4*>(y + i * 4) = o;
+    }
+}
+
+// HRNet fuse: y = act(base + sum_k nearest_up(z_k, 2^shift_k)); up to 3 low-resolution sources (hrnet.py:242-260)
+struct FuseUpArgs { const float* z[3]; int shift[3]; int n; };
+__global__ void fuse_up_kernel(const float* __restrict__ base, FuseUpArgs a, float* __restrict__ y, int N, int H, int W, int C, int relu) {
+    const int C4 = C >> 2;
+    const long long total = (long long)N * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int px = (int)(t % W); t /= W;
+        const int py = (int)(t % H);
+        const long long n = t / H;
+        f32x4 v = *reinterpret_cast<const f32x4*>(base + i * 4);
+        for (int k = 0; k < a.n; ++k) {
+            const int s = a.shift[k];
+            const int h2 = H >> s, w2 = W >> s;
+            const f32x4 z = *reinterpret_cast<const f32x4*>(a.z[k] + (((n * h2 + (py >> s)) * w2 + (px >> s)) * C4 + c4) * 4);
+            v[0] += z[0]; v[1] += z[1]; v[2] += z[2]; v[3] += z[3];
+        }
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    }
+}
+
 static inline int grid_for(long long total, int block = 256) {
     long long g = (total + block - 1) / block;
     if (g > 256 * 16) g = 256 * 16;
@@ -186,4 +248,32 @@ extern "C" int vatl_gap_fwd(const float* x, float* y, int N, int HW, int C, void
     if (!x || !y) return fail(VATL_EINVAL, "gap_fwd: null pointer");
     hipLaunchKernelGGL(gap_kernel, dim3(grid_for((long long)N * C)), dim3(256), 0, (hipStream_t)stream, x, y, N, HW, C);
     return check_launch("gap_fwd");
+}
+
+extern "C" int vatl_pixelshuffle2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    if (!x || !y || (C & 15)) return fail(VATL_EINVAL, "pixelshuffle2_fwd: C %d must be a multiple of 16", C);
+    hipLaunchKernelGGL(pixelshuffle2_kernel, dim3(grid_for((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C);
+    return check_launch("pixelshuffle2_fwd");
+}
+
+extern "C" int vatl_se_scale_add_relu(const float* x, const float* gate, const float* residual, float* y, int N, int HW, int C, void* stream) {
+    if (!x || !gate || !residual || !y || (C & 3)) return fail(VATL_EINVAL, "se_scale_add_relu: bad arguments");
+    hipLaunchKernelGGL(se_scale_add_relu_kernel, dim3(grid_for((long long)N * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, gate, residual, y, N, HW, C);
+    return check_launch("se_scale_add_relu");
+}
+
+extern "C" int vatl_fuse_upsample_add(const float* base, const float* z0, int shift0, const float* z1, int shift1, const float* z2, int shift2,
+                                      float* y, int N, int H, int W, int C, int relu, void* stream) {
+    if (!base || !y || (C & 3)) return fail(VATL_EINVAL, "fuse_upsample_add: bad arguments");
+    FuseUpArgs a{};
+    const float* zs[3] = {z0, z1, z2};
+    const int sh[3] = {shift0, shift1, shift2};
+    for (int k = 0; k < 3; ++k) {
+        if (!zs[k]) continue;
+        if (sh[k] < 1 || (H & ((1 << sh[k]) - 1)) || (W & ((1 << sh[k]) - 1)))
+            return fail(VATL_EINVAL, "fuse_upsample_add: %dx%d is not divisible by 2^%d", H, W, sh[k]);
+        a.z[a.n] = zs[k]; a.shift[a.n] = sh[k]; ++a.n;
+    }
+    hipLaunchKernelGGL(fuse_up_kernel, dim3(grid_for((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, base, a, y, N, H, W, C, relu);
+    return check_launch("fuse_upsample_add");
 }

@@ -35,6 +35,9 @@ SIGNATURES = {
     "vatl_deconv4x4s2_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_maxpool3x3s2_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vatl_gap_fwd": (_i, [_p, _p, _i, _i, _i, _p]),
+    "vatl_pixelshuffle2_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "vatl_se_scale_add_relu": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "vatl_fuse_upsample_add": (_i, [_p, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
     "vatl_decode_argmax_affine": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_thc_pairs": (_i, [_p, _p, _i64, _i64, _p, _i, _i, _i, _i, _p]),
     "vatl_thc_combine": (_i, [_p, _p, _p, _p, _i, _p]),
@@ -181,6 +184,30 @@ def gap_fwd(x):
     n, h, w, c = x.shape
     y = torch.empty((n, c), device=x.device, dtype=torch.float32)
     _check(lib().vatl_gap_fwd(_ptr(x), _ptr(y), n, h * w, c, _stream()), "vatl_gap_fwd")
+    return y
+
+
+def pixelshuffle2_fwd(x):
+    n, h, w, c = x.shape
+    y = torch.empty((n, 2 * h, 2 * w, c // 4), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_pixelshuffle2_fwd(_ptr(x), _ptr(y), n, h, w, c, _stream()), "vatl_pixelshuffle2_fwd")
+    return y
+
+
+def se_scale_add_relu(x, gate, residual):
+    n, h, w, c = x.shape
+    y = torch.empty_like(x)
+    _check(lib().vatl_se_scale_add_relu(_ptr(x), _ptr(gate), _ptr(residual), _ptr(y), n, h * w, c, _stream()), "vatl_se_scale_add_relu")
+    return y
+
+
+def fuse_upsample_add(base, ups, relu: bool):
+    """base (N,H,W,C); ups = [(z, shift)] with z (N,H>>shift,W>>shift,C), at most 3."""
+    n, h, w, c = base.shape
+    y = torch.empty_like(base)
+    a = list(ups) + [(None, 0)] * (3 - len(ups))
+    _check(lib().vatl_fuse_upsample_add(_ptr(base), _ptr(a[0][0]), a[0][1], _ptr(a[1][0]), a[1][1], _ptr(a[2][0]), a[2][1], _ptr(y),
+                                        n, h, w, c, int(relu), _stream()), "vatl_fuse_upsample_add")
     return y
 
 
