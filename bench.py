@@ -100,8 +100,15 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
     ms = sum(a.elapsed_time(b) for a, b in events)
     flops = GFLOP_PER_CROP * 1e9 * FRAMES
     achieved = flops / (ms * 1e-3) / 1e12
+    traffic = None                                     # HBM bytes of the same launches, from the committed PMC passes
+    try:
+        pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
+        with open(os.path.join(ROOT, "profiles", pmcs[-1])) as f:
+            traffic = json.load(f)["conv_igemm"]["hbm_bytes_per_step"]
+    except (OSError, IndexError, KeyError, ValueError):
+        pass
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": None,
+            "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
             "kernel": "conv_igemm_kernel (all conv/deconv launches of one step)", "launches": len(events),
             "avg_launch_us": round(ms * 1e3 / len(events), 2), "flops_per_step": flops}
 
