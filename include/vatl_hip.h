@@ -71,6 +71,9 @@ int vatl_bn_fold(const float* gamma, const float* beta, const float* mean, const
  * Replaces Conv2d+BatchNorm2d(+add)(+ReLU) chains of Bottleneck.forward
  * (Resnet.py:104-128), ResNet.forward stem (Resnet.py:171-172) and
  * SimplePose.final_layer (simplepose.py:85). */
+/* Tuning knob (benchmarks / A-B tests only; results are identical for every setting):
+ * knob 0 = k-loop schedule of the conv kernel, value 0..2 (see csrc/conv_igemm.hip). */
+int vatl_tune_set(int knob, int value);
 /* CoutPad the packer must use for a given Cout (multiple of the kernel's N tile). */
 int vatl_conv_cout_pad(int Cout);
 int vatl_conv2d_fwd(const float* x, const float* w, const float* scale, const float* bias, const float* residual,

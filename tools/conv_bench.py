@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the implicit-GEMM conv kernel on the SimplePose-R50 layer shapes.
+
+    python tools/conv_bench.py [--batch 1024] [--iters 5] [--layers l3.n.c2,deconv3,...]
+
+Each shape is launched `iters` times back to back between two HIP events; prints
+TFLOP/s per shape (algorithmic FLOPs) — the tuning harness behind DESIGN.md §4.1.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "vatl4pose-wacv2024_amd")):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import vatl_hip as vh  # noqa: E402
+
+SHAPES = {  # name: (H, W, Cin, Cout, k, stride, residual)
+    "stem": (256, 192, 3, 64, 7, 2, False),
+    "l1.c1": (64, 48, 256, 64, 1, 1, False), "l1.c2": (64, 48, 64, 64, 3, 1, False), "l1.c3": (64, 48, 64, 256, 1, 1, True),
+    "l2.c1": (32, 24, 512, 128, 1, 1, False), "l2.c2": (32, 24, 128, 128, 3, 1, False), "l2.c3": (32, 24, 128, 512, 1, 1, True),
+    "l3.c1": (16, 12, 1024, 256, 1, 1, False), "l3.c2": (16, 12, 256, 256, 3, 1, False), "l3.c3": (16, 12, 256, 1024, 1, 1, True),
+    "l4.c1": (8, 6, 2048, 512, 1, 1, False), "l4.c2": (8, 6, 512, 512, 3, 1, False), "l4.c3": (8, 6, 512, 2048, 1, 1, True),
+    "l3.c2s2": (32, 24, 256, 256, 3, 2, False),
+    "deconv1": (8, 6, 2048, 256, 0, 0, False), "deconv3": (32, 24, 256, 256, 0, 0, False),
+    "head": (64, 48, 256, 17, 1, 1, False),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--layers", default="")
+    ap.add_argument("--vars", default="", help="comma list of k-loop schedule variants to A/B (vatl_tune_set knob 0)")
+    a = ap.parse_args()
+    if a.vars:
+        for v in a.vars.split(","):
+            var, _, order = v.partition(":")
+            print(f"--- schedule variant {var} tile-order {order or 0}")
+            vh.tune_set(0, int(var))
+            vh.tune_set(1, int(order or 0))
+            run(a)
+        return
+    run(a)
+
+
+def run(a):
+    dev = torch.device("cuda:0")
+    names = a.layers.split(",") if a.layers else list(SHAPES)
+    tot_f = tot_t = 0.0
+    for name in names:
+        H, W, cin, cout, k, stride, res = SHAPES[name]
+        B = a.batch
+        if k == 0:                                   # deconv 4x4/2
+            x = torch.randn((B, H, W, cin), device=dev)
+            w = vh.pack_deconv_weight(torch.randn((cin, cout, 4, 4), device=dev) * 0.01)
+            sc = torch.ones(cout, device=dev); bi = torch.zeros(cout, device=dev)
+            fn = lambda: vh.deconv4x4s2_fwd(x, w, sc, bi, cout, True)
+            flops = 2.0 * B * H * W * 16 * cin * cout
+        else:
+            cpad = 4 if cin == 3 else cin
+            x = torch.randn((B, H, W, cpad), device=dev)
+            w = vh.pack_conv_weight(torch.randn((cout, cin, k, k), device=dev) * 0.01)
+            sc = torch.ones(cout, device=dev); bi = torch.zeros(cout, device=dev)
+            Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+            r = torch.randn((B, Ho, Wo, cout), device=dev) if res else None
+            nchw = name == "head"
+            fn = lambda: vh.conv2d_fwd(x, w, sc, bi, cout, k, k, stride, k // 2, True, residual=r, out_nchw=nchw)
+            flops = 2.0 * B * Ho * Wo * cin * cout * k * k
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        tot_f += flops; tot_t += ms
+        print(f"{name:10s} {ms * 1e3:9.1f} us  {flops / ms / 1e9:7.1f} TF/s", flush=True)
+    print(f"sum: {tot_t:.2f} ms, {tot_f / tot_t / 1e9:.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()

@@ -54,7 +54,8 @@ struct ConvParams {
     int relu, out_nchw, deconv;
     int kpr;                          // k-tiles per filter tap  (Cin/32; 1 for the stem)
     int ktiles;                       // total k-tiles
-    int n_tiles;
+    int n_tiles, m_tiles;
+    int order;                        // tile order inside an XCD's run: 0 n-tile fastest, 1 m-tile fastest
     int K;                            // packed K per output channel
     unsigned x_bytes, w_bytes, y_bytes;   // buffer extents (hardware bounds checks: OOB loads read 0, OOB stores drop)
 };
@@ -78,7 +79,17 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned by
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, bool STEM>
+// VAR selects the k-loop schedule (tuning knob, see vatl_tune_set).  Measured on MI355X, 3x3 512->512
+// @8x6, batch 1024 (tools/conv_bench.py, TFLOP/s): VAR0 126, VAR2 132, VAR3 131, VAR4 138; ablations of
+// VAR2: no global loads / LDS writes 150, no barrier 130, no fragment reads 140 (profiles/r01_notes.md).
+//   0  two-phase: [address math + global loads] [64 MFMA with fragment reads] [LDS writes] barrier
+//   1  same work, branch-free body (tail tile loads are out-of-range offsets)
+//   2  fine-grained: the next tile's loads/address math and the next group's fragment reads are
+//      issued in the shadow of the MFMAs (one 32x32x2 MFMA occupies the matrix pipe for 64 cycles;
+//      the wave is free to issue other instructions meanwhile), pinned with sched_group_barrier
+//   3  2 + rotated loop (tile hand-over buried inside the last MFMA group)
+//   4  2 + distance-2 prefetch through two staging register sets (DEFAULT)
+template <int BM, int BN, int WM, int WN, bool STEM, int VAR>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                          // [2][BM][LDK]
@@ -100,8 +111,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3, q = nblk >> 3, r8 = nblk & 7;
     const int t = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
-    const int m_tile = t / p.n_tiles;
-    const int n_tile = t - m_tile * p.n_tiles;
+    int m_tile, n_tile;
+    if (p.order == 0) { m_tile = t / p.n_tiles; n_tile = t - m_tile * p.n_tiles; }
+    else              { n_tile = t / p.m_tiles; m_tile = t - n_tile * p.m_tiles; }
     const int m0 = m_tile * BM, n0 = n_tile * BN;
 
     int pad_y = p.pad_y, pad_x = p.pad_x, ooy = p.ooy, oox = p.oox;
@@ -143,23 +155,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     for (int j = 0; j < LB; ++j) boff[j] = (unsigned)(((n0 + lrow + 32 * j) * p.K + kq * 4) * 4);
 
     f32x4 ra[LA], rb[LB];
-    auto gload = [&](int kt) {
-        int r, s, off;
+    int g_r = 0, g_s = 0, g_off = 0;
+    auto gtap = [&](int kt) {          // filter tap / channel offset of k-tile kt (wave-uniform)
         if (STEM) {                    // k-tile = one filter row: 8 taps x 4 channels
-            r = kt; s = kq; off = r * p.W * p.Cin;
+            g_r = kt; g_s = kq; g_off = kt * p.W * p.Cin;
         } else {
             const int rs = kt / p.kpr;
             const int c0 = (kt - rs * p.kpr) * BK;
-            r = rs / p.S; s = rs - r * p.S;
-            off = (r * p.W + s) * p.Cin + c0;
+            g_r = rs / p.S; g_s = rs - g_r * p.S;
+            g_off = (g_r * p.W + g_s) * p.Cin + c0;
         }
+    };
+    auto gloadA = [&](int i, bool live) {
+        const bool ok = live && (unsigned)(iy0[i] + g_r) < (unsigned)p.H && (unsigned)(ix0[i] + g_s) < (unsigned)p.W;
+        ra[i] = buf_load4(xr, ok ? (unsigned)(abase[i] + g_off) << 2 : OOB);
+    };
+    auto gloadB = [&](int j, int kt, bool live) {
+        rb[j] = buf_load4(wr, live ? boff[j] + (unsigned)kt * (BK * 4) : OOB);
+    };
+    auto gload = [&](int kt, bool live) {
+        gtap(kt);
 #pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const bool ok = (unsigned)(iy0[i] + r) < (unsigned)p.H && (unsigned)(ix0[i] + s) < (unsigned)p.W;
-            ra[i] = buf_load4(xr, ok ? (unsigned)(abase[i] + off) << 2 : OOB);
-        }
+        for (int i = 0; i < LA; ++i) gloadA(i, live);
 #pragma unroll
-        for (int j = 0; j < LB; ++j) rb[j] = buf_load4(wr, boff[j] + (unsigned)kt * (BK * 4));
+        for (int j = 0; j < LB; ++j) gloadB(j, kt, live);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
@@ -181,33 +200,227 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     const int frow = lane & 31;
     const int fk = (lane >> 5) * 4;
 
-    gload(0);
+    gload(0, true);
     lstore(0);
     __syncthreads();
 
-    for (int kt = 0; kt < p.ktiles; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < p.ktiles;
-        if (more) gload(kt + 1);
-        const float* Ab = As + (buf * BM + wm * WM + frow) * LDK + fk;
-        const float* Bb = Bs + (buf * BN + wn * WN + frow) * LDK + fk;
+    auto frag_read = [&](f32x4 (&af)[TM], f32x4 (&bf)[TN], int buf, int g) {
+        const float* Ab = As + (buf * BM + wm * WM + frow) * LDK + fk + g * 8;
+        const float* Bb = Bs + (buf * BN + wn * WN + frow) * LDK + fk + g * 8;
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            f32x4 af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + g * 8);
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);
+    };
+    auto mfma_group = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + g * 8);
+        for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+    };
+
+    if (VAR == 0) {
+        for (int kt = 0; kt < p.ktiles; ++kt) {
+            const int buf = kt & 1;
+            const bool more = kt + 1 < p.ktiles;
+            if (more) gload(kt + 1, true);
+#pragma unroll
+            for (int g = 0; g < BK / 8; ++g) {
+                f32x4 af[TM], bf[TN];
+                frag_read(af, bf, buf, g);
+                mfma_group(af, bf);
+            }
+            if (more) lstore(buf ^ 1);
+            __syncthreads();
+        }
+    } else if (VAR == 1) {
+        for (int kt = 0; kt < p.ktiles; ++kt) {
+            const int buf = kt & 1;
+            gload(kt + 1, kt + 1 < p.ktiles);
+#pragma unroll
+            for (int g = 0; g < BK / 8; ++g) {
+                f32x4 af[TM], bf[TN];
+                frag_read(af, bf, buf, g);
+                mfma_group(af, bf);
+            }
+            lstore(buf ^ 1);                               // tail iteration stores zeros into the idle buffer
+            __syncthreads();
+        }
+    } else if (VAR == 4) {
+        // Distance-2 prefetch: tile kt+2 is requested while tile kt is multiplied and is written to
+        // LDS a full k-tile later (two staging register sets, loop unrolled by two so that the sets
+        // are statically indexed).  Covers L2-miss latency (MALL/HBM, ~2 us) with >= 4096 pipe cycles.
+        constexpr int NG = BK / 8;
+        constexpr int MPG = 4 * TM * TN;
+        f32x4 sa[2][LA], sb[2][LB];
+        auto issue = [&](f32x4 (&da)[LA], f32x4 (&db)[LB], int kt) {      // kt may be past the end: OOB loads
+            const bool live = kt < p.ktiles;
+            gtap(kt);
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                const bool ok = live && (unsigned)(iy0[i] + g_r) < (unsigned)p.H && (unsigned)(ix0[i] + g_s) < (unsigned)p.W;
+                da[i] = buf_load4(xr, ok ? (unsigned)(abase[i] + g_off) << 2 : OOB);
+            }
+#pragma unroll
+            for (int j = 0; j < LB; ++j) db[j] = buf_load4(wr, live ? boff[j] + (unsigned)kt * (BK * 4) : OOB);
+        };
+        auto stash = [&](const f32x4 (&da)[LA], const f32x4 (&db)[LB], int buf) {
+#pragma unroll
+            for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + 32 * i) * LDK + kq * 4]) = da[i];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + 32 * j) * LDK + kq * 4]) = db[j];
+        };
+        issue(sa[0], sb[0], 1);
+        for (int kt = 0; kt < p.ktiles; kt += 2) {
+            // step kt   : stash set0 (tile kt+1), request tile kt+2 into set1
+            // step kt+1 : stash set1 (tile kt+2), request tile kt+3 into set0
+            {
+                const int buf = kt & 1;
+                f32x4 af[2][TM], bf[2][TN];
+                frag_read(af[0], bf[0], buf, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g + 1 < NG) frag_read(af[(g + 1) & 1], bf[(g + 1) & 1], buf, g + 1);
+                    if (g == 0) issue(sa[1], sb[1], kt + 2);
+                    if (g == NG - 1) stash(sa[0], sb[0], buf ^ 1);
+                    mfma_group(af[g & 1], bf[g & 1]);
+                    if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+                    for (int q = 0; q < MPG; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x216, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();
+            }
+            if (kt + 1 < p.ktiles) {
+                const int buf = (kt + 1) & 1;
+                f32x4 af[2][TM], bf[2][TN];
+                frag_read(af[0], bf[0], buf, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g + 1 < NG) frag_read(af[(g + 1) & 1], bf[(g + 1) & 1], buf, g + 1);
+                    if (g == 0) issue(sa[0], sb[0], kt + 3);
+                    if (g == NG - 1) stash(sa[1], sb[1], buf ^ 1);
+                    mfma_group(af[g & 1], bf[g & 1]);
+                    if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+                    for (int q = 0; q < MPG; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x216, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();
+            }
+        }
+    } else if (VAR == 3) {
+        // Rotated loop: the tile hand-over (LDS writes, barrier, first fragment read of the next
+        // tile) is buried inside the last MFMA group instead of standing between two tiles.
+        //   g0..g2 : next group's fragment reads + (g0) the next tile's global loads, 16 MFMAs each
+        //   g3a    : LDS writes of the prefetched tile interleaved with the first 8 MFMAs of g3
+        //   barrier
+        //   g3b    : fragment reads of the NEXT tile's group 0, covered by the last 8 MFMAs of g3
+        constexpr int NG = BK / 8;
+        constexpr int MPG = 4 * TM * TN;
+        auto mfma_part = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int t0, int t1) {
+#pragma unroll
+            for (int tt = t0; tt < t1; ++tt)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+        };
+        f32x4 af[2][TM], bf[2][TN];
+        frag_read(af[0], bf[0], 0, 0);
+        for (int kt = 0; kt < p.ktiles; ++kt) {
+            const int buf = kt & 1;
+            const bool live = kt + 1 < p.ktiles;
+            gtap(kt + 1);
+#pragma unroll
+            for (int g = 0; g < NG - 1; ++g) {
+                frag_read(af[(g + 1) & 1], bf[(g + 1) & 1], buf, g + 1);
+                if (g == 0) {
+#pragma unroll
+                    for (int i = 0; i < LA; ++i) gloadA(i, live);
+#pragma unroll
+                    for (int j = 0; j < LB; ++j) gloadB(j, kt + 1, live);
+                }
+                mfma_group(af[g & 1], bf[g & 1]);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+                for (int q = 0; q < MPG; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x016, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // g3a: hand the prefetched tile to LDS under the first half of the last group
+            lstore(buf ^ 1);
+            mfma_part(af[(NG - 1) & 1], bf[(NG - 1) & 1], 0, 2);
+#pragma unroll
+            for (int q = 0; q < MPG / 2; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            // g3b: first fragments of the next tile, latency covered by the second half of the group
+            frag_read(af[0], bf[0], buf ^ 1, 0);
+            mfma_part(af[(NG - 1) & 1], bf[(NG - 1) & 1], 2, 4);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+            for (int q = 0; q < MPG / 2; ++q) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) lstore(buf ^ 1);
-        __syncthreads();
+        __syncthreads();                                   // stray next-tile fragment reads done before Cs is written
+    } else {
+        // VAR 2 = shipped schedule.  VAR 10/11/12 are ABLATIONS for profiling only (wrong results):
+        // 10 = no global loads / LDS writes, 11 = no barrier, 12 = no fragment reads in the loop.
+        constexpr bool NO_GL = VAR == 10, NO_BAR = VAR == 11, NO_FRAG = VAR == 12;
+        constexpr int NG = BK / 8;                          // 4 fragment groups per k-tile
+        constexpr int MPG = 4 * TM * TN;                    // MFMAs per group
+        f32x4 af[2][TM], bf[2][TN];
+        if (NO_FRAG) { frag_read(af[0], bf[0], 0, 0); frag_read(af[1], bf[1], 0, 1); }
+        for (int kt = 0; kt < p.ktiles; ++kt) {
+            const int buf = kt & 1;
+            const bool live = kt + 1 < p.ktiles;
+            if (!NO_FRAG) frag_read(af[0], bf[0], buf, 0);
+            gtap(kt + 1);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG && !NO_FRAG) frag_read(af[(g + 1) & 1], bf[(g + 1) & 1], buf, g + 1);
+                // the next tile's global loads ride in the first two groups (A then B) so that
+                // two groups of MFMAs (>= 2048 pipe cycles) cover their latency before the LDS writes
+                if (g == 0 && !NO_GL) {
+#pragma unroll
+                    for (int i = 0; i < LA; ++i) gloadA(i, live);
+                }
+                if (g == 1 && !NO_GL) {
+#pragma unroll
+                    for (int j = 0; j < LB; ++j) gloadB(j, kt + 1, live);
+                }
+                mfma_group(af[g & 1], bf[g & 1]);
+                // pin the interleave: fragment reads first, then MFMAs with the VALU/VMEM work in their shadow
+                if (g + 1 < NG && !NO_FRAG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+                for (int q = 0; q < MPG; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x016, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!NO_GL) lstore(buf ^ 1);
+            if (!NO_BAR) __syncthreads();
+        }
+        if (NO_BAR) __syncthreads();
     }
 
     // ---- epilogue -------------------------------------------------------------
@@ -307,9 +520,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool STEM>
+static std::atomic<int> g_var{4};      // k-loop schedule (vatl_tune_set(0, v)); 4 = shipped default
+static std::atomic<int> g_order{0};    // tile order (vatl_tune_set(1, v))
+
+template <int BM, int BN, int WM, int WN, bool STEM, int VAR>
 static int launch(const ConvParams& p, int phases, hipStream_t st) {
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM, VAR>;
     constexpr int smem = 2 * (BM + BN) * LDK * (int)sizeof(float);
     static std::atomic<int> configured{0};
     if (!configured.load(std::memory_order_acquire)) {
@@ -320,6 +536,8 @@ static int launch(const ConvParams& p, int phases, hipStream_t st) {
     }
     ConvParams q = p;
     q.n_tiles = p.CoutPad / BN;
+    q.m_tiles = cdiv(p.M, BM);
+    q.order = g_order.load(std::memory_order_relaxed);
     static_assert(2 * (BM + BN) * LDK >= BM * (BN + 4), "epilogue tile must fit in the staging buffers");
     const int m_tiles = cdiv(p.M, BM);
     dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, 1);
@@ -333,19 +551,42 @@ static int tile_n_for(int Cout) { return Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 12
 static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st) {
     const int bn = tile_n_for(p.Cout);
     if (p.CoutPad % bn != 0) return fail(VATL_EINVAL, "CoutPad %d must be a multiple of %d for Cout %d", p.CoutPad, bn, p.Cout);
+    const int var = g_var.load(std::memory_order_relaxed);
     if (stem) {
-        if (bn == 64) return launch<128, 64, 64, 32, true>(p, phases, st);
-        if (bn == 128) return launch<128, 128, 64, 64, true>(p, phases, st);
-        return launch<128, 32, 32, 32, true>(p, phases, st);
+        if (bn == 64) return launch<128, 64, 64, 32, true, 0>(p, phases, st);
+        if (bn == 128) return launch<128, 128, 64, 64, true, 0>(p, phases, st);
+        return launch<128, 32, 32, 32, true, 0>(p, phases, st);
     }
-    if (bn == 128) return launch<128, 128, 64, 64, false>(p, phases, st);
-    if (bn == 64) return launch<128, 64, 64, 32, false>(p, phases, st);
-    return launch<128, 32, 32, 32, false>(p, phases, st);
+    if (bn == 128) {
+        if (var == 1) return launch<128, 128, 64, 64, false, 1>(p, phases, st);
+        if (var == 2) return launch<128, 128, 64, 64, false, 2>(p, phases, st);
+        if (var == 3) return launch<128, 128, 64, 64, false, 3>(p, phases, st);
+        if (var == 4) return launch<128, 128, 64, 64, false, 4>(p, phases, st);
+        if (var == 10) return launch<128, 128, 64, 64, false, 10>(p, phases, st);
+        if (var == 11) return launch<128, 128, 64, 64, false, 11>(p, phases, st);
+        if (var == 12) return launch<128, 128, 64, 64, false, 12>(p, phases, st);
+        if (var == 0) return launch<128, 128, 64, 64, false, 0>(p, phases, st);
+        return launch<128, 128, 64, 64, false, 4>(p, phases, st);
+    }
+    if (bn == 64) {
+        if (var == 1) return launch<128, 64, 64, 32, false, 1>(p, phases, st);
+        if (var == 2) return launch<128, 64, 64, 32, false, 2>(p, phases, st);
+        if (var == 3) return launch<128, 64, 64, 32, false, 3>(p, phases, st);
+        if (var == 0) return launch<128, 64, 64, 32, false, 0>(p, phases, st);
+        return launch<128, 64, 64, 32, false, 4>(p, phases, st);
+    }
+    return launch<128, 32, 32, 32, false, 0>(p, phases, st);
 }
 
 }  // namespace vatl
 
 using namespace vatl;
+
+extern "C" int vatl_tune_set(int knob, int value) {
+    if (knob == 0 && value >= 0 && value <= 12) { g_var.store(value, std::memory_order_relaxed); return 0; }
+    if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }
+    return fail(VATL_EINVAL, "tune_set: unknown knob %d / value %d", knob, value);
+}
 
 extern "C" int vatl_conv_cout_pad(int Cout) {
     const int bn = tile_n_for(Cout);

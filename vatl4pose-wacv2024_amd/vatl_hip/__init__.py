@@ -30,6 +30,7 @@ SIGNATURES = {
     "vatl_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_pack_deconv4x4s2_weight": (_i, [_p, _p, _i, _i, _i, _p]),
     "vatl_bn_fold": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _i, _p]),
+    "vatl_tune_set": (_i, [_i, _i]),
     "vatl_conv_cout_pad": (_i, [_i]),
     "vatl_conv2d_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_deconv4x4s2_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -73,6 +74,8 @@ def lib() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        if os.environ.get("VATL_CONV_VAR"):          # A/B knob for benchmarks and tests (results are identical)
+            l.vatl_tune_set(0, int(os.environ["VATL_CONV_VAR"]))
     return _lib
 
 
@@ -114,6 +117,10 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
     _check(lib().vatl_nhwc_to_nchw(_ptr(x), _ptr(y), n, c, h, w, _stream()), "vatl_nhwc_to_nchw")
     return y
+
+
+def tune_set(knob: int, value: int):
+    _check(lib().vatl_tune_set(knob, value), "vatl_tune_set")
 
 
 def conv_cout_pad(cout: int) -> int:
