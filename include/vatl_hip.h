@@ -166,6 +166,55 @@ int vatl_hybrid_feature_f64(const double* kpts, const double* bbox_xywh, double*
 int vatl_localpeak_mask(const float* hm, uint8_t* mask, int planes, int H, int W, float order, void* stream);
 
 /* ------------------------------------------------------------------------ *
+ * Training-mode backbone (ActiveLearning.py:658-673: model.train(), loss.backward())
+ * ------------------------------------------------------------------------ */
+
+/* Generalised forward conv behind the data-gradient paths: explicit GEMM pixel grid Ho x Wo,
+ * separate paddings, and an output scatter (oy*osy+ooy, ox*osx+oox) into an OH x OW NHWC image
+ * (dgrad of a strided conv = per-parity launches over the output-gradient grid). Cin % 32 == 0. */
+int vatl_conv2d_fwd_ex(const float* x, const float* w, const float* scale, const float* bias, const float* residual, float* y,
+                       int N, int H, int W, int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad_y, int pad_x,
+                       int Ho, int Wo, int OH, int OW, int osy, int osx, int ooy, int oox, int relu, void* stream);
+/* Data-gradient weights of nn.Conv2d (Cout,Cin,R,S): out[c][t][n] = w[n][c][tap_r[t]][tap_s[t]],
+ * shape [CinPad][ntaps][CoutK] (rows c >= Cin and columns n >= Cout zero); tap_r/tap_s are HOST arrays,
+ * ntaps <= 16. */
+int vatl_pack_dgrad_weight(const float* w_oihw, float* out, int Cout, int Cin, int R, int S, int CinPad, int CoutK,
+                           int ntaps, const int* tap_r, const int* tap_s, void* stream);
+/* Weight gradient of nn.Conv2d: dw (Cout,Cin,R,S) = sum over pixels of dz (x) x.  x NHWC (N,H,W,Cin)
+ * (Cin = 3 means the 4-channel padded stem input), dz NHWC (N,Ho,Wo,CoutG) with channel stride
+ * CoutG >= Cout; workspace: vatl_conv2d_wgrad_workspace_floats floats.  fp32 MFMA, split over pixels,
+ * fp32 atomics (summation order across splits not fixed). */
+int64_t vatl_conv2d_wgrad_workspace_floats(int Cout, int Cin, int R, int S);
+int vatl_conv2d_wgrad(const float* x, const float* dz, float* dw, float* workspace, int N, int H, int W, int Cin,
+                      int Cout, int CoutG, int R, int S, int stride, int pad, void* stream);
+/* Weight gradient of nn.ConvTranspose2d(4,2,1): dw (Cin,Cout,4,4); x NHWC (N,H,W,Cin), dy NHWC (N,2H,2W,Cout). */
+int64_t vatl_deconv4x4s2_wgrad_workspace_floats(int Cin, int Cout);
+int vatl_deconv4x4s2_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int H, int W, int Cin,
+                           int Cout, void* stream);
+
+/* BatchNorm2d in training mode on NHWC rows (M = N*H*W, C): batch mean / biased variance ->
+ * save_mean, save_invstd and the affine (scale = gamma*invstd, bias = beta - mean*scale); running stats
+ * updated in place with `momentum` (unbiased variance), NULL to skip.  workspace:
+ * vatl_col_reduce_workspace_doubles(M, C) doubles.  (Resnet.py:67 etc. under model.train()) */
+int64_t vatl_col_reduce_workspace_doubles(int64_t M, int C);
+int vatl_bn_train_fwd_stats(const float* z, int64_t M, int C, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float momentum, float eps, float* save_mean, float* save_invstd,
+                            float* scale, float* bias, double* workspace, void* stream);
+/* y = act(z*scale[c] + bias[c] (+ residual)) on NHWC rows; C % 4 == 0. */
+int vatl_scale_bias_act(const float* z, const float* scale, const float* bias, const float* residual, float* y,
+                        int64_t M, int C, int relu, void* stream);
+/* Backward of BN(train)+ReLU: g = dy*[y>0] (y NULL: no ReLU), dbeta = sum g, dgamma = sum g*xhat,
+ * dz = gamma*invstd*(g - dbeta/M - xhat*dgamma/M); g_out (may be NULL) receives g (the gradient of a
+ * residual input).  coef3C: 3*C floats scratch; workspace as above. */
+int vatl_bn_train_bwd(const float* dy, const float* y_or_null, const float* z, const float* gamma, const float* save_mean,
+                      const float* save_invstd, float* dz, float* g_out_or_null, float* dgamma, float* dbeta,
+                      int64_t M, int C, float* coef3C, double* workspace, void* stream);
+/* MaxPool2d(3,2,1) backward on NHWC: x (N,H,W,C) forward input, dy (N,Ho,Wo,C) -> dx. */
+int vatl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* out[c] = sum over rows of x (M,C)  (conv bias gradient). */
+int vatl_col_sum(const float* x, int64_t M, int C, float* out, double* workspace, void* stream);
+
+/* ------------------------------------------------------------------------ *
  * Fine-tune step pieces (ActiveLearning.py:662-677)
  * ------------------------------------------------------------------------ */
 

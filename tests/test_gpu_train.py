@@ -1,0 +1,195 @@
+"""Training-mode kernels (BN batch stats, dgrad, wgrad, pool backward) vs torch-CPU autograd in float64,
+and one whole SimplePose-R50 fine-tune step vs the reference-generated golden step."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import synth
+from tests.gpu_util import dev, record, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vh():
+    import vatl_hip
+    vatl_hip.lib()
+    return vatl_hip
+
+
+def _nhwc(x):
+    return np.ascontiguousarray(np.transpose(x, (0, 2, 3, 1)))
+
+
+def _nchw(x):
+    return np.transpose(x, (0, 3, 1, 2))
+
+
+def test_bn_train_forward_backward(vh):
+    r = np.random.RandomState(0)
+    for (n, c, h, w, relu, skip) in ((3, 64, 9, 7, True, True), (2, 256, 8, 6, True, False), (2, 128, 5, 5, False, False)):
+        z = (r.standard_normal((n, c, h, w)) * 2 + 0.5).astype(np.float32)
+        res = r.standard_normal((n, c, h, w)).astype(np.float32) if skip else None
+        gamma, beta = r.uniform(0.5, 1.5, c).astype(np.float32), (0.1 * r.standard_normal(c)).astype(np.float32)
+        rm, rv = (0.1 * r.standard_normal(c)).astype(np.float32), r.uniform(0.5, 1.5, c).astype(np.float32)
+        dy = r.standard_normal((n, c, h, w)).astype(np.float32)
+        # reference (float64 autograd)
+        zt = torch.from_numpy(z).double().requires_grad_()
+        gt, bt = torch.from_numpy(gamma).double().requires_grad_(), torch.from_numpy(beta).double().requires_grad_()
+        rmt, rvt = torch.from_numpy(rm).double(), torch.from_numpy(rv).double()
+        rt = torch.from_numpy(res).double().requires_grad_() if skip else None
+        yt = F.batch_norm(zt, rmt, rvt, gt, bt, True, 0.1, 1e-5)
+        if skip:
+            yt = yt + rt
+        if relu:
+            yt = yt.relu()
+        yt.backward(torch.from_numpy(dy).double())
+        # HIP
+        zd = to_dev(_nhwc(z)); drm, drv = to_dev(rm), to_dev(rv)
+        mean, invstd, scale, bias = vh.bn_train_fwd_stats(zd, to_dev(gamma), to_dev(beta), drm, drv, 0.1, 1e-5)
+        y = vh.scale_bias_act(zd, scale, bias, to_dev(_nhwc(res)) if skip else None, relu)
+        assert rel_err(_nchw(y.cpu().numpy()), yt.detach().numpy()) < 1e-5
+        np.testing.assert_allclose(drm.cpu().numpy(), rmt.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(drv.cpu().numpy(), rvt.numpy(), rtol=1e-5, atol=1e-6)
+        dz, g, dgamma, dbeta = vh.bn_train_bwd(to_dev(_nhwc(dy)), y if relu else None, zd, to_dev(gamma), mean, invstd, want_g=skip)
+        assert rel_err(_nchw(dz.cpu().numpy()), zt.grad.numpy()) < 2e-5
+        assert rel_err(dgamma.cpu().numpy(), gt.grad.numpy()) < 2e-5 and rel_err(dbeta.cpu().numpy(), bt.grad.numpy()) < 2e-5
+        if skip:
+            assert rel_err(_nchw(g.cpu().numpy()), rt.grad.numpy()) < 1e-6
+
+
+GRAD_CASES = [  # name, N, H, W, Cin, Cout, k, stride, pad
+    ("1x1_256_64", 2, 16, 12, 256, 64, 1, 1, 0),
+    ("1x1_64_256", 2, 16, 12, 64, 256, 1, 1, 0),
+    ("3x3_64_64", 2, 16, 12, 64, 64, 3, 1, 1),
+    ("3x3_128_128", 3, 8, 6, 128, 128, 3, 1, 1),
+    ("3x3s2_128_128", 2, 16, 12, 128, 128, 3, 2, 1),
+    ("1x1s2_256_512", 2, 16, 12, 256, 512, 1, 2, 0),
+    ("3x3_512_512_oddM", 1, 8, 6, 512, 512, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", GRAD_CASES, ids=[c[0] for c in GRAD_CASES])
+def test_conv_dgrad_wgrad(vh, case):
+    from alphapose.models import hip_train
+    name, n, h, w, cin, cout, k, stride, pad = case
+    import zlib
+    r = np.random.RandomState(zlib.crc32(name.encode()) % 2 ** 31)
+    x = r.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (r.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    xt = torch.from_numpy(x).double().requires_grad_()
+    wtt = torch.from_numpy(wt).double().requires_grad_()
+    out = F.conv2d(xt, wtt, None, stride, pad)
+    dz = r.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(torch.from_numpy(dz).double())
+    conv = torch.nn.Conv2d(cin, cout, k, stride, pad, bias=False).to(dev())
+    conv.weight.data.copy_(torch.from_numpy(wt))
+    layer = hip_train._ConvBN(conv, torch.nn.BatchNorm2d(cout), False)
+    dzd = to_dev(_nhwc(dz))
+    dw = vh.conv2d_wgrad(vh.nchw_to_nhwc(to_dev(x)), dzd, cout, cin, k, k, stride, pad)
+    dx = layer._dgrad(dzd, (n, h, w, cin), None)
+    ew, ex = rel_err(dw.cpu().numpy(), wtt.grad.numpy()), rel_err(_nchw(dx.cpu().numpy()), xt.grad.numpy())
+    record("grad_" + name, wgrad_rel=ew, dgrad_rel=ex)
+    assert ew < 5e-5 and ex < 2e-5, (name, ew, ex)
+
+
+def test_stem_and_head_wgrad(vh):
+    r = np.random.RandomState(3)
+    x = r.standard_normal((2, 3, 32, 24)).astype(np.float32)
+    wt = (r.standard_normal((64, 3, 7, 7)) / 12).astype(np.float32)
+    xt, wtt = torch.from_numpy(x).double(), torch.from_numpy(wt).double().requires_grad_()
+    out = F.conv2d(xt, wtt, None, 2, 3)
+    dz = r.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(torch.from_numpy(dz).double())
+    dw = vh.conv2d_wgrad(vh.nchw_to_nhwc(to_dev(x), 4), to_dev(_nhwc(dz)), 64, 3, 7, 7, 2, 3)
+    assert rel_err(dw.cpu().numpy(), wtt.grad.numpy()) < 5e-5
+    # head: 17 output channels carried in a 32-channel NHWC gradient
+    x = r.standard_normal((2, 256, 16, 12)).astype(np.float32)
+    wt = (r.standard_normal((17, 256, 1, 1)) / 16).astype(np.float32)
+    xt, wtt = torch.from_numpy(x).double().requires_grad_(), torch.from_numpy(wt).double().requires_grad_()
+    bt = torch.zeros(17, dtype=torch.float64, requires_grad=True)
+    out = F.conv2d(xt, wtt, bt)
+    dy = r.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(torch.from_numpy(dy).double())
+    dyd = vh.nchw_to_nhwc(to_dev(dy), 32)
+    dw = vh.conv2d_wgrad(vh.nchw_to_nhwc(to_dev(x)), dyd, 17, 256, 1, 1, 1, 0)
+    assert rel_err(dw.cpu().numpy(), wtt.grad.numpy()) < 5e-5
+    assert rel_err(vh.col_sum(dyd).cpu().numpy()[:17], bt.grad.numpy()) < 1e-5
+    wd = vh.pack_dgrad_weight(to_dev(wt), [(0, 0)], cout_k=32)
+    dx = vh.conv2d_fwd_ex(dyd, wd, 256, 1, 1, 1, 0, 0, 16, 12, 16, 12, 1, 1, 0, 0)
+    assert rel_err(_nchw(dx.cpu().numpy()), xt.grad.numpy()) < 2e-5
+
+
+def test_deconv_backward(vh):
+    r = np.random.RandomState(4)
+    for (n, h, w, cin, cout) in ((2, 8, 6, 256, 128), (1, 5, 3, 64, 64)):
+        x = r.standard_normal((n, cin, h, w)).astype(np.float32)
+        wt = (r.standard_normal((cin, cout, 4, 4)) / np.sqrt(cin * 4)).astype(np.float32)
+        xt, wtt = torch.from_numpy(x).double().requires_grad_(), torch.from_numpy(wt).double().requires_grad_()
+        out = F.conv_transpose2d(xt, wtt, None, 2, 1)
+        dy = r.standard_normal(tuple(out.shape)).astype(np.float32)
+        out.backward(torch.from_numpy(dy).double())
+        dyd = to_dev(_nhwc(dy))
+        dw = vh.deconv4x4s2_wgrad(vh.nchw_to_nhwc(to_dev(x)), dyd)
+        dx = vh.conv2d_fwd(dyd, vh.pack_conv_weight(to_dev(wt)), None, None, cin, 4, 4, 2, 1, False)
+        assert rel_err(dw.cpu().numpy(), wtt.grad.numpy()) < 5e-5
+        assert rel_err(_nchw(dx.cpu().numpy()), xt.grad.numpy()) < 2e-5
+
+
+def test_maxpool_backward(vh):
+    r = np.random.RandomState(5)
+    for (n, c, h, w) in ((2, 64, 32, 24), (1, 8, 7, 5)):
+        x = np.round(r.standard_normal((n, c, h, w)) * 2).astype(np.float32) / 2          # ties inside windows
+        xt = torch.from_numpy(x).requires_grad_()
+        out = F.max_pool2d(xt, 3, 2, 1)
+        dy = r.standard_normal(tuple(out.shape)).astype(np.float32)
+        out.backward(torch.from_numpy(dy))
+        dx = vh.maxpool3x3s2_bwd(vh.nchw_to_nhwc(to_dev(x)), to_dev(_nhwc(dy)))
+        np.testing.assert_allclose(_nchw(dx.cpu().numpy()), xt.grad.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_simplepose_finetune_step_vs_reference_golden(vh, golden_simplepose):
+    """retrain_model's step (ActiveLearning.py:662-673): forward in train mode, 0.5*masked MSE, backward, AdamW with
+    the three reference param groups — against the step the reference itself took (tools/make_golden.py)."""
+    from active_learning.optim import AdamW
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    g = golden_simplepose
+    cfg = edict({"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50})
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    m = builder.build_sppe(cfg, preset_cfg=preset)
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    m = m.to(dev()).train()
+    lr, wd = 2.5e-4, 0.7
+    opt = AdamW(params=[{"params": m.final_layer.parameters(), "lr": lr * 10}, {"params": m.preact.parameters(), "lr": lr},
+                        {"params": m.deconv_layers.parameters(), "lr": lr * 5}], weight_decay=wd)
+    x = to_dev(synth.crops(2))
+    labels, masks = synth.gaussian_targets(2, seed=11)
+    labels, masks = to_dev(labels), to_dev(masks)
+    out = m(x.requires_grad_())
+    loss = 0.5 * torch.nn.MSELoss()(out.mul(masks), labels.mul(masks))                     # the reference's own expression
+    opt.zero_grad(); loss.backward(); opt.step()
+    torch.cuda.synchronize()
+    record("train_step", loss=float(loss), loss_ref=float(g["train_loss"]))
+    np.testing.assert_allclose(float(loss), float(g["train_loss"]), rtol=1e-4)
+    # fused loss kernel agrees with the torch expression
+    lk, gk = vh.masked_mse_fwd_bwd(out.detach().contiguous(), labels, masks)
+    np.testing.assert_allclose(float(lk), float(loss), rtol=1e-5)
+    named = dict(m.named_parameters())
+    sd = m.state_dict()
+    worst = 0.0
+    for key in [k[10:] for k in g.files if k.startswith("grad_idx::")]:
+        idx = g[f"grad_idx::{key}"]
+        got = named[key].grad.reshape(-1)[torch.from_numpy(idx).to(dev())].cpu().numpy()
+        ref = g[f"grad_val::{key}"]
+        e = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+        worst = max(worst, e)
+        record("train_grad", key=key, rel=e)
+        assert e < 2e-3, (key, e)
+        new = sd[key].reshape(-1)[torch.from_numpy(idx).to(dev())].cpu().numpy()
+        np.testing.assert_allclose(new, g[f"new_val::{key}"], rtol=1e-3, atol=2e-4)       # AdamW's first step is sign-like: lr-sized
+    for key in [k[8:] for k in g.files if k.startswith("bnstat::")]:
+        np.testing.assert_allclose(sd[key].cpu().numpy(), g[f"bnstat::{key}"], rtol=1e-4, atol=1e-5)
+    assert int(sd["preact.bn1.num_batches_tracked"]) == int(g["bn_tracked"])
+    record("train_step_worst_grad_rel", rel=worst)

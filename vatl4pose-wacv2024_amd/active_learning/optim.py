@@ -1,0 +1,42 @@
+"""Optimizers of the fine-tune step on MI355X (reference: ActiveLearning.py:219-231).
+
+``AdamW`` has torch.optim.AdamW's constructor and param-group semantics (the reference builds
+three groups with lr x{10, 1, 5}); ``step()`` launches ``vatl_adamw_step`` per parameter tensor
+instead of torch's element-wise kernels.  ``lr`` is read from the group at every step, so
+``torch.optim.lr_scheduler.ExponentialLR`` works on it unchanged.
+"""
+from __future__ import annotations
+
+import torch
+
+import vatl_hip as vh
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError("invalid AdamW hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                vh.adamw_step(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], st["step"], group["lr"],
+                              group["weight_decay"], group["betas"], group["eps"])
+                # the in-place update went through the C ABI: bump the version counter ourselves, the
+                # inference plans key their packed-weight caches on it
+                torch.autograd.graph.increment_version(p)
+        return loss

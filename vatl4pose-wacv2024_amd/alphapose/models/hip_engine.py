@@ -308,9 +308,6 @@ def _prepare_input(m: nn.Module, x: torch.Tensor):
     if not x.is_cuda:
         raise vh.VatlError("the pose network runs on MI355X only: move the model and inputs to a HIP device "
                            "(there is deliberately no CPU fallback)")
-    if m.training:
-        raise NotImplementedError("training-mode forward (batch-stat BN + autograd) is not part of this build yet; "
-                                  "call .eval() for inference")
     p = next(m.parameters())
     if p.device != x.device:
         raise vh.VatlError(f"model on {p.device}, input on {x.device}")
@@ -318,6 +315,9 @@ def _prepare_input(m: nn.Module, x: torch.Tensor):
 
 
 def run_module_nchw(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    if m.training:                                   # batch-statistics BN + backward tape (hip_train.py)
+        from . import hip_train
+        return hip_train.forward_train(m, x)
     x = _prepare_input(m, x)
     plan = _plan_for(m, x.device)
     if x.shape[0] <= MAX_CHUNK:
@@ -328,6 +328,8 @@ def run_module_nchw(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
 def forward_into(m: nn.Module, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """Heat-maps of ``x`` written straight into ``out`` (N,J,H/4,W/4), a contiguous fp32
     device tensor (e.g. a slice of a whole-video buffer): no concat / copy kernels."""
+    if m.training:
+        raise vh.VatlError("forward_into is an inference entry point: call model.eval() first")
     x = _prepare_input(m, x)
     plan = _plan_for(m, x.device)
     for i in range(0, x.shape[0], MAX_CHUNK):
@@ -337,6 +339,8 @@ def forward_into(m: nn.Module, x: torch.Tensor, out: torch.Tensor) -> torch.Tens
 
 def embedding(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
     """trunk -> global average pool -> (B, 2048)   (simplepose.py:88-91)."""
+    if m.training:
+        raise vh.VatlError("get_embedding is used in evaluation only (ActiveLearning.py:259,284): call model.eval() first")
     x = _prepare_input(m, x)
     plan = _plan_for(m, x.device)
     return torch.cat([vh.gap_fwd(plan.features(c)) for c in x.split(MAX_CHUNK)], 0)

@@ -1,0 +1,218 @@
+"""Training-mode forward and backward of the pose networks on libvatl_hip.so.
+
+What runs under ``model.train()`` in the reference's fine-tune loop
+(ActiveLearning.py:658-673): conv -> BatchNorm with *batch* statistics (+ running-stat
+update) -> ReLU, and the matching backward.  Every arithmetic step is a hand-written
+gfx950 kernel; torch only owns the buffers and (through one ``autograd.Function`` per
+network) receives the parameter gradients, so the reference's
+``loss.backward(); optimizer.step()`` works unchanged.
+
+Per Conv+BN(+add)(+ReLU) layer:
+  forward   z = conv(x) (fp32 MFMA implicit GEMM, no epilogue affine) ; batch mean/var over
+            N*H*W -> (scale, bias), running stats ; y = relu(z*scale + bias (+ skip))
+  backward  g = dy*[y>0] ; (dgamma, dbeta) ; dz = gamma*invstd*(g - dbeta/M - xhat*dgamma/M) ;
+            dW = wgrad(x, dz) (MFMA, split over pixels) ;
+            dx = conv(dz, flipped/transposed W) — for a stride-2 conv as per-parity launches over
+            the dz grid (no zero stuffing), the skip gradient rides in as the epilogue residual.
+Only SimplePose (ResNet bottlenecks + deconv head) is wired so far; FastPose / HRNet training is
+listed as next in DESIGN.md.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+import vatl_hip as vh
+
+
+def _flipped_taps(r, s):
+    return [(r - 1 - i, s - 1 - j) for i in range(r) for j in range(s)]
+
+
+class _ConvBN:
+    """Conv2d (bias-free) + BatchNorm2d(train) (+ residual) (+ ReLU)."""
+
+    def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, need_dx: bool = True):
+        self.conv, self.bn, self.relu, self.need_dx = conv, bn, relu, need_dx
+        self.cout, self.cin, self.r, self.s = conv.weight.shape
+        self.stride, self.pad = conv.stride[0], conv.padding[0]
+
+    # ---- forward -------------------------------------------------------------
+    def forward(self, x, skip=None):
+        w = vh.pack_conv_weight(self.conv.weight.detach())
+        z = vh.conv2d_fwd(x, w, None, None, self.cout, self.r, self.s, self.stride, self.pad, False)
+        bn = self.bn
+        mean, invstd, scale, bias = vh.bn_train_fwd_stats(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                                          bn.momentum, bn.eps)
+        bn.num_batches_tracked += 1
+        y = vh.scale_bias_act(z, scale, bias, skip, self.relu)
+        self.saved = (x, z, y if self.relu else None, mean, invstd, skip is not None)
+        return y
+
+    # ---- backward ------------------------------------------------------------
+    def backward(self, dy, grads, dx_residual=None):
+        """dy: gradient of the layer output.  Returns (dx, g_skip); parameter gradients go to ``grads``."""
+        x, z, y, mean, invstd, had_skip = self.saved
+        self.saved = None
+        dz, g, dgamma, dbeta = vh.bn_train_bwd(dy, y, z, self.bn.weight.detach(), mean, invstd, want_g=had_skip)
+        grads[self.bn.weight] = dgamma
+        grads[self.bn.bias] = dbeta
+        cin_w = 3 if self.cin == 3 else self.cin
+        grads[self.conv.weight] = vh.conv2d_wgrad(x, dz, self.cout, cin_w, self.r, self.s, self.stride, self.pad)
+        dx = self._dgrad(dz, x.shape, dx_residual) if self.need_dx else None
+        return dx, g
+
+    def _dgrad(self, dz, xshape, residual):
+        n, h, w, cin = xshape
+        wt = self.conv.weight.detach()
+        ho, wo = dz.shape[1], dz.shape[2]
+        if self.stride == 1:
+            wd = vh.pack_dgrad_weight(wt, _flipped_taps(self.r, self.s))
+            return vh.conv2d_fwd_ex(dz, wd, cin, self.r, self.s, 1, self.r - 1 - self.pad, self.s - 1 - self.pad, h, w, h, w, 1, 1, 0, 0,
+                                    residual=residual)
+        assert self.stride == 2 and h == 2 * ho and w == 2 * wo
+        if self.r == 1:                                   # 1x1/2 projection: only even pixels receive gradient
+            dx = torch.zeros((n, h, w, cin), device=dz.device, dtype=torch.float32) if residual is None else residual.clone()
+            wd = vh.pack_dgrad_weight(wt, [(0, 0)])
+            res_view = None
+            if residual is not None:
+                # even pixels: dx = W^T dz + residual; the kernel reads the residual at the scattered positions
+                res_view = residual
+            return vh.conv2d_fwd_ex(dz, wd, cin, 1, 1, 1, 0, 0, ho, wo, h, w, 2, 2, 0, 0, out=dx, residual=res_view)
+        assert self.r == 3 and self.pad == 1
+        dx = torch.empty((n, h, w, cin), device=dz.device, dtype=torch.float32)
+        for py in (0, 1):                                 # input-pixel parity -> which filter rows reach it
+            rows = [1] if py == 0 else [2, 0]             # dz row y+t  <->  filter row rows[t]
+            for px in (0, 1):
+                cols = [1] if px == 0 else [2, 0]
+                wd = vh.pack_dgrad_weight(wt, [(a, b) for a in rows for b in cols])
+                vh.conv2d_fwd_ex(dz, wd, cin, len(rows), len(cols), 1, 0, 0, ho, wo, h, w, 2, 2, py, px, out=dx, residual=residual)
+        return dx
+
+
+class _DeconvBN:
+    """ConvTranspose2d(4,2,1, bias-free) + BatchNorm2d(train) + ReLU."""
+
+    def __init__(self, dc: nn.ConvTranspose2d, bn: nn.BatchNorm2d):
+        self.dc, self.bn = dc, bn
+        self.cin, self.cout = dc.weight.shape[:2]
+
+    def forward(self, x):
+        z = vh.deconv4x4s2_fwd(x, vh.pack_deconv_weight(self.dc.weight.detach()), None, None, self.cout, False)
+        bn = self.bn
+        mean, invstd, scale, bias = vh.bn_train_fwd_stats(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                                          bn.momentum, bn.eps)
+        bn.num_batches_tracked += 1
+        y = vh.scale_bias_act(z, scale, bias, None, True)
+        self.saved = (x, z, y, mean, invstd)
+        return y
+
+    def backward(self, dy, grads):
+        x, z, y, mean, invstd = self.saved
+        self.saved = None
+        dz, _, dgamma, dbeta = vh.bn_train_bwd(dy, y, z, self.bn.weight.detach(), mean, invstd)
+        grads[self.bn.weight] = dgamma
+        grads[self.bn.bias] = dbeta
+        grads[self.dc.weight] = vh.deconv4x4s2_wgrad(x, dz)
+        # dx[y][x][ci] = sum_{ky,kx,co} dz[2y-1+ky][2x-1+kx][co] * W[ci][co][ky][kx]: a 4x4/2 pad-1 conv whose
+        # "OIHW" weight is the deconv weight itself (O = Cin, I = Cout)
+        wd = vh.pack_conv_weight(self.dc.weight.detach())
+        return vh.conv2d_fwd(dz, wd, None, None, self.cin, 4, 4, 2, 1, False)
+
+
+class _BottleneckT:
+    def __init__(self, blk):
+        self.c1 = _ConvBN(blk.conv1, blk.bn1, True)
+        self.c2 = _ConvBN(blk.conv2, blk.bn2, True)
+        self.c3 = _ConvBN(blk.conv3, blk.bn3, True)
+        self.proj = _ConvBN(blk.downsample[0], blk.downsample[1], False) if blk.downsample is not None else None
+
+    def forward(self, x):
+        skip = x if self.proj is None else self.proj.forward(x)
+        return self.c3.forward(self.c2.forward(self.c1.forward(x)), skip=skip)
+
+    def backward(self, dy, grads):
+        db, g = self.c3.backward(dy, grads)                # g = gradient of the skip input (masked dy)
+        da, _ = self.c2.backward(db, grads)
+        dskip = g if self.proj is None else self.proj.backward(g, grads)[0]
+        dx, _ = self.c1.backward(da, grads, dx_residual=dskip)   # dx = dgrad(c1) + dskip in one epilogue
+        return dx
+
+
+class SimplePoseTrainer:
+    """Tape-based forward/backward of SimplePose in training mode."""
+
+    def __init__(self, m):
+        t = m.preact
+        self.m = m
+        self.stem = _ConvBN(t.conv1, t.bn1, True, need_dx=False)   # the input gradient is never read
+        self.blocks = [_BottleneckT(b) for stage in t.stages() for b in stage]
+        d = m.deconv_layers
+        self.deconvs = [_DeconvBN(d[0], d[1]), _DeconvBN(d[3], d[4]), _DeconvBN(d[6], d[7])]
+        self.head = m.final_layer
+
+    def forward(self, x_nchw):
+        x = vh.nchw_to_nhwc(x_nchw, 4)
+        s = self.stem.forward(x)
+        p = vh.maxpool3x3s2_fwd(s)
+        self.pool_in = s
+        x = p
+        for b in self.blocks:
+            x = b.forward(x)
+        for d in self.deconvs:
+            x = d.forward(x)
+        self.head_in = x
+        hw = vh.pack_conv_weight(self.head.weight.detach())
+        _, hb = vh.bn_fold(None, None, None, None, 0.0, self.head.bias.detach(), channels=self.head.weight.shape[0])
+        return vh.conv2d_fwd(x, hw, None, hb, self.head.weight.shape[0], 1, 1, 1, 0, False, out_nchw=True)
+
+    def backward(self, dout_nchw):
+        """dout (B,J,H,W) NCHW -> {parameter: gradient} for every parameter of the model."""
+        grads = {}
+        j = self.head.weight.shape[0]
+        cin = self.head.weight.shape[1]
+        dy = vh.nchw_to_nhwc(dout_nchw.contiguous(), 32)                         # 17 -> 32 channels (zeros)
+        grads[self.head.bias] = vh.col_sum(dy)[:j].contiguous()
+        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, 1, 1, 1, 0)
+        wd = vh.pack_dgrad_weight(self.head.weight.detach(), [(0, 0)], cout_k=32)
+        n, h, w, _ = self.head_in.shape
+        dx = vh.conv2d_fwd_ex(dy, wd, cin, 1, 1, 1, 0, 0, h, w, h, w, 1, 1, 0, 0)
+        self.head_in = None
+        for d in reversed(self.deconvs):
+            dx = d.backward(dx, grads)
+        for b in reversed(self.blocks):
+            dx = b.backward(dx, grads)
+        dx = vh.maxpool3x3s2_bwd(self.pool_in, dx)
+        self.pool_in = None
+        self.stem.backward(dx, grads)
+        return grads
+
+
+class _TrainFn(torch.autograd.Function):
+    """Bridges the HIP forward/backward into torch autograd so that the reference's
+    `loss.backward()` fills `.grad` of every parameter (ActiveLearning.py:669-673)."""
+
+    @staticmethod
+    def forward(ctx, x, trainer, *params):
+        ctx.trainer, ctx.params = trainer, params
+        with torch.no_grad():
+            return trainer.forward(x)
+
+    @staticmethod
+    def backward(ctx, dout):
+        with torch.no_grad():
+            grads = ctx.trainer.backward(dout.contiguous().float())
+        return (None, None) + tuple(grads.get(p) for p in ctx.params)
+
+
+def forward_train(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    from .simplepose import SimplePose
+    if not isinstance(m, SimplePose):
+        raise NotImplementedError(f"training-mode HIP path is implemented for SimplePose only, not {type(m).__name__}")
+    if not x.is_cuda:
+        raise vh.VatlError("the pose network trains on MI355X only (there is deliberately no CPU fallback)")
+    tr = m.__dict__.get("_vatl_trainer")
+    if tr is None:
+        tr = m.__dict__["_vatl_trainer"] = SimplePoseTrainer(m)
+    params = tuple(p for p in m.parameters() if p.requires_grad)
+    return _TrainFn.apply(x.detach().float().contiguous(), tr, *params)

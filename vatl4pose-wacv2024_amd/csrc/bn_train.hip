@@ -1,0 +1,252 @@
+// Training-mode BatchNorm2d forward/backward on NHWC (M = N*H*W rows, C channels) and the
+// other HBM-bound pieces of the fine-tune step (ActiveLearning.py:658-673 with model.train()):
+//   forward   batch mean / biased variance -> per-channel (scale, bias); running-stat update
+//             (momentum 0.1, unbiased variance into running_var); y = act(z*scale + bias (+ res))
+//   backward  g = dy * [y > 0];  dbeta = sum g;  dgamma = sum g * xhat;
+//             dz = gamma*invstd * (g - dbeta/M - xhat*dgamma/M)  = A[c]*g + B[c]*z + C[c]
+//   max-pool 3x3/2 backward, per-channel column sums (conv bias gradient).
+// Reductions are two-stage (per-block double partials, then a finalize kernel): deterministic.
+#include "common.h"
+
+namespace vatl {
+
+constexpr int ROWS_PER_BLOCK = 512;      // rows reduced by one block of the column-reduction kernels
+constexpr int CH_PER_BLOCK = 64;
+
+// partial[(rb * C + c) * 2 + {0,1}] = sum, sum of squares over the block's rows
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ z, double* __restrict__ partial, long long M, int C) {
+    const int c = blockIdx.y * CH_PER_BLOCK + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.x * ROWS_PER_BLOCK;
+    const long long r1 = r0 + ROWS_PER_BLOCK < M ? r0 + ROWS_PER_BLOCK : M;
+    float s = 0.f, q = 0.f;
+    if (c < C)
+        for (long long r = r0 + rl; r < r1; r += 4) { const float v = z[r * C + c]; s += v; q += v * v; }
+    __shared__ double sh[2][4][64];
+    sh[0][rl][threadIdx.x & 63] = s; sh[1][rl][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const int l = threadIdx.x & 63;
+        partial[((long long)blockIdx.x * C + c) * 2 + 0] = sh[0][0][l] + sh[0][1][l] + sh[0][2][l] + sh[0][3][l];
+        partial[((long long)blockIdx.x * C + c) * 2 + 1] = sh[1][0][l] + sh[1][1][l] + sh[1][2][l] + sh[1][3][l];
+    }
+}
+
+__global__ void bn_train_finalize_kernel(const double* __restrict__ partial, int nrb, long long M, int C,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                         float* __restrict__ scale, float* __restrict__ bias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int rb = 0; rb < nrb; ++rb) { s += partial[((long long)rb * C + c) * 2]; q += partial[((long long)rb * C + c) * 2 + 1]; }
+    const double mean = s / (double)M;
+    double var = q / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = (float)mean;
+    save_invstd[c] = invstd;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = g * invstd;
+    bias[c] = b - (float)mean * g * invstd;
+    if (running_mean) {
+        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// y = act(z*scale[c] + bias[c] (+ res))
+__global__ void scale_bias_act_kernel(const float* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ bias,
+                                      const float* __restrict__ res, float* __restrict__ y, long long n4, int C4, int relu) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(z + i * 4);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c4 * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[e] * s[e] + b[e];
+        if (res) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(res + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += r[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = o;
+    }
+}
+
+// partial sums of g and g*xhat,  g = dy * [y > 0] (mask only when y != nullptr)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            double* __restrict__ partial, long long M, int C) {
+    const int c = blockIdx.y * CH_PER_BLOCK + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.x * ROWS_PER_BLOCK;
+    const long long r1 = r0 + ROWS_PER_BLOCK < M ? r0 + ROWS_PER_BLOCK : M;
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+        const float mu = mean[c], is = invstd[c];
+        for (long long r = r0 + rl; r < r1; r += 4) {
+            float g = dy[r * C + c];
+            if (y && !(y[r * C + c] > 0.f)) g = 0.f;
+            s += g; q += g * ((z[r * C + c] - mu) * is);
+        }
+    }
+    __shared__ double sh[2][4][64];
+    sh[0][rl][threadIdx.x & 63] = s; sh[1][rl][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const int l = threadIdx.x & 63;
+        partial[((long long)blockIdx.x * C + c) * 2 + 0] = sh[0][0][l] + sh[0][1][l] + sh[0][2][l] + sh[0][3][l];
+        partial[((long long)blockIdx.x * C + c) * 2 + 1] = sh[1][0][l] + sh[1][1][l] + sh[1][2][l] + sh[1][3][l];
+    }
+}
+
+// dgamma, dbeta and the coefficients of dz = A*g + B*z + Cc
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nrb, long long M, int C, const float* __restrict__ gamma,
+                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coefA,
+                                       float* __restrict__ coefB, float* __restrict__ coefC) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sg = 0.0, sgx = 0.0;
+    for (int rb = 0; rb < nrb; ++rb) { sg += partial[((long long)rb * C + c) * 2]; sgx += partial[((long long)rb * C + c) * 2 + 1]; }
+    if (dbeta) dbeta[c] = (float)sg;
+    if (dgamma) dgamma[c] = (float)sgx;
+    const double s = (double)(gamma ? gamma[c] : 1.f) * (double)invstd[c];
+    const double kb = -s * (double)invstd[c] * sgx / (double)M;
+    coefA[c] = (float)s;
+    coefB[c] = (float)kb;
+    coefC[c] = (float)(-s * sg / (double)M - kb * (double)mean[c]);
+}
+
+// dz = A[c]*g + B[c]*z + C[c], g = dy*[y>0]; optionally also stores g (gradient of the skip connection)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
+                                    const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ Cc,
+                                    float* __restrict__ dz, float* __restrict__ gout, long long n4, int C4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+        if (y) {
+            const f32x4 yy = *reinterpret_cast<const f32x4*>(y + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
+        }
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + i * 4);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(A + c4 * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(B + c4 * 4);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(Cc + c4 * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = a[e] * g[e] + b[e] * zz[e] + c[e];
+        *reinterpret_cast<f32x4*>(dz + i * 4) = o;
+        if (gout) *reinterpret_cast<f32x4*>(gout + i * 4) = g;
+    }
+}
+
+// MaxPool2d(3,2,1) backward on NHWC: each input pixel collects dy of the windows whose FIRST maximum
+// (row-major scan of the window, like ATen) it is.
+__global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                        int N, int H, int W, int C, int Ho, int Wo) {
+    const long long total = (long long)N * H * W * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const long long n = t / H;
+        float acc = 0.f;
+        // windows (oy, ox) with 2*oy-1 <= iy <= 2*oy+1
+        for (int oy = (iy >> 1); oy <= ((iy + 1) >> 1); ++oy) {
+            if (oy >= Ho) continue;
+            for (int ox = (ix >> 1); ox <= ((ix + 1) >> 1); ++ox) {
+                if (ox >= Wo) continue;
+                float best = -INFINITY; int by = -1, bx = -1;
+                for (int dy_ = 0; dy_ < 3; ++dy_) {
+                    const int yy = 2 * oy - 1 + dy_;
+                    if ((unsigned)yy >= (unsigned)H) continue;
+                    for (int dx_ = 0; dx_ < 3; ++dx_) {
+                        const int xx = 2 * ox - 1 + dx_;
+                        if ((unsigned)xx >= (unsigned)W) continue;
+                        const float v = x[((n * H + yy) * W + xx) * C + c];
+                        if (v > best || by < 0) { best = v; by = yy; bx = xx; }
+                    }
+                }
+                if (by == iy && bx == ix) acc += dy[((n * Ho + oy) * Wo + ox) * C + c];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+// out[c] = sum over rows of x[r][c]  (conv bias gradient); same two-stage scheme
+__global__ void col_sum_finalize_kernel(const double* __restrict__ partial, int nrb, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int rb = 0; rb < nrb; ++rb) s += partial[((long long)rb * C + c) * 2];
+    out[c] = (float)s;
+}
+
+static inline int ew_grid(long long n) { long long g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (int)g; }
+
+}  // namespace vatl
+
+using namespace vatl;
+
+extern "C" int64_t vatl_col_reduce_workspace_doubles(int64_t M, int C) { return 2 * ((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * (int64_t)C; }
+
+extern "C" int vatl_bn_train_fwd_stats(const float* z, int64_t M, int C, const float* gamma, const float* beta, float* running_mean,
+                                       float* running_var, float momentum, float eps, float* save_mean, float* save_invstd,
+                                       float* scale, float* bias, double* workspace, void* stream) {
+    if (!z || !save_mean || !save_invstd || !scale || !bias || !workspace || M <= 0) return fail(VATL_EINVAL, "bn_train_fwd_stats: bad arguments");
+    const int nrb = cdiv(M, ROWS_PER_BLOCK);
+    hipLaunchKernelGGL(col_stats_kernel, dim3(nrb, cdiv(C, CH_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, z, workspace, (long long)M, C);
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, workspace, nrb, (long long)M, C, gamma, beta,
+                       running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, bias);
+    return check_launch("bn_train_fwd_stats");
+}
+
+extern "C" int vatl_scale_bias_act(const float* z, const float* scale, const float* bias, const float* residual, float* y,
+                                   int64_t M, int C, int relu, void* stream) {
+    if (!z || !scale || !bias || !y || (C & 3)) return fail(VATL_EINVAL, "scale_bias_act: bad arguments");
+    const long long n4 = M * C / 4;
+    hipLaunchKernelGGL(scale_bias_act_kernel, dim3(ew_grid(n4)), dim3(256), 0, (hipStream_t)stream, z, scale, bias, residual, y, n4, C / 4, relu);
+    return check_launch("scale_bias_act");
+}
+
+extern "C" int vatl_bn_train_bwd(const float* dy, const float* y_or_null, const float* z, const float* gamma, const float* save_mean,
+                                 const float* save_invstd, float* dz, float* g_out_or_null, float* dgamma, float* dbeta,
+                                 int64_t M, int C, float* coef3C, double* workspace, void* stream) {
+    if (!dy || !z || !save_mean || !save_invstd || !dz || !coef3C || !workspace || (C & 3) || M <= 0)
+        return fail(VATL_EINVAL, "bn_train_bwd: bad arguments");
+    const int nrb = cdiv(M, ROWS_PER_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nrb, cdiv(C, CH_PER_BLOCK)), dim3(256), 0, st, dy, y_or_null, z, save_mean, save_invstd, workspace, (long long)M, C);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, workspace, nrb, (long long)M, C, gamma, save_mean, save_invstd,
+                       dgamma, dbeta, coef3C, coef3C + C, coef3C + 2 * C);
+    const long long n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, y_or_null, z, coef3C, coef3C + C, coef3C + 2 * C, dz, g_out_or_null, n4, C / 4);
+    return check_launch("bn_train_bwd");
+}
+
+extern "C" int vatl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    if (!x || !dy || !dx) return fail(VATL_EINVAL, "maxpool3x3s2_bwd: null pointer");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(ew_grid((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C, Ho, Wo);
+    return check_launch("maxpool3x3s2_bwd");
+}
+
+extern "C" int vatl_col_sum(const float* x, int64_t M, int C, float* out, double* workspace, void* stream) {
+    if (!x || !out || !workspace || M <= 0) return fail(VATL_EINVAL, "col_sum: bad arguments");
+    const int nrb = cdiv(M, ROWS_PER_BLOCK);
+    hipLaunchKernelGGL(col_stats_kernel, dim3(nrb, cdiv(C, CH_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, x, workspace, (long long)M, C);
+    hipLaunchKernelGGL(col_sum_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, workspace, nrb, C, out);
+    return check_launch("col_sum");
+}

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? p.y_bytes : 0u, 0x00020000);
     const float lo = p.relu ? 0.f : -INFINITY;
     const int OHW = p.OH * p.OW;
-    const bool plain = !p.deconv;                      // NHWC output row index == m
+    const bool plain = !p.deconv && p.osy == 1 && p.osx == 1 && p.OH == p.Ho && p.OW == p.Wo;   // NHWC output row index == m
     if (!p.out_nchw && (p.Cout & 3) == 0) {
         constexpr int C4 = BN / 4;                     // float4 columns per tile row
         constexpr int RPP = 256 / C4;                  // tile rows per pass
@@ -635,4 +635,28 @@ extern "C" int vatl_deconv4x4s2_fwd(const float* x, const float* w, const float*
         return fail(VATL_EINVAL, "deconv4x4s2_fwd: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
     p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.w_bytes = (unsigned)(we * 4);   // w: one phase
     return dispatch(p, 4, false, (hipStream_t)stream);
+}
+
+// General form behind the data-gradient paths: explicit GEMM pixel grid (Ho x Wo), separate paddings and an
+// output scatter (oy*osy+ooy, ox*osx+oox) into an OH x OW image.  Transposed-conv style gradients are
+// phase-decomposed by the caller (alphapose/models/hip_train.py): e.g. the data gradient of a 3x3/2 conv is
+// four launches with 1x1 / 1x2 / 2x1 / 2x2 taps over the output-gradient grid, scattered with osy = osx = 2.
+extern "C" int vatl_conv2d_fwd_ex(const float* x, const float* w, const float* scale, const float* bias, const float* residual, float* y,
+                                  int N, int H, int W, int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad_y, int pad_x,
+                                  int Ho, int Wo, int OH, int OW, int osy, int osx, int ooy, int oox, int relu, void* stream) {
+    if (!x || !w || !y || N <= 0) return fail(VATL_EINVAL, "conv2d_fwd_ex: null pointer or empty batch");
+    if (Cin % 32 != 0) return fail(VATL_EINVAL, "conv2d_fwd_ex: Cin %d must be a multiple of 32", Cin);
+    ConvParams p{};
+    p.x = x; p.w = w; p.scale = scale; p.bias = bias; p.res = residual; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.CoutPad = CoutPad;
+    p.R = R; p.S = S; p.stride = stride; p.pad_y = pad_y; p.pad_x = pad_x;
+    p.Ho = Ho; p.Wo = Wo; p.M = N * Ho * Wo;
+    p.OH = OH; p.OW = OW; p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox;
+    p.relu = relu; p.out_nchw = 0; p.deconv = 0;
+    p.kpr = Cin / BK; p.ktiles = R * S * p.kpr; p.K = R * S * Cin;
+    const long long xe = (long long)N * H * W * Cin, ye = (long long)N * OH * OW * Cout, we = (long long)CoutPad * p.K;
+    if (xe >= (1LL << 30) || ye >= (1LL << 30) || we >= (1LL << 30))
+        return fail(VATL_EINVAL, "conv2d_fwd_ex: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
+    p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.w_bytes = (unsigned)(we * 4);
+    return dispatch(p, 1, false, (hipStream_t)stream);
 }

@@ -191,6 +191,20 @@ __global__ void fuse_up_kernel(const float* __restrict__ base, FuseUpArgs a, flo
     }
 }
 
+// data-gradient weights: out[c][t][n] = w[n][c][tap_r[t]][tap_s[t]]  ([CinPad][ntaps][Cout], rows c >= Cin zero)
+struct TapList { int r[16]; int s[16]; int n; };
+__global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int R, int S, int CinPad,
+                                         int CoutK, TapList taps) {
+    const long long total = (long long)CinPad * taps.n * CoutK;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % CoutK);
+        long long t = i / CoutK;
+        const int tp = (int)(t % taps.n);
+        const int c = (int)(t / taps.n);
+        out[i] = (c < Cin && n < Cout) ? w[(((long long)n * Cin + c) * R + taps.r[tp]) * S + taps.s[tp]] : 0.f;
+    }
+}
+
 static inline int grid_for(long long total, int block = 256) {
     long long g = (total + block - 1) / block;
     if (g > 256 * 16) g = 256 * 16;
@@ -276,4 +290,17 @@ extern "C" int vatl_fuse_upsample_add(const float* base, const float* z0, int sh
     }
     hipLaunchKernelGGL(fuse_up_kernel, dim3(grid_for((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, base, a, y, N, H, W, C, relu);
     return check_launch("fuse_upsample_add");
+}
+
+extern "C" int vatl_pack_dgrad_weight(const float* w_oihw, float* out, int Cout, int Cin, int R, int S, int CinPad, int CoutK,
+                                      int ntaps, const int* tap_r, const int* tap_s, void* stream) {
+    if (!w_oihw || !out || !tap_r || !tap_s || ntaps < 1 || ntaps > 16 || CinPad < Cin || CoutK < Cout) return fail(VATL_EINVAL, "pack_dgrad_weight: bad arguments");
+    TapList t{};
+    t.n = ntaps;
+    for (int i = 0; i < ntaps; ++i) {
+        if (tap_r[i] < 0 || tap_r[i] >= R || tap_s[i] < 0 || tap_s[i] >= S) return fail(VATL_EINVAL, "pack_dgrad_weight: tap %d out of range", i);
+        t.r[i] = tap_r[i]; t.s[i] = tap_s[i];
+    }
+    hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3(grid_for((long long)CinPad * ntaps * CoutK)), dim3(256), 0, (hipStream_t)stream, w_oihw, out, Cout, Cin, R, S, CinPad, CoutK, t);
+    return check_launch("pack_dgrad_weight");
 }

@@ -49,6 +49,18 @@ SIGNATURES = {
     "vatl_ae_forward": (_i, [_p, _p, _i, _i, _p, _p, _i, _p]),
     "vatl_hybrid_feature_f64": (_i, [_p, _p, _p, _p, _i, _p]),
     "vatl_localpeak_mask": (_i, [_p, _p, _i, _i, _i, _f, _p]),
+    "vatl_conv2d_fwd_ex": (_i, [_p] * 6 + [_i] * 20 + [_p]),
+    "vatl_pack_dgrad_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "vatl_conv2d_wgrad_workspace_floats": (_i64, [_i, _i, _i, _i]),
+    "vatl_conv2d_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vatl_deconv4x4s2_wgrad_workspace_floats": (_i64, [_i, _i]),
+    "vatl_deconv4x4s2_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vatl_col_reduce_workspace_doubles": (_i64, [_i64, _i]),
+    "vatl_bn_train_fwd_stats": (_i, [_p, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "vatl_scale_bias_act": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _p]),
+    "vatl_bn_train_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p]),
+    "vatl_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "vatl_col_sum": (_i, [_p, _i64, _i, _p, _p, _p]),
     "vatl_masked_mse_workspace_floats": (_i64, [_i64]),
     "vatl_masked_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vatl_adamw_step": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _p]),
@@ -338,6 +350,105 @@ def localpeak_mask(hm: torch.Tensor, order: float = 0.5) -> torch.Tensor:
     mask = torch.empty(hm.shape, device=hm.device, dtype=torch.uint8)
     _check(lib().vatl_localpeak_mask(_ptr(hm), _ptr(mask, torch.uint8), planes, h, w, order, _stream()), "vatl_localpeak_mask")
     return mask
+
+
+# ----------------------------------------------------------------------------
+# training-mode backbone ops (NHWC)
+# ----------------------------------------------------------------------------
+
+def conv2d_fwd_ex(x, w_packed, cout, r, s, stride, pad_y, pad_x, ho, wo, oh, ow, osy, osx, ooy, oox, out=None, residual=None,
+                  scale=None, bias=None, relu=False):
+    n, h, w, cin = x.shape
+    y = out if out is not None else torch.empty((n, oh, ow, cout), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_conv2d_fwd_ex(_ptr(x), _ptr(w_packed), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(y), n, h, w, cin, cout,
+                                    w_packed.shape[0], r, s, stride, pad_y, pad_x, ho, wo, oh, ow, osy, osx, ooy, oox, int(relu), _stream()),
+           "vatl_conv2d_fwd_ex")
+    return y
+
+
+def pack_dgrad_weight(w: torch.Tensor, taps, cout_k: int | None = None) -> torch.Tensor:
+    """(Cout,Cin,R,S) -> [CinPad][len(taps)][CoutK] with out[c][t][n] = w[n][c][taps[t]]."""
+    cout, cin, r, s = w.shape
+    cinpad = conv_cout_pad(cin)
+    cout_k = cout_k or cout
+    out = torch.empty((cinpad, len(taps), cout_k), device=w.device, dtype=torch.float32)
+    tr = (C.c_int * len(taps))(*[t[0] for t in taps])
+    ts = (C.c_int * len(taps))(*[t[1] for t in taps])
+    _check(lib().vatl_pack_dgrad_weight(_ptr(w.contiguous()), _ptr(out), cout, cin, r, s, cinpad, cout_k, len(taps),
+                                        C.cast(tr, C.c_void_p), C.cast(ts, C.c_void_p), _stream()), "vatl_pack_dgrad_weight")
+    return out
+
+
+def conv2d_wgrad(x, dz, cout: int, cin: int, r: int, s: int, stride: int, pad: int) -> torch.Tensor:
+    """x NHWC (N,H,W,Cin or 4 for the stem), dz NHWC (N,Ho,Wo,CoutG) -> dw (Cout,Cin,R,S)."""
+    n, h, w, _ = x.shape
+    dw = torch.empty((cout, cin, r, s), device=x.device, dtype=torch.float32)
+    ws = torch.empty(int(lib().vatl_conv2d_wgrad_workspace_floats(cout, cin, r, s)), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_conv2d_wgrad(_ptr(x), _ptr(dz), _ptr(dw), _ptr(ws), n, h, w, cin, cout, dz.shape[3], r, s, stride, pad, _stream()),
+           "vatl_conv2d_wgrad")
+    return dw
+
+
+def deconv4x4s2_wgrad(x, dy) -> torch.Tensor:
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    dw = torch.empty((cin, cout, 4, 4), device=x.device, dtype=torch.float32)
+    ws = torch.empty(int(lib().vatl_deconv4x4s2_wgrad_workspace_floats(cin, cout)), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_deconv4x4s2_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), n, h, w, cin, cout, _stream()), "vatl_deconv4x4s2_wgrad")
+    return dw
+
+
+def _col_ws(m: int, c: int, device):
+    return torch.empty(int(lib().vatl_col_reduce_workspace_doubles(m, c)), device=device, dtype=torch.float64)
+
+
+def bn_train_fwd_stats(z, gamma, beta, running_mean, running_var, momentum: float, eps: float):
+    """z NHWC (..., C) -> save_mean, save_invstd, scale, bias (C,); running stats updated in place."""
+    c = z.shape[-1]
+    m = z.numel() // c
+    outs = [torch.empty(c, device=z.device, dtype=torch.float32) for _ in range(4)]
+    _check(lib().vatl_bn_train_fwd_stats(_ptr(z), m, c, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), momentum, eps,
+                                         _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), _ptr(_col_ws(m, c, z.device), torch.float64),
+                                         _stream()), "vatl_bn_train_fwd_stats")
+    return outs
+
+
+def scale_bias_act(z, scale, bias, residual=None, relu=True):
+    c = z.shape[-1]
+    y = torch.empty_like(z)
+    _check(lib().vatl_scale_bias_act(_ptr(z), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(y), z.numel() // c, c, int(relu), _stream()),
+           "vatl_scale_bias_act")
+    return y
+
+
+def bn_train_bwd(dy, y, z, gamma, save_mean, save_invstd, want_g: bool = False):
+    """-> dz, g (or None), dgamma, dbeta."""
+    c = z.shape[-1]
+    m = z.numel() // c
+    dz = torch.empty_like(z)
+    g = torch.empty_like(z) if want_g else None
+    dgamma = torch.empty(c, device=z.device, dtype=torch.float32)
+    dbeta = torch.empty(c, device=z.device, dtype=torch.float32)
+    coef = torch.empty(3 * c, device=z.device, dtype=torch.float32)
+    _check(lib().vatl_bn_train_bwd(_ptr(dy), _ptr(y), _ptr(z), _ptr(gamma), _ptr(save_mean), _ptr(save_invstd), _ptr(dz), _ptr(g),
+                                   _ptr(dgamma), _ptr(dbeta), m, c, _ptr(coef), _ptr(_col_ws(m, c, z.device), torch.float64), _stream()),
+           "vatl_bn_train_bwd")
+    return dz, g, dgamma, dbeta
+
+
+def maxpool3x3s2_bwd(x, dy):
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    _check(lib().vatl_maxpool3x3s2_bwd(_ptr(x), _ptr(dy), _ptr(dx), n, h, w, c, _stream()), "vatl_maxpool3x3s2_bwd")
+    return dx
+
+
+def col_sum(x2d):
+    c = x2d.shape[-1]
+    m = x2d.numel() // c
+    out = torch.empty(c, device=x2d.device, dtype=torch.float32)
+    _check(lib().vatl_col_sum(_ptr(x2d), m, c, _ptr(out), _ptr(_col_ws(m, c, x2d.device), torch.float64), _stream()), "vatl_col_sum")
+    return out
 
 
 # ----------------------------------------------------------------------------
