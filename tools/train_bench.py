@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Fine-tune step benchmark (BASELINE.json configs[2]): SimpleBaseline-R50,
+B = 120 crops, forward in train mode + masked MSE + backward + AdamW (3 param groups).
+
+    python tools/train_bench.py [--batch 120] [--steps 5] [--warmup 2]
+Prints one JSON line: steps/s, crops/s and the conv-path TFLOP/s (3 x 10.853 GFLOP per crop).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "vatl4pose-wacv2024_amd")):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=120)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    a = ap.parse_args()
+    import vatl_hip as vh
+    from active_learning.optim import AdamW
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    dev = torch.device("cuda:0")
+    cfg = edict({"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50})
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    torch.manual_seed(166)
+    m = builder.build_sppe(cfg, preset_cfg=preset).to(dev).train()
+    lr = 2.5e-4
+    opt = AdamW(params=[{"params": m.final_layer.parameters(), "lr": lr * 10}, {"params": m.preact.parameters(), "lr": lr},
+                        {"params": m.deconv_layers.parameters(), "lr": lr * 5}], weight_decay=0.7)
+    g = torch.Generator(device=dev); g.manual_seed(166)
+    x = torch.rand((a.batch, 3, 256, 192), device=dev, generator=g) - 0.45
+    labels = torch.rand((a.batch, 17, 64, 48), device=dev, generator=g) * 0.1
+    masks = (torch.rand((a.batch, 17, 1, 1), device=dev, generator=g) > 0.2).float()
+    from alphapose.models import hip_train
+
+    def step():
+        tr = m.__dict__.get("_vatl_trainer") or hip_train.SimplePoseTrainer(m)
+        m.__dict__["_vatl_trainer"] = tr
+        with torch.no_grad():
+            out = tr.forward(x)
+            loss, dout = vh.masked_mse_fwd_bwd(out, labels, masks)       # fused loss + gradient
+            grads = tr.backward(dout)
+            for p_, g_ in grads.items():
+                p_.grad = g_
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(json.dumps({"metric": "fine-tune steps/s (fwd+bwd+AdamW), SimpleBaseline-R50 256x192", "batch": a.batch, "ms_per_step": round(dt * 1e3, 2),
+                      "crops_per_s": round(a.batch / dt, 1), "conv_tflops": round(3 * 10.853e9 * a.batch / dt / 1e12, 2),
+                      "loss": float(loss)}))
+
+
+if __name__ == "__main__":
+    main()
