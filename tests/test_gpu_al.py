@@ -1,0 +1,69 @@
+"""End-to-end active-learning rounds on MI355X with the seeded SyntheticVideo dataset: the reference's driver
+sequence (Run_active_learning.py:165-173: eval_and_query -> outcome -> ... until the pool is empty)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scorers
+from tests.gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg():
+    from alphapose.utils.config import edict
+    return edict({
+        "DATASET": {"TRAIN": {"TYPE": "SyntheticVideo", "NUM_ITEMS": 24, "TRACKS": 2}, "EVAL": {"TYPE": "SyntheticVideo", "NUM_ITEMS": 24, "TRACKS": 2}},
+        "DATA_PRESET": {"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]},
+        "MODEL": {"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50},
+        "LOSS": {"TYPE": "MSELoss"},
+        "AE": {"Z_DIM": 4, "INPUT_DIM": 42, "PRETRAINED": ""},
+        "RETRAIN": {"BATCH_SIZE": 8, "BASE": 1, "OPTIMIZER": "AdamW", "LR": 2.5e-4, "ALPHA": 2, "WEIGHT_DECAY": 0.7, "LR_GAMMA": 0.99},
+        "VAL": {"BATCH_SIZE": 10, "W_UNC": 0.01, "UNC_LAMBDA": 0.01, "QUERY_RATIO": [0.25, 0.5, 1.0]},
+    })
+
+
+@pytest.mark.parametrize("unc", ["THC+WPU", "TPC", "HP"])
+def test_active_learning_rounds(unc):
+    from active_learning import ActiveLearning
+    opt = types.SimpleNamespace(uncertainty=unc, representativeness="None", filter="None", strategy=unc, video_id="syn", get_prenext=True,
+                                from_scratch=True, continual=True, num_gpu=1, onebyone=False, retrain_thresh=1, THCvsWPU="const")
+    torch.manual_seed(0)
+    al = ActiveLearning(_cfg(), opt)
+    assert al.dedup
+    al.eval_and_query()
+    # first evaluation: the stream scorer agrees with the per-item oracle on the produced heat-maps
+    ds = al.eval_dataset
+    al.model.eval()
+    with torch.no_grad():
+        hm = al.model(torch.stack([ds[i][1][0] for i in range(4)]).to(dev())).cpu().numpy()
+    for i in range(4):
+        d = scorers.decode_heatmaps(hm[i], ds.bbox[i])
+        np.testing.assert_allclose(al.keypoints[i].reshape(17, 3)[:, :2], d["coords"], rtol=1e-4, atol=1e-4)
+    assert len(al.labeled_id) == 6 and len(al.unlabeled_id) == 18
+    if unc != "HP":
+        u = al.uncertainty_dict["Round0"]
+        picked = al.query_list_list["Round0"]
+        score = al._total_score(np.array([[*(u[i] if isinstance(u[i], list) else [u[i], 0])] for i in range(24)]))
+        assert set(picked) == set(np.argsort(-score, kind="stable")[:6].tolist())              # top-k by normalised uncertainty
+    rounds = 0
+    result = None
+    while result is None and rounds < 6:
+        result = al.outcome()
+        rounds += 1
+        if result is None:
+            assert np.isfinite(al.last_train_loss)
+            al.eval_and_query()
+    assert result is not None and len(result) == 20                                            # the reference's 20-tuple
+    assert len(al.unlabeled_id) == 0 and sorted(al.labeled_id) == list(range(24))
+    assert result[0][-1] == 100.0                                                              # label percentage reaches 100
+
+
+def test_unsupported_strategies_raise():
+    from active_learning import ActiveLearning
+    base = dict(uncertainty="THC_L1", representativeness="None", filter="None", from_scratch=True)
+    for bad in (dict(uncertainty="Nope"), dict(filter="Coreset"), dict(representativeness="Influence")):
+        with pytest.raises(ValueError):
+            ActiveLearning(_cfg(), types.SimpleNamespace(**{**base, **bad}))

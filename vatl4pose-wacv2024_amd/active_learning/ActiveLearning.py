@@ -1,0 +1,294 @@
+"""Active-learning loop around the MI355X hot path (reference: active_learning/ActiveLearning.py).
+
+Same entry points as the reference class — ``ActiveLearning(cfg, opt)``, ``eval_and_query()``,
+``outcome()``, ``retrain_model()`` — with the two hot loops rebuilt around batched device kernels:
+
+* ``eval_and_query`` (:253-429): one backbone forward per item (prev/next heat-maps are the neighbours'
+  when the dataset is an id-sorted stream, else three forwards like the reference), then ONE
+  ``score_batch`` launch sequence per batch instead of a per-item Python loop with D2H copies.
+* ``retrain_model`` (:651-686): train-mode forward, fused masked-MSE loss+gradient, HIP backward, AdamW.
+
+In scope: uncertainty None | HP | TPC | THC_L1 | THC_L2 | WPU | THC+WPU, representativeness None,
+filter None | Random.  Query strategies built on sklearn / umap (Influence, K-Means, Coreset), COCO mAP and
+OSPA evaluation, plots and the VL4Pose branch are out of scope and raise.
+Offline metrics can be plugged in through ``opt.evaluate_fn(pred_records, gt_records) -> dict``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Subset
+
+import vatl_hip as vh
+from alphapose.models import builder
+from alphapose.utils.bbox import bbox_xyxy_to_xywh
+from alphapose.utils.metrics import DataLogger, calc_accuracy
+from alphapose.utils.transforms import get_func_heatmap_to_coord
+
+from .al_metric import compute_OKS_batch
+from .optim import AdamW
+from .scoring import score_batch
+
+_UNC = ("None", "HP", "TPC", "THC_L1", "THC_L2", "THC", "WPU", "THC+WPU")
+
+
+class ActiveLearning:
+    def __init__(self, cfg, opt, eval_dataset=None, train_dataset=None):
+        self.cfg, self.opt = cfg, opt
+        self.round_cnt = 0
+        self.uncertainty = getattr(opt, "uncertainty", "None")
+        self.representativeness = getattr(opt, "representativeness", "None")
+        self.filter = getattr(opt, "filter", "None")
+        self.strategy = getattr(opt, "strategy", self.uncertainty)
+        self.video_id = getattr(opt, "video_id", "synthetic")
+        self.get_prenext = bool(getattr(opt, "get_prenext", "THC" in self.uncertainty or self.uncertainty == "TPC"))
+        if self.uncertainty not in _UNC:
+            raise ValueError("Uncertainty type is not supported")
+        if self.representativeness != "None":
+            raise ValueError("Representativeness type is not supported (Influence needs the sklearn kNN path: out of scope)")
+        if self.filter not in ("None", "Random"):
+            raise ValueError("Filter type is not supported (K-Means / Coreset are out of scope of the MI355X hot path)")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        ngpu = max(1, int(getattr(opt, "num_gpu", 1)))
+
+        self.eval_dataset = eval_dataset if eval_dataset is not None else builder.build_dataset(
+            cfg.DATASET.EVAL, preset_cfg=cfg.DATA_PRESET, train=False, get_prenext=self.get_prenext)
+        self.train_dataset = train_dataset if train_dataset is not None else builder.build_dataset(
+            cfg.DATASET.TRAIN, preset_cfg=cfg.DATA_PRESET, train=True, get_prenext=False)
+        self.collate_fn = self.eval_dataset.my_collate_fn
+        workers = int(getattr(opt, "num_workers", 0))
+        self.eval_loader = DataLoader(self.eval_dataset, batch_size=cfg.VAL.BATCH_SIZE * ngpu, shuffle=False, num_workers=workers,
+                                      drop_last=False, pin_memory=True, collate_fn=self.collate_fn)
+        self.eval_len = len(self.eval_dataset)
+        self.dedup = bool(getattr(self.eval_dataset, "ID_SORTED_STREAM", False))
+
+        self.query_ratio = list(cfg.VAL.QUERY_RATIO)
+        self.query_sizes = [int(self.eval_len * x) for x in self.query_ratio]
+        self.query_size = max(1, self.query_sizes[0])
+        self.unlabeled_id = list(range(self.eval_len))
+        self.labeled_id = []
+        self.retrain_id = []
+        self.percentage, self.performance, self.performance_ann = [], [], []
+        self.ospa_list, self.ospa_list_ann, self.combine_weight, self.uncertainty_mean, self.moksQ_list = [], [], [], [], []
+        self.query_list_list, self.uncertainty_dict, self.influence_dict = {}, {}, {}
+        self.spearmanr_list, self.corr_list = [], []
+        self.true_labeled_dict, self.false_labeled_dict, self.true_unlabeled_dict, self.false_unlabeled_dict = {}, {}, {}, {}
+        self.actual_finish = self.finished_minerror = self.finished_oursc = 100
+        self.finish_acc = getattr(opt, "retrain_thresh", 1)
+        self.is_early_stop = False
+        self.one_by_one = bool(getattr(opt, "onebyone", False))
+        self.continual = bool(getattr(opt, "continual", True))
+
+        self.retrain_epoch = cfg.RETRAIN.BASE
+        self.lr = cfg.RETRAIN.LR
+        self.moks_queried = 0
+        self.model, self.optimizer, self.scheduler = self.initialize_estimator()
+        self.criterion = builder.build_loss(cfg.LOSS)
+        self.AE = self.initialize_AE() if "WPU" in self.strategy or "WPU" in self.uncertainty else None
+        self.eval_joints = self.eval_dataset.EVAL_JOINTS
+        self.norm_type = cfg.LOSS.get("NORM_TYPE", None)
+        self.hm_size = cfg.DATA_PRESET.HEATMAP_SIZE
+        self.heatmap_to_coord = get_func_heatmap_to_coord(cfg)
+
+    # ------------------------------------------------------------------ estimator
+    def initialize_estimator(self):
+        cfg = self.cfg
+        model = builder.build_sppe(cfg.MODEL, preset_cfg=cfg.DATA_PRESET)
+        if getattr(self.opt, "from_scratch", False):
+            pass
+        elif cfg.MODEL.PRETRAINED:
+            model.load_state_dict(torch.load(cfg.MODEL.PRETRAINED, map_location="cpu"))
+        else:
+            raise ValueError("No pretrained model is given!")
+        model = model.to(self.device)
+        kind = cfg.RETRAIN.OPTIMIZER
+        if kind == "AdamW":
+            if cfg.MODEL.TYPE == "SimplePose":
+                groups = [{"params": model.final_layer.parameters(), "lr": self.lr * 10}, {"params": model.preact.parameters(), "lr": self.lr},
+                          {"params": model.deconv_layers.parameters(), "lr": self.lr * 5}]
+            elif cfg.MODEL.TYPE == "FastPose":
+                groups = [{"params": model.conv_out.parameters(), "lr": self.lr * 10}, {"params": model.preact.parameters(), "lr": self.lr},
+                          {"params": model.duc1.parameters(), "lr": self.lr * 5}, {"params": model.duc2.parameters(), "lr": self.lr * 5}]
+            else:
+                raise ValueError("Optimizer not supported!")          # the reference leaves `optimizer` unbound here
+            optimizer = AdamW(params=groups, weight_decay=cfg.RETRAIN.WEIGHT_DECAY)
+        elif kind == "Adam":
+            optimizer = AdamW(model.parameters(), lr=self.lr, weight_decay=0.0)   # Adam == AdamW without decay
+        else:
+            raise ValueError("Optimizer not supported!")
+        scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=cfg.RETRAIN.LR_GAMMA)
+        return model, optimizer, scheduler
+
+    def initialize_AE(self):
+        from .Whole_body_AE.AutoEncoder import WholeBodyAE
+        ae = WholeBodyAE(z_dim=self.cfg.AE.Z_DIM, input_dim=int(self.cfg.AE.get("INPUT_DIM", 42)))
+        path = self.cfg.AE.get("PRETRAINED", "")
+        if path:
+            ae.load_state_dict(torch.load(path, map_location="cpu"))
+        return ae.to(self.device).eval()
+
+    # ------------------------------------------------------------------ hot loop 1
+    def _heatmaps(self, inps):
+        m = self.model
+        x = inps[:, 0].to(self.device, non_blocking=True)
+        with torch.no_grad():
+            cur = m(x)
+            if not self.get_prenext or self.dedup:
+                return cur, None, None
+            return cur, m(inps[:, 1].to(self.device)), m(inps[:, 2].to(self.device))
+
+    def eval_and_query(self):
+        self.model.eval()
+        n = self.eval_len
+        J, (hh, hw) = self.cfg.DATA_PRESET.NUM_JOINTS, self.hm_size
+        # the whole id-sorted stream of heat-maps stays on the device (209 KB per item) and is scored in one pass,
+        # so THC/TPC neighbours across loader batches need no special casing
+        hm_all = torch.empty((n, J, hh, hw), device=self.device)
+        bb_all = torch.empty((n, 4), device=self.device)
+        ip_all = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        in_all = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        thc_ref = torch.zeros(n, device=self.device)
+        gt_all = np.zeros((n, 3 * J), np.float64)
+        ann_all = np.zeros((n, 4), np.float64)
+        thc_norm = {"THC_L1": "L1", "THC": "L1", "THC+WPU": "L1", "THC_L2": "L2"}.get(self.uncertainty)
+        for (idxs, inps, labels, label_masks, GTkpts, img_ids, ann_ids, bboxes_crop, bboxes_ann, isPrev, isNext) in self.eval_loader:
+            cur, prev, nxt = self._heatmaps(inps)
+            assert cur.dim() == 4, "the dimension of output must be 4"
+            idx = torch.as_tensor(idxs, device=self.device)
+            ip = torch.as_tensor(isPrev, dtype=torch.uint8, device=self.device)
+            inx = torch.as_tensor(isNext, dtype=torch.uint8, device=self.device)
+            hm_all[idx] = cur
+            bb_all[idx] = bboxes_crop.to(self.device).float()
+            ip_all[idx], in_all[idx] = ip, inx
+            if thc_norm is not None and not self.dedup:                   # reference-faithful: explicit prev/next forwards
+                tp, tn = vh.thc_pairs(cur, prev, thc_norm), vh.thc_pairs(cur, nxt, thc_norm)
+                one = (ip ^ inx).float()
+                thc_ref[idx] = (tp * ip + tn * inx) * (1 + one)
+            gt_all[np.asarray(idxs)] = GTkpts.reshape(len(idxs), -1).numpy()
+            ann_all[np.asarray(idxs)] = np.asarray([bbox_xyxy_to_xywh(b.tolist()) for b in bboxes_ann])
+        ae_flat = self.AE.packed() if self.AE is not None else None
+        s = score_batch(hm_all, bb_all, ip_all, in_all, thc_norm=thc_norm if self.dedup else None, ae_flat=ae_flat,
+                        ae_dims=(self.AE.input_dim, self.AE.z_dim) if self.AE is not None else (42, 4),
+                        wpu_only38=(self.uncertainty == "WPU"))
+        if thc_norm is not None and not self.dedup:
+            s.thc = thc_ref
+        unc = np.zeros((n, 2), np.float64)
+        if self.uncertainty == "HP":
+            unc[:, 0] = s.hp.cpu().numpy()
+        elif self.uncertainty == "TPC":
+            if not self.dedup:
+                raise ValueError("TPC needs an id-sorted stream dataset in this build")
+            unc[:, 0] = vh.tpc_stream(hm_all, bb_all, s.keypoints[:, :, :2].contiguous(), ip_all, in_all).cpu().numpy()
+        elif thc_norm is not None:
+            unc[:, 0] = s.thc.cpu().numpy()
+            if self.uncertainty == "THC+WPU":
+                self._check_wpu(s.wpu_status)
+                unc[:, 1] = s.wpu.cpu().numpy()
+        elif self.uncertainty == "WPU":
+            self._check_wpu(s.wpu_status)
+            unc[:, 0] = s.wpu.cpu().numpy()
+        kp_all = s.keypoints.reshape(n, -1).cpu().numpy()
+        lp = s.localpeak.cpu().numpy().astype(np.float64)
+        oks = compute_OKS_batch(ann_all, kp_all, gt_all)
+        self.keypoints, self.oks = kp_all, oks
+        evaluate = getattr(self.opt, "evaluate_fn", None)
+        res = evaluate(kp_all, self) if evaluate else {"AP": None, "mOKS": float(oks.mean())}
+        self.percentage.append(len(self.labeled_id) / n * 100)
+        self.performance.append(res)
+        self.performance_ann.append(res)
+        self.ospa_list.append(None)
+        self.ospa_list_ann.append(None)
+        self.uncertainty_mean.append(float(unc[:, 0].sum() / n))
+        un = np.asarray(self.unlabeled_id, int)
+        if len(un) > 0:
+            self.combine_weight.append(float(np.nansum(lp[un]) / len(un)))
+        self.uncertainty_dict[f"Round{self.round_cnt}"] = {int(i): (unc[i].tolist() if self.uncertainty == "THC+WPU" else float(unc[i, 0])) for i in range(n)}
+        if len(un) == 0:
+            return
+        score = self._total_score(unc[un])
+        if self.filter == "Random" or self.uncertainty == "None":
+            order = np.random.permutation(len(un))
+        else:
+            order = np.argsort(-score, kind="stable")
+        query = [int(i) for i in un[order][: self.query_size]]
+        self.moks_queried = float(np.mean(oks[query])) if query else 0.0
+        self.moksQ_list.append(self.moks_queried)
+        self.retrain_id = sorted(set(self.labeled_id) | set(query))
+        self.labeled_id = sorted(set(self.labeled_id) | set(query))
+        self.unlabeled_id = [i for i in self.unlabeled_id if i not in set(query)]
+        self.query_list_list[f"Round{self.round_cnt}"] = query
+
+    @staticmethod
+    def _check_wpu(status):
+        st = status.cpu().numpy()
+        assert not (st == 1).any(), "height of human body must be positive!"
+        assert not (st == 2).any(), "at least one visible keypoint is required!"
+
+    def _total_score(self, u):
+        """Min-max normalised uncertainty of the unlabeled items (ActiveLearning.py:492-519)."""
+        def norm(v):
+            rng = v.max() - v.min()
+            return (v - v.min()) / rng if rng > 0 else np.zeros_like(v)
+        if len(u) < 2 or self.uncertainty == "None":
+            return np.zeros(len(u))
+        if self.uncertainty == "THC+WPU":
+            t, w = norm(u[:, 0]), norm(u[:, 1])
+            mode = getattr(self.opt, "THCvsWPU", "const")
+            r = len(self.labeled_id) / self.eval_len
+            mix = t + w if mode == "const" else (r * t + (1 - r) * w if mode == "increase" else (1 - r) * t + r * w)
+            return norm(mix)
+        return norm(u[:, 0])
+
+    # ------------------------------------------------------------------ hot loop 2
+    def retrain_model(self):
+        from alphapose.models import hip_train
+        loss_logger, acc_logger = DataLogger(), DataLogger()
+        subset = Subset(self.train_dataset, self.retrain_id)
+        ngpu = max(1, int(getattr(self.opt, "num_gpu", 1)))
+        loader = DataLoader(subset, batch_size=self.cfg.RETRAIN.BATCH_SIZE * ngpu, shuffle=True, num_workers=0, drop_last=False,
+                            collate_fn=self.collate_fn)
+        self.model.train()
+        trainer = self.model.__dict__.get("_vatl_trainer") or hip_train.SimplePoseTrainer(self.model)
+        self.model.__dict__["_vatl_trainer"] = trainer
+        for _ in range(self.retrain_epoch):
+            for (idxs, inps, labels, label_masks, *_rest) in loader:
+                x = inps[:, 0].to(self.device).float().contiguous()
+                labels, label_masks = labels.to(self.device).float().contiguous(), label_masks.to(self.device).float()
+                with torch.no_grad():
+                    out = trainer.forward(x)
+                    loss, dout = vh.masked_mse_fwd_bwd(out, labels, label_masks)          # 0.5 * MSE(out*m, label*m) and its gradient
+                    for p, g in trainer.backward(dout).items():
+                        p.grad = g
+                self.optimizer.step()
+                loss_logger.update(float(loss), x.size(0))
+                m = label_masks.reshape(label_masks.shape[0], -1, 1, 1)
+                acc_logger.update(calc_accuracy(out * m, labels * m), x.size(0))
+            self.scheduler.step()
+        self.last_train_loss, self.last_train_acc = loss_logger.avg, acc_logger.avg
+
+    # ------------------------------------------------------------------ round logic (ActiveLearning.py:166-205)
+    def outcome(self):
+        if self.is_early_stop or self.one_by_one:
+            finish = True
+        else:
+            if not self.continual:
+                self.model, self.optimizer, self.scheduler = self.initialize_estimator()
+                self.retrain_epoch = int(self.cfg.RETRAIN.BASE * len(self.labeled_id) / self.eval_len + self.cfg.RETRAIN.ALPHA * (1 - self.moks_queried))
+            else:
+                self.retrain_epoch = int(self.cfg.RETRAIN.ALPHA * (1 - self.moks_queried))
+            self.retrain_model()
+            self.round_cnt += 1
+            finish = False
+            if len(self.unlabeled_id) == 0:
+                self.eval_and_query()
+                finish = True
+            elif self.round_cnt >= len(self.query_ratio):
+                self.query_size = len(self.unlabeled_id)
+            else:
+                self.query_size = max(1, self.query_sizes[self.round_cnt] - len(self.labeled_id))
+        if not finish:
+            return None
+        return (self.percentage, self.performance, self.performance_ann, self.query_list_list, self.uncertainty_dict, self.uncertainty_mean,
+                self.influence_dict, self.combine_weight, self.spearmanr_list, self.corr_list, self.true_labeled_dict, self.true_unlabeled_dict,
+                self.false_labeled_dict, self.false_unlabeled_dict, self.actual_finish, self.finished_minerror, self.finished_oursc,
+                self.ospa_list, self.ospa_list_ann, self.moksQ_list)

@@ -1,0 +1,10 @@
+"""Dataset registry entries shipped with the MI355X build.
+
+The reference's COCO-json datasets (Posetrack21, JRDB2022, Mscoco, Mpii) are host-side I/O on files
+that are not part of the hot path; they register themselves in
+``alphapose.models.builder.DATASET`` when installed beside this package.  ``SyntheticVideo`` produces
+the same 11-tuple item contract (posetrack21.py:181,205) from a seed, for tests, smoke and benchmarks.
+"""
+from .synthetic import SyntheticVideo
+
+__all__ = ["SyntheticVideo"]
