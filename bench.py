@@ -173,11 +173,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = world > 1
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)                        # (a 1-GPU box can host a 2-rank smoke run: VATL_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("VATL_DIST_BACKEND", "nccl")           # "nccl" is RCCL over xGMI on MI355X
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=dev)
+        else:
+            td.init_process_group(backend)
 
     model = build_model(dev)
     x, bbox, is_prev, is_next = make_video(dev, 166 + rank)
@@ -186,9 +192,9 @@ def main():
     def step():
         s = one_step(model, x, bbox, is_prev, is_next, hm_buf)
         if dist:                                        # the only exchange: ~290 B of results per item
-            row = torch.cat([s.keypoints.reshape(FRAMES, -1), s.argmax.float(), s.hp[:, None], s.thc[:, None], s.localpeak[:, None]], 1)
-            out = torch.empty((world * FRAMES, row.shape[1]), device=dev)
-            td.all_gather_into_tensor(out, row.contiguous())
+            row = torch.cat([s.keypoints.reshape(FRAMES, -1), s.argmax.float(), s.hp[:, None], s.thc[:, None], s.localpeak[:, None]], 1).contiguous()
+            out = [torch.empty_like(row) for _ in range(world)]
+            td.all_gather(out, row)
         return s
 
     for _ in range(a.warmup):

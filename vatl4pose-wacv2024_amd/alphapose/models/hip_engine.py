@@ -30,6 +30,11 @@ import vatl_hip as vh
 # every tensor below the kernels' 2^30-element guard (32-bit buffer byte offsets);
 # large chunks keep every layer's tile grid a multiple of the 512 resident blocks
 MAX_CHUNK = int(os.environ.get("VATL_MAX_CHUNK", "1024"))
+# The stem / max-pool / layer-1 tensors are the largest of the network (3.1 MB + 0.8 MB x 7 per crop) and their
+# 1x1 convolutions are HBM-bound in fp32.  Running that first stage in sub-batches keeps its intermediates inside
+# the 256 MB Infinity Cache (the allocator hands the same buffers to every sub-batch); the MFMA-bound later stages
+# run on the whole batch so that their tile grids stay large.  0 disables.
+STAGE1_CHUNK = int(os.environ.get("VATL_STAGE1_CHUNK", "0"))   # measured neutral-to-negative on MI355X (profiles/r01_notes.md): off
 
 
 class _Conv:
@@ -78,23 +83,38 @@ class _BottleneckPlan:
         self.c3 = _Conv(blk.conv3, blk.bn3)
         self.proj = _Conv(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
 
-    def __call__(self, x):
+    def __call__(self, x, out=None):
         y = self.c1(x, relu=True)
         y = self.c2(y, relu=True)
         skip = x if self.proj is None else self.proj(x, relu=False)
-        return self.c3(y, relu=True, residual=skip)                 # relu(bn3(conv3) + skip)
+        return self.c3(y, relu=True, residual=skip, out=out)        # relu(bn3(conv3) + skip)
 
 
 class _TrunkPlan:
     def __init__(self, net):
         self.stem = _Conv(net.conv1, net.bn1)
         self.blocks = [_BottleneckPlan(b) for stage in net.stages() for b in stage]
+        self.n_stage1 = len(net.stages()[0])
 
-    def __call__(self, x_nchw):
+    def _stage1(self, x_nchw, out=None):
         x = vh.nchw_to_nhwc(x_nchw, 4)                              # 3 -> 4 channels (zero), 16-byte pixels
         x = self.stem(x, relu=True)
         x = vh.maxpool3x3s2_fwd(x)
-        for b in self.blocks:
+        for k, b in enumerate(self.blocks[:self.n_stage1]):
+            last = k == self.n_stage1 - 1
+            x = b(x, out=out) if (last and out is not None and type(b) is _BottleneckPlan) else b(x)
+        return x
+
+    def __call__(self, x_nchw):
+        n = x_nchw.shape[0]
+        if STAGE1_CHUNK <= 0 or n <= STAGE1_CHUNK or type(self.blocks[self.n_stage1 - 1]) is not _BottleneckPlan:
+            x = self._stage1(x_nchw)
+        else:
+            h, w = x_nchw.shape[2] // 4, x_nchw.shape[3] // 4
+            x = torch.empty((n, h, w, self.blocks[self.n_stage1 - 1].c3.cout), device=x_nchw.device, dtype=torch.float32)
+            for i in range(0, n, STAGE1_CHUNK):
+                self._stage1(x_nchw[i:i + STAGE1_CHUNK], out=x[i:i + STAGE1_CHUNK])
+        for b in self.blocks[self.n_stage1:]:
             x = b(x)
         return x
 
@@ -151,6 +171,7 @@ class _SETrunkPlan(_TrunkPlan):
         self.stem = _Conv(net.conv1, net.bn1)
         self.blocks = [(_SEBottleneckPlan(b) if getattr(b, "reduc", False) else _BottleneckPlan(b))
                        for stage in net.stages() for b in stage]
+        self.n_stage1 = len(net.stages()[0])
 
 
 class _FastPosePlan:
