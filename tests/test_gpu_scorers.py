@@ -145,3 +145,21 @@ def test_masked_mse_and_adamw(vh):
         p, m, v = scorers.adamw_step(p, g_, m, v, step, 2.5e-3, 0.7)
     np.testing.assert_allclose(dp.cpu().numpy(), tp.detach().numpy(), rtol=2e-5, atol=1e-6)   # vs torch.optim.AdamW
     np.testing.assert_allclose(dp.cpu().numpy(), p, rtol=2e-5, atol=1e-6)                      # vs the numpy oracle
+
+
+def test_empty_and_ragged_batches(vh):
+    """Edge cases: empty streams return empty results, a 1-item stream has no neighbours, odd sizes work."""
+    d = dev()
+    e = torch.empty((0, 17, 64, 48), device=d)
+    assert vh.thc_stream(e, torch.empty(0, dtype=torch.uint8, device=d), torch.empty(0, dtype=torch.uint8, device=d)).shape == (0,)
+    m, c = vh.localpeak_mean(e)
+    assert m.shape == (0,) and c.shape == (0, 17)
+    w, s = vh.hybrid_ae_wpu(torch.empty((0, 17, 3), device=d), torch.empty((0, 4), device=d), torch.zeros(4000, device=d), 42, 4)
+    assert w.shape == (0,)
+    hm = synth.blob_heatmaps(3, seed=8)
+    for n in (1, 3):                                  # every prefix length agrees with the oracle item by item
+        flags = np.ones(n, np.uint8)
+        got = vh.thc_stream(to_dev(hm[:n]), to_dev(flags, torch.uint8), to_dev(flags, torch.uint8)).cpu().numpy()
+        for i in range(n):
+            want = scorers.thc_item(hm[i], hm[i - 1] if i else None, hm[i + 1] if i + 1 < n else None, i > 0, i + 1 < n)
+            np.testing.assert_allclose(got[i], want, rtol=1e-5)

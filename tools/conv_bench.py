@@ -38,10 +38,12 @@ def main():
     a = ap.parse_args()
     if a.vars:
         for v in a.vars.split(","):
-            var, _, order = v.partition(":")
-            print(f"--- schedule variant {var} tile-order {order or 0}")
+            parts = (v.split(":") + ["0", "0"])[:3]
+            var, order, stag = parts
+            print(f"--- schedule variant {var} tile-order {order} stagger {stag}%")
             vh.tune_set(0, int(var))
-            vh.tune_set(1, int(order or 0))
+            vh.tune_set(1, int(order))
+            vh.tune_set(2, int(stag))
             run(a)
         return
     run(a)
@@ -70,7 +72,9 @@ def run(a):
             nchw = name == "head"
             fn = lambda: vh.conv2d_fwd(x, w, sc, bi, cout, k, k, stride, k // 2, True, residual=r, out_nchw=nchw)
             flops = 2.0 * B * Ho * Wo * cin * cout * k * k
-        fn(); torch.cuda.synchronize()
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.iters):

@@ -56,6 +56,7 @@ struct ConvParams {
     int ktiles;                       // total k-tiles
     int n_tiles, m_tiles;
     int order;                        // tile order inside an XCD's run: 0 n-tile fastest, 1 m-tile fastest
+    int stagger;                      // start the second resident block of every CU half a block-time late
     int K;                            // packed K per output channel
     unsigned x_bytes, w_bytes, y_bytes;   // buffer extents (hardware bounds checks: OOB loads read 0, OOB stores drop)
 };
@@ -116,6 +117,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     else              { n_tile = t / p.m_tiles; m_tile = t - n_tile * p.m_tiles; }
     const int m0 = m_tile * BM, n0 = n_tile * BN;
 
+    // All resident blocks of a launch start together and take the same time, so chip-wide the matrix-bound
+    // k-loops and the memory-bound epilogues would alternate instead of overlapping.  Delaying the second block
+    // of every CU (blocks 256..511 under in-order dispatch; later blocks inherit the phase of the slot they
+    // take over) by half a k-loop puts the two phases side by side.  Performance only.
+    if (p.stagger && bid >= 256 && bid < 512 && nblk >= 1024) {
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     int pad_y = p.pad_y, pad_x = p.pad_x, ooy = p.ooy, oox = p.oox;
     const float* wbase = p.w;
     if (p.deconv) {
@@ -428,6 +436,43 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     //    loop's last barrier).  D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31].
     constexpr int LDC = BN + 4;
     float* Cs = smem;
+    // 0. output offsets of this thread's float4 columns and the residual tile, requested BEFORE the LDS
+    //    transpose so that its HBM latency hides behind the accumulator write-out and the barrier
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? p.y_bytes : 0u, 0x00020000);
+    const int OHW = p.OH * p.OW;
+    const bool plain = !p.deconv && p.osy == 1 && p.osx == 1 && p.OH == p.Ho && p.OW == p.Wo;   // NHWC output row index == m
+    const bool vec = !p.out_nchw && (p.Cout & 3) == 0;
+    constexpr int C4 = BN / 4;                         // float4 columns per tile row
+    constexpr int RPP = 256 / C4;                      // tile rows per pass
+    constexpr int NP = BM / RPP;                       // passes
+    unsigned offv[NP];
+    f32x4 rsv[NP];
+    if (vec) {
+        const int c4 = tid % C4, r0 = tid / C4;
+        const int n = n0 + c4 * 4;
+        const bool nv = n < p.Cout;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int m = m0 + r0 + u * RPP;
+            int orow = m;
+            if (!plain) {
+                const int b = m / HoWo;
+                const int rem = m - b * HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                orow = b * OHW + (oy * p.osy + ooy) * p.OW + (ox * p.osx + oox);
+            }
+            offv[u] = (nv && m < p.M) ? (unsigned)(orow * p.Cout + n) << 2 : OOB;
+        }
+        if (p.res) {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) rsv[u] = buf_load4(rr, offv[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) rsv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int cl = wn * WN + j * 32 + (lane & 31);
@@ -446,45 +491,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     __syncthreads();
 
     // 2. LDS -> HBM with full rows: (+ residual) (ReLU), branch-free through descriptors
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? p.y_bytes : 0u, 0x00020000);
     const float lo = p.relu ? 0.f : -INFINITY;
-    const int OHW = p.OH * p.OW;
-    const bool plain = !p.deconv && p.osy == 1 && p.osx == 1 && p.OH == p.Ho && p.OW == p.Wo;   // NHWC output row index == m
-    if (!p.out_nchw && (p.Cout & 3) == 0) {
-        constexpr int C4 = BN / 4;                     // float4 columns per tile row
-        constexpr int RPP = 256 / C4;                  // tile rows per pass
+    if (vec) {
         const int c4 = tid % C4, r0 = tid / C4;
-        const int n = n0 + c4 * 4;
-        const bool nv = n < p.Cout;
-        constexpr int UNR = 4;
 #pragma unroll
-        for (int ps = 0; ps < BM / RPP; ps += UNR) {
-            unsigned off[UNR];
-            f32x4 v[UNR], rs[UNR];
+        for (int u = 0; u < NP; ++u) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[(r0 + u * RPP) * LDC + c4 * 4]);
+            f32x4 o;
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int row = r0 + (ps + u) * RPP;
-                const int m = m0 + row;
-                int orow = m;
-                if (!plain) {
-                    const int b = m / HoWo;
-                    const int rem = m - b * HoWo;
-                    const int oy = rem / p.Wo;
-                    const int ox = rem - oy * p.Wo;
-                    orow = b * OHW + (oy * p.osy + ooy) * p.OW + (ox * p.osx + oox);
-                }
-                off[u] = (nv && m < p.M) ? (unsigned)(orow * p.Cout + n) << 2 : OOB;
-                rs[u] = buf_load4(rr, off[u]);
-                v[u] = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4 * 4]);
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                f32x4 o;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = fmaxf(v[u][c] + rs[u][c], lo);
-                buf_store4(yr, off[u], o);
-            }
+            for (int c = 0; c < 4; ++c) o[c] = fmaxf(v[c] + rsv[u][c], lo);
+            buf_store4(yr, offv[u], o);
         }
     } else {
         // NCHW output (heat-map head) or a channel count that is not a multiple of 4:
@@ -522,6 +538,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 
 static std::atomic<int> g_var{4};      // k-loop schedule (vatl_tune_set(0, v)); 4 = shipped default
 static std::atomic<int> g_order{0};    // tile order (vatl_tune_set(1, v))
+static std::atomic<int> g_stagger{0};  // block stagger in percent of the k-loop time (vatl_tune_set(2, v)); 0 = off
 
 template <int BM, int BN, int WM, int WN, bool STEM, int VAR>
 static int launch(const ConvParams& p, int phases, hipStream_t st) {
@@ -538,6 +555,8 @@ static int launch(const ConvParams& p, int phases, hipStream_t st) {
     q.n_tiles = p.CoutPad / BN;
     q.m_tiles = cdiv(p.M, BM);
     q.order = g_order.load(std::memory_order_relaxed);
+    // one s_sleep(127) = 8128 cycles; a k-tile costs ~8192 cycles when two blocks share the SIMDs
+    q.stagger = (int)((long long)g_stagger.load(std::memory_order_relaxed) * p.ktiles / 100);
     static_assert(2 * (BM + BN) * LDK >= BM * (BN + 4), "epilogue tile must fit in the staging buffers");
     const int m_tiles = cdiv(p.M, BM);
     dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, 1);
@@ -585,6 +604,7 @@ using namespace vatl;
 extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 0 && value >= 0 && value <= 12) { g_var.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }
+    if (knob == 2 && value >= 0 && value <= 200) { g_stagger.store(value, std::memory_order_relaxed); return 0; }
     return fail(VATL_EINVAL, "tune_set: unknown knob %d / value %d", knob, value);
 }
 

@@ -284,9 +284,9 @@ extern "C" int vatl_decode_argmax_affine(const float* hm, const float* bbox, flo
 
 extern "C" int vatl_thc_pairs(const float* a, const float* b, int64_t stride_a, int64_t stride_b, float* out,
                               int P, int J, int HW, int norm, void* stream) {
-    if (!a || !b || !out) return fail(VATL_EINVAL, "thc_pairs: null pointer");
     if (norm != 1 && norm != 2) return fail(VATL_EINVAL, "thc_pairs: norm must be 1 (L1) or 2 (L2)");
     if (P <= 0) return 0;
+    if (!a || !b || !out) return fail(VATL_EINVAL, "thc_pairs: null pointer");
     if (((uintptr_t)a | (uintptr_t)b) & 15 || (stride_a & 3) || (stride_b & 3))
         return fail(VATL_EINVAL, "thc_pairs: operands must be 16-byte aligned");
     if (norm == 1) hipLaunchKernelGGL(thc_pairs_kernel<1>, dim3(P), dim3(256), 0, (hipStream_t)stream, a, b, (long long)stride_a, (long long)stride_b, out, J, J * HW);
@@ -295,15 +295,15 @@ extern "C" int vatl_thc_pairs(const float* a, const float* b, int64_t stride_a, 
 }
 
 extern "C" int vatl_thc_combine(const float* pair, const uint8_t* is_prev, const uint8_t* is_next, float* thc, int N, void* stream) {
-    if (!is_prev || !is_next || !thc || (N > 1 && !pair)) return fail(VATL_EINVAL, "thc_combine: null pointer");
     if (N <= 0) return 0;
+    if (!is_prev || !is_next || !thc || (N > 1 && !pair)) return fail(VATL_EINVAL, "thc_combine: null pointer");
     hipLaunchKernelGGL(thc_combine_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, pair, is_prev, is_next, thc, N);
     return check_launch("thc_combine");
 }
 
 extern "C" int vatl_localpeak_mean(const float* hm, float* mean, int32_t* count, int N, int J, int H, int W, float order, void* stream) {
-    if (!hm || !mean) return fail(VATL_EINVAL, "localpeak_mean: null pointer");
     if (N <= 0) return 0;
+    if (!hm || !mean) return fail(VATL_EINVAL, "localpeak_mean: null pointer");
     const size_t smem = (size_t)(H + 2) * (W + 2) * sizeof(float);
     if (smem > 60 * 1024) return fail(VATL_EINVAL, "localpeak_mean: heat-map %dx%d too large for the LDS tile", H, W);
     hipLaunchKernelGGL(localpeak_kernel, dim3(N), dim3(256), smem, (hipStream_t)stream, hm, mean, count, J, H, W, order);
@@ -312,6 +312,7 @@ extern "C" int vatl_localpeak_mean(const float* hm, float* mean, int32_t* count,
 
 extern "C" int vatl_hybrid_ae_wpu(const float* kpts, const float* bbox, const float* ae, int D, int z, int only38,
                                   float* wpu, int32_t* status, int N, void* stream) {
+    if (N <= 0) return 0;
     if (!kpts || !bbox || !ae || !wpu) return fail(VATL_EINVAL, "hybrid_ae_wpu: null pointer");
     if (D != 38 && D != 42) return fail(VATL_EINVAL, "hybrid_ae_wpu: D must be 38 or 42, got %d", D);
     if (z < 1 || z > 64) return fail(VATL_EINVAL, "hybrid_ae_wpu: code width %d out of range", z);
