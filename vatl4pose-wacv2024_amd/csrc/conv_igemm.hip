@@ -80,16 +80,128 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned by
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);
 }
 
+// Epilogue shared by the conv kernels: scale/bias in registers, tile staged through LDS, then full-row 16-byte
+// stores with the residual read the same way (or per-element stores for NCHW / odd channel counts).
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[WM / 32][WN / 32], float* smem, int m0, int n0,
+                                              int ooy, int oox, int wm, int wn, int tid, int lane, int HoWo) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    // ---- epilogue -------------------------------------------------------------
+    // 1. scale/bias in registers, tile -> LDS (the staging buffers are free after the
+    //    loop's last barrier).  D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31].
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;
+    // 0. output offsets of this thread's float4 columns and the residual tile, requested BEFORE the LDS
+    //    transpose so that its HBM latency hides behind the accumulator write-out and the barrier
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? p.y_bytes : 0u, 0x00020000);
+    const int OHW = p.OH * p.OW;
+    const bool plain = !p.deconv && p.osy == 1 && p.osx == 1 && p.OH == p.Ho && p.OW == p.Wo;   // NHWC output row index == m
+    const bool vec = !p.out_nchw && (p.Cout & 3) == 0;
+    constexpr int C4 = BN / 4;                         // float4 columns per tile row
+    constexpr int RPP = 256 / C4;                      // tile rows per pass
+    constexpr int NP = BM / RPP;                       // passes
+    unsigned offv[NP];
+    f32x4 rsv[NP];
+    if (vec) {
+        const int c4 = tid % C4, r0 = tid / C4;
+        const int n = n0 + c4 * 4;
+        const bool nv = n < p.Cout;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int m = m0 + r0 + u * RPP;
+            int orow = m;
+            if (!plain) {
+                const int b = m / HoWo;
+                const int rem = m - b * HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                orow = b * OHW + (oy * p.osy + ooy) * p.OW + (ox * p.osx + oox);
+            }
+            offv[u] = (nv && m < p.M) ? (unsigned)(orow * p.Cout + n) << 2 : OOB;
+        }
+        if (p.res) {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) rsv[u] = buf_load4(rr, offv[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) rsv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int cl = wn * WN + j * 32 + (lane & 31);
+        const int n = n0 + cl;
+        const bool nv = n < p.Cout;
+        const float sc = (nv && p.scale) ? p.scale[n] : 1.f;
+        const float bi = (nv && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                Cs[row * LDC + cl] = acc[i][j][e] * sc + bi;
+            }
+    }
+    __syncthreads();
+
+    // 2. LDS -> HBM with full rows: (+ residual) (ReLU), branch-free through descriptors
+    const float lo = p.relu ? 0.f : -INFINITY;
+    if (vec) {
+        const int c4 = tid % C4, r0 = tid / C4;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[(r0 + u * RPP) * LDC + c4 * 4]);
+            f32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = fmaxf(v[c] + rsv[u][c], lo);
+            buf_store4(yr, offv[u], o);
+        }
+    } else {
+        // NCHW output (heat-map head) or a channel count that is not a multiple of 4:
+        // one tile row per thread, lanes run along pixels (contiguous in NCHW)
+        constexpr int CPP = 256 / BM;                  // tile columns per pass
+        const int row = tid % BM, cl0 = tid / BM;
+        const int m = m0 + row;
+        const bool mv = m < p.M;
+        const int b = m / HoWo;
+        const int rem = m - b * HoWo;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        const int opix = (oy * p.osy + ooy) * p.OW + (ox * p.osx + oox);
+        const int nstride = p.out_nchw ? OHW : 1;
+        const int obase = p.out_nchw ? b * p.Cout * OHW + opix : (b * OHW + opix) * p.Cout;
+        if (p.res) {
+#pragma unroll 4
+            for (int ps = 0; ps < BN / CPP; ++ps) {
+                const int cl = cl0 + ps * CPP;
+                const int n = n0 + cl;
+                const unsigned off = (mv && n < p.Cout) ? (unsigned)(obase + n * nstride) << 2 : OOB;
+                buf_store1(yr, off, fmaxf(Cs[row * LDC + cl] + buf_load1(rr, off), lo));
+            }
+        } else {
+#pragma unroll 8
+            for (int ps = 0; ps < BN / CPP; ++ps) {
+                const int cl = cl0 + ps * CPP;
+                const int n = n0 + cl;
+                const unsigned off = (mv && n < p.Cout) ? (unsigned)(obase + n * nstride) << 2 : OOB;
+                buf_store1(yr, off, fmaxf(Cs[row * LDC + cl], lo));
+            }
+        }
+    }
+}
+
 // VAR selects the k-loop schedule (tuning knob, see vatl_tune_set).  Measured on MI355X, 3x3 512->512
 // @8x6, batch 1024 (tools/conv_bench.py, TFLOP/s): VAR0 126, VAR2 132, VAR3 131, VAR4 138; ablations of
 // VAR2: no global loads / LDS writes 150, no barrier 130, no fragment reads 140 (profiles/r01_notes.md).
 //   0  two-phase: [address math + global loads] [64 MFMA with fragment reads] [LDS writes] barrier
-//   1  same work, branch-free body (tail tile loads are out-of-range offsets)
 //   2  fine-grained: the next tile's loads/address math and the next group's fragment reads are
 //      issued in the shadow of the MFMAs (one 32x32x2 MFMA occupies the matrix pipe for 64 cycles;
 //      the wave is free to issue other instructions meanwhile), pinned with sched_group_barrier
-//   3  2 + rotated loop (tile hand-over buried inside the last MFMA group)
 //   4  2 + distance-2 prefetch through two staging register sets (DEFAULT)
+//   5  LDS-DMA kernel below (buffer_load ... lds, source-side XOR swizzle): 134 — equal to VAR2, the saved
+//      ds_write pass (+5 %, ablation VAR13) is offset by its distance-1 prefetch
+// (a rotated loop that buries the tile hand-over in the last MFMA group measured equal to VAR2 and was dropped)
 template <int BM, int BN, int WM, int WN, bool STEM, int VAR>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -244,19 +356,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
             if (more) lstore(buf ^ 1);
             __syncthreads();
         }
-    } else if (VAR == 1) {
-        for (int kt = 0; kt < p.ktiles; ++kt) {
-            const int buf = kt & 1;
-            gload(kt + 1, kt + 1 < p.ktiles);
-#pragma unroll
-            for (int g = 0; g < BK / 8; ++g) {
-                f32x4 af[TM], bf[TN];
-                frag_read(af, bf, buf, g);
-                mfma_group(af, bf);
-            }
-            lstore(buf ^ 1);                               // tail iteration stores zeros into the idle buffer
-            __syncthreads();
-        }
     } else if (VAR == 4) {
         // Distance-2 prefetch: tile kt+2 is requested while tile kt is multiplied and is written to
         // LDS a full k-tile later (two staging register sets, loop unrolled by two so that the sets
@@ -326,73 +425,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
                 __syncthreads();
             }
         }
-    } else if (VAR == 3) {
-        // Rotated loop: the tile hand-over (LDS writes, barrier, first fragment read of the next
-        // tile) is buried inside the last MFMA group instead of standing between two tiles.
-        //   g0..g2 : next group's fragment reads + (g0) the next tile's global loads, 16 MFMAs each
-        //   g3a    : LDS writes of the prefetched tile interleaved with the first 8 MFMAs of g3
-        //   barrier
-        //   g3b    : fragment reads of the NEXT tile's group 0, covered by the last 8 MFMAs of g3
-        constexpr int NG = BK / 8;
-        constexpr int MPG = 4 * TM * TN;
-        auto mfma_part = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int t0, int t1) {
-#pragma unroll
-            for (int tt = t0; tt < t1; ++tt)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
-        };
-        f32x4 af[2][TM], bf[2][TN];
-        frag_read(af[0], bf[0], 0, 0);
-        for (int kt = 0; kt < p.ktiles; ++kt) {
-            const int buf = kt & 1;
-            const bool live = kt + 1 < p.ktiles;
-            gtap(kt + 1);
-#pragma unroll
-            for (int g = 0; g < NG - 1; ++g) {
-                frag_read(af[(g + 1) & 1], bf[(g + 1) & 1], buf, g + 1);
-                if (g == 0) {
-#pragma unroll
-                    for (int i = 0; i < LA; ++i) gloadA(i, live);
-#pragma unroll
-                    for (int j = 0; j < LB; ++j) gloadB(j, kt + 1, live);
-                }
-                mfma_group(af[g & 1], bf[g & 1]);
-                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-#pragma unroll
-                for (int q = 0; q < MPG; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x016, 2, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // g3a: hand the prefetched tile to LDS under the first half of the last group
-            lstore(buf ^ 1);
-            mfma_part(af[(NG - 1) & 1], bf[(NG - 1) & 1], 0, 2);
-#pragma unroll
-            for (int q = 0; q < MPG / 2; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            // g3b: first fragments of the next tile, latency covered by the second half of the group
-            frag_read(af[0], bf[0], buf ^ 1, 0);
-            mfma_part(af[(NG - 1) & 1], bf[(NG - 1) & 1], 2, 4);
-            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-#pragma unroll
-            for (int q = 0; q < MPG / 2; ++q) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();                                   // stray next-tile fragment reads done before Cs is written
     } else {
-        // VAR 2 = shipped schedule.  VAR 10/11/12 are ABLATIONS for profiling only (wrong results):
+        // VAR 2 = fine-grained schedule with distance-1 prefetch.  VAR 10..13 are ABLATIONS for profiling only (wrong results):
         // 10 = no global loads / LDS writes, 11 = no barrier, 12 = no fragment reads in the loop.
-        constexpr bool NO_GL = VAR == 10, NO_BAR = VAR == 11, NO_FRAG = VAR == 12;
+        constexpr bool NO_GL = VAR == 10, NO_BAR = VAR == 11, NO_FRAG = VAR == 12, NO_ST = VAR == 13;   // 13 = loads kept, no LDS writes
         constexpr int NG = BK / 8;                          // 4 fragment groups per k-tile
         constexpr int MPG = 4 * TM * TN;                    // MFMAs per group
         f32x4 af[2][TM], bf[2][TN];
@@ -425,116 +461,176 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!NO_GL) lstore(buf ^ 1);
+            if (!NO_GL && !NO_ST) lstore(buf ^ 1);
+            if (NO_ST) {                                   // keep the loaded registers alive
+#pragma unroll
+                for (int i = 0; i < LA; ++i) asm volatile("" ::"v"(ra[i]));
+#pragma unroll
+                for (int j = 0; j < LB; ++j) asm volatile("" ::"v"(rb[j]));
+            }
             if (!NO_BAR) __syncthreads();
         }
         if (NO_BAR) __syncthreads();
     }
 
-    // ---- epilogue -------------------------------------------------------------
-    // 1. scale/bias in registers, tile -> LDS (the staging buffers are free after the
-    //    loop's last barrier).  D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31].
-    constexpr int LDC = BN + 4;
-    float* Cs = smem;
-    // 0. output offsets of this thread's float4 columns and the residual tile, requested BEFORE the LDS
-    //    transpose so that its HBM latency hides behind the accumulator write-out and the barrier
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? p.y_bytes : 0u, 0x00020000);
-    const int OHW = p.OH * p.OW;
-    const bool plain = !p.deconv && p.osy == 1 && p.osx == 1 && p.OH == p.Ho && p.OW == p.Wo;   // NHWC output row index == m
-    const bool vec = !p.out_nchw && (p.Cout & 3) == 0;
-    constexpr int C4 = BN / 4;                         // float4 columns per tile row
-    constexpr int RPP = 256 / C4;                      // tile rows per pass
-    constexpr int NP = BM / RPP;                       // passes
-    unsigned offv[NP];
-    f32x4 rsv[NP];
-    if (vec) {
-        const int c4 = tid % C4, r0 = tid / C4;
-        const int n = n0 + c4 * 4;
-        const bool nv = n < p.Cout;
+    conv_epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, ooy, oox, wm, wn, tid, lane, HoWo);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (VAR 5): operand tiles go HBM/L2 -> LDS directly (buffer_load ... lds, 1 KiB per wave
+// instruction, no staging VGPRs, no ds_write pass).  The DMA destination is lane-linear (base + lane*16 B), so
+// the LDS rows are unpadded 32-float rows and bank conflicts are avoided by an XOR swizzle applied on the
+// SOURCE side: LDS chunk position p of tile row r holds global chunk p ^ ((r>>1)&7); the fragment reader asks
+// for chunk (2g+half) ^ ((r>>1)&7).  16 consecutive rows then cover all 16 16-byte slots of a 256-byte bank row
+// (conflict-free ds_read_b128).  Out-of-image taps / tail tiles use out-of-range offsets: the DMA writes zeros
+// (verified on MI355X).  Two stages of 32 KiB; the epilogue reuses the space.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+
+// (body in a __device__ function: with the DMA builtin called from a lambda directly inside the __global__
+// template, hipcc 7.2 silently drops the HOST stub of the kernel and the library fails to load)
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, float* smem) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int STAGE = (BM + BN) * BK;            // floats per stage: A rows, then B rows, 32 floats each
+    constexpr int IA = BM / 32, IB = BN / 32;        // DMA instructions per wave per stage (8 rows x 128 B each)
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, loc = bid >> 3, q = nblk >> 3, r8 = nblk & 7;
+    const int t = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + loc;
+    const int m_tile = t / p.n_tiles;
+    const int n_tile = t - m_tile * p.n_tiles;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    int pad_y = p.pad_y, pad_x = p.pad_x, ooy = p.ooy, oox = p.oox;
+    const float* wbase = p.w;
+    if (p.deconv) {
+        const int py = blockIdx.y >> 1, px = blockIdx.y & 1;
+        pad_y = 1 - py; pad_x = 1 - px; ooy = py; oox = px;
+        wbase += (long long)blockIdx.y * p.CoutPad * p.K;
+    }
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase), 0, p.w_bytes, 0x00020000);
+
+    // ---- loader state: instruction i of wave w fills tile rows (4i + w)*8 .. +7; lane -> (row, chunk position)
+    const int lrow = lane >> 3;                       // row inside the 8-row group
+    const int lpos = lane & 7;                        // 16-byte position inside the LDS row
+    const int lswz = ((lane >> 4) + 4 * (wave & 1)) & 7;   // ((row >> 1) & 7) for every row this lane loads
+    const int lchk = lpos ^ lswz;                     // global 16-byte chunk that belongs at this position
+    int abase[IA], iy0[IA], ix0[IA];
+    const int HoWo = p.Ho * p.Wo;
 #pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            const int m = m0 + r0 + u * RPP;
-            int orow = m;
-            if (!plain) {
-                const int b = m / HoWo;
-                const int rem = m - b * HoWo;
-                const int oy = rem / p.Wo;
-                const int ox = rem - oy * p.Wo;
-                orow = b * OHW + (oy * p.osy + ooy) * p.OW + (ox * p.osx + oox);
-            }
-            offv[u] = (nv && m < p.M) ? (unsigned)(orow * p.Cout + n) << 2 : OOB;
-        }
-        if (p.res) {
-#pragma unroll
-            for (int u = 0; u < NP; ++u) rsv[u] = buf_load4(rr, offv[u]);
+    for (int i = 0; i < IA; ++i) {
+        const int m = m0 + (4 * i + wave) * 8 + lrow;
+        if (m < p.M) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            iy0[i] = oy * p.stride - pad_y;
+            ix0[i] = ox * p.stride - pad_x;
+            abase[i] = ((b * p.H + iy0[i]) * p.W + ix0[i]) * p.Cin + lchk * 4;
         } else {
-#pragma unroll
-            for (int u = 0; u < NP; ++u) rsv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); abase[i] = 0;
         }
     }
+    unsigned boff[IB];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int cl = wn * WN + j * 32 + (lane & 31);
-        const int n = n0 + cl;
-        const bool nv = n < p.Cout;
-        const float sc = (nv && p.scale) ? p.scale[n] : 1.f;
-        const float bi = (nv && p.bias) ? p.bias[n] : 0.f;
+    for (int j = 0; j < IB; ++j) boff[j] = (unsigned)(((n0 + (4 * j + wave) * 8 + lrow) * p.K + lchk * 4) * 4);
+
+    auto issue = [&](int buf, int kt) {               // DMA of k-tile kt into stage buf (zeros past the end)
+        const bool live = kt < p.ktiles;
+        const int rs = kt / p.kpr;
+        const int c0 = (kt - rs * p.kpr) * BK;
+        const int r = rs / p.S, sx = rs - r * p.S;
+        const int off = (r * p.W + sx) * p.Cin + c0;
+        float* stage = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < IA; ++i) {
+            const bool ok = live && (unsigned)(iy0[i] + r) < (unsigned)p.H && (unsigned)(ix0[i] + sx) < (unsigned)p.W;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(stage + (4 * i + wave) * 8 * BK), 16,
+                                                     ok ? (unsigned)(abase[i] + off) << 2 : OOB, 0, 0, 0);
+        }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                Cs[row * LDC + cl] = acc[i][j][e] * sc + bi;
-            }
-    }
+        for (int j = 0; j < IB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(stage + (BM + (4 * j + wave) * 8) * BK), 16,
+                                                     live ? boff[j] + (unsigned)kt * (BK * 4) : OOB, 0, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment addressing: row = frow (+32 i), logical chunk 2g + half, stored at position chunk ^ ((frow>>1)&7)
+    const int frow = lane & 31;
+    const int half = lane >> 5;
+    const int fswz = (frow >> 1) & 7;
+    int koff[BK / 8];
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) koff[g] = ((2 * g + half) ^ fswz) * 4;
+    auto frag_read = [&](f32x4 (&af)[TM], f32x4 (&bf)[TN], int buf, int g) {
+        const float* Ab = smem + buf * STAGE + (wm * WM + frow) * BK + koff[g];
+        const float* Bb = smem + buf * STAGE + (BM + wn * WN + frow) * BK + koff[g];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * BK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * BK);
+    };
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // 2. LDS -> HBM with full rows: (+ residual) (ReLU), branch-free through descriptors
-    const float lo = p.relu ? 0.f : -INFINITY;
-    if (vec) {
-        const int c4 = tid % C4, r0 = tid / C4;
+    constexpr int NG = BK / 8;
+    constexpr int MPG = 4 * TM * TN;
+    for (int kt = 0; kt < p.ktiles; ++kt) {
+        const int buf = kt & 1;
+        f32x4 af[2][TM], bf[2][TN];
+        frag_read(af[0], bf[0], buf, 0);
 #pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[(r0 + u * RPP) * LDC + c4 * 4]);
-            f32x4 o;
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) frag_read(af[(g + 1) & 1], bf[(g + 1) & 1], buf, g + 1);
+            if (g == 0) issue(buf ^ 1, kt + 1);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = fmaxf(v[c] + rsv[u][c], lo);
-            buf_store4(yr, offv[u], o);
-        }
-    } else {
-        // NCHW output (heat-map head) or a channel count that is not a multiple of 4:
-        // one tile row per thread, lanes run along pixels (contiguous in NCHW)
-        constexpr int CPP = 256 / BM;                  // tile columns per pass
-        const int row = tid % BM, cl0 = tid / BM;
-        const int m = m0 + row;
-        const bool mv = m < p.M;
-        const int b = m / HoWo;
-        const int rem = m - b * HoWo;
-        const int oy = rem / p.Wo;
-        const int ox = rem - oy * p.Wo;
-        const int opix = (oy * p.osy + ooy) * p.OW + (ox * p.osx + oox);
-        const int nstride = p.out_nchw ? OHW : 1;
-        const int obase = p.out_nchw ? b * p.Cout * OHW + opix : (b * OHW + opix) * p.Cout;
-        if (p.res) {
-#pragma unroll 4
-            for (int ps = 0; ps < BN / CPP; ++ps) {
-                const int cl = cl0 + ps * CPP;
-                const int n = n0 + cl;
-                const unsigned off = (mv && n < p.Cout) ? (unsigned)(obase + n * nstride) << 2 : OOB;
-                buf_store1(yr, off, fmaxf(Cs[row * LDC + cl] + buf_load1(rr, off), lo));
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][tt], bf[g & 1][j][tt], acc[i][j], 0, 0, 0);
+            if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+            for (int q2 = 0; q2 < MPG; ++q2) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x016, 2, 0);
             }
-        } else {
-#pragma unroll 8
-            for (int ps = 0; ps < BN / CPP; ++ps) {
-                const int cl = cl0 + ps * CPP;
-                const int n = n0 + cl;
-                const unsigned off = (mv && n < p.Cout) ? (unsigned)(obase + n * nstride) << 2 : OOB;
-                buf_store1(yr, off, fmaxf(Cs[row * LDC + cl], lo));
-            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next stage has landed in LDS
+        __syncthreads();
     }
+    conv_epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, ooy, oox, wm, wn, tid, lane, HoWo);
 }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_igemm_dma_body<BM, BN, WM, WN>(p, smem);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_dma(const ConvParams& p, int phases, hipStream_t st);
 
 static std::atomic<int> g_var{4};      // k-loop schedule (vatl_tune_set(0, v)); 4 = shipped default
 static std::atomic<int> g_order{0};    // tile order (vatl_tune_set(1, v))
@@ -564,6 +660,27 @@ static int launch(const ConvParams& p, int phases, hipStream_t st) {
     return check_launch("conv_igemm");
 }
 
+template <int BM, int BN, int WM, int WN>
+static int launch_dma(const ConvParams& p, int phases, hipStream_t st) {
+    auto kern = conv_igemm_dma_kernel<BM, BN, WM, WN>;
+    constexpr int stage_bytes = 2 * (BM + BN) * BK * (int)sizeof(float);
+    constexpr int epi_bytes = BM * (BN + 4) * (int)sizeof(float);
+    constexpr int smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
+    static std::atomic<int> configured{0};
+    if (!configured.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return fail(VATL_ELAUNCH, "hipFuncSetAttribute(conv_igemm_dma): %s", hipGetErrorString(e));
+        configured.store(1, std::memory_order_release);
+    }
+    ConvParams q = p;
+    q.n_tiles = p.CoutPad / BN;
+    q.m_tiles = cdiv(p.M, BM);
+    q.order = 0; q.stagger = 0;
+    dim3 grid((unsigned)(q.m_tiles * q.n_tiles), (unsigned)phases, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
+    return check_launch("conv_igemm_dma");
+}
+
 // CoutPad granularity the packer must honour for a given Cout.
 static int tile_n_for(int Cout) { return Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128); }
 
@@ -576,21 +693,20 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st) 
         if (bn == 128) return launch<128, 128, 64, 64, true, 0>(p, phases, st);
         return launch<128, 32, 32, 32, true, 0>(p, phases, st);
     }
+    if (bn == 128 && var == 5) return launch_dma<128, 128, 64, 64>(p, phases, st);
+    if (bn == 64 && var == 5) return launch_dma<128, 64, 64, 32>(p, phases, st);
     if (bn == 128) {
-        if (var == 1) return launch<128, 128, 64, 64, false, 1>(p, phases, st);
         if (var == 2) return launch<128, 128, 64, 64, false, 2>(p, phases, st);
-        if (var == 3) return launch<128, 128, 64, 64, false, 3>(p, phases, st);
         if (var == 4) return launch<128, 128, 64, 64, false, 4>(p, phases, st);
         if (var == 10) return launch<128, 128, 64, 64, false, 10>(p, phases, st);
         if (var == 11) return launch<128, 128, 64, 64, false, 11>(p, phases, st);
         if (var == 12) return launch<128, 128, 64, 64, false, 12>(p, phases, st);
+        if (var == 13) return launch<128, 128, 64, 64, false, 13>(p, phases, st);
         if (var == 0) return launch<128, 128, 64, 64, false, 0>(p, phases, st);
         return launch<128, 128, 64, 64, false, 4>(p, phases, st);
     }
     if (bn == 64) {
-        if (var == 1) return launch<128, 64, 64, 32, false, 1>(p, phases, st);
         if (var == 2) return launch<128, 64, 64, 32, false, 2>(p, phases, st);
-        if (var == 3) return launch<128, 64, 64, 32, false, 3>(p, phases, st);
         if (var == 0) return launch<128, 64, 64, 32, false, 0>(p, phases, st);
         return launch<128, 64, 64, 32, false, 4>(p, phases, st);
     }
@@ -602,7 +718,7 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st) 
 using namespace vatl;
 
 extern "C" int vatl_tune_set(int knob, int value) {
-    if (knob == 0 && value >= 0 && value <= 12) { g_var.store(value, std::memory_order_relaxed); return 0; }
+    if (knob == 0 && value >= 0 && value <= 13) { g_var.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 2 && value >= 0 && value <= 200) { g_stagger.store(value, std::memory_order_relaxed); return 0; }
     return fail(VATL_EINVAL, "tune_set: unknown knob %d / value %d", knob, value);
