@@ -211,6 +211,10 @@ int vatl_bn_train_bwd(const float* dy, const float* y_or_null, const float* z, c
                       int64_t M, int C, float* coef3C, double* workspace, void* stream);
 /* MaxPool2d(3,2,1) backward on NHWC: x (N,H,W,C) forward input, dy (N,Ho,Wo,C) -> dx. */
 int vatl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* Training-mode max-pool: forward that also records the winning tap (0..8, first maximum) per pooled element,
+ * and the backward that consumes it.  idx (N,Ho,Wo,C) uint8. */
+int vatl_maxpool3x3s2_fwd_idx(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int vatl_maxpool3x3s2_bwd_idx(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream);
 /* out[c] = sum over rows of x (M,C)  (conv bias gradient). */
 int vatl_col_sum(const float* x, int64_t M, int C, float* out, double* workspace, void* stream);
 

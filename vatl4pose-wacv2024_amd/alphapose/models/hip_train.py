@@ -154,9 +154,8 @@ class SimplePoseTrainer:
     def forward(self, x_nchw):
         x = vh.nchw_to_nhwc(x_nchw, 4)
         s = self.stem.forward(x)
-        p = vh.maxpool3x3s2_fwd(s)
-        self.pool_in = s
-        x = p
+        x, self.pool_idx = vh.maxpool3x3s2_fwd_idx(s)
+        self.pool_hw = (s.shape[1], s.shape[2])
         for b in self.blocks:
             x = b.forward(x)
         for d in self.deconvs:
@@ -182,8 +181,8 @@ class SimplePoseTrainer:
             dx = d.backward(dx, grads)
         for b in reversed(self.blocks):
             dx = b.backward(dx, grads)
-        dx = vh.maxpool3x3s2_bwd(self.pool_in, dx)
-        self.pool_in = None
+        dx = vh.maxpool3x3s2_bwd_idx(dx, self.pool_idx, self.pool_hw)
+        self.pool_idx = None
         self.stem.backward(dx, grads)
         return grads
 

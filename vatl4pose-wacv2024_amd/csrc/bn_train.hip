@@ -10,15 +10,79 @@
 
 namespace vatl {
 
-constexpr int ROWS_PER_BLOCK = 512;      // rows reduced by one block of the column-reduction kernels
-constexpr int CH_PER_BLOCK = 64;
+constexpr int MAX_ROW_BLOCKS = 256;      // partial sums per channel (bounds the finalize work)
 
-// partial[(rb * C + c) * 2 + {0,1}] = sum, sum of squares over the block's rows
-__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ z, double* __restrict__ partial, long long M, int C) {
-    const int c = blockIdx.y * CH_PER_BLOCK + (threadIdx.x & 63);
+// Column reductions over NHWC rows: a 256-thread block owns a row range; thread t always handles the same four
+// channels (float4 column t % C4 of a 256-column slab selected by blockIdx.y) and every 256/C4-th row, so global
+// loads are 16-byte and fully coalesced; threads sharing a column are combined through LDS.  Partials are doubles:
+// partial[(rb * C + c) * 2 + {0,1}].
+struct RowSplit { long long rows_per_block; int nrb; };
+static inline RowSplit row_split(long long M) {
+    long long nrb = (M + 511) / 512;
+    if (nrb > MAX_ROW_BLOCKS) nrb = MAX_ROW_BLOCKS;
+    if (nrb < 1) nrb = 1;
+    const long long rpb = (M + nrb - 1) / nrb;
+    return {rpb, (int)((M + rpb - 1) / rpb)};
+}
+
+template <int MODE>   // 0: (sum z, sum z^2)   1: (sum g, sum g*xhat) with g = dy*[y>0]
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ a, const float* __restrict__ y, const float* __restrict__ z,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         double* __restrict__ partial, long long M, int C, long long rows_per_block) {
+    const int C4 = C >> 2;
+    const int cols = C4 < 256 ? C4 : 256;                 // float4 columns handled by this block
+    const int col = threadIdx.x % cols;
+    const int rlane = threadIdx.x / cols, rstep = 256 / cols;
+    const int c4 = blockIdx.y * 256 + col;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < C4 && rlane < rstep) {
+        f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+        if (MODE == 1) { mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4); is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4); }
+        for (long long r = r0 + rlane; r < r1; r += rstep) {
+            const long long o = r * C + c4 * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(a + o);
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+            } else {
+                if (y) {
+                    const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = yy[e] > 0.f ? v[e] : 0.f;
+                }
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * ((zz[e] - mu[e]) * is[e]); }
+            }
+        }
+    }
+    __shared__ float sh[2][256][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sh[0][threadIdx.x][e] = s[e]; sh[1][threadIdx.x][e] = q[e]; }
+    __syncthreads();
+    if (rlane == 0 && c4 < C4) {
+        double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+        for (int k = 0; k < rstep; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ds[e] += sh[0][k * cols + col][e]; dq[e] += sh[1][k * cols + col][e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            partial[((long long)blockIdx.x * C + c4 * 4 + e) * 2 + 0] = ds[e];
+            partial[((long long)blockIdx.x * C + c4 * 4 + e) * 2 + 1] = dq[e];
+        }
+    }
+}
+
+// scalar fallback for channel counts that are not a multiple of 4 (conv bias gradient of the 17-joint head is
+// carried in 32 channels, so this is only a safety net)
+__global__ __launch_bounds__(256) void col_stats_scalar_kernel(const float* __restrict__ z, double* __restrict__ partial, long long M, int C,
+                                                               long long rows_per_block) {
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
-    const long long r0 = (long long)blockIdx.x * ROWS_PER_BLOCK;
-    const long long r1 = r0 + ROWS_PER_BLOCK < M ? r0 + ROWS_PER_BLOCK : M;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
     float s = 0.f, q = 0.f;
     if (c < C)
         for (long long r = r0 + rl; r < r1; r += 4) { const float v = z[r * C + c]; s += v; q += v * v; }
@@ -32,15 +96,23 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
     }
 }
 
-__global__ void bn_train_finalize_kernel(const double* __restrict__ partial, int nrb, long long M, int C,
+// one wave per channel: lanes stride over the row-block partials
+__device__ __forceinline__ void sum_partials(const double* __restrict__ partial, int nrb, int C, int c, int lane, double& s, double& q) {
+    s = 0.0; q = 0.0;
+    for (int rb = lane; rb < nrb; rb += 64) { s += partial[((long long)rb * C + c) * 2]; q += partial[((long long)rb * C + c) * 2 + 1]; }
+    s = wave_sum(s); q = wave_sum(q);
+}
+
+__global__ __launch_bounds__(256) void bn_train_finalize_kernel(const double* __restrict__ partial, int nrb, long long M, int C,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                          float* __restrict__ scale, float* __restrict__ bias) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int rb = 0; rb < nrb; ++rb) { s += partial[((long long)rb * C + c) * 2]; q += partial[((long long)rb * C + c) * 2 + 1]; }
+    double s, q;
+    sum_partials(partial, nrb, C, c, threadIdx.x & 63, s, q);
+    if ((threadIdx.x & 63) != 0) return;
     const double mean = s / (double)M;
     double var = q / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -81,42 +153,16 @@ __global__ void scale_bias_act_kernel(const float* __restrict__ z, const float* 
     }
 }
 
-// partial sums of g and g*xhat,  g = dy * [y > 0] (mask only when y != nullptr)
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
-                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                            double* __restrict__ partial, long long M, int C) {
-    const int c = blockIdx.y * CH_PER_BLOCK + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
-    const long long r0 = (long long)blockIdx.x * ROWS_PER_BLOCK;
-    const long long r1 = r0 + ROWS_PER_BLOCK < M ? r0 + ROWS_PER_BLOCK : M;
-    float s = 0.f, q = 0.f;
-    if (c < C) {
-        const float mu = mean[c], is = invstd[c];
-        for (long long r = r0 + rl; r < r1; r += 4) {
-            float g = dy[r * C + c];
-            if (y && !(y[r * C + c] > 0.f)) g = 0.f;
-            s += g; q += g * ((z[r * C + c] - mu) * is);
-        }
-    }
-    __shared__ double sh[2][4][64];
-    sh[0][rl][threadIdx.x & 63] = s; sh[1][rl][threadIdx.x & 63] = q;
-    __syncthreads();
-    if (rl == 0 && c < C) {
-        const int l = threadIdx.x & 63;
-        partial[((long long)blockIdx.x * C + c) * 2 + 0] = sh[0][0][l] + sh[0][1][l] + sh[0][2][l] + sh[0][3][l];
-        partial[((long long)blockIdx.x * C + c) * 2 + 1] = sh[1][0][l] + sh[1][1][l] + sh[1][2][l] + sh[1][3][l];
-    }
-}
-
 // dgamma, dbeta and the coefficients of dz = A*g + B*z + Cc
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nrb, long long M, int C, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nrb, long long M, int C, const float* __restrict__ gamma,
                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coefA,
                                        float* __restrict__ coefB, float* __restrict__ coefC) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double sg = 0.0, sgx = 0.0;
-    for (int rb = 0; rb < nrb; ++rb) { sg += partial[((long long)rb * C + c) * 2]; sgx += partial[((long long)rb * C + c) * 2 + 1]; }
+    double sg, sgx;
+    sum_partials(partial, nrb, C, c, threadIdx.x & 63, sg, sgx);
+    if ((threadIdx.x & 63) != 0) return;
     if (dbeta) dbeta[c] = (float)sg;
     if (dgamma) dgamma[c] = (float)sgx;
     const double s = (double)(gamma ? gamma[c] : 1.f) * (double)invstd[c];
@@ -185,13 +231,60 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float
     }
 }
 
+// MaxPool2d(3,2,1) forward that also records which of the 9 window taps won (first maximum in scan order), and the
+// backward that uses it: every input pixel looks at the <= 4 windows covering it (4 byte loads instead of 36 float loads)
+__global__ void maxpool3x3s2_fwd_idx_kernel(const float* __restrict__ x, float* __restrict__ y, uint8_t* __restrict__ idx,
+                                            int N, int H, int W, int C, int Ho, int Wo) {
+    const long long total = (long long)N * Ho * Wo * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const long long n = t / Ho;
+        float best = -INFINITY; int bk = 255;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = 2 * oy - 1 + k / 3, xx = 2 * ox - 1 + k % 3;
+            if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+            const float v = x[((n * H + yy) * W + xx) * C + c];
+            if (v > best || bk == 255) { best = v; bk = k; }
+        }
+        y[i] = best;
+        idx[i] = (uint8_t)bk;
+    }
+}
+
+__global__ void maxpool3x3s2_bwd_idx_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                                            int N, int H, int W, int C, int Ho, int Wo) {
+    const long long total = (long long)N * H * W * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const long long n = t / H;
+        float acc = 0.f;
+        for (int oy = (iy >> 1); oy <= ((iy + 1) >> 1); ++oy) {
+            if (oy >= Ho) continue;
+            for (int ox = (ix >> 1); ox <= ((ix + 1) >> 1); ++ox) {
+                if (ox >= Wo) continue;
+                const long long o = ((n * Ho + oy) * Wo + ox) * C + c;
+                const int k = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));      // this pixel's tap inside that window
+                if (idx[o] == k) acc += dy[o];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
 // out[c] = sum over rows of x[r][c]  (conv bias gradient); same two-stage scheme
-__global__ void col_sum_finalize_kernel(const double* __restrict__ partial, int nrb, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void col_sum_finalize_kernel(const double* __restrict__ partial, int nrb, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s = 0.0;
-    for (int rb = 0; rb < nrb; ++rb) s += partial[((long long)rb * C + c) * 2];
-    out[c] = (float)s;
+    double s, q;
+    sum_partials(partial, nrb, C, c, threadIdx.x & 63, s, q);
+    if ((threadIdx.x & 63) == 0) out[c] = (float)s;
 }
 
 static inline int ew_grid(long long n) { long long g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (int)g; }
@@ -200,15 +293,26 @@ static inline int ew_grid(long long n) { long long g = (n + 255) / 256; if (g > 
 
 using namespace vatl;
 
-extern "C" int64_t vatl_col_reduce_workspace_doubles(int64_t M, int C) { return 2 * ((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * (int64_t)C; }
+extern "C" int64_t vatl_col_reduce_workspace_doubles(int64_t M, int C) { return 2 * (int64_t)row_split(M).nrb * (int64_t)C; }
+
+static void launch_col_reduce(int mode, const float* a, const float* y, const float* z, const float* mean, const float* invstd,
+                              double* ws, long long M, int C, const RowSplit& rs, hipStream_t st) {
+    if (C & 3) {                                              // stats only (mode 0) on odd channel counts
+        hipLaunchKernelGGL(col_stats_scalar_kernel, dim3(rs.nrb, cdiv(C, 64)), dim3(256), 0, st, a, ws, M, C, rs.rows_per_block);
+        return;
+    }
+    const dim3 grid(rs.nrb, cdiv(C / 4, 256));
+    if (mode == 0) hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, st, a, y, z, mean, invstd, ws, M, C, rs.rows_per_block);
+    else           hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, st, a, y, z, mean, invstd, ws, M, C, rs.rows_per_block);
+}
 
 extern "C" int vatl_bn_train_fwd_stats(const float* z, int64_t M, int C, const float* gamma, const float* beta, float* running_mean,
                                        float* running_var, float momentum, float eps, float* save_mean, float* save_invstd,
                                        float* scale, float* bias, double* workspace, void* stream) {
     if (!z || !save_mean || !save_invstd || !scale || !bias || !workspace || M <= 0) return fail(VATL_EINVAL, "bn_train_fwd_stats: bad arguments");
-    const int nrb = cdiv(M, ROWS_PER_BLOCK);
-    hipLaunchKernelGGL(col_stats_kernel, dim3(nrb, cdiv(C, CH_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, z, workspace, (long long)M, C);
-    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, workspace, nrb, (long long)M, C, gamma, beta,
+    const RowSplit rs = row_split(M);
+    launch_col_reduce(0, z, nullptr, nullptr, nullptr, nullptr, workspace, (long long)M, C, rs, (hipStream_t)stream);
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, workspace, rs.nrb, (long long)M, C, gamma, beta,
                        running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, bias);
     return check_launch("bn_train_fwd_stats");
 }
@@ -226,10 +330,10 @@ extern "C" int vatl_bn_train_bwd(const float* dy, const float* y_or_null, const 
                                  int64_t M, int C, float* coef3C, double* workspace, void* stream) {
     if (!dy || !z || !save_mean || !save_invstd || !dz || !coef3C || !workspace || (C & 3) || M <= 0)
         return fail(VATL_EINVAL, "bn_train_bwd: bad arguments");
-    const int nrb = cdiv(M, ROWS_PER_BLOCK);
+    const RowSplit rs = row_split(M);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nrb, cdiv(C, CH_PER_BLOCK)), dim3(256), 0, st, dy, y_or_null, z, save_mean, save_invstd, workspace, (long long)M, C);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, workspace, nrb, (long long)M, C, gamma, save_mean, save_invstd,
+    launch_col_reduce(1, dy, y_or_null, z, save_mean, save_invstd, workspace, (long long)M, C, rs, st);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, workspace, rs.nrb, (long long)M, C, gamma, save_mean, save_invstd,
                        dgamma, dbeta, coef3C, coef3C + C, coef3C + 2 * C);
     const long long n4 = M * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, y_or_null, z, coef3C, coef3C + C, coef3C + 2 * C, dz, g_out_or_null, n4, C / 4);
@@ -245,8 +349,22 @@ extern "C" int vatl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx,
 
 extern "C" int vatl_col_sum(const float* x, int64_t M, int C, float* out, double* workspace, void* stream) {
     if (!x || !out || !workspace || M <= 0) return fail(VATL_EINVAL, "col_sum: bad arguments");
-    const int nrb = cdiv(M, ROWS_PER_BLOCK);
-    hipLaunchKernelGGL(col_stats_kernel, dim3(nrb, cdiv(C, CH_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, x, workspace, (long long)M, C);
-    hipLaunchKernelGGL(col_sum_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, workspace, nrb, C, out);
+    const RowSplit rs = row_split(M);
+    launch_col_reduce(0, x, nullptr, nullptr, nullptr, nullptr, workspace, (long long)M, C, rs, (hipStream_t)stream);
+    hipLaunchKernelGGL(col_sum_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, workspace, rs.nrb, C, out);
     return check_launch("col_sum");
+}
+
+extern "C" int vatl_maxpool3x3s2_fwd_idx(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    if (!x || !y || !idx) return fail(VATL_EINVAL, "maxpool3x3s2_fwd_idx: null pointer");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_idx_kernel, dim3(ew_grid((long long)N * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, H, W, C, Ho, Wo);
+    return check_launch("maxpool3x3s2_fwd_idx");
+}
+
+extern "C" int vatl_maxpool3x3s2_bwd_idx(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream) {
+    if (!dy || !idx || !dx) return fail(VATL_EINVAL, "maxpool3x3s2_bwd_idx: null pointer");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_idx_kernel, dim3(ew_grid((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W, C, Ho, Wo);
+    return check_launch("maxpool3x3s2_bwd_idx");
 }

@@ -60,6 +60,8 @@ SIGNATURES = {
     "vatl_scale_bias_act": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _p]),
     "vatl_bn_train_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p]),
     "vatl_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "vatl_maxpool3x3s2_fwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "vatl_maxpool3x3s2_bwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_col_sum": (_i, [_p, _i64, _i, _p, _p, _p]),
     "vatl_masked_mse_workspace_floats": (_i64, [_i64]),
     "vatl_masked_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
@@ -440,6 +442,21 @@ def maxpool3x3s2_bwd(x, dy):
     n, h, w, c = x.shape
     dx = torch.empty_like(x)
     _check(lib().vatl_maxpool3x3s2_bwd(_ptr(x), _ptr(dy), _ptr(dx), n, h, w, c, _stream()), "vatl_maxpool3x3s2_bwd")
+    return dx
+
+
+def maxpool3x3s2_fwd_idx(x):
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), device=x.device, dtype=torch.float32)
+    idx = torch.empty(y.shape, device=x.device, dtype=torch.uint8)
+    _check(lib().vatl_maxpool3x3s2_fwd_idx(_ptr(x), _ptr(y), _ptr(idx, torch.uint8), n, h, w, c, _stream()), "vatl_maxpool3x3s2_fwd_idx")
+    return y, idx
+
+
+def maxpool3x3s2_bwd_idx(dy, idx, in_hw):
+    n, _, _, c = dy.shape
+    dx = torch.empty((n, in_hw[0], in_hw[1], c), device=dy.device, dtype=torch.float32)
+    _check(lib().vatl_maxpool3x3s2_bwd_idx(_ptr(dy), _ptr(idx, torch.uint8), _ptr(dx), n, in_hw[0], in_hw[1], c, _stream()), "vatl_maxpool3x3s2_bwd_idx")
     return dx
 
 
