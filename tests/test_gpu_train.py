@@ -185,9 +185,11 @@ def test_simplepose_finetune_step_vs_reference_golden(vh, golden_simplepose):
     # A 2-crop step through 53 batch-norm layers is ill-conditioned (96 samples per channel in layer4) and
     # chaotic at the 1e-3 level: the reference graph in fp32 on the CPU lands 2.5e-3 .. 8e-3 (max over a whole
     # tensor, relative to its largest entry) away from float64 depending only on thread count / memory format
-    # (measured with oracle/nets.py: 8 threads 7.9e-3, 1 thread 7.8e-3, channels_last 2.5e-3 on deconv_layers.6).
-    # Yardstick: the oracle graph in float64; we must sit inside that same band (every per-op kernel is checked
-    # to <= 5e-5 against float64 autograd in the tests above).
+    # (measured with oracle/nets.py, max-norm: 8 threads 7.9e-3, 1 thread 7.8e-3, channels_last 2.5e-3 on
+    # deconv_layers.6; up to 4.4e-2 on layer4.0.downsample; L2-norm 1e-4 .. 5.3e-3) — ReLU masks flip on values
+    # near zero.  Yardstick: the oracle graph in float64; we must sit inside that same band: L2-relative error
+    # < 2e-2 and max-relative < 5e-2 per tensor (every per-op kernel is checked to <= 5e-5 against float64
+    # autograd in the tests above; a real defect shows up here as an O(0.1..1) error).
     from oracle import nets
     ref64 = nets.SimplePoseRef(50)
     ref64.load_state_dict(synth.state_dict_for(ref64), strict=True)
@@ -206,7 +208,8 @@ def test_simplepose_finetune_step_vs_reference_golden(vh, golden_simplepose):
         e_ours, e_ref = float(np.abs(got - ex).max() / scale), float(np.abs(ref - ex).max() / scale)
         worst = max(worst, e_ours)
         record("train_grad", key=key, ours_vs_fp64=e_ours, reference_fp32_vs_fp64=e_ref, ours_vs_reference=float(np.abs(got - ref).max() / scale))
-        assert e_ours < max(1e-2, 3 * e_ref), (key, e_ours, e_ref)
+        l2_ours = float(np.linalg.norm(got - ex) / max(np.linalg.norm(ex), 1e-30))
+        assert l2_ours < 2e-2 and e_ours < 5e-2, (key, l2_ours, e_ours, e_ref)
         new = sd[key].reshape(-1)[torch.from_numpy(idx).to(dev())].cpu().numpy()
         # AdamW's first step moves every weight by ~lr*sign(g): compare the updated values where the gradient's sign is certain
         sure = np.abs(ex) > 100 * np.abs(ref - ex).max()

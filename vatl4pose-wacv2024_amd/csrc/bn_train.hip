@@ -10,7 +10,7 @@
 
 namespace vatl {
 
-constexpr int MAX_ROW_BLOCKS = 256;      // partial sums per channel (bounds the finalize work)
+constexpr int MAX_ROW_BLOCKS = 4096;     // partial sums per channel (the finalize kernels stride 64 lanes over them)
 
 // Column reductions over NHWC rows: a 256-thread block owns a row range; thread t always handles the same four
 // channels (float4 column t % C4 of a 256-column slab selected by blockIdx.y) and every 256/C4-th row, so global
@@ -18,7 +18,7 @@ constexpr int MAX_ROW_BLOCKS = 256;      // partial sums per channel (bounds the
 // partial[(rb * C + c) * 2 + {0,1}].
 struct RowSplit { long long rows_per_block; int nrb; };
 static inline RowSplit row_split(long long M) {
-    long long nrb = (M + 511) / 512;
+    long long nrb = (M + 255) / 256;                  // ~256 rows per block: thousands of blocks keep HBM busy
     if (nrb > MAX_ROW_BLOCKS) nrb = MAX_ROW_BLOCKS;
     if (nrb < 1) nrb = 1;
     const long long rpb = (M + nrb - 1) / nrb;
