@@ -215,6 +215,16 @@ int vatl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int
  * and the backward that consumes it.  idx (N,Ho,Wo,C) uint8. */
 int vatl_maxpool3x3s2_fwd_idx(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
 int vatl_maxpool3x3s2_bwd_idx(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream);
+/* Backward of nn.PixelShuffle(2) on NHWC: x (N,2H,2W,C/4) -> y (N,H,W,C). */
+int vatl_pixelunshuffle2(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* Backward of the SE-gated residual y = relu(u*sigmoid(gate) + shortcut) (SE_Resnet.py:125-135), two stages:
+ *  1 (dgate != NULL): dgate[n][c] = sigmoid'(gate) * sum_hw dy*[y>0]*u  — gradient of the second Linear's output;
+ *  2 (du != NULL):    gm = dy*[y>0] (shortcut gradient), du = gm*sigmoid(gate) + dpool[n][c]/HW where dpool is the
+ *                     gradient that came back through the two Linear layers to the average-pooled vector. */
+int vatl_se_bwd(const float* dy, const float* y, const float* u, const float* gate, const float* dpool_or_null,
+                float* dgate_or_null, float* du_or_null, float* gm_or_null, int N, int HW, int C, void* stream);
+/* dx = dy * [y > 0] on a flat fp32 span (ReLU backward of the SE MLP). */
+int vatl_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
 /* out[c] = sum over rows of x (M,C)  (conv bias gradient). */
 int vatl_col_sum(const float* x, int64_t M, int C, float* out, double* workspace, void* stream);
 

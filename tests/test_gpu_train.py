@@ -218,3 +218,81 @@ def test_simplepose_finetune_step_vs_reference_golden(vh, golden_simplepose):
         np.testing.assert_allclose(sd[key].cpu().numpy(), g[f"bnstat::{key}"], rtol=1e-4, atol=1e-5)
     assert int(sd["preact.bn1.num_batches_tracked"]) == int(g["bn_tracked"])
     record("train_step_worst_grad_rel", rel=worst)
+
+
+def test_fastpose_training_kernels(vh):
+    """PixelShuffle backward, SE gate backward, Linear backward vs float64 autograd."""
+    r = np.random.RandomState(9)
+    x = r.standard_normal((2, 64, 5, 3)).astype(np.float32)
+    y = F.pixel_shuffle(torch.from_numpy(x), 2).numpy()
+    back = vh.pixelunshuffle2(vh.nchw_to_nhwc(to_dev(y)))
+    assert np.array_equal(_nchw(back.cpu().numpy()), x)
+    # SE-gated residual
+    n, c, h, w = 3, 64, 4, 6
+    u = r.standard_normal((n, c, h, w)).astype(np.float32); sc = r.standard_normal((n, c, h, w)).astype(np.float32)
+    g = r.standard_normal((n, c)).astype(np.float32); dy = r.standard_normal((n, c, h, w)).astype(np.float32)
+    ut, st, gt = (torch.from_numpy(a).double().requires_grad_() for a in (u, sc, g))
+    yt = (ut * torch.sigmoid(gt)[:, :, None, None] + st).relu()
+    yt.backward(torch.from_numpy(dy).double())
+    ud, dyd = to_dev(_nhwc(u)), to_dev(_nhwc(dy))
+    yd = vh.se_scale_add_relu(ud, to_dev(g), to_dev(_nhwc(sc)))
+    dgate = vh.se_bwd_gate(dyd, yd, ud, to_dev(g))
+    assert rel_err(dgate.cpu().numpy(), gt.grad.numpy()) < 2e-5
+    du, gm = vh.se_bwd_apply(dyd, yd, to_dev(g), torch.zeros((n, c), device=dev()))
+    assert rel_err(_nchw(du.cpu().numpy()), ut.grad.numpy()) < 2e-5 and rel_err(_nchw(gm.cpu().numpy()), st.grad.numpy()) < 1e-6
+    # Linear + ReLU
+    from alphapose.models import hip_train
+    lin = torch.nn.Linear(256, 128).to(dev())
+    xt = torch.from_numpy(r.standard_normal((5, 256)).astype(np.float32))
+    ref_lin = torch.nn.Linear(256, 128).double()
+    ref_lin.load_state_dict({k: v.detach().cpu().double() for k, v in lin.state_dict().items()})
+    xr = xt.double().requires_grad_()
+    out = ref_lin(xr).relu()
+    dyl = torch.from_numpy(r.standard_normal((5, 128)).astype(np.float32))
+    out.backward(dyl.double())
+    lt = hip_train._LinearT(lin, True)
+    grads = {}
+    yl = lt.forward(xt.to(dev()))
+    dxl = lt.backward(dyl.to(dev()), grads)
+    assert rel_err(yl.cpu().numpy(), out.detach().numpy()) < 1e-5 and rel_err(dxl.cpu().numpy(), xr.grad.numpy()) < 2e-5
+    assert rel_err(grads[lin.weight].cpu().numpy(), ref_lin.weight.grad.numpy()) < 5e-5
+    assert rel_err(grads[lin.bias].cpu().numpy(), ref_lin.bias.grad.numpy()) < 1e-5
+
+
+def test_fastpose_finetune_step_vs_reference_golden(vh):
+    """FastPose-R50 (SE blocks, DUC head) in training mode: loss and gradients against the reference's own step,
+    judged with the float64 oracle as for SimplePose."""
+    import os
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    from oracle import nets
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fastpose_hrnet.npz"))
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    m = builder.build_sppe(edict({"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50}), preset_cfg=preset)
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    m = m.to(dev()).train()
+    x = to_dev(synth.crops(2))
+    labels, masks = synth.gaussian_targets(2, seed=11)
+    labels, masks = to_dev(labels), to_dev(masks)
+    out = m(x.requires_grad_())
+    loss = 0.5 * torch.nn.MSELoss()(out.mul(masks), labels.mul(masks))
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["fastpose_train_loss"]), rtol=1e-4)
+    ref64 = nets.FastPoseRef()
+    ref64.load_state_dict(synth.state_dict_for(ref64), strict=True)
+    ref64 = ref64.double().train()
+    o64 = ref64(torch.from_numpy(synth.crops(2)).double())
+    (0.5 * torch.nn.MSELoss()(o64 * masks.cpu().double(), labels.cpu().double() * masks.cpu().double())).backward()
+    exact = {k: p.grad.numpy() for k, p in ref64.named_parameters()}
+    named = dict(m.named_parameters())
+    assert all(p.grad is not None for p in m.parameters())
+    for key in [k[19:] for k in g.files if k.startswith("fastpose_grad_idx::")]:
+        idx = g[f"fastpose_grad_idx::{key}"]
+        got = named[key].grad.reshape(-1)[torch.from_numpy(idx).to(dev())].cpu().numpy()
+        ex = exact[key].reshape(-1)[idx]
+        ref = g[f"fastpose_grad_val::{key}"]
+        scale = max(np.abs(ex).max(), 1e-30)
+        l2 = float(np.linalg.norm(got - ex) / max(np.linalg.norm(ex), 1e-30))
+        record("fastpose_train_grad", key=key, ours_l2_vs_fp64=l2, reference_fp32_l2_vs_fp64=float(np.linalg.norm(ref - ex) / max(np.linalg.norm(ex), 1e-30)),
+               ours_max_vs_fp64=float(np.abs(got - ex).max() / scale))
+        assert l2 < 2e-2 and np.abs(got - ex).max() / scale < 5e-2, (key, l2)

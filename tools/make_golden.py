@@ -394,6 +394,23 @@ def gen_fastpose_hrnet(EasyDict, out: str):
             res[f"{name}_heatmaps"] = hm
             if hasattr(m, "get_embedding"):
                 res[f"{name}_embedding"] = m.get_embedding(x).numpy()
+        if name == "fastpose":                                   # one fine-tune step (ActiveLearning.py:662-673), gradients sampled
+            torch.manual_seed(synth.SEED)
+            mt = builder.build_sppe(EasyDict(c), preset_cfg=preset)
+            mt.load_state_dict(synth.state_dict_for(mt), strict=True)
+            mt.train()
+            labels, masks = synth.gaussian_targets(2, seed=11)
+            outp = mt(x.clone().requires_grad_())
+            loss = 0.5 * torch.nn.MSELoss()(outp.mul(torch.from_numpy(masks)), torch.from_numpy(labels).mul(torch.from_numpy(masks)))
+            loss.backward()
+            res["fastpose_train_loss"] = np.float64(loss.item())
+            named = dict(mt.named_parameters())
+            for k in ("conv_out.weight", "conv_out.bias", "duc2.conv.weight", "duc1.bn.weight", "preact.layer4.0.se.fc.2.weight",
+                      "preact.layer4.0.se.fc.0.bias", "preact.layer4.0.conv3.weight", "preact.layer2.0.se.fc.0.weight",
+                      "preact.layer1.0.conv1.weight", "preact.conv1.weight"):
+                ii = _sample_idx(named[k].numel(), "fg" + k, 512)
+                res[f"fastpose_grad_idx::{k}"] = ii
+                res[f"fastpose_grad_val::{k}"] = named[k].grad.reshape(-1)[ii].numpy()
         sd = m.state_dict()
         res[f"{name}_keys"] = np.array(list(sd.keys()))
         res[f"{name}_shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])

@@ -43,8 +43,7 @@ def main():
     from alphapose.models import hip_train
 
     def step():
-        tr = m.__dict__.get("_vatl_trainer") or hip_train.SimplePoseTrainer(m)
-        m.__dict__["_vatl_trainer"] = tr
+        tr = hip_train.trainer_for(m)
         with torch.no_grad():
             out = tr.forward(x)
             loss, dout = vh.masked_mse_fwd_bwd(out, labels, masks)       # fused loss + gradient

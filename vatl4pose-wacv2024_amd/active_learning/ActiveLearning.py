@@ -248,8 +248,7 @@ class ActiveLearning:
         loader = DataLoader(subset, batch_size=self.cfg.RETRAIN.BATCH_SIZE * ngpu, shuffle=True, num_workers=0, drop_last=False,
                             collate_fn=self.collate_fn)
         self.model.train()
-        trainer = self.model.__dict__.get("_vatl_trainer") or hip_train.SimplePoseTrainer(self.model)
-        self.model.__dict__["_vatl_trainer"] = trainer
+        trainer = hip_train.trainer_for(self.model)
         for _ in range(self.retrain_epoch):
             for (idxs, inps, labels, label_masks, *_rest) in loader:
                 x = inps[:, 0].to(self.device).float().contiguous()

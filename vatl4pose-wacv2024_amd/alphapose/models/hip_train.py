@@ -14,8 +14,8 @@ Per Conv+BN(+add)(+ReLU) layer:
             dW = wgrad(x, dz) (MFMA, split over pixels) ;
             dx = conv(dz, flipped/transposed W) — for a stride-2 conv as per-parity launches over
             the dz grid (no zero stuffing), the skip gradient rides in as the epilogue residual.
-Only SimplePose (ResNet bottlenecks + deconv head) is wired so far; FastPose / HRNet training is
-listed as next in DESIGN.md.
+SimplePose (ResNet bottlenecks + deconv head) and FastPose (SE bottlenecks, PixelShuffle/DUC head, biased 3x3
+output conv) are wired; HRNet has no fine-tune path in the reference's loop either.
 """
 from __future__ import annotations
 
@@ -187,6 +187,110 @@ class SimplePoseTrainer:
         return grads
 
 
+class _LinearT:
+    """nn.Linear (+ReLU) on (B,C): the 1x1-conv kernel forward, transposed-weight conv / MFMA wgrad / column sum backward."""
+
+    def __init__(self, lin: nn.Linear, relu: bool):
+        self.lin, self.relu = lin, relu
+        self.co, self.ci = lin.weight.shape
+
+    def forward(self, x2d):
+        b = x2d.shape[0]
+        w4 = self.lin.weight.detach().reshape(self.co, self.ci, 1, 1)
+        _, bias = vh.bn_fold(None, None, None, None, 0.0, self.lin.bias.detach(), channels=self.co)
+        y = vh.conv2d_fwd(x2d.reshape(b, 1, 1, self.ci), vh.pack_conv_weight(w4), None, bias, self.co, 1, 1, 1, 0, self.relu).reshape(b, self.co)
+        self.saved = (x2d, y)
+        return y
+
+    def backward(self, dy, grads):
+        x2d, y = self.saved
+        self.saved = None
+        b = x2d.shape[0]
+        if self.relu:
+            dy = vh.relu_bwd(dy.contiguous(), y)
+        grads[self.lin.bias] = vh.col_sum(dy)
+        grads[self.lin.weight] = vh.conv2d_wgrad(x2d.reshape(b, 1, 1, self.ci), dy.reshape(b, 1, 1, self.co), self.co, self.ci, 1, 1, 1, 0).reshape(self.co, self.ci)
+        wd = vh.pack_dgrad_weight(self.lin.weight.detach().reshape(self.co, self.ci, 1, 1), [(0, 0)])
+        return vh.conv2d_fwd_ex(dy.reshape(b, 1, 1, self.co), wd, self.ci, 1, 1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 0, 0).reshape(b, self.ci)
+
+
+class _SEBottleneckT:
+    """First block of a FastPose stage: y = relu(bn3(conv3(..)) * sigmoid(fc(avgpool(.))) + projection(x))
+    (SE_Resnet.py:110-137, SE_module.py:20-24)."""
+
+    def __init__(self, blk):
+        self.c1 = _ConvBN(blk.conv1, blk.bn1, True)
+        self.c2 = _ConvBN(blk.conv2, blk.bn2, True)
+        self.c3 = _ConvBN(blk.conv3, blk.bn3, False)
+        self.proj = _ConvBN(blk.downsample[0], blk.downsample[1], False)
+        self.fc1, self.fc2 = _LinearT(blk.se.fc[0], True), _LinearT(blk.se.fc[2], False)
+
+    def forward(self, x):
+        u = self.c3.forward(self.c2.forward(self.c1.forward(x)))
+        gate = self.fc2.forward(self.fc1.forward(vh.gap_fwd(u)))              # pre-sigmoid
+        y = vh.se_scale_add_relu(u, gate, self.proj.forward(x))
+        self.saved = (u, gate, y)
+        return y
+
+    def backward(self, dy, grads):
+        u, gate, y = self.saved
+        self.saved = None
+        dgate = vh.se_bwd_gate(dy, y, u, gate)
+        dpool = self.fc1.backward(self.fc2.backward(dgate, grads), grads)
+        du, gm = vh.se_bwd_apply(dy, y, gate, dpool)
+        db, _ = self.c3.backward(du, grads)
+        da, _ = self.c2.backward(db, grads)
+        dskip, _ = self.proj.backward(gm, grads)
+        dx, _ = self.c1.backward(da, grads, dx_residual=dskip)
+        return dx
+
+
+class FastPoseTrainer:
+    """Tape-based forward/backward of FastPose in training mode (fastpose.py:52-59)."""
+
+    def __init__(self, m):
+        t = m.preact
+        self.stem = _ConvBN(t.conv1, t.bn1, True, need_dx=False)
+        self.blocks = [(_SEBottleneckT(b) if getattr(b, "reduc", False) else _BottleneckT(b)) for stage in t.stages() for b in stage]
+        self.duc1 = _ConvBN(m.duc1.conv, m.duc1.bn, True)
+        self.duc2 = _ConvBN(m.duc2.conv, m.duc2.bn, True)
+        self.head = m.conv_out
+
+    def forward(self, x_nchw):
+        s = self.stem.forward(vh.nchw_to_nhwc(x_nchw, 4))
+        x, self.pool_idx = vh.maxpool3x3s2_fwd_idx(s)
+        self.pool_hw = (s.shape[1], s.shape[2])
+        for b in self.blocks:
+            x = b.forward(x)
+        x = vh.pixelshuffle2_fwd(x)
+        x = vh.pixelshuffle2_fwd(self.duc1.forward(x))
+        x = vh.pixelshuffle2_fwd(self.duc2.forward(x))
+        self.head_in = x
+        j = self.head.weight.shape[0]
+        _, hb = vh.bn_fold(None, None, None, None, 0.0, self.head.bias.detach(), channels=j)
+        return vh.conv2d_fwd(x, vh.pack_conv_weight(self.head.weight.detach()), None, hb, j, 3, 3, 1, 1, False, out_nchw=True)
+
+    def backward(self, dout_nchw):
+        grads = {}
+        j, cin = self.head.weight.shape[:2]
+        dy = vh.nchw_to_nhwc(dout_nchw.contiguous(), 32)
+        grads[self.head.bias] = vh.col_sum(dy)[:j].contiguous()
+        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, 3, 3, 1, 1)
+        wd = vh.pack_dgrad_weight(self.head.weight.detach(), _flipped_taps(3, 3), cout_k=32)
+        n, h, w, _ = self.head_in.shape
+        dx = vh.conv2d_fwd_ex(dy, wd, cin, 3, 3, 1, 1, 1, h, w, h, w, 1, 1, 0, 0)
+        self.head_in = None
+        dx, _ = self.duc2.backward(vh.pixelunshuffle2(dx), grads)
+        dx, _ = self.duc1.backward(vh.pixelunshuffle2(dx), grads)
+        dx = vh.pixelunshuffle2(dx)
+        for b in reversed(self.blocks):
+            dx = b.backward(dx, grads)
+        dx = vh.maxpool3x3s2_bwd_idx(dx, self.pool_idx, self.pool_hw)
+        self.pool_idx = None
+        self.stem.backward(dx, grads)
+        return grads
+
+
 class _TrainFn(torch.autograd.Function):
     """Bridges the HIP forward/backward into torch autograd so that the reference's
     `loss.backward()` fills `.grad` of every parameter (ActiveLearning.py:669-673)."""
@@ -204,14 +308,26 @@ class _TrainFn(torch.autograd.Function):
         return (None, None) + tuple(grads.get(p) for p in ctx.params)
 
 
-def forward_train(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
+def trainer_for(m: nn.Module):
+    """The (cached) tape trainer of a pose network."""
+    from .fastpose import FastPose
     from .simplepose import SimplePose
-    if not isinstance(m, SimplePose):
-        raise NotImplementedError(f"training-mode HIP path is implemented for SimplePose only, not {type(m).__name__}")
-    if not x.is_cuda:
-        raise vh.VatlError("the pose network trains on MI355X only (there is deliberately no CPU fallback)")
     tr = m.__dict__.get("_vatl_trainer")
     if tr is None:
-        tr = m.__dict__["_vatl_trainer"] = SimplePoseTrainer(m)
+        if isinstance(m, SimplePose):
+            tr = SimplePoseTrainer(m)
+        elif isinstance(m, FastPose):
+            tr = FastPoseTrainer(m)
+        else:
+            raise NotImplementedError(f"training-mode HIP path is implemented for SimplePose and FastPose, not {type(m).__name__} "
+                                      "(the reference's loop cannot fine-tune it either: ActiveLearning.py:224-228)")
+        m.__dict__["_vatl_trainer"] = tr
+    return tr
+
+
+def forward_train(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    if not x.is_cuda:
+        raise vh.VatlError("the pose network trains on MI355X only (there is deliberately no CPU fallback)")
+    tr = trainer_for(m)
     params = tuple(p for p in m.parameters() if p.requires_grad)
     return _TrainFn.apply(x.detach().float().contiguous(), tr, *params)

@@ -205,6 +205,72 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __r
     }
 }
 
+
+// inverse of PixelShuffle(2) on NHWC (its backward): in (N,2H,2W,C/4) -> out (N,H,W,C), out[y][x][4c+2i+j] = in[2y+i][2x+j][c]
+__global__ void pixelunshuffle2_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+    const int C4 = C >> 2;
+    const long long total = (long long)N * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long t = i / C4;
+        const int px = (int)(t % W); t /= W;
+        const int py = (int)(t % H);
+        const long long n = t / H;
+        const float* s = x + ((n * 2 * H + 2 * py) * 2 * W + 2 * px) * C4 + c;
+        f32x4 v;
+        v[0] = s[0]; v[1] = s[C4]; v[2] = s[(long long)2 * W * C4]; v[3] = s[(long long)2 * W * C4 + C4];
+        *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    }
+}
+
+// SE block backward, stage 1 (per item and channel): gm = dy*[y>0];  dgate[n][c] = sig'(g) * sum_hw gm*u
+__global__ void se_bwd_gate_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ u,
+                                   const float* __restrict__ gate, float* __restrict__ dgate, int N, int HW, int C) {
+    const long long total = (long long)N * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / C;
+        const int c = (int)(i - n * C);
+        const long long base = n * HW * C + c;
+        float s = 0.f;
+        for (int k = 0; k < HW; ++k) {
+            const long long o = base + (long long)k * C;
+            if (y[o] > 0.f) s += dy[o] * u[o];
+        }
+        const float sg = 1.f / (1.f + expf(-gate[i]));
+        dgate[i] = s * sg * (1.f - sg);
+    }
+}
+
+// SE block backward, stage 2: gm = dy*[y>0] (gradient of the shortcut), du = gm*sigmoid(g) + dpool[n][c]/HW
+__global__ void se_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ gate,
+                                    const float* __restrict__ dpool, float* __restrict__ du, float* __restrict__ gm, int N, int HW, int C) {
+    const int C4 = C >> 2;
+    const long long total = (long long)N * HW * C4;
+    const float inv = 1.f / (float)HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long long n = i / ((long long)HW * C4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gate + n * C + c4 * 4);
+        const f32x4 dp = *reinterpret_cast<const f32x4*>(dpool + n * C + c4 * 4);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dy + i * 4);
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + i * 4);
+        f32x4 o, m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            m[e] = yy[e] > 0.f ? d[e] : 0.f;
+            o[e] = m[e] * (1.f / (1.f + expf(-g[e]))) + dp[e] * inv;
+        }
+        *reinterpret_cast<f32x4*>(du + i * 4) = o;
+        *reinterpret_cast<f32x4*>(gm + i * 4) = m;
+    }
+}
+
+// dx = dy * [y > 0]   (ReLU backward on a flat fp32 span)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
 static inline int grid_for(long long total, int block = 256) {
     long long g = (total + block - 1) / block;
     if (g > 256 * 16) g = 256 * 16;
@@ -303,4 +369,32 @@ extern "C" int vatl_pack_dgrad_weight(const float* w_oihw, float* out, int Cout,
     }
     hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3(grid_for((long long)CinPad * ntaps * CoutK)), dim3(256), 0, (hipStream_t)stream, w_oihw, out, Cout, Cin, R, S, CinPad, CoutK, t);
     return check_launch("pack_dgrad_weight");
+}
+
+extern "C" int vatl_pixelunshuffle2(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    if (!x || !y || (C & 15)) return fail(VATL_EINVAL, "pixelunshuffle2: C %d must be a multiple of 16", C);
+    hipLaunchKernelGGL(pixelunshuffle2_kernel, dim3(grid_for((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C);
+    return check_launch("pixelunshuffle2");
+}
+
+extern "C" int vatl_se_bwd(const float* dy, const float* y, const float* u, const float* gate, const float* dpool_or_null,
+                           float* dgate_or_null, float* du_or_null, float* gm_or_null, int N, int HW, int C, void* stream) {
+    if (!dy || !y || !gate || (C & 3)) return fail(VATL_EINVAL, "se_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (dgate_or_null) {
+        if (!u) return fail(VATL_EINVAL, "se_bwd: stage 1 needs u");
+        hipLaunchKernelGGL(se_bwd_gate_kernel, dim3(grid_for((long long)N * C)), dim3(256), 0, st, dy, y, u, gate, dgate_or_null, N, HW, C);
+    }
+    if (du_or_null) {
+        if (!dpool_or_null || !gm_or_null) return fail(VATL_EINVAL, "se_bwd: stage 2 needs dpool and gm");
+        hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(grid_for((long long)N * HW * (C / 4))), dim3(256), 0, st, dy, y, gate, dpool_or_null, du_or_null, gm_or_null, N, HW, C);
+    }
+    return check_launch("se_bwd");
+}
+
+extern "C" int vatl_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream) {
+    if (!dy || !y || !dx) return fail(VATL_EINVAL, "relu_bwd: null pointer");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, (long long)n);
+    return check_launch("relu_bwd");
 }

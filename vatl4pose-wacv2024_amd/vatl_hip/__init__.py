@@ -62,6 +62,9 @@ SIGNATURES = {
     "vatl_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_maxpool3x3s2_fwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_maxpool3x3s2_bwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "vatl_pixelunshuffle2": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "vatl_se_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "vatl_relu_bwd": (_i, [_p, _p, _p, _i64, _p]),
     "vatl_col_sum": (_i, [_p, _i64, _i, _p, _p, _p]),
     "vatl_masked_mse_workspace_floats": (_i64, [_i64]),
     "vatl_masked_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
@@ -457,6 +460,33 @@ def maxpool3x3s2_bwd_idx(dy, idx, in_hw):
     n, _, _, c = dy.shape
     dx = torch.empty((n, in_hw[0], in_hw[1], c), device=dy.device, dtype=torch.float32)
     _check(lib().vatl_maxpool3x3s2_bwd_idx(_ptr(dy), _ptr(idx, torch.uint8), _ptr(dx), n, in_hw[0], in_hw[1], c, _stream()), "vatl_maxpool3x3s2_bwd_idx")
+    return dx
+
+
+def pixelunshuffle2(x):
+    n, h2, w2, c4 = x.shape
+    y = torch.empty((n, h2 // 2, w2 // 2, c4 * 4), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_pixelunshuffle2(_ptr(x), _ptr(y), n, h2 // 2, w2 // 2, c4 * 4, _stream()), "vatl_pixelunshuffle2")
+    return y
+
+
+def se_bwd_gate(dy, y, u, gate):
+    n, h, w, c = dy.shape
+    dgate = torch.empty((n, c), device=dy.device, dtype=torch.float32)
+    _check(lib().vatl_se_bwd(_ptr(dy), _ptr(y), _ptr(u), _ptr(gate), None, _ptr(dgate), None, None, n, h * w, c, _stream()), "vatl_se_bwd")
+    return dgate
+
+
+def se_bwd_apply(dy, y, gate, dpool):
+    n, h, w, c = dy.shape
+    du, gm = torch.empty_like(dy), torch.empty_like(dy)
+    _check(lib().vatl_se_bwd(_ptr(dy), _ptr(y), None, _ptr(gate), _ptr(dpool), None, _ptr(du), _ptr(gm), n, h * w, c, _stream()), "vatl_se_bwd")
+    return du, gm
+
+
+def relu_bwd(dy, y):
+    dx = torch.empty_like(dy)
+    _check(lib().vatl_relu_bwd(_ptr(dy), _ptr(y), _ptr(dx), dy.numel(), _stream()), "vatl_relu_bwd")
     return dx
 
 
