@@ -137,12 +137,13 @@ class ActiveLearning:
                 return cur, None, None
             return cur, m(inps[:, 1].to(self.device)), m(inps[:, 2].to(self.device))
 
-    def eval_and_query(self):
-        self.model.eval()
-        n = self.eval_len
+    def _score_range(self, lo, hi):
+        """Forward + score the id-sorted items lo..hi-1 (one shard plus its halo); returns (hi-lo, 55) float32 rows:
+        51 key-point values, 2 uncertainty values, local-peak mean, OKS."""
+        n = hi - lo
         J, (hh, hw) = self.cfg.DATA_PRESET.NUM_JOINTS, self.hm_size
-        # the whole id-sorted stream of heat-maps stays on the device (209 KB per item) and is scored in one pass,
-        # so THC/TPC neighbours across loader batches need no special casing
+        # the shard's heat-maps stay on the device (209 KB per item) and are scored in one pass, so THC/TPC
+        # neighbours across loader batches need no special casing
         hm_all = torch.empty((n, J, hh, hw), device=self.device)
         bb_all = torch.empty((n, 4), device=self.device)
         ip_all = torch.zeros(n, dtype=torch.uint8, device=self.device)
@@ -151,10 +152,14 @@ class ActiveLearning:
         gt_all = np.zeros((n, 3 * J), np.float64)
         ann_all = np.zeros((n, 4), np.float64)
         thc_norm = {"THC_L1": "L1", "THC": "L1", "THC+WPU": "L1", "THC_L2": "L2"}.get(self.uncertainty)
-        for (idxs, inps, labels, label_masks, GTkpts, img_ids, ann_ids, bboxes_crop, bboxes_ann, isPrev, isNext) in self.eval_loader:
+        loader = self.eval_loader if (lo == 0 and hi == self.eval_len) else DataLoader(
+            Subset(self.eval_dataset, list(range(lo, hi))), batch_size=self.eval_loader.batch_size, shuffle=False, num_workers=0,
+            collate_fn=self.collate_fn)
+        for (idxs, inps, labels, label_masks, GTkpts, img_ids, ann_ids, bboxes_crop, bboxes_ann, isPrev, isNext) in loader:
             cur, prev, nxt = self._heatmaps(inps)
             assert cur.dim() == 4, "the dimension of output must be 4"
-            idx = torch.as_tensor(idxs, device=self.device)
+            loc = np.asarray(idxs) - lo
+            idx = torch.as_tensor(loc, device=self.device)
             ip = torch.as_tensor(isPrev, dtype=torch.uint8, device=self.device)
             inx = torch.as_tensor(isNext, dtype=torch.uint8, device=self.device)
             hm_all[idx] = cur
@@ -164,32 +169,44 @@ class ActiveLearning:
                 tp, tn = vh.thc_pairs(cur, prev, thc_norm), vh.thc_pairs(cur, nxt, thc_norm)
                 one = (ip ^ inx).float()
                 thc_ref[idx] = (tp * ip + tn * inx) * (1 + one)
-            gt_all[np.asarray(idxs)] = GTkpts.reshape(len(idxs), -1).numpy()
-            ann_all[np.asarray(idxs)] = np.asarray([bbox_xyxy_to_xywh(b.tolist()) for b in bboxes_ann])
+            gt_all[loc] = GTkpts.reshape(len(idxs), -1).numpy()
+            ann_all[loc] = np.asarray([bbox_xyxy_to_xywh(b.tolist()) for b in bboxes_ann])
         ae_flat = self.AE.packed() if self.AE is not None else None
         s = score_batch(hm_all, bb_all, ip_all, in_all, thc_norm=thc_norm if self.dedup else None, ae_flat=ae_flat,
                         ae_dims=(self.AE.input_dim, self.AE.z_dim) if self.AE is not None else (42, 4),
                         wpu_only38=(self.uncertainty == "WPU"))
         if thc_norm is not None and not self.dedup:
             s.thc = thc_ref
-        unc = np.zeros((n, 2), np.float64)
+        unc = torch.zeros((n, 2), device=self.device)
         if self.uncertainty == "HP":
-            unc[:, 0] = s.hp.cpu().numpy()
+            unc[:, 0] = s.hp
         elif self.uncertainty == "TPC":
             if not self.dedup:
                 raise ValueError("TPC needs an id-sorted stream dataset in this build")
-            unc[:, 0] = vh.tpc_stream(hm_all, bb_all, s.keypoints[:, :, :2].contiguous(), ip_all, in_all).cpu().numpy()
+            unc[:, 0] = vh.tpc_stream(hm_all, bb_all, s.keypoints[:, :, :2].contiguous(), ip_all, in_all)
         elif thc_norm is not None:
-            unc[:, 0] = s.thc.cpu().numpy()
+            unc[:, 0] = s.thc
             if self.uncertainty == "THC+WPU":
                 self._check_wpu(s.wpu_status)
-                unc[:, 1] = s.wpu.cpu().numpy()
+                unc[:, 1] = s.wpu
         elif self.uncertainty == "WPU":
             self._check_wpu(s.wpu_status)
-            unc[:, 0] = s.wpu.cpu().numpy()
-        kp_all = s.keypoints.reshape(n, -1).cpu().numpy()
-        lp = s.localpeak.cpu().numpy().astype(np.float64)
-        oks = compute_OKS_batch(ann_all, kp_all, gt_all)
+            unc[:, 0] = s.wpu
+        kp = s.keypoints.reshape(n, -1)
+        oks = compute_OKS_batch(ann_all, kp.cpu().numpy(), gt_all)
+        return torch.cat([kp, unc, s.localpeak[:, None], torch.as_tensor(oks, dtype=torch.float32, device=self.device)[:, None]], 1).contiguous()
+
+    def eval_and_query(self):
+        from . import distributed as D
+        self.model.eval()
+        n = self.eval_len
+        # one process per GPU: every rank scores a contiguous shard (+ a one-item halo for the temporal scores)
+        # and the (n, 55) result rows are all-gathered (active_learning/distributed.py); world size 1 = whole stream
+        rows = D.sharded_rows(n, self._score_range, 55, self.device, halo=1 if self.dedup else 0).cpu().numpy()
+        kp_all = rows[:, :51].copy()
+        unc = rows[:, 51:53].astype(np.float64)
+        lp = rows[:, 53].astype(np.float64)
+        oks = rows[:, 54].astype(np.float64)
         self.keypoints, self.oks = kp_all, oks
         evaluate = getattr(self.opt, "evaluate_fn", None)
         res = evaluate(kp_all, self) if evaluate else {"AP": None, "mOKS": float(oks.mean())}
@@ -242,6 +259,7 @@ class ActiveLearning:
     # ------------------------------------------------------------------ hot loop 2
     def retrain_model(self):
         from alphapose.models import hip_train
+        from . import distributed as D
         loss_logger, acc_logger = DataLogger(), DataLogger()
         subset = Subset(self.train_dataset, self.retrain_id)
         ngpu = max(1, int(getattr(self.opt, "num_gpu", 1)))
@@ -256,13 +274,16 @@ class ActiveLearning:
                 with torch.no_grad():
                     out = trainer.forward(x)
                     loss, dout = vh.masked_mse_fwd_bwd(out, labels, label_masks)          # 0.5 * MSE(out*m, label*m) and its gradient
-                    for p, g in trainer.backward(dout).items():
+                    grads = trainer.backward(dout)
+                    D.allreduce_mean_(list(grads.values()))                # data-parallel ranks: one flat fp32 all-reduce per step
+                    for p, g in grads.items():
                         p.grad = g
                 self.optimizer.step()
                 loss_logger.update(float(loss), x.size(0))
                 m = label_masks.reshape(label_masks.shape[0], -1, 1, 1)
                 acc_logger.update(calc_accuracy(out * m, labels * m), x.size(0))
             self.scheduler.step()
+        D.broadcast_buffers_(self.model)           # BN statistics are per rank; rank 0's survive (DataParallel semantics)
         self.last_train_loss, self.last_train_acc = loss_logger.avg, acc_logger.avg
 
     # ------------------------------------------------------------------ round logic (ActiveLearning.py:166-205)

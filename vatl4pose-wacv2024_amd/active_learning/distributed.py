@@ -60,3 +60,12 @@ def allreduce_mean_(tensors, group=None):
     for t in tensors:
         t.copy_(flat[off:off + t.numel()].view_as(t))
         off += t.numel()
+
+
+def broadcast_buffers_(module, src: int = 0):
+    """BatchNorm running statistics are computed per rank during a data-parallel fine-tune (like the replicas of
+    nn.DataParallel); the copy that survives is rank ``src``'s."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for b in module.buffers():
+        dist.broadcast(b, src=src)
