@@ -101,6 +101,11 @@ int vatl_se_scale_add_relu(const float* x, const float* gate, const float* resid
  * (N, H>>shift_k, W>>shift_k, C) or NULL (hrnet.py:199-203 Upsample(nearest), :242-260 sum + ReLU). */
 int vatl_fuse_upsample_add(const float* base, const float* z0, int shift0, const float* z1, int shift1, const float* z2, int shift2,
                            float* y, int N, int H, int W, int C, int relu, void* stream);
+/* Backward of the nearest up-sampling term of that fusion: dz (N,H>>shift,W>>shift,C) = block sums of
+ * dy * [yact > 0] over 2^shift x 2^shift pixels (yact = the fused output, NULL = unmasked); autograd of hrnet.py:199-203. */
+int vatl_upsample_nearest_bwd(const float* dy, const float* yact_or_null, float* dz, int N, int H, int W, int C, int shift, void* stream);
+/* Backward of AdaptiveAvgPool2d(1) (simplepose.py:88-91, SE_module.py:21): dx[n][p][c] = dy[n][c] / HW. */
+int vatl_gap_bwd(const float* dy, float* dx, int N, int HW, int C, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * Scorers on heat-maps (N,J,H,W) fp32 NCHW, one pass over HBM each
@@ -243,6 +248,17 @@ int vatl_masked_mse_fwd_bwd(const float* out, const float* target, const float* 
  * per-step scalars from; `step` is the 1-based step count. */
 int vatl_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                     double eps, double weight_decay, int step, void* stream);
+
+/* torch.optim.Adam step (ActiveLearning.py:222-223): like AdamW but `weight_decay`
+ * is an L2 term added to the gradient (the reference passes none: 0). */
+int vatl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, int step, void* stream);
+
+/* torch.optim.SGD step with momentum (dampening 0, no Nesterov), ActiveLearning.py:220-221
+ * (momentum 0.9, weight_decay 5e-4): g' = g + wd*p; buf = g' on step 1, momentum*buf + g' after;
+ * p -= lr*buf. */
+int vatl_sgd_step(float* p, const float* g, float* buf, int64_t n, double lr, double momentum, double weight_decay, int step,
+                  void* stream);
 
 #ifdef __cplusplus
 }

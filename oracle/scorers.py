@@ -362,6 +362,27 @@ def adamw_step(p, g, m, v, step: int, lr: float, wd: float,
     return p.astype(f), m.astype(f), v.astype(f)
 
 
+def adam_step(p, g, m, v, step: int, lr: float, wd: float = 0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    """torch.optim.Adam single-tensor update (ActiveLearning.py:222-223): L2 decay enters the gradient."""
+    f = np.float32
+    g = g + f(wd) * p
+    m = m + (g - m) * f(1.0 - beta1)
+    v = v * f(beta2) + g * g * f(1.0 - beta2)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    p = p - f(lr / bc1) * (m / (np.sqrt(v) / f(np.sqrt(bc2)) + f(eps)))
+    return p.astype(f), m.astype(f), v.astype(f)
+
+
+def sgd_step(p, g, buf, step: int, lr: float, momentum: float = 0.9, wd: float = 0.0):
+    """torch.optim.SGD with momentum, dampening 0, no Nesterov (ActiveLearning.py:220-221)."""
+    f = np.float32
+    g = g + f(wd) * p
+    buf = g.copy() if step == 1 else buf * f(momentum) + g
+    p = p - f(lr) * buf
+    return p.astype(f), buf.astype(f)
+
+
 # --------------------------------------------------------------------------
 # §8f rank 1: OKS and heat-map accuracy         al_metric.py:42-69, metrics.py:118-245
 # --------------------------------------------------------------------------

@@ -147,6 +147,28 @@ def test_masked_mse_and_adamw(vh):
     np.testing.assert_allclose(dp.cpu().numpy(), p, rtol=2e-5, atol=1e-6)                      # vs the numpy oracle
 
 
+def test_adam_and_sgd_steps(vh):
+    """ActiveLearning.py:220-223: the two other optimisers the reference can be configured with."""
+    from active_learning.optim import SGD, Adam
+    r = np.random.RandomState(5)
+    n = 70001
+    p0 = r.standard_normal(n).astype(np.float32)
+    a, m, v = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    b, buf = p0.copy(), np.zeros(n, np.float32)
+    da = torch.nn.Parameter(to_dev(p0)); ds = torch.nn.Parameter(to_dev(p0))
+    oa, os_ = Adam([da], lr=2.5e-4), SGD([ds], lr=2.5e-4, momentum=0.9, weight_decay=0.0005)
+    for step in range(1, 5):
+        g = r.standard_normal(n).astype(np.float32)
+        da.grad = to_dev(g); ds.grad = to_dev(g)
+        oa.step(); os_.step()
+        a, m, v = scorers.adam_step(a, g, m, v, step, 2.5e-4)
+        b, buf = scorers.sgd_step(b, g, buf, step, 2.5e-4, 0.9, 0.0005)
+    record("adam_step", rel=rel_err(da.detach().cpu().numpy(), a)); record("sgd_step", rel=rel_err(ds.detach().cpu().numpy(), b))
+    np.testing.assert_allclose(da.detach().cpu().numpy(), a, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(ds.detach().cpu().numpy(), b, rtol=2e-6, atol=1e-7)
+    assert da._version > 0 and ds._version > 0           # plan caches key on the version counter
+
+
 def test_empty_and_ragged_batches(vh):
     """Edge cases: empty streams return empty results, a 1-item stream has no neighbours, odd sizes work."""
     d = dev()

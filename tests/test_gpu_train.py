@@ -296,3 +296,75 @@ def test_fastpose_finetune_step_vs_reference_golden(vh):
         record("fastpose_train_grad", key=key, ours_l2_vs_fp64=l2, reference_fp32_l2_vs_fp64=float(np.linalg.norm(ref - ex) / max(np.linalg.norm(ex), 1e-30)),
                ours_max_vs_fp64=float(np.abs(got - ex).max() / scale))
         assert l2 < 2e-2 and np.abs(got - ex).max() / scale < 5e-2, (key, l2)
+
+
+def test_upsample_and_gap_backward_kernels(vh):
+    r = np.random.RandomState(9)
+    for shift in (1, 2, 3):
+        dy = r.standard_normal((2, 16, 24, 32)).astype(np.float32)
+        y = r.standard_normal((2, 16, 24, 32)).astype(np.float32)
+        f = 1 << shift
+        for mask in (None, y):
+            g = dy if mask is None else dy * (mask > 0)
+            want = g.reshape(2, 16 // f, f, 24 // f, f, 32).astype(np.float64).sum((2, 4))
+            got = vh.upsample_nearest_bwd(to_dev(dy), None if mask is None else to_dev(mask), shift).cpu().numpy()
+            assert rel_err(got, want) < 1e-6
+    dy = r.standard_normal((3, 64)).astype(np.float32)
+    got = vh.gap_bwd(to_dev(dy), 48).cpu().numpy()
+    np.testing.assert_allclose(got, np.broadcast_to(dy[:, None, :] / np.float32(48), (3, 48, 64)), rtol=1e-6)
+
+
+def _hrnet_cfg():
+    from alphapose.utils.config import edict
+    return edict({"TYPE": "PoseHighResolutionNet", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50, "FINAL_CONV_KERNEL": 1,
+                  "PRETRAINED_LAYERS": ["*"],
+                  "STAGE2": {"NUM_MODULES": 1, "NUM_BRANCHES": 2, "NUM_BLOCKS": [4, 4], "NUM_CHANNELS": [32, 64], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"},
+                  "STAGE3": {"NUM_MODULES": 4, "NUM_BRANCHES": 3, "NUM_BLOCKS": [4, 4, 4], "NUM_CHANNELS": [32, 64, 128], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"},
+                  "STAGE4": {"NUM_MODULES": 3, "NUM_BRANCHES": 4, "NUM_BLOCKS": [4, 4, 4, 4], "NUM_CHANNELS": [32, 64, 128, 256], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"}})
+
+
+def test_hrnet_finetune_step_vs_reference_golden(vh):
+    """HRNet-W32 in training mode (basic blocks, transitions, multi-resolution fusion backward): loss, BN running
+    statistics and gradients against the reference's own step, judged with the float64 oracle."""
+    import os
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    from oracle import nets
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fastpose_hrnet.npz"))
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    m = builder.build_sppe(_hrnet_cfg(), preset_cfg=preset)
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    m = m.to(dev()).train()
+    x = to_dev(synth.crops(2))
+    labels, masks = synth.gaussian_targets(2, seed=11)
+    labels, masks = to_dev(labels), to_dev(masks)
+    out = m(x.requires_grad_())
+    loss = 0.5 * torch.nn.MSELoss()(out.mul(masks), labels.mul(masks))
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["hrnet_train_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(m.bn1.running_mean.cpu().numpy(), g["hrnet_bn1_running_mean"], rtol=1e-4, atol=1e-6)
+    ref64 = nets.HRNetRef()
+    ref64.load_state_dict(synth.state_dict_for(ref64), strict=True)
+    ref64 = ref64.double().train()
+    o64 = ref64(torch.from_numpy(synth.crops(2)).double())
+    (0.5 * torch.nn.MSELoss()(o64 * masks.cpu().double(), labels.cpu().double() * masks.cpu().double())).backward()
+    exact = {k: p.grad.numpy() for k, p in ref64.named_parameters()}
+    named = dict(m.named_parameters())
+    assert all(p.grad is not None for p in m.parameters())
+    worst = 0.0
+    for key, p in named.items():                           # every one of the 900+ parameter tensors against float64
+        ex = exact[key]
+        l2 = float(np.linalg.norm(p.grad.cpu().numpy() - ex) / max(np.linalg.norm(ex), 1e-30))
+        worst = max(worst, l2)
+        assert l2 < 2e-2, (key, l2)
+    record("hrnet_train_grad_all", tensors=len(named), worst_l2_vs_fp64=worst)
+    for key in [k[16:] for k in g.files if k.startswith("hrnet_grad_idx::")]:
+        idx = g[f"hrnet_grad_idx::{key}"]
+        got = named[key].grad.reshape(-1)[torch.from_numpy(idx).to(dev())].cpu().numpy()
+        ex = exact[key].reshape(-1)[idx]
+        ref = g[f"hrnet_grad_val::{key}"]
+        scale = max(np.abs(ex).max(), 1e-30)
+        l2 = float(np.linalg.norm(got - ex) / max(np.linalg.norm(ex), 1e-30))
+        record("hrnet_train_grad", key=key, ours_l2_vs_fp64=l2, reference_fp32_l2_vs_fp64=float(np.linalg.norm(ref - ex) / max(np.linalg.norm(ex), 1e-30)),
+               ours_max_vs_fp64=float(np.abs(got - ex).max() / scale))
+        assert l2 < 2e-2 and np.abs(got - ex).max() / scale < 5e-2, (key, l2)

@@ -140,6 +140,24 @@ def test_masked_mse_and_adamw_against_torch():
         np.testing.assert_allclose(pn, p.detach().numpy(), rtol=2e-5, atol=1e-6)
 
 
+def test_adam_and_sgd_against_torch():
+    r = np.random.RandomState(3)
+    p0 = r.standard_normal(1000).astype(np.float32)
+    pa = torch.from_numpy(p0.copy()).requires_grad_(); ps = torch.from_numpy(p0.copy()).requires_grad_()
+    oa = torch.optim.Adam([pa], lr=2.5e-4)
+    os_ = torch.optim.SGD([ps], lr=2.5e-4, momentum=0.9, weight_decay=0.0005)
+    a, m, v = p0.copy(), np.zeros(1000, np.float32), np.zeros(1000, np.float32)
+    b, buf = p0.copy(), np.zeros(1000, np.float32)
+    for step in range(1, 5):
+        g = r.standard_normal(1000).astype(np.float32)
+        pa.grad = torch.from_numpy(g.copy()); oa.step()
+        ps.grad = torch.from_numpy(g.copy()); os_.step()
+        a, m, v = scorers.adam_step(a, g, m, v, step, 2.5e-4)
+        b, buf = scorers.sgd_step(b, g, buf, step, 2.5e-4, 0.9, 0.0005)
+        np.testing.assert_allclose(a, pa.detach().numpy(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(b, ps.detach().numpy(), rtol=2e-6, atol=1e-7)
+
+
 @pytest.fixture(scope="module")
 def golden_nets2():
     import os

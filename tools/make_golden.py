@@ -411,6 +411,24 @@ def gen_fastpose_hrnet(EasyDict, out: str):
                 ii = _sample_idx(named[k].numel(), "fg" + k, 512)
                 res[f"fastpose_grad_idx::{k}"] = ii
                 res[f"fastpose_grad_val::{k}"] = named[k].grad.reshape(-1)[ii].numpy()
+        if name == "hrnet":                                      # same step on HRNet-W32 (trained by posetrack_train.py:207-231 / SGD, Adam in the AL loop)
+            torch.manual_seed(synth.SEED)
+            mt = builder.build_sppe(EasyDict(c), preset_cfg=preset)
+            mt.load_state_dict(synth.state_dict_for(mt), strict=True)
+            mt.train()
+            labels, masks = synth.gaussian_targets(2, seed=11)
+            outp = mt(x.clone().requires_grad_())
+            loss = 0.5 * torch.nn.MSELoss()(outp.mul(torch.from_numpy(masks)), torch.from_numpy(labels).mul(torch.from_numpy(masks)))
+            loss.backward()
+            res["hrnet_train_loss"] = np.float64(loss.item())
+            named = dict(mt.named_parameters())
+            for k in ("final_layer.weight", "final_layer.bias", "stage4.2.fuse_layers.0.3.0.weight", "stage4.0.fuse_layers.3.0.1.0.weight",
+                      "stage4.0.fuse_layers.2.3.1.weight", "stage3.1.branches.2.3.conv2.weight", "stage2.0.fuse_layers.1.0.0.0.weight",
+                      "transition1.1.0.0.weight", "transition3.3.0.0.weight", "layer1.0.conv1.weight", "conv1.weight"):
+                ii = _sample_idx(named[k].numel(), "hg" + k, 512)
+                res[f"hrnet_grad_idx::{k}"] = ii
+                res[f"hrnet_grad_val::{k}"] = named[k].grad.reshape(-1)[ii].numpy()
+            res["hrnet_bn1_running_mean"] = mt.bn1.running_mean.numpy().copy()
         sd = m.state_dict()
         res[f"{name}_keys"] = np.array(list(sd.keys()))
         res[f"{name}_shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])

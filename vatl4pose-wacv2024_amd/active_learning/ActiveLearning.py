@@ -26,7 +26,7 @@ from alphapose.utils.metrics import DataLogger, calc_accuracy
 from alphapose.utils.transforms import get_func_heatmap_to_coord
 
 from .al_metric import compute_OKS_batch
-from .optim import AdamW
+from .optim import SGD, Adam, AdamW
 from .scoring import score_batch
 
 _UNC = ("None", "HP", "TPC", "THC_L1", "THC_L2", "THC", "WPU", "THC+WPU")
@@ -113,7 +113,9 @@ class ActiveLearning:
                 raise ValueError("Optimizer not supported!")          # the reference leaves `optimizer` unbound here
             optimizer = AdamW(params=groups, weight_decay=cfg.RETRAIN.WEIGHT_DECAY)
         elif kind == "Adam":
-            optimizer = AdamW(model.parameters(), lr=self.lr, weight_decay=0.0)   # Adam == AdamW without decay
+            optimizer = Adam(model.parameters(), lr=self.lr)
+        elif kind == "SGD":
+            optimizer = SGD(model.parameters(), lr=self.lr, momentum=0.9, weight_decay=0.0005)
         else:
             raise ValueError("Optimizer not supported!")
         scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=cfg.RETRAIN.LR_GAMMA)

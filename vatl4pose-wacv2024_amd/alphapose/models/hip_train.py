@@ -14,8 +14,9 @@ Per Conv+BN(+add)(+ReLU) layer:
             dW = wgrad(x, dz) (MFMA, split over pixels) ;
             dx = conv(dz, flipped/transposed W) — for a stride-2 conv as per-parity launches over
             the dz grid (no zero stuffing), the skip gradient rides in as the epilogue residual.
-SimplePose (ResNet bottlenecks + deconv head) and FastPose (SE bottlenecks, PixelShuffle/DUC head, biased 3x3
-output conv) are wired; HRNet has no fine-tune path in the reference's loop either.
+SimplePose (ResNet bottlenecks + deconv head), FastPose (SE bottlenecks, PixelShuffle/DUC head, biased 3x3
+output conv) and HRNet (basic blocks, transitions, multi-resolution fusion; trained by the reference with
+RETRAIN.OPTIMIZER SGD/Adam) are wired.
 """
 from __future__ import annotations
 
@@ -38,15 +39,16 @@ class _ConvBN:
         self.stride, self.pad = conv.stride[0], conv.padding[0]
 
     # ---- forward -------------------------------------------------------------
-    def forward(self, x, skip=None):
+    def forward(self, x, skip=None, relu=None):
+        relu = self.relu if relu is None else relu
         w = vh.pack_conv_weight(self.conv.weight.detach())
         z = vh.conv2d_fwd(x, w, None, None, self.cout, self.r, self.s, self.stride, self.pad, False)
         bn = self.bn
         mean, invstd, scale, bias = vh.bn_train_fwd_stats(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                           bn.momentum, bn.eps)
         bn.num_batches_tracked += 1
-        y = vh.scale_bias_act(z, scale, bias, skip, self.relu)
-        self.saved = (x, z, y if self.relu else None, mean, invstd, skip is not None)
+        y = vh.scale_bias_act(z, scale, bias, skip, relu)
+        self.saved = (x, z, y if relu else None, mean, invstd, skip is not None)
         return y
 
     # ---- backward ------------------------------------------------------------
@@ -54,7 +56,9 @@ class _ConvBN:
         """dy: gradient of the layer output.  Returns (dx, g_skip); parameter gradients go to ``grads``."""
         x, z, y, mean, invstd, had_skip = self.saved
         self.saved = None
-        dz, g, dgamma, dbeta = vh.bn_train_bwd(dy, y, z, self.bn.weight.detach(), mean, invstd, want_g=had_skip)
+        dz, g, dgamma, dbeta = vh.bn_train_bwd(dy, y, z, self.bn.weight.detach(), mean, invstd, want_g=had_skip and y is not None)
+        if had_skip and y is None:
+            g = dy                                         # no ReLU between the sum and the output: the skip gradient is dy
         grads[self.bn.weight] = dgamma
         grads[self.bn.bias] = dbeta
         cin_w = 3 if self.cin == 3 else self.cin
@@ -291,6 +295,156 @@ class FastPoseTrainer:
         return grads
 
 
+class _BasicBlockT:
+    """hrnet.py:24-56: relu(bn2(conv2(relu(bn1(conv1(x))))) + skip)."""
+
+    def __init__(self, blk):
+        self.c1 = _ConvBN(blk.conv1, blk.bn1, True)
+        self.c2 = _ConvBN(blk.conv2, blk.bn2, True)
+        self.proj = _ConvBN(blk.downsample[0], blk.downsample[1], False) if blk.downsample is not None else None
+
+    def forward(self, x):
+        skip = x if self.proj is None else self.proj.forward(x)
+        return self.c2.forward(self.c1.forward(x), skip=skip)
+
+    def backward(self, dy, grads):
+        da, g = self.c2.backward(dy, grads)
+        dskip = g if self.proj is None else self.proj.backward(g, grads)[0]
+        return self.c1.backward(da, grads, dx_residual=dskip)[0]
+
+
+def _block_t(blk):
+    return _BottleneckT(blk) if hasattr(blk, "conv3") else _BasicBlockT(blk)
+
+
+class _ChainT:
+    """Sequential of Conv-BN(-ReLU) groups: HRNet transitions and the strided paths of a fusion row."""
+
+    def __init__(self, seq):
+        groups = [seq] if isinstance(seq[0], nn.Conv2d) else list(seq)
+        self.steps = [_ConvBN(g[0], g[1], len(g) > 2 and isinstance(g[2], nn.ReLU)) for g in groups]
+
+    def forward(self, x, skip=None):
+        for k, st in enumerate(self.steps):
+            x = st.forward(x, skip=skip if k == len(self.steps) - 1 else None)
+        return x
+
+    def backward(self, dy, grads, dx_residual=None):
+        for k in range(len(self.steps) - 1, -1, -1):
+            dy = self.steps[k].backward(dy, grads, dx_residual=dx_residual if k == 0 else None)[0]
+        return dy
+
+
+class _HRModuleT:
+    """HighResolutionModule (hrnet.py:242-260): y_i = relu(x_i + sum_{j<i} down_ij(x_j) + sum_{j>i} up(bn(conv1x1_ij(x_j)))).
+    Forward: strided paths accumulate through the skip input of their last BN, the up-sampled terms and the ReLU
+    are one vatl_fuse_upsample_add launch.  Backward: g_i = dy_i*[y_i>0] goes to x_i unchanged, to the strided
+    paths as is and to the 1x1 paths as 2^s x 2^s block sums; the per-branch sums ride on the dgrad epilogues."""
+
+    def __init__(self, mod):
+        self.branches = [[_block_t(b) for b in br] for br in mod.branches]
+        self.rows = []
+        if mod.fuse_layers is not None:
+            for i, row in enumerate(mod.fuse_layers):
+                self.rows.append((i, [(j, _ChainT(row[j])) for j in range(i)],
+                                  [(j, _ConvBN(row[j][0], row[j][1], False)) for j in range(i + 1, len(row))]))
+
+    def forward(self, xs):
+        xs = list(xs)
+        for i, br in enumerate(self.branches):
+            for blk in br:
+                xs[i] = blk.forward(xs[i])
+        if not self.rows:
+            return xs
+        out = []
+        for i, downs, ups in self.rows:
+            acc = xs[i]
+            for j, chain in downs:
+                acc = chain.forward(xs[j], skip=acc)
+            out.append(vh.fuse_upsample_add(acc, [(cb.forward(xs[j]), j - i) for j, cb in ups], relu=True))
+        self.saved = out
+        return out
+
+    def backward(self, dys, grads):
+        nb = len(self.branches)
+        if self.rows:
+            ys, self.saved = self.saved, None
+            dxs = [None] * nb
+            for i, downs, ups in self.rows:                # identity terms first: they seed the accumulators
+                dxs[i] = vh.relu_bwd(dys[i], ys[i])
+            gs = list(dxs)
+            for i, downs, ups in self.rows:
+                for j, chain in downs:
+                    dxs[j] = chain.backward(gs[i], grads, dx_residual=dxs[j])
+                for j, cb in ups:
+                    dxs[j] = cb.backward(vh.upsample_nearest_bwd(dys[i], ys[i], j - i), grads, dx_residual=dxs[j])[0]
+        else:
+            dxs = list(dys)
+        for i, br in enumerate(self.branches):
+            for blk in reversed(br):
+                dxs[i] = blk.backward(dxs[i], grads)
+        return dxs
+
+
+class HRNetTrainer:
+    """Tape-based forward/backward of PoseHighResolutionNet in training mode (hrnet.py:421-456)."""
+
+    def __init__(self, m):
+        self.stem1 = _ConvBN(m.conv1, m.bn1, True, need_dx=False)
+        self.stem2 = _ConvBN(m.conv2, m.bn2, True)
+        self.layer1 = [_block_t(b) for b in m.layer1]
+        self.stages = []
+        for s in (2, 3, 4):
+            trans = [None if t is None else _ChainT(t) for t in getattr(m, f"transition{s - 1}")]
+            self.stages.append((trans, [_HRModuleT(mod) for mod in getattr(m, f"stage{s}")]))
+        self.head = m.final_layer
+
+    def forward(self, x_nchw):
+        x = self.stem2.forward(self.stem1.forward(vh.nchw_to_nhwc(x_nchw, 4)))
+        for b in self.layer1:
+            x = b.forward(x)
+        ys = [x]
+        self.widths = []
+        for trans, mods in self.stages:
+            self.widths.append(len(ys))
+            xs = [ys[i] if t is None else t.forward(ys[-1]) for i, t in enumerate(trans)]
+            for mod in mods:
+                xs = mod.forward(xs)
+            ys = xs
+        self.head_in = ys[0]
+        j, _, k, _ = self.head.weight.shape
+        _, hb = vh.bn_fold(None, None, None, None, 0.0, self.head.bias.detach(), channels=j)
+        return vh.conv2d_fwd(ys[0], vh.pack_conv_weight(self.head.weight.detach()), None, hb, j, k, k, 1, k // 2, False, out_nchw=True)
+
+    def backward(self, dout_nchw):
+        grads = {}
+        j, cin, k, _ = self.head.weight.shape
+        dy = vh.nchw_to_nhwc(dout_nchw.contiguous(), 32)
+        grads[self.head.bias] = vh.col_sum(dy)[:j].contiguous()
+        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, k, k, 1, k // 2)
+        wd = vh.pack_dgrad_weight(self.head.weight.detach(), _flipped_taps(k, k), cout_k=32)
+        n, h, w, _ = self.head_in.shape
+        dys = [vh.conv2d_fwd_ex(dy, wd, cin, k, k, 1, k // 2, k // 2, h, w, h, w, 1, 1, 0, 0)]
+        self.head_in = None
+        for (trans, mods), width in zip(reversed(self.stages), reversed(self.widths)):
+            for mod in reversed(mods):
+                dys = mod.backward(dys, grads)
+            prev = [None] * width
+            for i, t in enumerate(trans):                  # identity inputs first, then the paths that branch off ys[-1]
+                if t is None:
+                    prev[i] = dys[i]
+            for i, t in enumerate(trans):
+                if t is not None:
+                    prev[width - 1] = t.backward(dys[i], grads, dx_residual=prev[width - 1])
+            dys = prev
+        dx = dys[0]
+        for b in reversed(self.layer1):
+            dx = b.backward(dx, grads)
+        dx, _ = self.stem2.backward(dx, grads)
+        self.stem1.backward(dx, grads)
+        return grads
+
+
 class _TrainFn(torch.autograd.Function):
     """Bridges the HIP forward/backward into torch autograd so that the reference's
     `loss.backward()` fills `.grad` of every parameter (ActiveLearning.py:669-673)."""
@@ -311,6 +465,7 @@ class _TrainFn(torch.autograd.Function):
 def trainer_for(m: nn.Module):
     """The (cached) tape trainer of a pose network."""
     from .fastpose import FastPose
+    from .hrnet import PoseHighResolutionNet
     from .simplepose import SimplePose
     tr = m.__dict__.get("_vatl_trainer")
     if tr is None:
@@ -318,9 +473,10 @@ def trainer_for(m: nn.Module):
             tr = SimplePoseTrainer(m)
         elif isinstance(m, FastPose):
             tr = FastPoseTrainer(m)
+        elif isinstance(m, PoseHighResolutionNet):
+            tr = HRNetTrainer(m)
         else:
-            raise NotImplementedError(f"training-mode HIP path is implemented for SimplePose and FastPose, not {type(m).__name__} "
-                                      "(the reference's loop cannot fine-tune it either: ActiveLearning.py:224-228)")
+            raise NotImplementedError(f"no training-mode HIP path for {type(m).__name__}")
         m.__dict__["_vatl_trainer"] = tr
     return tr
 

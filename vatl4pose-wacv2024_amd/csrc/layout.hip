@@ -191,6 +191,46 @@ __global__ void fuse_up_kernel(const float* __restrict__ base, FuseUpArgs a, flo
     }
 }
 
+// backward of the nearest up-sampling inside the HRNet fusion: dz[n][y][x][c] = sum over the 2^s x 2^s block of
+// g = dy * [yact > 0] (yact = the fused, rectified output; NULL = no mask)
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ yact, float* __restrict__ dz, int N, int H, int W,
+                                    int C, int s) {
+    const int C4 = C >> 2, h2 = H >> s, w2 = W >> s, f = 1 << s;
+    const long long total = (long long)N * h2 * w2 * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int px = (int)(t % w2); t /= w2;
+        const int py = (int)(t % h2);
+        const long long n = t / h2;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < f; ++a)
+            for (int b = 0; b < f; ++b) {
+                const long long o = (((n * H + (py * f + a)) * W + (px * f + b)) * C4 + c4) * 4;
+                f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+                if (yact) {
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(yact + o);
+                    g[0] = y[0] > 0.f ? g[0] : 0.f; g[1] = y[1] > 0.f ? g[1] : 0.f; g[2] = y[2] > 0.f ? g[2] : 0.f; g[3] = y[3] > 0.f ? g[3] : 0.f;
+                }
+                acc[0] += g[0]; acc[1] += g[1]; acc[2] += g[2]; acc[3] += g[3];
+            }
+        *reinterpret_cast<f32x4*>(dz + i * 4) = acc;
+    }
+}
+
+// backward of the global average pool: dx[n][p][c] = dy[n][c] / HW
+__global__ void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int HW, int C, float inv) {
+    const int C4 = C >> 2;
+    const long long total = (long long)N * HW * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long long n = i / ((long long)HW * C4);
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + (n * C4 + c4) * 4);
+        g[0] *= inv; g[1] *= inv; g[2] *= inv; g[3] *= inv;
+        *reinterpret_cast<f32x4*>(dx + i * 4) = g;
+    }
+}
+
 // data-gradient weights: out[c][t][n] = w[n][c][tap_r[t]][tap_s[t]]  ([CinPad][ntaps][Cout], rows c >= Cin zero)
 struct TapList { int r[16]; int s[16]; int n; };
 __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int R, int S, int CinPad,
@@ -356,6 +396,23 @@ extern "C" int vatl_fuse_upsample_add(const float* base, const float* z0, int sh
     }
     hipLaunchKernelGGL(fuse_up_kernel, dim3(grid_for((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, base, a, y, N, H, W, C, relu);
     return check_launch("fuse_upsample_add");
+}
+
+extern "C" int vatl_upsample_nearest_bwd(const float* dy, const float* yact_or_null, float* dz, int N, int H, int W, int C, int shift, void* stream) {
+    if (!dy || !dz || (C & 3)) return fail(VATL_EINVAL, "upsample_nearest_bwd: bad arguments");
+    if (shift < 1 || shift > 5 || (H & ((1 << shift) - 1)) || (W & ((1 << shift) - 1)))
+        return fail(VATL_EINVAL, "upsample_nearest_bwd: %dx%d is not divisible by 2^%d", H, W, shift);
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for((long long)N * (H >> shift) * (W >> shift) * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       dy, yact_or_null, dz, N, H, W, C, shift);
+    return check_launch("upsample_nearest_bwd");
+}
+
+extern "C" int vatl_gap_bwd(const float* dy, float* dx, int N, int HW, int C, void* stream) {
+    if (!dy || !dx || (C & 3) || HW < 1) return fail(VATL_EINVAL, "gap_bwd: bad arguments");
+    if (N <= 0) return 0;
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for((long long)N * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dx, N, HW, C, 1.0f / (float)HW);
+    return check_launch("gap_bwd");
 }
 
 extern "C" int vatl_pack_dgrad_weight(const float* w_oihw, float* out, int Cout, int Cin, int R, int S, int CinPad, int CoutK,

@@ -74,6 +74,53 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// torch.optim.Adam (L2 decay folded into the gradient) and torch.optim.SGD (momentum, dampening 0, no Nesterov)
+// ActiveLearning.py:220-223.  MODE 0 = Adam, 1 = SGD first step (buf = g), 2 = SGD later steps (buf = mu*buf + g).
+template <int MODE>
+__device__ __forceinline__ void opt_elem(float& P, float G, float& M, float& V, float wd, float omb1, float b2, float omb2, float bc2s,
+                                         float eps, float step_size) {
+    G = G + wd * P;
+    if (MODE == 0) {
+        M = M + (G - M) * omb1;
+        V = V * b2 + G * G * omb2;
+        P = P - step_size * (M / (sqrtf(V) / bc2s + eps));
+    } else {
+        M = (MODE == 1) ? G : M * b2 + G;          // b2 carries the momentum for SGD
+        P = P - step_size * M;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void opt_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, long long n, float wd, float omb1, float b2, float omb2,
+                                                  float bc2s, float eps, float step_size) {
+    const long long n4 = n >> 2;
+    for (long long q = blockIdx.x * 256LL + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        f32x4 P = *reinterpret_cast<f32x4*>(p + 4 * q);
+        const f32x4 G = *reinterpret_cast<const f32x4*>(g + 4 * q);
+        f32x4 M = *reinterpret_cast<f32x4*>(m + 4 * q);
+        f32x4 V = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == 0) V = *reinterpret_cast<f32x4*>(v + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float pe = P[e], me = M[e], ve = V[e];
+            opt_elem<MODE>(pe, G[e], me, ve, wd, omb1, b2, omb2, bc2s, eps, step_size);
+            P[e] = pe; M[e] = me; V[e] = ve;
+        }
+        *reinterpret_cast<f32x4*>(p + 4 * q) = P;
+        *reinterpret_cast<f32x4*>(m + 4 * q) = M;
+        if (MODE == 0) *reinterpret_cast<f32x4*>(v + 4 * q) = V;
+    }
+    if (blockIdx.x == 0) {
+        for (long long i = 4 * n4 + threadIdx.x; i < n; i += 256) {
+            float P = p[i], M = m[i], V = (MODE == 0) ? v[i] : 0.f;
+            opt_elem<MODE>(P, g[i], M, V, wd, omb1, b2, omb2, bc2s, eps, step_size);
+            p[i] = P; m[i] = M;
+            if (MODE == 0) v[i] = V;
+        }
+    }
+}
+
 }  // namespace vatl
 
 using namespace vatl;
@@ -111,4 +158,37 @@ extern "C" int vatl_adamw_step(float* p, const float* g, float* m, float* v, int
                        (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
                        (float)sqrt(bc2), (float)eps, (float)(lr / bc1));
     return check_launch("adamw_step");
+}
+
+static unsigned opt_blocks(int64_t n) {
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    return (unsigned)(blocks < 1 ? 1 : blocks);
+}
+
+extern "C" int vatl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                              double eps, double weight_decay, int step, void* stream) {
+    if (!p || !g || !m || !v) return fail(VATL_EINVAL, "adam_step: null pointer");
+    if (step < 1) return fail(VATL_EINVAL, "adam_step: step is 1-based");
+    if (n <= 0) return 0;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return fail(VATL_EINVAL, "adam_step: spans must be 16-byte aligned");
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    hipLaunchKernelGGL(opt_kernel<0>, dim3(opt_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, (float)weight_decay,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(lr / bc1));
+    return check_launch("adam_step");
+}
+
+extern "C" int vatl_sgd_step(float* p, const float* g, float* buf, int64_t n, double lr, double momentum, double weight_decay, int step,
+                             void* stream) {
+    if (!p || !g || !buf) return fail(VATL_EINVAL, "sgd_step: null pointer");
+    if (step < 1) return fail(VATL_EINVAL, "sgd_step: step is 1-based");
+    if (n <= 0) return 0;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) return fail(VATL_EINVAL, "sgd_step: spans must be 16-byte aligned");
+    if (step == 1)
+        hipLaunchKernelGGL(opt_kernel<1>, dim3(opt_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, (float*)nullptr, (long long)n,
+                           (float)weight_decay, 0.f, (float)momentum, 0.f, 1.f, 0.f, (float)lr);
+    else
+        hipLaunchKernelGGL(opt_kernel<2>, dim3(opt_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, (float*)nullptr, (long long)n,
+                           (float)weight_decay, 0.f, (float)momentum, 0.f, 1.f, 0.f, (float)lr);
+    return check_launch("sgd_step");
 }

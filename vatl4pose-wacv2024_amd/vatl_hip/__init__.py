@@ -39,6 +39,8 @@ SIGNATURES = {
     "vatl_pixelshuffle2_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vatl_se_scale_add_relu": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "vatl_fuse_upsample_add": (_i, [_p, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "vatl_upsample_nearest_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vatl_gap_bwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "vatl_decode_argmax_affine": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_thc_pairs": (_i, [_p, _p, _i64, _i64, _p, _i, _i, _i, _i, _p]),
     "vatl_thc_combine": (_i, [_p, _p, _p, _p, _i, _p]),
@@ -69,6 +71,8 @@ SIGNATURES = {
     "vatl_masked_mse_workspace_floats": (_i64, [_i64]),
     "vatl_masked_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vatl_adamw_step": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _p]),
+    "vatl_adam_step": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _p]),
+    "vatl_sgd_step": (_i, [_p, _p, _p, _i64, _d, _d, _d, _i, _p]),
 }
 
 _lib = None
@@ -233,6 +237,21 @@ def fuse_upsample_add(base, ups, relu: bool):
     _check(lib().vatl_fuse_upsample_add(_ptr(base), _ptr(a[0][0]), a[0][1], _ptr(a[1][0]), a[1][1], _ptr(a[2][0]), a[2][1], _ptr(y),
                                         n, h, w, c, int(relu), _stream()), "vatl_fuse_upsample_add")
     return y
+
+
+def upsample_nearest_bwd(dy, yact, shift: int):
+    """dy (N,H,W,C) [masked by yact > 0] -> block sums (N,H>>shift,W>>shift,C)."""
+    n, h, w, c = dy.shape
+    dz = torch.empty((n, h >> shift, w >> shift, c), device=dy.device, dtype=torch.float32)
+    _check(lib().vatl_upsample_nearest_bwd(_ptr(dy), _ptr(yact), _ptr(dz), n, h, w, c, shift, _stream()), "vatl_upsample_nearest_bwd")
+    return dz
+
+
+def gap_bwd(dy, hw: int):
+    n, c = dy.shape
+    dx = torch.empty((n, hw, c), device=dy.device, dtype=torch.float32)
+    _check(lib().vatl_gap_bwd(_ptr(dy), _ptr(dx), n, hw, c, _stream()), "vatl_gap_bwd")
+    return dx
 
 
 # ----------------------------------------------------------------------------
@@ -512,6 +531,15 @@ def masked_mse_fwd_bwd(out: torch.Tensor, target: torch.Tensor, mask: torch.Tens
     _check(lib().vatl_masked_mse_fwd_bwd(_ptr(out), _ptr(target), _ptr(m), _ptr(grad), _ptr(loss), _ptr(ws), n, j, h * w, _stream()),
            "vatl_masked_mse_fwd_bwd")
     return loss, grad
+
+
+def adam_step(p, g, m, v, step: int, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8):
+    _check(lib().vatl_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step, _stream()),
+           "vatl_adam_step")
+
+
+def sgd_step(p, g, buf, step: int, lr: float, momentum: float = 0.9, weight_decay: float = 0.0):
+    _check(lib().vatl_sgd_step(_ptr(p), _ptr(g), _ptr(buf), p.numel(), lr, momentum, weight_decay, step, _stream()), "vatl_sgd_step")
 
 
 def adamw_step(p, g, m, v, step: int, lr: float, weight_decay: float, betas=(0.9, 0.999), eps: float = 1e-8):
