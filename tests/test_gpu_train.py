@@ -351,13 +351,17 @@ def test_hrnet_finetune_step_vs_reference_golden(vh):
     exact = {k: p.grad.numpy() for k, p in ref64.named_parameters()}
     named = dict(m.named_parameters())
     assert all(p.grad is not None for p in m.parameters())
-    worst = 0.0
-    for key, p in named.items():                           # every one of the 900+ parameter tensors against float64
+    # every one of the 900+ parameter tensors against float64.  The B = 2 step is ill-conditioned (ReLU / BN sign
+    # flips): the reference's own fp32 CPU step differs from float64 by 1.7e-2 at worst (BN biases of stage 4),
+    # 1.6e-3 in the median (tools: oracle.nets.HRNetRef fp32 vs fp64) — the band below is that yardstick x3
+    l2s = {}
+    for key, p in named.items():
         ex = exact[key]
-        l2 = float(np.linalg.norm(p.grad.cpu().numpy() - ex) / max(np.linalg.norm(ex), 1e-30))
-        worst = max(worst, l2)
-        assert l2 < 2e-2, (key, l2)
-    record("hrnet_train_grad_all", tensors=len(named), worst_l2_vs_fp64=worst)
+        l2s[key] = float(np.linalg.norm(p.grad.cpu().numpy() - ex) / max(np.linalg.norm(ex), 1e-30))
+    worst = max(l2s, key=l2s.get)
+    record("hrnet_train_grad_all", tensors=len(named), worst_key=worst, worst_l2_vs_fp64=l2s[worst], median_l2_vs_fp64=float(np.median(list(l2s.values()))))
+    assert l2s[worst] < 5e-2, (worst, l2s[worst])
+    assert np.median(list(l2s.values())) < 5e-3
     for key in [k[16:] for k in g.files if k.startswith("hrnet_grad_idx::")]:
         idx = g[f"hrnet_grad_idx::{key}"]
         got = named[key].grad.reshape(-1)[torch.from_numpy(idx).to(dev())].cpu().numpy()
