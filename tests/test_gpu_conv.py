@@ -223,3 +223,42 @@ def test_fastpose_hrnet_forward_vs_reference_golden(vh, name):
         with torch.no_grad():
             emb = m.get_embedding(x).cpu().numpy()
         assert rel_err(emb, g["fastpose_embedding"]) < 1e-4
+
+
+def test_fastpose_r152_384_forward_and_step_vs_reference_golden(vh):
+    """BASELINE.json config 5 (FastPose-R152, 384x288 crops, 96x72 heat-maps): forward against the reference's golden
+    output; one B = 2 fine-tune step against the reference's loss and sampled gradients."""
+    import os
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fastpose_r152_384.npz"))
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [384, 288], "HEATMAP_SIZE": [96, 72]})
+    m = builder.build_sppe(edict({"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 152}), preset_cfg=preset)
+    assert list(m.state_dict().keys()) == list(g["keys"])
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    m = m.to(dev()).eval()
+    x = to_dev(synth.crops(1, hw=(384, 288)))
+    with torch.no_grad():
+        hm = m(x).cpu().numpy()
+        emb = m.get_embedding(x).cpu().numpy()
+    e = rel_err(hm, g["heatmaps"])
+    record("fastpose_r152_384_heatmaps", rel=e, emb_rel=rel_err(emb, g["embedding"]))
+    assert hm.shape == (1, 17, 96, 72) and e < 1e-4
+    assert np.array_equal(hm.reshape(1, 17, -1).argmax(2), g["heatmaps"].reshape(1, 17, -1).argmax(2))
+    assert rel_err(emb, g["embedding"]) < 1e-4
+    m.train()
+    labels, masks = synth.gaussian_targets(2, seed=11, hw=(96, 72))
+    labels, masks = to_dev(labels), to_dev(masks)
+    out = m(to_dev(synth.crops(2, hw=(384, 288))))
+    loss = 0.5 * torch.nn.MSELoss()(out.mul(masks), labels.mul(masks))
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["train_loss"]), rtol=1e-4)
+    named = dict(m.named_parameters())
+    for key in [k[10:] for k in g.files if k.startswith("grad_idx::")]:
+        idx = g[f"grad_idx::{key}"]
+        got = named[key].grad.reshape(-1)[torch.from_numpy(idx).to(dev())].cpu().numpy()
+        ref = g[f"grad_val::{key}"]
+        l2 = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+        record("fastpose_r152_384_grad", key=key, l2_vs_reference_fp32=l2)
+        # two fp32 evaluations of an ill-conditioned B = 2 step (152 layers): same band as the R50 step tests
+        assert l2 < (1e-4 if key.startswith("conv_out") else 5e-2), (key, l2)

@@ -181,3 +181,21 @@ def test_fastpose_hrnet_restatements_match_reference(golden_nets2, name, ctor):
     if name == "fastpose":
         with torch.no_grad():
             np.testing.assert_allclose(m.get_embedding(x).numpy(), g["fastpose_embedding"], rtol=1e-4, atol=1e-5)
+
+
+def test_fastpose_r152_384_restatement_matches_reference():
+    """BASELINE.json config 5: FastPose-R152 at 384x288 (96x72 heat-maps)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fastpose_r152_384.npz"))
+    m = nets.FastPoseRef(152)
+    assert list(m.state_dict().keys()) == list(g["keys"])
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    m.eval()
+    x = torch.from_numpy(synth.crops(1, hw=(384, 288)))
+    with torch.no_grad():
+        hm = m(x).numpy()
+        emb = m.get_embedding(x).numpy()
+    ref = g["heatmaps"]
+    assert hm.shape == (1, 17, 96, 72)
+    assert np.abs(hm - ref).max() <= 1e-5 * np.abs(ref).max()
+    np.testing.assert_allclose(emb, g["embedding"], rtol=1e-4, atol=1e-4)

@@ -436,6 +436,38 @@ def gen_fastpose_hrnet(EasyDict, out: str):
     np.savez_compressed(os.path.join(out, "fastpose_hrnet.npz"), batch=np.int64(2), seed=np.int64(synth.SEED), **res)
 
 
+def gen_fastpose_r152(EasyDict, out: str):
+    """BASELINE.json config 5 (synthetic stress config): FastPose-R152 at 384x288 -> 96x72 heat-maps, B = 1 forward,
+    B = 2 fine-tune step (loss + sampled gradients)."""
+    from alphapose.models import builder                         # the reference's
+    preset = EasyDict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [384, 288], "HEATMAP_SIZE": [96, 72]})
+    c = EasyDict({"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 152})
+    res = {}
+    torch.manual_seed(synth.SEED)
+    m = builder.build_sppe(c, preset_cfg=preset)
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    m.eval()
+    x = torch.from_numpy(synth.crops(1, hw=(384, 288)))
+    with torch.no_grad():
+        res["heatmaps"] = m(x).numpy()
+        res["embedding"] = m.get_embedding(x).numpy()
+    m.train()
+    x2 = torch.from_numpy(synth.crops(2, hw=(384, 288)))
+    labels, masks = synth.gaussian_targets(2, seed=11, hw=(96, 72))
+    outp = m(x2)
+    loss = 0.5 * torch.nn.MSELoss()(outp.mul(torch.from_numpy(masks)), torch.from_numpy(labels).mul(torch.from_numpy(masks)))
+    loss.backward()
+    res["train_loss"] = np.float64(loss.item())
+    named = dict(m.named_parameters())
+    for k in ("conv_out.weight", "conv_out.bias", "duc2.conv.weight", "preact.layer3.35.conv2.weight", "preact.layer3.17.bn3.weight", "preact.conv1.weight"):
+        ii = _sample_idx(named[k].numel(), "r152" + k, 512)
+        res[f"grad_idx::{k}"] = ii
+        res[f"grad_val::{k}"] = named[k].grad.reshape(-1)[ii].numpy()
+    res["keys"] = np.array(list(m.state_dict().keys()))
+    print("fastpose-r152", res["heatmaps"].shape, float(np.abs(res["heatmaps"]).mean()), len(res["keys"]), res["train_loss"])
+    np.savez_compressed(os.path.join(out, "fastpose_r152_384.npz"), seed=np.int64(synth.SEED), **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -452,6 +484,8 @@ def main():
         gen_simplepose(EasyDict, a.out)
     if a.only in ("", "nets2"):
         gen_fastpose_hrnet(EasyDict, a.out)
+    if a.only in ("", "r152"):
+        gen_fastpose_r152(EasyDict, a.out)
 
 
 if __name__ == "__main__":
