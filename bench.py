@@ -228,6 +228,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist:
+        td.barrier()                                    # rank 0 was busy with the roofline pass: leave together
         td.destroy_process_group()
 
 

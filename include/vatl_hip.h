@@ -72,7 +72,8 @@ int vatl_bn_fold(const float* gamma, const float* beta, const float* mean, const
  * (Resnet.py:104-128), ResNet.forward stem (Resnet.py:171-172) and
  * SimplePose.final_layer (simplepose.py:85). */
 /* Tuning knob (benchmarks / A-B tests only; results are identical for every setting):
- * knob 0 = k-loop schedule of the conv kernel, value 0..2 (see csrc/conv_igemm.hip). */
+ * knob 0 = k-loop schedule of the conv kernel (see csrc/conv_igemm.hip), 1 = tile order, 2 = block stagger,
+ * 3 = target block count of the weight-gradient launches (number of pixel splits). */
 int vatl_tune_set(int knob, int value);
 /* CoutPad the packer must use for a given Cout (multiple of the kernel's N tile). */
 int vatl_conv_cout_pad(int Cout);

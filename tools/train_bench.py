@@ -23,8 +23,11 @@ def main():
     ap.add_argument("--batch", type=int, default=120)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--wgrad-blocks", type=int, default=0, help="vatl_tune_set(3, v): target block count of the wgrad launches")
     a = ap.parse_args()
     import vatl_hip as vh
+    if a.wgrad_blocks:
+        vh.tune_set(3, a.wgrad_blocks)
     from active_learning.optim import AdamW
     from alphapose.models import builder
     from alphapose.utils.config import edict
@@ -63,7 +66,7 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     print(json.dumps({"metric": "fine-tune steps/s (fwd+bwd+AdamW), SimpleBaseline-R50 256x192", "batch": a.batch, "ms_per_step": round(dt * 1e3, 2),
                       "crops_per_s": round(a.batch / dt, 1), "conv_tflops": round(3 * 10.853e9 * a.batch / dt / 1e12, 2),
-                      "loss": float(loss)}))
+                      "loss": float(loss), "wgrad_blocks": a.wgrad_blocks}))
 
 
 if __name__ == "__main__":

@@ -717,7 +717,11 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st) 
 
 using namespace vatl;
 
+extern "C" int vatl_tune_wgrad_blocks(int blocks);
+
 extern "C" int vatl_tune_set(int knob, int value) {
+    if (knob == 3 && vatl_tune_wgrad_blocks(value) == 0) return 0;
+    if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
     if (knob == 0 && value >= 0 && value <= 13) { g_var.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 2 && value >= 0 && value <= 200) { g_stagger.store(value, std::memory_order_relaxed); return 0; }

@@ -30,7 +30,10 @@ struct WgradParams {
     int ktiles;          // ceil(M / 32)
     int kt_per_split;
     int n_tiles, j_tiles_per_tap, taps;
+    int d_oy, d_ox;      // (row, column) advance of a 32-pixel step: 32 = d_b*Ho*Wo + d_oy*Wo + d_ox
+    int adv, adv_cx, adv_cy;   // element-offset advance of the gathered operand for that step / a column carry / a row carry
     unsigned g_bytes, x_bytes;
+    int ablate;          // benchmarks only (vatl_tune_set(4, bits)): 1 = skip the atomic epilogue (wrong results)
 };
 
 constexpr unsigned WG_OOB = 0xFFFFFFFFu;
@@ -71,31 +74,53 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const int HoWo = p.Ho * p.Wo;
 
+    // Operand addresses advance by 32 pixels per k-tile.  G (plain rows): one add, rows >= M fall outside the buffer
+    // descriptor and read zeros.  X (gathered): byte-free element offset + (oy, ox) advanced with carries — the
+    // straightforward form (two integer divisions and three multiplies per load) cost more VALU time than the
+    // k-tile's MFMAs leave free.
     f32x4 rg[LG], rx[LX];
-    auto gload = [&](int kt) {
-        const int mb = kt * 32;
+    unsigned goff[LG], gadv[LG];
+#pragma unroll
+    for (int q = 0; q < LG; ++q) {
+        const int f = tid + 256 * q;
+        const int row = f / (BN / 4), n = n0 + (f % (BN / 4)) * 4;
+        const bool nv = n < p.Gs;
+        goff[q] = nv ? (unsigned)((kt0 * 32 + row) * p.Gs + n) << 2 : WG_OOB;
+        gadv[q] = nv ? (unsigned)(32 * p.Gs) << 2 : 0u;
+    }
+    int xm[LX], xoy[LX], xox[LX], xoff[LX];
+    bool xcv[LX];
+#pragma unroll
+    for (int q = 0; q < LX; ++q) {
+        const int f = tid + 256 * q;
+        const int c4 = f % (BJ / 4);
+        const int m = kt0 * 32 + f / (BJ / 4);
+        const int b = m / HoWo;
+        const int rem = m - b * HoWo;
+        xm[q] = m;
+        xoy[q] = rem / p.Wo;
+        xox[q] = rem - xoy[q] * p.Wo;
+        const int c = STEM ? 0 : c0 + c4 * 4;
+        xcv[q] = c < p.Cx;
+        // STEM: float4 = one of the 8 taps of this filter row (4 channels): the column offset c4 rides in the offset
+        xoff[q] = ((b * p.H + xoy[q] * p.stride - p.pad + r) * p.W + xox[q] * p.stride - p.pad + s + (STEM ? c4 : 0)) * p.Cx + c;
+    }
+    const int iyb = r - p.pad, ixb = s - p.pad;
+    auto gload = [&]() {                                   // loads the next k-tile and advances the pixel state
 #pragma unroll
         for (int q = 0; q < LG; ++q) {
-            const int f = tid + 256 * q;
-            const int row = f / (BN / 4), c4 = f % (BN / 4);
-            const int m = mb + row, n = n0 + c4 * 4;
-            rg[q] = wg_load4(gr, (m < p.M && n < p.Gs) ? (unsigned)(m * p.Gs + n) << 2 : WG_OOB);
+            rg[q] = wg_load4(gr, goff[q]);
+            goff[q] += gadv[q];
         }
 #pragma unroll
         for (int q = 0; q < LX; ++q) {
-            const int f = tid + 256 * q;
-            const int row = f / (BJ / 4), c4 = f % (BJ / 4);
-            const int m = mb + row;
-            const int b = m / HoWo;
-            const int rem = m - b * HoWo;
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
-            const int iy = oy * p.stride - p.pad + r;
-            int ix = ox * p.stride - p.pad + s;
-            int c = c0 + c4 * 4;
-            if (STEM) { ix += c4; c = 0; }                 // float4 = one of the 8 taps of this filter row, 4 channels
-            const bool ok = m < p.M && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.Cx;
-            rx[q] = wg_load4(xr, ok ? (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cx + c) << 2 : WG_OOB);
+            const int iy = xoy[q] * p.stride + iyb;
+            const int ix = xox[q] * p.stride + ixb + (STEM ? (int)((tid + 256 * q) % (BJ / 4)) : 0);
+            const bool ok = xcv[q] && xm[q] < p.M && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            rx[q] = wg_load4(xr, ok ? (unsigned)xoff[q] << 2 : WG_OOB);
+            xm[q] += 32; xoy[q] += p.d_oy; xox[q] += p.d_ox; xoff[q] += p.adv;
+            if (xox[q] >= p.Wo) { xox[q] -= p.Wo; ++xoy[q]; xoff[q] += p.adv_cx; }
+            if (xoy[q] >= p.Ho) { xoy[q] -= p.Ho; xoff[q] += p.adv_cy; }
         }
     };
     auto lstore = [&](int buf) {
@@ -119,32 +144,61 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    gload(kt0);
+    gload();
     lstore(0);
     __syncthreads();
     const int half = lane >> 5, l31 = lane & 31;
+    // k-loop: groups of SG k-steps (pixel pairs).  The next group's fragment reads, the next tile's global loads +
+    // address arithmetic (first group) and the staging writes (last group) are issued in the shadow of the current
+    // group's MFMAs (64 matrix-pipe cycles each), pinned with sched_group_barrier — same scheme as conv_igemm VAR2.
+    constexpr int STEPS = 16 / NWK, SG = 4, NG = STEPS / SG, MPG = SG * TN * TJ;
+    static_assert(NG >= 2, "k-loop needs at least two step groups");
+    auto frag = [&](float (&a)[SG][TN], float (&b)[SG][TJ], int buf, int g) {
+#pragma unroll
+        for (int st = 0; st < SG; ++st) {
+            const int row = 2 * ((g * SG + st) * NWK + wk) + half;    // pixel of this k-step handled by this lane half
+#pragma unroll
+            for (int i = 0; i < TN; ++i) a[st][i] = Gs[buf][row][wn * WN + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) b[st][j] = Xs[buf][row][wj * WJ + j * 32 + l31];
+        }
+    };
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
-        gload(more ? kt + 1 : kt);                         // tail: harmless reload, keeps the body branch-free
+        float a[2][SG][TN], b[2][SG][TJ];
+        frag(a[0], b[0], buf, 0);
 #pragma unroll
-        for (int st = 0; st < 16 / NWK; ++st) {
-            const int row = 2 * (st * NWK + wk) + half;    // pixel of this k-step handled by this lane half
-            float a[TN], b[TJ];
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) frag(a[(g + 1) & 1], b[(g + 1) & 1], buf, g + 1);
+            if (g == 0) gload();                           // tail: one harmless extra tile, keeps the body branch-free
+            if (g == NG - 1) lstore(buf ^ 1);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) a[i] = Gs[buf][row][wn * WN + i * 32 + l31];
+            for (int st = 0; st < SG; ++st)
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) b[j] = Xs[buf][row][wj * WJ + j * 32 + l31];
+                for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+                    for (int j = 0; j < TJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][st][i], b[g & 1][st][j], acc[i][j], 0, 0, 0);
+            if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, SG * (TN + TJ), 0);
+            if (g == 0) {
 #pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int q = 0; q < MPG; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x216, MPG >= 16 ? 6 : 12, 0);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < MPG; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x216, 2, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        lstore(buf ^ 1);
         __syncthreads();
     }
 
+    if (p.ablate & 1) return;
     // D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)] -> n,  [col = lane&31] -> channel: coalesced fp32 atomics
     const int Kp = (STEM ? p.R * 8 : p.R * p.S) * p.Cx;
 #pragma unroll
@@ -162,14 +216,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         }
 }
 
+static std::atomic<int> g_wgrad_blocks{1024};
+static std::atomic<int> g_wgrad_ablate{0};   // vatl_tune_set(3, v)
+
 template <int BN, int BJ, int WN, int WJ, bool STEM>
 static int launch_wgrad(WgradParams p, hipStream_t st) {
     p.n_tiles = cdiv(p.Cn, BN);
     p.taps = STEM ? p.R : p.R * p.S;
     p.j_tiles_per_tap = STEM ? 1 : cdiv(p.Cx, BJ);
     const int tiles = p.n_tiles * p.taps * p.j_tiles_per_tap;
-    // enough M-splits for ~2048 blocks, at least 4 k-tiles each
-    int splits = (2048 + tiles - 1) / tiles;
+    const int hw = p.Ho * p.Wo, rem = 32 % hw;
+    p.d_oy = rem / p.Wo; p.d_ox = rem % p.Wo;
+    p.adv = ((32 / hw) * p.H * p.W + p.d_oy * p.stride * p.W + p.d_ox * p.stride) * p.Cx;
+    p.adv_cx = (p.stride * p.W - p.Wo * p.stride) * p.Cx;
+    p.adv_cy = (p.H * p.W - p.Ho * p.stride * p.W) * p.Cx;
+    // M-splits for at most ~g_wgrad_blocks blocks (two per CU resident: 512 per wave), at least 4 k-tiles each
+    const int target = g_wgrad_blocks.load(std::memory_order_relaxed);
+    p.ablate = g_wgrad_ablate.load(std::memory_order_relaxed);
+    int splits = target / tiles;                           // floor: stay within a whole number of 512-block waves
     const int max_splits = (p.ktiles + 3) / 4;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -208,6 +272,13 @@ __global__ void unpack_deconv_grad_kernel(const float* __restrict__ packed, floa
 
 using namespace vatl;
 
+extern "C" int vatl_tune_wgrad_blocks(int blocks) {       // reached through vatl_tune_set(3, blocks) / (4, bits)
+    if (blocks < 0) { g_wgrad_ablate.store(-blocks - 1, std::memory_order_relaxed); return 0; }
+    if (blocks < 64 || blocks > 65536) return -1;
+    g_wgrad_blocks.store(blocks, std::memory_order_relaxed);
+    return 0;
+}
+
 extern "C" int64_t vatl_conv2d_wgrad_workspace_floats(int Cout, int Cin, int R, int S) {
     return Cin == 3 ? (int64_t)Cout * R * 8 * 4 : (int64_t)Cout * R * S * Cin;
 }
@@ -229,7 +300,7 @@ extern "C" int vatl_conv2d_wgrad(const float* x, const float* dz, float* dw, flo
     p.M = N * p.Ho * p.Wo; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.ktiles = cdiv(p.M, 32);
     const long long ge = (long long)p.M * CoutG, xe = (long long)N * H * W * Cx;
-    if (ge >= (1LL << 30) || xe >= (1LL << 30)) return fail(VATL_EINVAL, "conv2d_wgrad: a tensor exceeds 2^30 elements; split the batch");
+    if (ge + 64LL * CoutG >= (1LL << 30) || xe >= (1LL << 30)) return fail(VATL_EINVAL, "conv2d_wgrad: a tensor exceeds 2^30 elements; split the batch");
     p.g_bytes = (unsigned)(ge * 4); p.x_bytes = (unsigned)(xe * 4);
     hipStream_t st = (hipStream_t)stream;
     const int64_t wsn = vatl_conv2d_wgrad_workspace_floats(Cout, Cin, R, S);
@@ -264,7 +335,7 @@ extern "C" int vatl_deconv4x4s2_wgrad(const float* x, const float* dy, float* dw
     p.Ho = H; p.Wo = W; p.M = N * H * W; p.R = 4; p.S = 4; p.stride = 2; p.pad = 1;
     p.ktiles = cdiv(p.M, 32);
     const long long ge = (long long)p.M * Cin, xe = 4LL * p.M * Cout;
-    if (ge >= (1LL << 30) || xe >= (1LL << 30)) return fail(VATL_EINVAL, "deconv4x4s2_wgrad: a tensor exceeds 2^30 elements; split the batch");
+    if (ge + 64LL * Cin >= (1LL << 30) || xe >= (1LL << 30)) return fail(VATL_EINVAL, "deconv4x4s2_wgrad: a tensor exceeds 2^30 elements; split the batch");
     p.g_bytes = (unsigned)(ge * 4); p.x_bytes = (unsigned)(xe * 4);
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(workspace, 0, (size_t)Cin * 16 * Cout * sizeof(float), st) != hipSuccess) return fail(VATL_ELAUNCH, "deconv4x4s2_wgrad: memset failed");
