@@ -215,6 +215,25 @@ int vatl_scale_bias_act(const float* z, const float* scale, const float* bias, c
 int vatl_bn_train_bwd(const float* dy, const float* y_or_null, const float* z, const float* gamma, const float* save_mean,
                       const float* save_invstd, float* dz, float* g_out_or_null, float* dgamma, float* dbeta,
                       int64_t M, int C, float* coef3C, double* workspace, void* stream);
+/* The same backward for a Conv+BN+ReLU layer WITHOUT a skip input: the ReLU mask is recomputed from z as
+ * fmaf(z, scale, bias) > 0 (bit-identical to what vatl_scale_bias_act stored), so y is not read. */
+int vatl_bn_train_bwd_relu(const float* dy, const float* scale, const float* bias, const float* z, const float* gamma,
+                           const float* save_mean, const float* save_invstd, float* dz, float* dgamma, float* dbeta,
+                           int64_t M, int C, float* coef3C, double* workspace, void* stream);
+/* Training forward with the BatchNorm batch statistics taken in the conv epilogue (no separate pass over z):
+ * the conv / deconv writes z (no affine, no ReLU) and, per 128-row block of the implicit GEMM and channel, a partial
+ * (sum, sum of squares) pair into `stats` (vatl_conv_stats_row_blocks(rows, phases) * Cout * 2 doubles; rows = N*Ho*Wo,
+ * phases = 1, or N*H*W and 4 for the transposed conv).  vatl_bn_train_finalize reduces the partials in a fixed order
+ * and produces what vatl_bn_train_fwd_stats produces (nn.BatchNorm2d under model.train(), Resnet.py:104-128 via
+ * ActiveLearning.py:658-672); M = elements per channel (N*Ho*Wo of the layer OUTPUT). */
+int64_t vatl_conv_stats_row_blocks(int64_t gemm_rows, int phases);
+int vatl_conv2d_fwd_stats(const float* x, const float* w, float* y, double* stats, int N, int H, int W, int Cin, int Cout,
+                          int CoutPad, int R, int S, int stride, int pad, void* stream);
+int vatl_deconv4x4s2_fwd_stats(const float* x, const float* w, float* y, double* stats, int N, int H, int W, int Cin, int Cout,
+                               int CoutPad, void* stream);
+int vatl_bn_train_finalize(const double* partial, int64_t row_blocks, int64_t M, int C, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                           float* save_invstd, float* scale, float* bias, void* stream);
 /* MaxPool2d(3,2,1) backward on NHWC: x (N,H,W,C) forward input, dy (N,Ho,Wo,C) -> dx. */
 int vatl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 /* Training-mode max-pool: forward that also records the winning tap (0..8, first maximum) per pooled element,

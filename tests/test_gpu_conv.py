@@ -262,3 +262,23 @@ def test_fastpose_r152_384_forward_and_step_vs_reference_golden(vh):
         record("fastpose_r152_384_grad", key=key, l2_vs_reference_fp32=l2)
         # two fp32 evaluations of an ill-conditioned B = 2 step (152 layers): same band as the R50 step tests
         assert l2 < (1e-4 if key.startswith("conv_out") else 5e-2), (key, l2)
+
+
+def test_chunked_batches_are_bit_identical(vh):
+    """Batches above hip_engine.MAX_CHUNK are processed in chunks (32-bit buffer offsets): same bits as one launch
+    sequence, through forward(), forward_into() and get_embedding(), including a ragged last chunk."""
+    from alphapose.models import hip_engine
+    m = _build_simplepose()
+    x = to_dev(synth.crops(7))
+    with torch.no_grad():
+        whole, emb = m(x), m.get_embedding(x)
+    old = hip_engine.MAX_CHUNK
+    try:
+        hip_engine.MAX_CHUNK = 3
+        with torch.no_grad():
+            parts, emb_parts = m(x), m.get_embedding(x)
+            buf = torch.empty_like(whole)
+            hip_engine.forward_into(m, x, buf)
+    finally:
+        hip_engine.MAX_CHUNK = old
+    assert torch.equal(parts, whole) and torch.equal(buf, whole) and torch.equal(emb_parts, emb)

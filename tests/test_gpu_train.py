@@ -372,3 +372,38 @@ def test_hrnet_finetune_step_vs_reference_golden(vh):
         record("hrnet_train_grad", key=key, ours_l2_vs_fp64=l2, reference_fp32_l2_vs_fp64=float(np.linalg.norm(ref - ex) / max(np.linalg.norm(ex), 1e-30)),
                ours_max_vs_fp64=float(np.abs(got - ex).max() / scale))
         assert l2 < 2e-2 and np.abs(got - ex).max() / scale < 5e-2, (key, l2)
+
+
+def test_fused_bn_statistics_and_mask_recompute(vh):
+    """The training forward takes the BN batch statistics in the conv epilogue, the backward of a skip-less
+    Conv+BN+ReLU recomputes the ReLU mask from z: both must agree with the stand-alone kernels."""
+    r = np.random.RandomState(12)
+    for (n, h, w, cin, cout, k, stride, pad) in ((3, 9, 7, 64, 64, 3, 1, 1), (2, 16, 12, 128, 256, 1, 1, 0), (5, 8, 6, 32, 32, 3, 2, 1)):
+        x = to_dev(r.standard_normal((n, h, w, cin)).astype(np.float32))
+        wt = to_dev((r.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32))
+        gamma, beta = to_dev(r.uniform(0.5, 1.5, cout).astype(np.float32)), to_dev((0.1 * r.standard_normal(cout)).astype(np.float32))
+        rm1, rv1 = to_dev(np.zeros(cout, np.float32)), to_dev(np.ones(cout, np.float32))
+        rm2, rv2 = rm1.clone(), rv1.clone()
+        wp = vh.pack_conv_weight(wt)
+        z1 = vh.conv2d_fwd(x, wp, None, None, cout, k, k, stride, pad, False)
+        mean1, inv1, sc1, bi1 = vh.bn_train_fwd_stats(z1, gamma, beta, rm1, rv1, 0.1, 1e-5)
+        z2, mean2, inv2, sc2, bi2 = vh.conv2d_fwd_bnstats(x, wp, cout, k, k, stride, pad, gamma, beta, rm2, rv2, 0.1, 1e-5)
+        assert torch.equal(z1, z2)
+        for a, b in ((mean1, mean2), (inv1, inv2), (sc1, sc2), (bi1, bi2), (rm1, rm2), (rv1, rv2)):
+            np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-6, atol=1e-7)
+        y = vh.scale_bias_act(z1, sc1, bi1, None, True)
+        dy = to_dev(r.standard_normal(tuple(z1.shape)).astype(np.float32))
+        dz1, _, dg1, db1 = vh.bn_train_bwd(dy, y, z1, gamma, mean1, inv1)
+        dz2, dg2, db2 = vh.bn_train_bwd_relu(dy, sc1, bi1, z1, gamma, mean1, inv1)
+        assert torch.equal(dz1, dz2) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+    # transposed conv: four phases contribute to the same channel statistics
+    x = to_dev(r.standard_normal((2, 5, 3, 64)).astype(np.float32))
+    wt = to_dev((r.standard_normal((64, 128, 4, 4)) / 16).astype(np.float32))
+    gamma, beta = to_dev(np.ones(128, np.float32)), to_dev(np.zeros(128, np.float32))
+    wp = vh.pack_deconv_weight(wt)
+    z1 = vh.deconv4x4s2_fwd(x, wp, None, None, 128, False)
+    s1 = vh.bn_train_fwd_stats(z1, gamma, beta, None, None, 0.1, 1e-5)
+    out = vh.deconv4x4s2_fwd_bnstats(x, wp, 128, gamma, beta, None, None, 0.1, 1e-5)
+    assert torch.equal(out[0], z1)
+    for a, b in zip(s1, out[1:]):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-6, atol=1e-7)

@@ -42,21 +42,27 @@ class _ConvBN:
     def forward(self, x, skip=None, relu=None):
         relu = self.relu if relu is None else relu
         w = vh.pack_conv_weight(self.conv.weight.detach())
-        z = vh.conv2d_fwd(x, w, None, None, self.cout, self.r, self.s, self.stride, self.pad, False)
         bn = self.bn
-        mean, invstd, scale, bias = vh.bn_train_fwd_stats(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                                          bn.momentum, bn.eps)
+        # z = conv(x); the batch statistics come out of the conv epilogue (no extra pass over z)
+        z, mean, invstd, scale, bias = vh.conv2d_fwd_bnstats(x, w, self.cout, self.r, self.s, self.stride, self.pad, bn.weight.detach(),
+                                                             bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps)
         bn.num_batches_tracked += 1
         y = vh.scale_bias_act(z, scale, bias, skip, relu)
-        self.saved = (x, z, y if relu else None, mean, invstd, skip is not None)
+        # ReLU without a skip: the backward recomputes the mask from (z, scale, bias) and never reads y
+        mask = (scale, bias) if (relu and skip is None) else None
+        self.saved = (x, z, y if (relu and skip is not None) else None, mean, invstd, skip is not None, mask)
         return y
 
     # ---- backward ------------------------------------------------------------
     def backward(self, dy, grads, dx_residual=None):
         """dy: gradient of the layer output.  Returns (dx, g_skip); parameter gradients go to ``grads``."""
-        x, z, y, mean, invstd, had_skip = self.saved
+        x, z, y, mean, invstd, had_skip, mask = self.saved
         self.saved = None
-        dz, g, dgamma, dbeta = vh.bn_train_bwd(dy, y, z, self.bn.weight.detach(), mean, invstd, want_g=had_skip and y is not None)
+        if mask is not None:
+            dz, dgamma, dbeta = vh.bn_train_bwd_relu(dy, mask[0], mask[1], z, self.bn.weight.detach(), mean, invstd)
+            g = None
+        else:
+            dz, g, dgamma, dbeta = vh.bn_train_bwd(dy, y, z, self.bn.weight.detach(), mean, invstd, want_g=had_skip and y is not None)
         if had_skip and y is None:
             g = dy                                         # no ReLU between the sum and the output: the skip gradient is dy
         grads[self.bn.weight] = dgamma
@@ -102,19 +108,18 @@ class _DeconvBN:
         self.cin, self.cout = dc.weight.shape[:2]
 
     def forward(self, x):
-        z = vh.deconv4x4s2_fwd(x, vh.pack_deconv_weight(self.dc.weight.detach()), None, None, self.cout, False)
         bn = self.bn
-        mean, invstd, scale, bias = vh.bn_train_fwd_stats(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                                          bn.momentum, bn.eps)
+        z, mean, invstd, scale, bias = vh.deconv4x4s2_fwd_bnstats(x, vh.pack_deconv_weight(self.dc.weight.detach()), self.cout, bn.weight.detach(),
+                                                                  bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps)
         bn.num_batches_tracked += 1
         y = vh.scale_bias_act(z, scale, bias, None, True)
-        self.saved = (x, z, y, mean, invstd)
+        self.saved = (x, z, scale, bias, mean, invstd)
         return y
 
     def backward(self, dy, grads):
-        x, z, y, mean, invstd = self.saved
+        x, z, scale, bias, mean, invstd = self.saved
         self.saved = None
-        dz, _, dgamma, dbeta = vh.bn_train_bwd(dy, y, z, self.bn.weight.detach(), mean, invstd)
+        dz, dgamma, dbeta = vh.bn_train_bwd_relu(dy, scale, bias, z, self.bn.weight.detach(), mean, invstd)
         grads[self.bn.weight] = dgamma
         grads[self.bn.bias] = dbeta
         grads[self.dc.weight] = vh.deconv4x4s2_wgrad(x, dz)

@@ -25,10 +25,15 @@ static inline RowSplit row_split(long long M) {
     return {rpb, (int)((M + rpb - 1) / rpb)};
 }
 
+// ReLU mask of a layer without a skip input, recomputed from z exactly as scale_bias_act_kernel produced y (same
+// fmaf), so the backward passes need not read y
+__device__ __forceinline__ bool relu_on(float z, float sc, float bi) { return fmaf(z, sc, bi) > 0.f; }
+
 template <int MODE>   // 0: (sum z, sum z^2)   1: (sum g, sum g*xhat) with g = dy*[y>0]
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ a, const float* __restrict__ y, const float* __restrict__ z,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                         double* __restrict__ partial, long long M, int C, long long rows_per_block) {
+                                                         double* __restrict__ partial, long long M, int C, long long rows_per_block,
+                                                         const float* __restrict__ mscale = nullptr, const float* __restrict__ mbias = nullptr) {
     const int C4 = C >> 2;
     const int cols = C4 < 256 ? C4 : 256;                 // float4 columns handled by this block
     const int col = threadIdx.x % cols;
@@ -39,7 +44,9 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (c4 < C4 && rlane < rstep) {
         f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+        f32x4 msc = {0.f, 0.f, 0.f, 0.f}, mbi = {1.f, 1.f, 1.f, 1.f};
         if (MODE == 1) { mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4); is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4); }
+        if (MODE == 1 && mscale) { msc = *reinterpret_cast<const f32x4*>(mscale + c4 * 4); mbi = *reinterpret_cast<const f32x4*>(mbias + c4 * 4); }
         for (long long r = r0 + rlane; r < r1; r += rstep) {
             const long long o = r * C + c4 * 4;
             f32x4 v = *reinterpret_cast<const f32x4*>(a + o);
@@ -53,6 +60,10 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
                     for (int e = 0; e < 4; ++e) v[e] = yy[e] > 0.f ? v[e] : 0.f;
                 }
                 const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o);
+                if (mscale) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = relu_on(zz[e], msc[e], mbi[e]) ? v[e] : 0.f;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * ((zz[e] - mu[e]) * is[e]); }
             }
@@ -139,7 +150,7 @@ __global__ void scale_bias_act_kernel(const float* __restrict__ z, const float* 
         const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c4 * 4);
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = v[e] * s[e] + b[e];
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(v[e], s[e], b[e]);
         if (res) {
             const f32x4 r = *reinterpret_cast<const f32x4*>(res + i * 4);
 #pragma unroll
@@ -175,7 +186,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 // dz = A[c]*g + B[c]*z + C[c], g = dy*[y>0]; optionally also stores g (gradient of the skip connection)
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ z,
                                     const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ Cc,
-                                    float* __restrict__ dz, float* __restrict__ gout, long long n4, int C4) {
+                                    float* __restrict__ dz, float* __restrict__ gout, long long n4, int C4,
+                                    const float* __restrict__ mscale, const float* __restrict__ mbias) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4);
         f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
@@ -185,6 +197,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
             for (int e = 0; e < 4; ++e) g[e] = yy[e] > 0.f ? g[e] : 0.f;
         }
         const f32x4 zz = *reinterpret_cast<const f32x4*>(z + i * 4);
+        if (mscale) {
+            const f32x4 msc = *reinterpret_cast<const f32x4*>(mscale + c4 * 4), mbi = *reinterpret_cast<const f32x4*>(mbias + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = relu_on(zz[e], msc[e], mbi[e]) ? g[e] : 0.f;
+        }
         const f32x4 a = *reinterpret_cast<const f32x4*>(A + c4 * 4);
         const f32x4 b = *reinterpret_cast<const f32x4*>(B + c4 * 4);
         const f32x4 c = *reinterpret_cast<const f32x4*>(Cc + c4 * 4);
@@ -296,14 +313,16 @@ using namespace vatl;
 extern "C" int64_t vatl_col_reduce_workspace_doubles(int64_t M, int C) { return 2 * (int64_t)row_split(M).nrb * (int64_t)C; }
 
 static void launch_col_reduce(int mode, const float* a, const float* y, const float* z, const float* mean, const float* invstd,
-                              double* ws, long long M, int C, const RowSplit& rs, hipStream_t st) {
+                              double* ws, long long M, int C, const RowSplit& rs, hipStream_t st, const float* mscale = nullptr,
+                              const float* mbias = nullptr) {
     if (C & 3) {                                              // stats only (mode 0) on odd channel counts
         hipLaunchKernelGGL(col_stats_scalar_kernel, dim3(rs.nrb, cdiv(C, 64)), dim3(256), 0, st, a, ws, M, C, rs.rows_per_block);
         return;
     }
     const dim3 grid(rs.nrb, cdiv(C / 4, 256));
-    if (mode == 0) hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, st, a, y, z, mean, invstd, ws, M, C, rs.rows_per_block);
-    else           hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, st, a, y, z, mean, invstd, ws, M, C, rs.rows_per_block);
+    if (mode == 0) hipLaunchKernelGGL(col_reduce_kernel<0>, grid, dim3(256), 0, st, a, y, z, mean, invstd, ws, M, C, rs.rows_per_block,
+                                      (const float*)nullptr, (const float*)nullptr);
+    else           hipLaunchKernelGGL(col_reduce_kernel<1>, grid, dim3(256), 0, st, a, y, z, mean, invstd, ws, M, C, rs.rows_per_block, mscale, mbias);
 }
 
 extern "C" int vatl_bn_train_fwd_stats(const float* z, int64_t M, int C, const float* gamma, const float* beta, float* running_mean,
@@ -325,19 +344,43 @@ extern "C" int vatl_scale_bias_act(const float* z, const float* scale, const flo
     return check_launch("scale_bias_act");
 }
 
-extern "C" int vatl_bn_train_bwd(const float* dy, const float* y_or_null, const float* z, const float* gamma, const float* save_mean,
-                                 const float* save_invstd, float* dz, float* g_out_or_null, float* dgamma, float* dbeta,
-                                 int64_t M, int C, float* coef3C, double* workspace, void* stream) {
+static int bn_train_bwd_impl(const float* dy, const float* y_or_null, const float* mscale, const float* mbias, const float* z, const float* gamma,
+                             const float* save_mean, const float* save_invstd, float* dz, float* g_out_or_null, float* dgamma, float* dbeta,
+                             int64_t M, int C, float* coef3C, double* workspace, void* stream) {
     if (!dy || !z || !save_mean || !save_invstd || !dz || !coef3C || !workspace || (C & 3) || M <= 0)
         return fail(VATL_EINVAL, "bn_train_bwd: bad arguments");
     const RowSplit rs = row_split(M);
     hipStream_t st = (hipStream_t)stream;
-    launch_col_reduce(1, dy, y_or_null, z, save_mean, save_invstd, workspace, (long long)M, C, rs, st);
+    launch_col_reduce(1, dy, y_or_null, z, save_mean, save_invstd, workspace, (long long)M, C, rs, st, mscale, mbias);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, workspace, rs.nrb, (long long)M, C, gamma, save_mean, save_invstd,
                        dgamma, dbeta, coef3C, coef3C + C, coef3C + 2 * C);
     const long long n4 = M * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, y_or_null, z, coef3C, coef3C + C, coef3C + 2 * C, dz, g_out_or_null, n4, C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dy, y_or_null, z, coef3C, coef3C + C, coef3C + 2 * C, dz, g_out_or_null, n4, C / 4,
+                       mscale, mbias);
     return check_launch("bn_train_bwd");
+}
+
+extern "C" int vatl_bn_train_bwd(const float* dy, const float* y_or_null, const float* z, const float* gamma, const float* save_mean,
+                                 const float* save_invstd, float* dz, float* g_out_or_null, float* dgamma, float* dbeta,
+                                 int64_t M, int C, float* coef3C, double* workspace, void* stream) {
+    return bn_train_bwd_impl(dy, y_or_null, nullptr, nullptr, z, gamma, save_mean, save_invstd, dz, g_out_or_null, dgamma, dbeta, M, C, coef3C, workspace, stream);
+}
+
+extern "C" int vatl_bn_train_bwd_relu(const float* dy, const float* scale, const float* bias, const float* z, const float* gamma,
+                                      const float* save_mean, const float* save_invstd, float* dz, float* dgamma, float* dbeta,
+                                      int64_t M, int C, float* coef3C, double* workspace, void* stream) {
+    if (!scale || !bias) return fail(VATL_EINVAL, "bn_train_bwd_relu: null scale/bias");
+    return bn_train_bwd_impl(dy, nullptr, scale, bias, z, gamma, save_mean, save_invstd, dz, nullptr, dgamma, dbeta, M, C, coef3C, workspace, stream);
+}
+
+extern "C" int vatl_bn_train_finalize(const double* partial, int64_t row_blocks, int64_t M, int C, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
+                                      float* save_invstd, float* scale, float* bias, void* stream) {
+    if (!partial || !save_mean || !save_invstd || !scale || !bias || M <= 0 || row_blocks <= 0 || row_blocks > 0x7FFFFFFF)
+        return fail(VATL_EINVAL, "bn_train_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, partial, (int)row_blocks, (long long)M, C, gamma, beta,
+                       running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, bias);
+    return check_launch("bn_train_finalize");
 }
 
 extern "C" int vatl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {

@@ -58,6 +58,7 @@ struct ConvParams {
     int order;                        // tile order inside an XCD's run: 0 n-tile fastest, 1 m-tile fastest
     int stagger;                      // start the second resident block of every CU half a block-time late
     int K;                            // packed K per output channel
+    double* stats;                    // training: per (row block, channel) partial (sum, sum^2) of the stored tile, or NULL
     unsigned x_bytes, w_bytes, y_bytes;   // buffer extents (hardware bounds checks: OOB loads read 0, OOB stores drop)
 };
 
@@ -149,6 +150,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     const float lo = p.relu ? 0.f : -INFINITY;
     if (vec) {
         const int c4 = tid % C4, r0 = tid / C4;
+        f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[(r0 + u * RPP) * LDC + c4 * 4]);
@@ -156,6 +158,36 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = fmaxf(v[c] + rsv[u][c], lo);
             buf_store4(yr, offv[u], o);
+            if (p.stats) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { ssum[c] += o[c]; ssq[c] += o[c] * o[c]; }   // rows >= M hold exact zeros
+            }
+        }
+        if (p.stats) {
+            // BatchNorm batch statistics of the tile just stored (training forward): per-thread fp32 sums over NP rows,
+            // combined over the RPP row groups in double, one (sum, sum^2) pair per (row block, channel) — the layout
+            // bn_train_finalize_kernel reduces in a fixed order (deterministic, no atomics).
+            __syncthreads();                               // every thread is done reading Cs
+            f32x4* sh = reinterpret_cast<f32x4*>(smem);
+            sh[tid] = ssum; sh[256 + tid] = ssq;
+            __syncthreads();
+            if (tid < C4) {
+                double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+                for (int k = 0; k < RPP; ++k) {
+                    const f32x4 a = sh[k * C4 + tid], b = sh[256 + k * C4 + tid];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { ds[c] += a[c]; dq[c] += b[c]; }
+                }
+                const long long rb = (long long)blockIdx.y * p.m_tiles + m0 / BM;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int n = n0 + tid * 4 + c;
+                    if (n < p.Cout) {
+                        p.stats[(rb * p.Cout + n) * 2 + 0] = ds[c];
+                        p.stats[(rb * p.Cout + n) * 2 + 1] = dq[c];
+                    }
+                }
+            }
         }
     } else {
         // NCHW output (heat-map head) or a channel count that is not a multiple of 4:
@@ -733,10 +765,11 @@ extern "C" int vatl_conv_cout_pad(int Cout) {
     return (Cout + bn - 1) / bn * bn;
 }
 
-extern "C" int vatl_conv2d_fwd(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
-                               float* y, int N, int H, int W, int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad,
-                               int relu, int out_nchw, void* stream) {
+static int conv2d_fwd_impl(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
+                           float* y, int N, int H, int W, int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad,
+                           int relu, int out_nchw, double* stats, void* stream) {
     if (!x || !w || !y || N <= 0) return fail(VATL_EINVAL, "conv2d_fwd: null pointer or empty batch");
+    if (stats && ((Cout & 3) || out_nchw)) return fail(VATL_EINVAL, "conv2d_fwd_stats: Cout %d must be a multiple of 4 (NHWC output)", Cout);
     const bool stem = (Cin == 4);
     if (!stem && Cin % 32 != 0) return fail(VATL_EINVAL, "conv2d_fwd: Cin %d must be a multiple of 32 (or 4 for the stem)", Cin);
     if (stem && S > 8) return fail(VATL_EINVAL, "conv2d_fwd: stem filter width %d > 8", S);
@@ -755,12 +788,28 @@ extern "C" int vatl_conv2d_fwd(const float* x, const float* w, const float* scal
     if (xe >= (1LL << 30) || ye >= (1LL << 30) || we >= (1LL << 30))
         return fail(VATL_EINVAL, "conv2d_fwd: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
     p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.w_bytes = (unsigned)(we * 4);
+    p.stats = stats;
     return dispatch(p, 1, stem, (hipStream_t)stream);
 }
 
-extern "C" int vatl_deconv4x4s2_fwd(const float* x, const float* w, const float* scale, const float* bias, float* y,
-                                    int N, int H, int W, int Cin, int Cout, int CoutPad, int relu, void* stream) {
+extern "C" int vatl_conv2d_fwd(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
+                               float* y, int N, int H, int W, int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad,
+                               int relu, int out_nchw, void* stream) {
+    return conv2d_fwd_impl(x, w, scale, bias, residual, y, N, H, W, Cin, Cout, CoutPad, R, S, stride, pad, relu, out_nchw, nullptr, stream);
+}
+
+extern "C" int64_t vatl_conv_stats_row_blocks(int64_t gemm_rows, int phases) { return (gemm_rows + 127) / 128 * phases; }
+
+extern "C" int vatl_conv2d_fwd_stats(const float* x, const float* w, float* y, double* stats, int N, int H, int W, int Cin, int Cout,
+                                     int CoutPad, int R, int S, int stride, int pad, void* stream) {
+    if (!stats) return fail(VATL_EINVAL, "conv2d_fwd_stats: null statistics buffer");
+    return conv2d_fwd_impl(x, w, nullptr, nullptr, nullptr, y, N, H, W, Cin, Cout, CoutPad, R, S, stride, pad, 0, 0, stats, stream);
+}
+
+static int deconv4x4s2_fwd_impl(const float* x, const float* w, const float* scale, const float* bias, float* y,
+                                int N, int H, int W, int Cin, int Cout, int CoutPad, int relu, double* stats, void* stream) {
     if (!x || !w || !y || N <= 0) return fail(VATL_EINVAL, "deconv4x4s2_fwd: null pointer or empty batch");
+    if (stats && (Cout & 3)) return fail(VATL_EINVAL, "deconv4x4s2_fwd_stats: Cout %d must be a multiple of 4", Cout);
     if (Cin % 32 != 0) return fail(VATL_EINVAL, "deconv4x4s2_fwd: Cin %d must be a multiple of 32", Cin);
     ConvParams p{};
     p.x = x; p.w = w; p.scale = scale; p.bias = bias; p.res = nullptr; p.y = y;
@@ -774,7 +823,19 @@ extern "C" int vatl_deconv4x4s2_fwd(const float* x, const float* w, const float*
     if (xe >= (1LL << 30) || ye >= (1LL << 30) || 4 * we >= (1LL << 30))
         return fail(VATL_EINVAL, "deconv4x4s2_fwd: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
     p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.w_bytes = (unsigned)(we * 4);   // w: one phase
+    p.stats = stats;
     return dispatch(p, 4, false, (hipStream_t)stream);
+}
+
+extern "C" int vatl_deconv4x4s2_fwd(const float* x, const float* w, const float* scale, const float* bias, float* y,
+                                    int N, int H, int W, int Cin, int Cout, int CoutPad, int relu, void* stream) {
+    return deconv4x4s2_fwd_impl(x, w, scale, bias, y, N, H, W, Cin, Cout, CoutPad, relu, nullptr, stream);
+}
+
+extern "C" int vatl_deconv4x4s2_fwd_stats(const float* x, const float* w, float* y, double* stats, int N, int H, int W, int Cin, int Cout,
+                                          int CoutPad, void* stream) {
+    if (!stats) return fail(VATL_EINVAL, "deconv4x4s2_fwd_stats: null statistics buffer");
+    return deconv4x4s2_fwd_impl(x, w, nullptr, nullptr, y, N, H, W, Cin, Cout, CoutPad, 0, stats, stream);
 }
 
 // General form behind the data-gradient paths: explicit GEMM pixel grid (Ho x Wo), separate paddings and an

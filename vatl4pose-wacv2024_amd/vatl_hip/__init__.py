@@ -61,6 +61,11 @@ SIGNATURES = {
     "vatl_bn_train_fwd_stats": (_i, [_p, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
     "vatl_scale_bias_act": (_i, [_p, _p, _p, _p, _p, _i64, _i, _i, _p]),
     "vatl_bn_train_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p]),
+    "vatl_bn_train_bwd_relu": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p]),
+    "vatl_conv_stats_row_blocks": (_i64, [_i64, _i]),
+    "vatl_conv2d_fwd_stats": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vatl_deconv4x4s2_fwd_stats": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "vatl_bn_train_finalize": (_i, [_p, _i64, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
     "vatl_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_maxpool3x3s2_fwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_maxpool3x3s2_bwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
@@ -435,6 +440,53 @@ def bn_train_fwd_stats(z, gamma, beta, running_mean, running_var, momentum: floa
                                          _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), _ptr(_col_ws(m, c, z.device), torch.float64),
                                          _stream()), "vatl_bn_train_fwd_stats")
     return outs
+
+
+def _bn_finalize(stats, nblk, m, c, bn_args, device):
+    gamma, beta, running_mean, running_var, momentum, eps = bn_args
+    outs = [torch.empty(c, device=device, dtype=torch.float32) for _ in range(4)]
+    _check(lib().vatl_bn_train_finalize(_ptr(stats, torch.float64), nblk, m, c, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                        momentum, eps, _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), _stream()), "vatl_bn_train_finalize")
+    return outs
+
+
+def conv2d_fwd_bnstats(x, w_packed, cout: int, r: int, s: int, stride: int, pad: int, gamma, beta, running_mean, running_var,
+                       momentum: float, eps: float):
+    """Training forward: z = conv(x) with the BatchNorm batch statistics taken in the conv epilogue.
+    -> z, save_mean, save_invstd, scale, bias; running stats updated in place."""
+    n, h, w, cin = x.shape
+    ho, wo = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
+    z = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
+    m = n * ho * wo
+    nblk = int(lib().vatl_conv_stats_row_blocks(m, 1))
+    stats = torch.empty(nblk * cout * 2, device=x.device, dtype=torch.float64)
+    _check(lib().vatl_conv2d_fwd_stats(_ptr(x), _ptr(w_packed), _ptr(z), _ptr(stats, torch.float64), n, h, w, cin, cout, w_packed.shape[0],
+                                       r, s, stride, pad, _stream()), "vatl_conv2d_fwd_stats")
+    return [z] + _bn_finalize(stats, nblk, m, cout, (gamma, beta, running_mean, running_var, momentum, eps), x.device)
+
+
+def deconv4x4s2_fwd_bnstats(x, w_packed, cout: int, gamma, beta, running_mean, running_var, momentum: float, eps: float):
+    n, h, w, cin = x.shape
+    z = torch.empty((n, 2 * h, 2 * w, cout), device=x.device, dtype=torch.float32)
+    nblk = int(lib().vatl_conv_stats_row_blocks(n * h * w, 4))
+    stats = torch.empty(nblk * cout * 2, device=x.device, dtype=torch.float64)
+    _check(lib().vatl_deconv4x4s2_fwd_stats(_ptr(x), _ptr(w_packed), _ptr(z), _ptr(stats, torch.float64), n, h, w, cin, cout, w_packed.shape[1],
+                                            _stream()), "vatl_deconv4x4s2_fwd_stats")
+    return [z] + _bn_finalize(stats, nblk, 4 * n * h * w, cout, (gamma, beta, running_mean, running_var, momentum, eps), x.device)
+
+
+def bn_train_bwd_relu(dy, scale, bias, z, gamma, save_mean, save_invstd):
+    """Backward of Conv+BN+ReLU without a skip input; the ReLU mask is recomputed from z. -> dz, dgamma, dbeta."""
+    c = z.shape[-1]
+    m = z.numel() // c
+    dz = torch.empty_like(z)
+    dgamma = torch.empty(c, device=z.device, dtype=torch.float32)
+    dbeta = torch.empty(c, device=z.device, dtype=torch.float32)
+    coef = torch.empty(3 * c, device=z.device, dtype=torch.float32)
+    _check(lib().vatl_bn_train_bwd_relu(_ptr(dy), _ptr(scale), _ptr(bias), _ptr(z), _ptr(gamma), _ptr(save_mean), _ptr(save_invstd), _ptr(dz),
+                                        _ptr(dgamma), _ptr(dbeta), m, c, _ptr(coef), _ptr(_col_ws(m, c, z.device), torch.float64), _stream()),
+           "vatl_bn_train_bwd_relu")
+    return dz, dgamma, dbeta
 
 
 def scale_bias_act(z, scale, bias, residual=None, relu=True):
