@@ -26,6 +26,10 @@ SHAPES = {  # name: (H, W, Cin, Cout, k, stride, residual)
     "l3.c2s2": (32, 24, 256, 256, 3, 2, False),
     "deconv1": (8, 6, 2048, 256, 0, 0, False), "deconv3": (32, 24, 256, 256, 0, 0, False),
     "head": (64, 48, 256, 17, 1, 1, False),
+    # HRNet-W32 branches (basic blocks: 3x3, residual on the second conv), the 1x1 up paths and the 32->17 head
+    "hr.b32": (64, 48, 32, 32, 3, 1, True), "hr.b64": (32, 24, 64, 64, 3, 1, True), "hr.b128": (16, 12, 128, 128, 3, 1, True),
+    "hr.b256": (8, 6, 256, 256, 3, 1, True), "hr.up64_32": (32, 24, 64, 32, 1, 1, False), "hr.down32_64": (64, 48, 32, 64, 3, 2, False),
+    "hr.head": (64, 48, 32, 17, 1, 1, False),
 }
 
 
@@ -51,7 +55,9 @@ def main():
 
 def run(a):
     dev = torch.device("cuda:0")
-    names = a.layers.split(",") if a.layers else list(SHAPES)
+    names = a.layers.split(",") if a.layers else [n for n in SHAPES if not n.startswith("hr.")]
+    if a.layers == "hrnet":
+        names = [n for n in SHAPES if n.startswith("hr.")]
     tot_f = tot_t = 0.0
     for name in names:
         H, W, cin, cout, k, stride, res = SHAPES[name]
@@ -69,7 +75,7 @@ def run(a):
             sc = torch.ones(cout, device=dev); bi = torch.zeros(cout, device=dev)
             Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
             r = torch.randn((B, Ho, Wo, cout), device=dev) if res else None
-            nchw = name == "head"
+            nchw = name.endswith("head")
             fn = lambda: vh.conv2d_fwd(x, w, sc, bi, cout, k, k, stride, k // 2, True, residual=r, out_nchw=nchw)
             flops = 2.0 * B * Ho * Wo * cin * cout * k * k
         for _ in range(2):
