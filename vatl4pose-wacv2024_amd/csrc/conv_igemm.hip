@@ -742,7 +742,9 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st) 
         if (var == 0) return launch<128, 64, 64, 32, false, 0>(p, phases, st);
         return launch<128, 64, 64, 32, false, 4>(p, phases, st);
     }
-    return launch<128, 32, 32, 32, false, 0>(p, phases, st);
+    if (var == 2) return launch<128, 32, 32, 32, false, 2>(p, phases, st);
+    if (var == 0 || p.ktiles < 4) return launch<128, 32, 32, 32, false, 0>(p, phases, st);   // K <= 96: nothing to pipeline
+    return launch<128, 32, 32, 32, false, 4>(p, phases, st);
 }
 
 }  // namespace vatl
