@@ -173,6 +173,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             __syncthreads();
             if (tid < C4) {
                 double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+#pragma unroll 2                                           // (full unrolling cost the 128x32 kernel 256 VGPRs and spills)
                 for (int k = 0; k < RPP; ++k) {
                     const f32x4 a = sh[k * C4 + tid], b = sh[256 + k * C4 + tid];
 #pragma unroll
