@@ -73,7 +73,8 @@ int vatl_bn_fold(const float* gamma, const float* beta, const float* mean, const
  * SimplePose.final_layer (simplepose.py:85). */
 /* Tuning knob (benchmarks / A-B tests only; results are identical for every setting):
  * knob 0 = k-loop schedule of the conv kernel (see csrc/conv_igemm.hip), 1 = tile order, 2 = block stagger,
- * 3 = target block count of the weight-gradient launches (number of pixel splits). */
+ * 3 = target block count of the weight-gradient launches (number of pixel splits), 4 = wgrad ablation bits,
+ * 5 = rows of the conv block tile (0 = chosen from the grid size, 64, 128). */
 int vatl_tune_set(int knob, int value);
 /* CoutPad the packer must use for a given Cout (multiple of the kernel's N tile). */
 int vatl_conv_cout_pad(int Cout);
@@ -222,15 +223,17 @@ int vatl_bn_train_bwd_relu(const float* dy, const float* scale, const float* bia
                            int64_t M, int C, float* coef3C, double* workspace, void* stream);
 /* Training forward with the BatchNorm batch statistics taken in the conv epilogue (no separate pass over z):
  * the conv / deconv writes z (no affine, no ReLU) and, per 128-row block of the implicit GEMM and channel, a partial
- * (sum, sum of squares) pair into `stats` (vatl_conv_stats_row_blocks(rows, phases) * Cout * 2 doubles; rows = N*Ho*Wo,
- * phases = 1, or N*H*W and 4 for the transposed conv).  vatl_bn_train_finalize reduces the partials in a fixed order
+ * (sum, sum of squares) pair into `stats` (capacity vatl_conv_stats_row_blocks(rows, phases) * Cout * 2 doubles; rows =
+ * N*Ho*Wo, phases = 1, or N*H*W and 4 for the transposed conv; the number of row blocks actually written — it depends
+ * on the tile the launch picked — is returned in the HOST variable *row_blocks_used and is what vatl_bn_train_finalize
+ * takes as `row_blocks`).  vatl_bn_train_finalize reduces the partials in a fixed order
  * and produces what vatl_bn_train_fwd_stats produces (nn.BatchNorm2d under model.train(), Resnet.py:104-128 via
  * ActiveLearning.py:658-672); M = elements per channel (N*Ho*Wo of the layer OUTPUT). */
 int64_t vatl_conv_stats_row_blocks(int64_t gemm_rows, int phases);
-int vatl_conv2d_fwd_stats(const float* x, const float* w, float* y, double* stats, int N, int H, int W, int Cin, int Cout,
-                          int CoutPad, int R, int S, int stride, int pad, void* stream);
-int vatl_deconv4x4s2_fwd_stats(const float* x, const float* w, float* y, double* stats, int N, int H, int W, int Cin, int Cout,
-                               int CoutPad, void* stream);
+int vatl_conv2d_fwd_stats(const float* x, const float* w, float* y, double* stats, int64_t* row_blocks_used, int N, int H, int W,
+                          int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad, void* stream);
+int vatl_deconv4x4s2_fwd_stats(const float* x, const float* w, float* y, double* stats, int64_t* row_blocks_used, int N, int H, int W,
+                               int Cin, int Cout, int CoutPad, void* stream);
 int vatl_bn_train_finalize(const double* partial, int64_t row_blocks, int64_t M, int C, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
                            float* save_invstd, float* scale, float* bias, void* stream);

@@ -39,7 +39,14 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--layers", default="")
     ap.add_argument("--vars", default="", help="comma list of k-loop schedule variants to A/B (vatl_tune_set knob 0)")
+    ap.add_argument("--bm", default="", help="comma list of block-tile row counts to A/B (vatl_tune_set knob 5: 0 auto, 64, 128)")
     a = ap.parse_args()
+    if a.bm:
+        for v in a.bm.split(","):
+            print(f"--- block tile rows {v}")
+            vh.tune_set(5, int(v))
+            run(a)
+        return
     if a.vars:
         for v in a.vars.split(","):
             parts = (v.split(":") + ["0", "0"])[:3]

@@ -667,6 +667,7 @@ static int launch_dma(const ConvParams& p, int phases, hipStream_t st);
 
 static std::atomic<int> g_var{4};      // k-loop schedule (vatl_tune_set(0, v)); 4 = shipped default
 static std::atomic<int> g_order{0};    // tile order (vatl_tune_set(1, v))
+static std::atomic<int> g_bm{0};       // tile rows (vatl_tune_set(5, v)): 0 = by grid size, 64 or 128 = forced
 static std::atomic<int> g_stagger{0};  // block stagger in percent of the k-loop time (vatl_tune_set(2, v)); 0 = off
 
 template <int BM, int BN, int WM, int WN, bool STEM, int VAR>
@@ -717,10 +718,26 @@ static int launch_dma(const ConvParams& p, int phases, hipStream_t st) {
 // CoutPad granularity the packer must honour for a given Cout.
 static int tile_n_for(int Cout) { return Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128); }
 
-static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st) {
+// Rows per block tile.  512 blocks are resident at a time (two per CU); a launch that cannot fill them with 128-row
+// tiles (small batches: the B = 120 fine-tune step, single-frame inference) is cut into 64-row tiles instead.
+static int tile_m_for(const ConvParams& p, int phases, int bn, bool stem) {
+    if (stem || bn < 64) return 128;
+    const int forced = g_bm.load(std::memory_order_relaxed);
+    if (forced == 64 || forced == 128) return forced;
+    const long long blocks128 = (long long)cdiv(p.M, 128) * (p.CoutPad / bn) * phases;
+    return blocks128 < 512 ? 64 : 128;
+}
+
+static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, int64_t* row_blocks = nullptr) {
     const int bn = tile_n_for(p.Cout);
     if (p.CoutPad % bn != 0) return fail(VATL_EINVAL, "CoutPad %d must be a multiple of %d for Cout %d", p.CoutPad, bn, p.Cout);
     const int var = g_var.load(std::memory_order_relaxed);
+    const int bm = tile_m_for(p, phases, bn, stem);
+    if (row_blocks) *row_blocks = (int64_t)cdiv(p.M, bm) * phases;
+    if (bm == 64) {
+        if (bn == 128) return launch<64, 128, 32, 64, false, 4>(p, phases, st);
+        return launch<64, 64, 32, 32, false, 4>(p, phases, st);
+    }
     if (stem) {
         if (bn == 64) return launch<128, 64, 64, 32, true, 0>(p, phases, st);
         if (bn == 128) return launch<128, 128, 64, 64, true, 0>(p, phases, st);
@@ -756,6 +773,7 @@ extern "C" int vatl_tune_wgrad_blocks(int blocks);
 
 extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 3 && vatl_tune_wgrad_blocks(value) == 0) return 0;
+    if (knob == 5 && (value == 0 || value == 64 || value == 128)) { g_bm.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
     if (knob == 0 && value >= 0 && value <= 13) { g_var.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }
@@ -770,7 +788,7 @@ extern "C" int vatl_conv_cout_pad(int Cout) {
 
 static int conv2d_fwd_impl(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
                            float* y, int N, int H, int W, int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad,
-                           int relu, int out_nchw, double* stats, void* stream) {
+                           int relu, int out_nchw, double* stats, int64_t* row_blocks, void* stream) {
     if (!x || !w || !y || N <= 0) return fail(VATL_EINVAL, "conv2d_fwd: null pointer or empty batch");
     if (stats && ((Cout & 3) || out_nchw)) return fail(VATL_EINVAL, "conv2d_fwd_stats: Cout %d must be a multiple of 4 (NHWC output)", Cout);
     const bool stem = (Cin == 4);
@@ -792,25 +810,25 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* scale, c
         return fail(VATL_EINVAL, "conv2d_fwd: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
     p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.w_bytes = (unsigned)(we * 4);
     p.stats = stats;
-    return dispatch(p, 1, stem, (hipStream_t)stream);
+    return dispatch(p, 1, stem, (hipStream_t)stream, row_blocks);
 }
 
 extern "C" int vatl_conv2d_fwd(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
                                float* y, int N, int H, int W, int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad,
                                int relu, int out_nchw, void* stream) {
-    return conv2d_fwd_impl(x, w, scale, bias, residual, y, N, H, W, Cin, Cout, CoutPad, R, S, stride, pad, relu, out_nchw, nullptr, stream);
+    return conv2d_fwd_impl(x, w, scale, bias, residual, y, N, H, W, Cin, Cout, CoutPad, R, S, stride, pad, relu, out_nchw, nullptr, nullptr, stream);
 }
 
-extern "C" int64_t vatl_conv_stats_row_blocks(int64_t gemm_rows, int phases) { return (gemm_rows + 127) / 128 * phases; }
+extern "C" int64_t vatl_conv_stats_row_blocks(int64_t gemm_rows, int phases) { return (gemm_rows + 63) / 64 * phases; }   // capacity
 
-extern "C" int vatl_conv2d_fwd_stats(const float* x, const float* w, float* y, double* stats, int N, int H, int W, int Cin, int Cout,
-                                     int CoutPad, int R, int S, int stride, int pad, void* stream) {
-    if (!stats) return fail(VATL_EINVAL, "conv2d_fwd_stats: null statistics buffer");
-    return conv2d_fwd_impl(x, w, nullptr, nullptr, nullptr, y, N, H, W, Cin, Cout, CoutPad, R, S, stride, pad, 0, 0, stats, stream);
+extern "C" int vatl_conv2d_fwd_stats(const float* x, const float* w, float* y, double* stats, int64_t* row_blocks_used, int N, int H, int W,
+                                     int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad, void* stream) {
+    if (!stats || !row_blocks_used) return fail(VATL_EINVAL, "conv2d_fwd_stats: null statistics buffer");
+    return conv2d_fwd_impl(x, w, nullptr, nullptr, nullptr, y, N, H, W, Cin, Cout, CoutPad, R, S, stride, pad, 0, 0, stats, row_blocks_used, stream);
 }
 
 static int deconv4x4s2_fwd_impl(const float* x, const float* w, const float* scale, const float* bias, float* y,
-                                int N, int H, int W, int Cin, int Cout, int CoutPad, int relu, double* stats, void* stream) {
+                                int N, int H, int W, int Cin, int Cout, int CoutPad, int relu, double* stats, int64_t* row_blocks, void* stream) {
     if (!x || !w || !y || N <= 0) return fail(VATL_EINVAL, "deconv4x4s2_fwd: null pointer or empty batch");
     if (stats && (Cout & 3)) return fail(VATL_EINVAL, "deconv4x4s2_fwd_stats: Cout %d must be a multiple of 4", Cout);
     if (Cin % 32 != 0) return fail(VATL_EINVAL, "deconv4x4s2_fwd: Cin %d must be a multiple of 32", Cin);
@@ -827,18 +845,18 @@ static int deconv4x4s2_fwd_impl(const float* x, const float* w, const float* sca
         return fail(VATL_EINVAL, "deconv4x4s2_fwd: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
     p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.w_bytes = (unsigned)(we * 4);   // w: one phase
     p.stats = stats;
-    return dispatch(p, 4, false, (hipStream_t)stream);
+    return dispatch(p, 4, false, (hipStream_t)stream, row_blocks);
 }
 
 extern "C" int vatl_deconv4x4s2_fwd(const float* x, const float* w, const float* scale, const float* bias, float* y,
                                     int N, int H, int W, int Cin, int Cout, int CoutPad, int relu, void* stream) {
-    return deconv4x4s2_fwd_impl(x, w, scale, bias, y, N, H, W, Cin, Cout, CoutPad, relu, nullptr, stream);
+    return deconv4x4s2_fwd_impl(x, w, scale, bias, y, N, H, W, Cin, Cout, CoutPad, relu, nullptr, nullptr, stream);
 }
 
-extern "C" int vatl_deconv4x4s2_fwd_stats(const float* x, const float* w, float* y, double* stats, int N, int H, int W, int Cin, int Cout,
-                                          int CoutPad, void* stream) {
-    if (!stats) return fail(VATL_EINVAL, "deconv4x4s2_fwd_stats: null statistics buffer");
-    return deconv4x4s2_fwd_impl(x, w, nullptr, nullptr, y, N, H, W, Cin, Cout, CoutPad, 0, stats, stream);
+extern "C" int vatl_deconv4x4s2_fwd_stats(const float* x, const float* w, float* y, double* stats, int64_t* row_blocks_used, int N, int H, int W,
+                                          int Cin, int Cout, int CoutPad, void* stream) {
+    if (!stats || !row_blocks_used) return fail(VATL_EINVAL, "deconv4x4s2_fwd_stats: null statistics buffer");
+    return deconv4x4s2_fwd_impl(x, w, nullptr, nullptr, y, N, H, W, Cin, Cout, CoutPad, 0, stats, row_blocks_used, stream);
 }
 
 // General form behind the data-gradient paths: explicit GEMM pixel grid (Ho x Wo), separate paddings and an

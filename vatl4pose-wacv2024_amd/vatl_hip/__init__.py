@@ -63,8 +63,8 @@ SIGNATURES = {
     "vatl_bn_train_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p]),
     "vatl_bn_train_bwd_relu": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p]),
     "vatl_conv_stats_row_blocks": (_i64, [_i64, _i]),
-    "vatl_conv2d_fwd_stats": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "vatl_deconv4x4s2_fwd_stats": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "vatl_conv2d_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vatl_deconv4x4s2_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_bn_train_finalize": (_i, [_p, _i64, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
     "vatl_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_maxpool3x3s2_fwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
@@ -458,21 +458,21 @@ def conv2d_fwd_bnstats(x, w_packed, cout: int, r: int, s: int, stride: int, pad:
     ho, wo = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
     z = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
     m = n * ho * wo
-    nblk = int(lib().vatl_conv_stats_row_blocks(m, 1))
-    stats = torch.empty(nblk * cout * 2, device=x.device, dtype=torch.float64)
-    _check(lib().vatl_conv2d_fwd_stats(_ptr(x), _ptr(w_packed), _ptr(z), _ptr(stats, torch.float64), n, h, w, cin, cout, w_packed.shape[0],
-                                       r, s, stride, pad, _stream()), "vatl_conv2d_fwd_stats")
-    return [z] + _bn_finalize(stats, nblk, m, cout, (gamma, beta, running_mean, running_var, momentum, eps), x.device)
+    stats = torch.empty(int(lib().vatl_conv_stats_row_blocks(m, 1)) * cout * 2, device=x.device, dtype=torch.float64)
+    used = C.c_int64(0)
+    _check(lib().vatl_conv2d_fwd_stats(_ptr(x), _ptr(w_packed), _ptr(z), _ptr(stats, torch.float64), C.addressof(used), n, h, w, cin, cout,
+                                       w_packed.shape[0], r, s, stride, pad, _stream()), "vatl_conv2d_fwd_stats")
+    return [z] + _bn_finalize(stats, used.value, m, cout, (gamma, beta, running_mean, running_var, momentum, eps), x.device)
 
 
 def deconv4x4s2_fwd_bnstats(x, w_packed, cout: int, gamma, beta, running_mean, running_var, momentum: float, eps: float):
     n, h, w, cin = x.shape
     z = torch.empty((n, 2 * h, 2 * w, cout), device=x.device, dtype=torch.float32)
-    nblk = int(lib().vatl_conv_stats_row_blocks(n * h * w, 4))
-    stats = torch.empty(nblk * cout * 2, device=x.device, dtype=torch.float64)
-    _check(lib().vatl_deconv4x4s2_fwd_stats(_ptr(x), _ptr(w_packed), _ptr(z), _ptr(stats, torch.float64), n, h, w, cin, cout, w_packed.shape[1],
-                                            _stream()), "vatl_deconv4x4s2_fwd_stats")
-    return [z] + _bn_finalize(stats, nblk, 4 * n * h * w, cout, (gamma, beta, running_mean, running_var, momentum, eps), x.device)
+    stats = torch.empty(int(lib().vatl_conv_stats_row_blocks(n * h * w, 4)) * cout * 2, device=x.device, dtype=torch.float64)
+    used = C.c_int64(0)
+    _check(lib().vatl_deconv4x4s2_fwd_stats(_ptr(x), _ptr(w_packed), _ptr(z), _ptr(stats, torch.float64), C.addressof(used), n, h, w, cin, cout,
+                                            w_packed.shape[1], _stream()), "vatl_deconv4x4s2_fwd_stats")
+    return [z] + _bn_finalize(stats, used.value, 4 * n * h * w, cout, (gamma, beta, running_mean, running_var, momentum, eps), x.device)
 
 
 def bn_train_bwd_relu(dy, scale, bias, z, gamma, save_mean, save_invstd):
