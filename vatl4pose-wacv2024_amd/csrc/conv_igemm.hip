@@ -724,8 +724,11 @@ static int tile_m_for(const ConvParams& p, int phases, int bn, bool stem) {
     if (stem || bn < 64) return 128;
     const int forced = g_bm.load(std::memory_order_relaxed);
     if (forced == 64 || forced == 128) return forced;
-    const long long blocks128 = (long long)cdiv(p.M, 128) * (p.CoutPad / bn) * phases;
-    return blocks128 < 512 ? 64 : 128;
+    // rounds of 512 resident blocks x relative cost of one block (a 64-row tile does half the work at ~8 % lower
+    // efficiency: the weight tile is re-read for half as many rows)
+    const long long per_row_tile = (long long)(p.CoutPad / bn) * phases;
+    const long long r128 = (cdiv(p.M, 128) * per_row_tile + 511) / 512, r64 = (cdiv(p.M, 64) * per_row_tile + 511) / 512;
+    return r64 * 54 < r128 * 100 ? 64 : 128;
 }
 
 static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, int64_t* row_blocks = nullptr) {
