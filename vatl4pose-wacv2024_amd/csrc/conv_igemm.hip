@@ -718,17 +718,18 @@ static int launch_dma(const ConvParams& p, int phases, hipStream_t st) {
 // CoutPad granularity the packer must honour for a given Cout.
 static int tile_n_for(int Cout) { return Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128); }
 
-// Rows per block tile.  512 blocks are resident at a time (two per CU); a launch that cannot fill them with 128-row
-// tiles (small batches: the B = 120 fine-tune step, single-frame inference) is cut into 64-row tiles instead.
+// Rows per block tile (measured on MI355X, tools/conv_bench.py --bm 128,64 at batches 120..1024, profiles/r01_notes.md):
+//  * 64-channel outputs: the 64x64 tile (36.8 KB of LDS, four blocks = 16 waves per CU) beats 128x64 (two blocks) at
+//    every size (+10..20 %);
+//  * 128-wide tiles: 128 rows unless the launch has fewer than ~1.5 rounds of the 512 resident blocks (small batches:
+//    the B = 120 fine-tune step, single-frame inference), where 64-row tiles fill the chip better (+15..30 %).
 static int tile_m_for(const ConvParams& p, int phases, int bn, bool stem) {
     if (stem || bn < 64) return 128;
     const int forced = g_bm.load(std::memory_order_relaxed);
     if (forced == 64 || forced == 128) return forced;
-    // rounds of 512 resident blocks x relative cost of one block (a 64-row tile does half the work at ~8 % lower
-    // efficiency: the weight tile is re-read for half as many rows)
-    const long long per_row_tile = (long long)(p.CoutPad / bn) * phases;
-    const long long r128 = (cdiv(p.M, 128) * per_row_tile + 511) / 512, r64 = (cdiv(p.M, 64) * per_row_tile + 511) / 512;
-    return r64 * 54 < r128 * 100 ? 64 : 128;
+    if (bn == 64) return 64;
+    const long long blocks128 = (long long)cdiv(p.M, 128) * (p.CoutPad / bn) * phases;
+    return blocks128 < 768 ? 64 : 128;
 }
 
 static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, int64_t* row_blocks = nullptr) {
