@@ -13,9 +13,12 @@ import sys
 def layers(B):
     L = []
 
-    def conv(name, H, W, cin, cout, k, s):
+    def conv(name, H, W, cin, cout, k, s, res=False):
         Ho, Wo = H // s, W // s
-        L.append((name, 2 * B * Ho * Wo * cin * cout * k * k, B * Ho * Wo, cout, cin * k * k))
+        # compulsory HBM bytes: input pixels that are read (a strided 1x1 reads every other pixel), output, residual, weights
+        rd_in = B * (Ho * Wo if k == 1 else H * W) * max(cin, 4) * 4
+        byts = rd_in + B * Ho * Wo * cout * 4 * (2 if res else 1) + cin * cout * k * k * 4
+        L.append((name, 2 * B * Ho * Wo * cin * cout * k * k, B * Ho * Wo, cout, cin * k * k, byts))
     conv("stem", 256, 192, 3, 64, 7, 2)
     H, W, cin = 64, 48, 64
     for si, (n, wd) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512))):
@@ -27,10 +30,10 @@ def layers(B):
             if b == 0:
                 conv(tag + ".proj", H, W, cin, 4 * wd, 1, s)
             H, W = H // s, W // s
-            conv(tag + ".c3", H, W, wd, 4 * wd, 1, 1)
+            conv(tag + ".c3", H, W, wd, 4 * wd, 1, 1, res=True)
             cin = 4 * wd
     for i, (ci, co) in enumerate(((2048, 256), (256, 256), (256, 256))):
-        L.append((f"deconv{i + 1}", 2 * B * H * W * 16 * ci * co, B * H * W, co, 4 * ci))
+        L.append((f"deconv{i + 1}", 2 * B * H * W * 16 * ci * co, B * H * W, co, 4 * ci, B * H * W * (ci + 4 * co) * 4 + 16 * ci * co * 4))
         H, W = 2 * H, 2 * W
     conv("head", H, W, 256, 17, 1, 1)
     return L
@@ -44,16 +47,21 @@ def main():
     L = layers(B)
     last = rows[-len(L):]
     agg = {}
-    for (name, fl, M, N, K), r in zip(L, last):
+    for (name, fl, M, N, K, by), r in zip(L, last):
         du = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-        a = agg.setdefault((name, M, N, K), [0, 0, 0])
-        a[0] += fl; a[1] += du; a[2] += 1
+        a = agg.setdefault((name, M, N, K), [0, 0, 0, 0])
+        a[0] += fl; a[1] += du; a[2] += 1; a[3] += by
     tot = sum(a[1] for a in agg.values())
     totf = sum(a[0] for a in agg.values())
-    print(f"{'layer':12s} {'M':>8s} {'N':>5s} {'K':>5s}  cnt   us/launch   TF/s   share%  ideal_ms")
-    for (name, M, N, K), (fl, du, c) in agg.items():
-        print(f"{name:12s} {M:8d} {N:5d} {K:5d}  x{c:<2d} {du / c / 1e3:10.1f} {fl / du / 1e3:7.1f} {100 * du / tot:7.2f} {fl / 157.3e12 * 1e3:8.3f}")
+    print(f"{'layer':12s} {'M':>8s} {'N':>5s} {'K':>5s}  cnt   us/launch   TF/s   share%  mfma_ms   hbm_ms  (ideal at 157.3 TFLOP/s / compulsory bytes at 8 TB/s)")
+    bound = 0.0
+    for (name, M, N, K), (fl, du, c, by) in agg.items():
+        t_m, t_h = fl / 157.3e12 * 1e3, by / 8e12 * 1e3
+        bound += max(t_m, t_h)
+        print(f"{name:12s} {M:8d} {N:5d} {K:5d}  x{c:<2d} {du / c / 1e3:10.1f} {fl / du / 1e3:7.1f} {100 * du / tot:7.2f} {t_m:8.3f} {t_h:8.3f}{'  <- HBM-bound' if t_h > t_m else ''}")
     print(f"total {tot / 1e6:.2f} ms for {B} frames -> {totf / tot / 1e3:.1f} TF/s, {B / (tot / 1e9):.0f} frames/s (conv only)")
+    print(f"layer-by-layer roofline (each launch at max(MFMA, HBM) time): {bound:.2f} ms -> {B / bound * 1e3:.0f} frames/s; "
+          f"measured / that bound = {bound / (tot / 1e6):.3f}")
 
 
 if __name__ == "__main__":
