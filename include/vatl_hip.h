@@ -172,6 +172,17 @@ int vatl_hybrid_feature_f64(const double* kpts, const double* bbox_xywh, double*
  * kept local peak of plane p (planes = N*J maps of H x W). */
 int vatl_localpeak_mask(const float* hm, uint8_t* mask, int planes, int H, int W, float order, void* stream);
 
+/* Multiple-peak criteria (ActiveLearning.py:762-788): per (item, joint) plane the <= 5 local peaks that
+ * skimage.feature.peak_local_max(plane, min_distance, num_peaks=5) returns (values, flat indices y*W+x or -1, count),
+ * the plane's MPE term entropy(softmax(peak values)) and its Margin term |peak0 - peak1| (0 with fewer than two
+ * peaks).  compute_mpe / compute_margin are the sums of those terms over the joints of an item.
+ * peak_val, peak_idx: N*J*5; npeaks, mpe, margin: N*J. */
+int vatl_peaks5(const float* hm, float* peak_val, int32_t* peak_idx, int32_t* npeaks, float* mpe, float* margin,
+                int N, int J, int H, int W, int min_distance, void* stream);
+/* compute_entropy (ActiveLearning.py:790-796): out[n*J + j] = scipy.stats.entropy(plane.flatten()) — normalised by the
+ * plane sum, -inf for a negative entry, nan for a zero sum, exactly as scipy returns them. */
+int vatl_plane_entropy(const float* hm, float* out, int N, int J, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * Training-mode backbone (ActiveLearning.py:658-673: model.train(), loss.backward())
  * ------------------------------------------------------------------------ */

@@ -384,6 +384,74 @@ def sgd_step(p, g, buf, step: int, lr: float, momentum: float = 0.9, wd: float =
 
 
 # --------------------------------------------------------------------------
+# a13: MPE / Margin / Entropy          ActiveLearning.py:387-396, 762-796
+# --------------------------------------------------------------------------
+# `peak_local_max` is scikit-image's (pinned scikit-image==0.24.0, requirements.txt:172); the package is ABSENT from
+# this image, so the function below restates its published algorithm (skimage/feature/peak.py: maximum filter over a
+# (2*min_distance+1)^2 footprint with mode='nearest', threshold = image.min(), border of width min_distance excluded,
+# candidates sorted by descending intensity with a stable sort, `ensure_spacing` = greedy rejection of candidates at
+# Chebyshev distance < min_distance from an accepted one, first `num_peaks` kept).  PARITY UNPINNED for this one
+# function: it is checked against hand-built cases only.  softmax / entropy are scipy's (present: pinned directly).
+
+def peak_local_max_5(img: np.ndarray, min_distance: int = 5, num_peaks: int = 5) -> np.ndarray:
+    """(H,W) -> (k,2) int rows of (row, col), k <= num_peaks, highest peaks first."""
+    from scipy import ndimage
+    size = 2 * min_distance + 1
+    mx = ndimage.maximum_filter(img, footprint=np.ones((size, size), bool), mode="nearest")
+    out = img == mx
+    if np.all(out):
+        out[:] = False
+    out &= img > img.min()
+    b = min_distance
+    out[:b, :] = False; out[-b:, :] = False; out[:, :b] = False; out[:, -b:] = False
+    rows, cols = np.nonzero(out)
+    order = np.argsort(-img[rows, cols], kind="stable")
+    coords = np.stack([rows[order], cols[order]], 1)
+    kept = []
+    for c in coords:
+        if all(max(abs(int(c[0]) - k[0]), abs(int(c[1]) - k[1])) >= min_distance for k in kept):
+            kept.append((int(c[0]), int(c[1])))
+            if len(kept) == num_peaks:
+                break
+    return np.asarray(kept, np.int64).reshape(-1, 2)
+
+
+def mpe_item(hm: np.ndarray) -> float:
+    """compute_mpe (ActiveLearning.py:762-778): sum over joints of entropy(softmax(values of <= 5 local peaks))."""
+    from scipy.special import softmax
+    from scipy.stats import entropy
+    total = 0
+    for h in hm:
+        loc = peak_local_max_5(h)
+        peaks = h[loc[:, 0], loc[:, 1]]
+        if peaks.shape[0] > 0:
+            total += entropy(softmax(peaks))
+    return float(total)
+
+
+def margin_item(hm: np.ndarray) -> float:
+    """compute_margin (ActiveLearning.py:780-788): sum over joints of |top peak - second peak|."""
+    total = 0
+    for h in hm:
+        loc = peak_local_max_5(h)
+        peaks = h[loc[:, 0], loc[:, 1]]
+        if peaks.shape[0] > 1:
+            total += np.linalg.norm(peaks[0] - peaks[1])
+    return float(total)
+
+
+def entropy_item(hm: np.ndarray) -> float:
+    """compute_entropy (ActiveLearning.py:790-796): sum over joints of scipy.stats.entropy(flattened map).  scipy
+    normalises by the sum and uses entr(): -inf for a negative entry, nan for a zero sum — kept as is."""
+    from scipy.stats import entropy
+    total = 0
+    with np.errstate(all="ignore"):
+        for h in hm:
+            total += entropy(h.flatten())
+    return float(total)
+
+
+# --------------------------------------------------------------------------
 # §8f rank 1: OKS and heat-map accuracy         al_metric.py:42-69, metrics.py:118-245
 # --------------------------------------------------------------------------
 

@@ -120,3 +120,41 @@ def test_score_batch_all_scores(golden_scorers):
         np.testing.assert_allclose(float(s.thc[i]), want, rtol=1e-5)
     ok = g["kp_ok"]
     np.testing.assert_allclose(s.wpu.cpu().numpy()[ok], g["wpu42"][ok], rtol=1e-4)
+
+
+def test_mpe_margin_entropy_criteria():
+    """MPE / Margin (<= 5 local peaks per plane: positions and counts exact) and Entropy
+    (scipy semantics incl. -inf on signed maps) against the oracle."""
+    import vatl_hip as vh
+    from active_learning.scoring import multi_peak_scores
+    from oracle import scorers, synth
+    from tests.gpu_util import record, rel_err, to_dev
+    hm = synth.blob_heatmaps(6, seed=21)                      # signed (noise) maps with 1-3 bumps per joint
+    r = np.random.RandomState(4)
+    hm[1, 3] = 0.25                                           # constant plane: no peak
+    hm[2, 5] = 0.0; hm[2, 5, 20, 20] = 1.0; hm[2, 5, 20, 24] = 1.0; hm[2, 5, 20, 25] = 1.0   # plateau ties inside / at the spacing
+    hm[3, 0] = 0.0; hm[3, 0, 4, 10] = 2.0; hm[3, 0, 5, 10] = 1.0                             # border exclusion (row 4 is border, row 5 is not)
+    hm[4] = np.abs(hm[4]) + 1e-3                              # non-negative item: finite entropy
+    hm[5, 2] = 0.0                                            # zero plane: entropy nan, no peaks
+    d = to_dev(hm)
+    val, idx, cnt, mpe, mar = vh.peaks5(d, 5)
+    val, idx, cnt = val.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy()
+    for n in range(hm.shape[0]):
+        for j in range(hm.shape[1]):
+            loc = scorers.peak_local_max_5(hm[n, j])
+            assert cnt[n, j] == len(loc), (n, j)
+            assert np.array_equal(idx[n, j, :len(loc)], loc[:, 0] * hm.shape[3] + loc[:, 1]), (n, j)
+            assert np.array_equal(val[n, j, :len(loc)], hm[n, j][loc[:, 0], loc[:, 1]])
+            assert (idx[n, j, len(loc):] == -1).all()
+    assert cnt[1, 3] == 0 and cnt[5, 2] == 0 and cnt[2, 5] == 2 and list(idx[3, 0, :1]) == [5 * hm.shape[3] + 10]
+    want_mpe = np.array([scorers.mpe_item(h) for h in hm]); want_mar = np.array([scorers.margin_item(h) for h in hm])
+    got_mpe, got_mar = multi_peak_scores(d, "MPE").cpu().numpy(), multi_peak_scores(d, "Margin").cpu().numpy()
+    record("mpe_margin", mpe_rel=rel_err(got_mpe, want_mpe), margin_rel=rel_err(got_mar, want_mar))
+    np.testing.assert_allclose(got_mpe, want_mpe, rtol=1e-5)
+    np.testing.assert_allclose(got_mar, want_mar, rtol=1e-6)
+    want_ent = np.array([scorers.entropy_item(h) for h in hm])
+    got_ent = multi_peak_scores(d, "Entropy").cpu().numpy()
+    fin = np.isfinite(want_ent)
+    assert fin[4] and not fin[0] and np.isnan(want_ent[5])
+    assert np.array_equal(np.isnan(got_ent), np.isnan(want_ent)) and np.array_equal(np.isneginf(got_ent), np.isneginf(want_ent))
+    np.testing.assert_allclose(got_ent[fin], want_ent[fin], rtol=1e-5)

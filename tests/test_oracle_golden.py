@@ -199,3 +199,30 @@ def test_fastpose_r152_384_restatement_matches_reference():
     assert hm.shape == (1, 17, 96, 72)
     assert np.abs(hm - ref).max() <= 1e-5 * np.abs(ref).max()
     np.testing.assert_allclose(emb, g["embedding"], rtol=1e-4, atol=1e-4)
+
+
+def test_multi_peak_criteria_restatement():
+    """MPE / Margin / Entropy (ActiveLearning.py:762-796).  scikit-image is absent here, so `peak_local_max_5` is
+    checked on cases whose answer follows from the documented algorithm; softmax / entropy are scipy's own."""
+    from scipy.special import softmax
+    from scipy.stats import entropy
+    h = np.zeros((64, 48), np.float32)
+    h[10, 10], h[30, 30], h[50, 20] = 3.0, 2.0, 1.0
+    h[10, 14] = 2.5                                            # inside the 11x11 window of (10,10): not a local maximum
+    h[4, 30] = 9.0                                             # in the excluded border
+    loc = scorers.peak_local_max_5(h)
+    assert loc.tolist() == [[10, 10], [30, 30], [50, 20]]
+    hm = np.stack([h, np.full_like(h, 0.5)])
+    peaks = np.array([3.0, 2.0, 1.0], np.float32)
+    np.testing.assert_allclose(scorers.mpe_item(hm), entropy(softmax(peaks)), rtol=1e-6)
+    np.testing.assert_allclose(scorers.margin_item(hm), 1.0)
+    p = h + 1.0
+    np.testing.assert_allclose(scorers.entropy_item(p[None]), entropy(p.flatten()), rtol=1e-6)
+    assert scorers.entropy_item(-p[None]) == entropy(-p.flatten())          # scipy normalises by the (negative) sum
+    g = h.copy(); g[0, 0] = -1.0
+    assert scorers.entropy_item(g[None]) == -np.inf
+    # plateau: equal maxima 4 apart -> the later one (row-major) is rejected; exactly 5 apart -> both stay
+    q = np.zeros((64, 48), np.float32); q[20, 20] = q[20, 24] = 1.0
+    assert scorers.peak_local_max_5(q).tolist() == [[20, 20]]
+    q = np.zeros((64, 48), np.float32); q[20, 20] = q[20, 25] = 1.0
+    assert scorers.peak_local_max_5(q).tolist() == [[20, 20], [20, 25]]

@@ -8,7 +8,7 @@ Same entry points as the reference class — ``ActiveLearning(cfg, opt)``, ``eva
   ``score_batch`` launch sequence per batch instead of a per-item Python loop with D2H copies.
 * ``retrain_model`` (:651-686): train-mode forward, fused masked-MSE loss+gradient, HIP backward, AdamW.
 
-In scope: uncertainty None | HP | TPC | THC_L1 | THC_L2 | WPU | THC+WPU, representativeness None,
+In scope: uncertainty None | HP | TPC | THC_L1 | THC_L2 | WPU | THC+WPU | MPE | Margin | Entropy, representativeness None,
 filter None | Random.  Query strategies built on sklearn / umap (Influence, K-Means, Coreset), COCO mAP and
 OSPA evaluation, plots and the VL4Pose branch are out of scope and raise.
 Offline metrics can be plugged in through ``opt.evaluate_fn(pred_records, gt_records) -> dict``.
@@ -27,9 +27,9 @@ from alphapose.utils.transforms import get_func_heatmap_to_coord
 
 from .al_metric import compute_OKS_batch
 from .optim import SGD, Adam, AdamW
-from .scoring import score_batch
+from .scoring import multi_peak_scores, score_batch
 
-_UNC = ("None", "HP", "TPC", "THC_L1", "THC_L2", "THC", "WPU", "THC+WPU")
+_UNC = ("None", "HP", "TPC", "THC_L1", "THC_L2", "THC", "WPU", "THC+WPU", "MPE", "Margin", "Entropy")
 
 
 class ActiveLearning:
@@ -194,6 +194,8 @@ class ActiveLearning:
         elif self.uncertainty == "WPU":
             self._check_wpu(s.wpu_status)
             unc[:, 0] = s.wpu
+        elif self.uncertainty in ("MPE", "Margin", "Entropy"):
+            unc[:, 0] = multi_peak_scores(hm_all, self.uncertainty).float()
         kp = s.keypoints.reshape(n, -1)
         oks = compute_OKS_batch(ann_all, kp.cpu().numpy(), gt_all)
         return torch.cat([kp, unc, s.localpeak[:, None], torch.as_tensor(oks, dtype=torch.float32, device=self.device)[:, None]], 1).contiguous()

@@ -8,6 +8,7 @@ whole batch instead of per-item ``.cpu().numpy()`` round trips:
   THC               compute_thc + isPrev/isNext rule   :345-363, 747-760
   WPU               compute_hybrid -> AE -> MSELoss    :364-386
   local-peak mean   localpeak_mean ("combine weight")  :411-414
+  MPE / Margin / Entropy   compute_mpe / compute_margin / compute_entropy   :387-396, 762-796 (``multi_peak_scores``)
 
 The stream is id-sorted and de-duplicated: the "prev"/"next" crops of item i are
 the "current" crops of items i-1 / i+1 when isPrev / isNext hold (SURVEY.md §9
@@ -48,3 +49,17 @@ def score_batch(heatmaps: torch.Tensor, bboxes: torch.Tensor, is_prev: torch.Ten
     if ae_flat is not None:
         out.wpu, out.wpu_status = vh.hybrid_ae_wpu(kpts.contiguous(), bboxes, ae_flat, ae_dims[0], ae_dims[1], wpu_only38)
     return out
+
+
+def multi_peak_scores(heatmaps: torch.Tensor, which: str) -> torch.Tensor:
+    """(N,J,H,W) -> (N,) float64: the reference's 'MPE' / 'Margin' / 'Entropy' uncertainty of every item
+    (ActiveLearning.py:762-796); per-plane terms from one launch, summed over the joints in float64 like the
+    reference's Python accumulation."""
+    if which == "Entropy":
+        return vh.plane_entropy(heatmaps).double().sum(dim=1)
+    _, _, _, mpe, margin = vh.peaks5(heatmaps, 5)
+    if which == "MPE":
+        return mpe.double().sum(dim=1)
+    if which == "Margin":
+        return margin.double().sum(dim=1)
+    raise ValueError("Uncertainty type is not supported")

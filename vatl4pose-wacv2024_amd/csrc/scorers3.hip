@@ -1,0 +1,150 @@
+// Third group of scorers: the heat-map criteria beside HP
+//   MPE / Margin  compute_mpe / compute_margin    ActiveLearning.py:762-788  (skimage.feature.peak_local_max(min_distance=5,
+//                                                  num_peaks=5) + scipy softmax / entropy)
+//   Entropy       compute_entropy                  ActiveLearning.py:790-796  (scipy.stats.entropy of the flattened map)
+// One block per (item, joint) plane; the plane lives in LDS.
+#include "common.h"
+
+namespace vatl {
+
+// Block-wide arg-max over (value desc, index asc); -inf entries never win.  Returns the flat index or -1.
+__device__ __forceinline__ int block_argmax(const float* v, int n, float* sval, int* sidx, float& best_val) {
+    float bv = -INFINITY; int bi = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float x = v[i];
+        if (x > bv) { bv = x; bi = i; }                        // strided scan keeps the lowest index among equals per thread
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sval[threadIdx.x >> 6] = bv; sidx[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    bv = sval[0]; bi = sidx[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (sval[w] > bv || (sval[w] == bv && sidx[w] < bi)) { bv = sval[w]; bi = sidx[w]; }
+    __syncthreads();
+    best_val = bv;
+    return bv == -INFINITY ? -1 : bi;
+}
+
+// peak_local_max(plane, min_distance = D, num_peaks = 5): (2D+1)^2 maximum filter with replicated edges, strictly
+// above the plane minimum, D-wide border excluded, greedy spacing (Chebyshev distance < D rejected) in descending
+// intensity / ascending index order, first five kept.  Also the per-plane MPE and Margin terms.
+__global__ __launch_bounds__(256) void peaks5_kernel(const float* __restrict__ hm, float* __restrict__ peak_val, int32_t* __restrict__ peak_idx,
+                                                     int32_t* __restrict__ npeaks, float* __restrict__ mpe, float* __restrict__ margin,
+                                                     int H, int W, int D) {
+    extern __shared__ float sm[];
+    float* img = sm;                 // plane, later the candidate values (-inf = not a candidate)
+    float* tmp = sm + H * W;         // row-filtered plane
+    __shared__ float sval[4]; __shared__ int sidx[4];
+    const int HW = H * W;
+    const float* src = hm + (long long)blockIdx.x * HW;
+    float mn = INFINITY;
+    for (int i = threadIdx.x; i < HW; i += 256) { const float v = src[i]; img[i] = v; mn = fminf(mn, v); }
+    mn = -wave_max(-mn);
+    if ((threadIdx.x & 63) == 0) sval[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    mn = fminf(fminf(sval[0], sval[1]), fminf(sval[2], sval[3]));
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const int y = i / W, x = i - y * W;
+        const int x0 = max(x - D, 0), x1 = min(x + D, W - 1);
+        float m = img[y * W + x0];
+        for (int xx = x0 + 1; xx <= x1; ++xx) m = fmaxf(m, img[y * W + xx]);
+        tmp[i] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const int y = i / W, x = i - y * W;
+        const int y0 = max(y - D, 0), y1 = min(y + D, H - 1);
+        float m = tmp[y0 * W + x];
+        for (int yy = y0 + 1; yy <= y1; ++yy) m = fmaxf(m, tmp[yy * W + x]);
+        const float v = img[i];
+        const bool inside = y >= D && y < H - D && x >= D && x < W - D;
+        img[i] = (inside && v == m && v > mn) ? v : -INFINITY;     // each thread rewrites only what it alone reads
+    }
+    __syncthreads();
+    float pv[5]; int pi[5]; int n = 0;
+    for (int k = 0; k < 5; ++k) {
+        float bv;
+        const int bi = block_argmax(img, HW, sval, sidx, bv);
+        if (bi < 0) break;
+        pv[n] = bv; pi[n] = bi; ++n;
+        const int by = bi / W, bx = bi - by * W;
+        // reject everything at Chebyshev distance < D (the accepted peak itself included)
+        const int side = 2 * D - 1;
+        for (int t = threadIdx.x; t < side * side; t += 256) {
+            const int yy = by - (D - 1) + t / side, xx = bx - (D - 1) + t % side;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) img[yy * W + xx] = -INFINITY;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const long long o = (long long)blockIdx.x;
+        npeaks[o] = n;
+        for (int k = 0; k < 5; ++k) { peak_val[o * 5 + k] = k < n ? pv[k] : 0.f; peak_idx[o * 5 + k] = k < n ? pi[k] : -1; }
+        float e = 0.f;
+        if (n > 0) {                                            // entropy(softmax(peaks)), float32 like scipy on a float32 array
+            float ex[5], s = 0.f;
+            for (int k = 0; k < n; ++k) { ex[k] = expf(pv[k] - pv[0]); s += ex[k]; }
+            float q[5], qs = 0.f;
+            for (int k = 0; k < n; ++k) { q[k] = ex[k] / s; qs += q[k]; }
+            for (int k = 0; k < n; ++k) { const float p = q[k] / qs; e += p > 0.f ? -p * logf(p) : 0.f; }
+        }
+        mpe[o] = e;
+        margin[o] = n > 1 ? fabsf(pv[0] - pv[1]) : 0.f;
+    }
+}
+
+// scipy.stats.entropy(plane.flatten()): p = h / sum(h); sum of entr(p) with entr(p) = -p ln p (p > 0), 0 (p == 0),
+// -inf (p < 0); a zero sum gives nan like numpy's 0/0 and x/0.
+__global__ __launch_bounds__(256) void plane_entropy_kernel(const float* __restrict__ hm, float* __restrict__ out, int HW) {
+    const float* src = hm + (long long)blockIdx.x * HW;
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < HW; i += 256) s += (double)src[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float total = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+    __syncthreads();
+    double e = 0.0;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float p = src[i] / total;
+        float t;
+        if (p > 0.f) t = -p * logf(p);
+        else if (p == 0.f) t = 0.f;
+        else if (p < 0.f) t = -INFINITY;
+        else t = p;                                             // nan
+        e += (double)t;
+    }
+    e = wave_sum(e);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+}  // namespace vatl
+
+using namespace vatl;
+
+extern "C" int vatl_peaks5(const float* hm, float* peak_val, int32_t* peak_idx, int32_t* npeaks, float* mpe, float* margin,
+                           int N, int J, int H, int W, int min_distance, void* stream) {
+    if (N <= 0) return 0;
+    if (!hm || !peak_val || !peak_idx || !npeaks || !mpe || !margin) return fail(VATL_EINVAL, "peaks5: null pointer");
+    if (min_distance < 1 || H <= 2 * min_distance || W <= 2 * min_distance) return fail(VATL_EINVAL, "peaks5: %dx%d plane too small for min_distance %d", H, W, min_distance);
+    const size_t smem = 2 * (size_t)H * W * sizeof(float);
+    if (smem > 60 * 1024) return fail(VATL_EINVAL, "peaks5: heat-map %dx%d too large for the LDS tile", H, W);
+    hipLaunchKernelGGL(peaks5_kernel, dim3((unsigned)(N * J)), dim3(256), smem, (hipStream_t)stream, hm, peak_val, peak_idx, npeaks, mpe, margin, H, W, min_distance);
+    return check_launch("peaks5");
+}
+
+extern "C" int vatl_plane_entropy(const float* hm, float* out, int N, int J, int H, int W, void* stream) {
+    if (N <= 0) return 0;
+    if (!hm || !out) return fail(VATL_EINVAL, "plane_entropy: null pointer");
+    hipLaunchKernelGGL(plane_entropy_kernel, dim3((unsigned)(N * J)), dim3(256), 0, (hipStream_t)stream, hm, out, H * W);
+    return check_launch("plane_entropy");
+}

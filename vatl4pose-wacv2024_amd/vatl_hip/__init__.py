@@ -51,6 +51,8 @@ SIGNATURES = {
     "vatl_ae_forward": (_i, [_p, _p, _i, _i, _p, _p, _i, _p]),
     "vatl_hybrid_feature_f64": (_i, [_p, _p, _p, _p, _i, _p]),
     "vatl_localpeak_mask": (_i, [_p, _p, _i, _i, _i, _f, _p]),
+    "vatl_peaks5": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vatl_plane_entropy": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vatl_conv2d_fwd_ex": (_i, [_p] * 6 + [_i] * 20 + [_p]),
     "vatl_pack_dgrad_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "vatl_conv2d_wgrad_workspace_floats": (_i64, [_i, _i, _i, _i]),
@@ -242,6 +244,27 @@ def fuse_upsample_add(base, ups, relu: bool):
     _check(lib().vatl_fuse_upsample_add(_ptr(base), _ptr(a[0][0]), a[0][1], _ptr(a[1][0]), a[1][1], _ptr(a[2][0]), a[2][1], _ptr(y),
                                         n, h, w, c, int(relu), _stream()), "vatl_fuse_upsample_add")
     return y
+
+
+def peaks5(hm: torch.Tensor, min_distance: int = 5):
+    """(N,J,H,W) -> peak values (N,J,5), flat indices (N,J,5) int32 (-1 = none), counts (N,J) int32, MPE terms (N,J),
+    Margin terms (N,J)   [skimage.feature.peak_local_max(min_distance, num_peaks=5) per plane]."""
+    n, j, h, w = hm.shape
+    val = torch.empty((n, j, 5), device=hm.device, dtype=torch.float32)
+    idx = torch.empty((n, j, 5), device=hm.device, dtype=torch.int32)
+    cnt = torch.empty((n, j), device=hm.device, dtype=torch.int32)
+    mpe = torch.empty((n, j), device=hm.device, dtype=torch.float32)
+    mar = torch.empty((n, j), device=hm.device, dtype=torch.float32)
+    _check(lib().vatl_peaks5(_ptr(hm), _ptr(val), _ptr(idx, torch.int32), _ptr(cnt, torch.int32), _ptr(mpe), _ptr(mar), n, j, h, w, min_distance,
+                             _stream()), "vatl_peaks5")
+    return val, idx, cnt, mpe, mar
+
+
+def plane_entropy(hm: torch.Tensor) -> torch.Tensor:
+    n, j, h, w = hm.shape
+    out = torch.empty((n, j), device=hm.device, dtype=torch.float32)
+    _check(lib().vatl_plane_entropy(_ptr(hm), _ptr(out), n, j, h, w, _stream()), "vatl_plane_entropy")
+    return out
 
 
 def upsample_nearest_bwd(dy, yact, shift: int):
