@@ -133,7 +133,7 @@ def test_mpe_margin_entropy_criteria():
     r = np.random.RandomState(4)
     hm[1, 3] = 0.25                                           # constant plane: no peak
     hm[2, 5] = 0.0; hm[2, 5, 20, 20] = 1.0; hm[2, 5, 20, 24] = 1.0; hm[2, 5, 20, 25] = 1.0   # plateau ties inside / at the spacing
-    hm[3, 0] = 0.0; hm[3, 0, 4, 10] = 2.0; hm[3, 0, 5, 10] = 1.0                             # border exclusion (row 4 is border, row 5 is not)
+    hm[3, 0] = 0.0; hm[3, 0, 4, 10] = 2.0; hm[3, 0, 5, 10] = 1.0; hm[3, 0, 40, 5] = 0.5         # a border maximum is dropped but still shadows (5,10); (40,5) is the first non-border column
     hm[4] = np.abs(hm[4]) + 1e-3                              # non-negative item: finite entropy
     hm[5, 2] = 0.0                                            # zero plane: entropy nan, no peaks
     d = to_dev(hm)
@@ -146,7 +146,7 @@ def test_mpe_margin_entropy_criteria():
             assert np.array_equal(idx[n, j, :len(loc)], loc[:, 0] * hm.shape[3] + loc[:, 1]), (n, j)
             assert np.array_equal(val[n, j, :len(loc)], hm[n, j][loc[:, 0], loc[:, 1]])
             assert (idx[n, j, len(loc):] == -1).all()
-    assert cnt[1, 3] == 0 and cnt[5, 2] == 0 and cnt[2, 5] == 2 and list(idx[3, 0, :1]) == [5 * hm.shape[3] + 10]
+    assert cnt[1, 3] == 0 and cnt[5, 2] == 0 and cnt[2, 5] == 2 and list(idx[3, 0]) == [40 * hm.shape[3] + 5, -1, -1, -1, -1]
     want_mpe = np.array([scorers.mpe_item(h) for h in hm]); want_mar = np.array([scorers.margin_item(h) for h in hm])
     got_mpe, got_mar = multi_peak_scores(d, "MPE").cpu().numpy(), multi_peak_scores(d, "Margin").cpu().numpy()
     record("mpe_margin", mpe_rel=rel_err(got_mpe, want_mpe), margin_rel=rel_err(got_mar, want_mar))
