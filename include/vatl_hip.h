@@ -294,6 +294,23 @@ int vatl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doub
 int vatl_sgd_step(float* p, const float* g, float* buf, int64_t n, double lr, double momentum, double weight_decay, int step,
                   void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * Query selection on the (N, D) fp32 embeddings; float64 accumulation like the
+ * reference's float64 fvecs_matrix.
+ * ------------------------------------------------------------------------ */
+/* out[i] = sum_j cosine_distance(x_i, x_j): the row sums of sklearn's KNeighborsTransformer(mode='distance',
+ * metric='cosine', n_neighbors=n-1) matrix used as "influence" / "diversity" score (ActiveLearning.py:467-476,
+ * 583-592).  workspace: n + D doubles. */
+int vatl_cosine_rowsum(const float* emb, int64_t n, int D, double* out, double* workspace, void* stream);
+/* k-center greedy (ActiveLearning.py:798-850).  update: min_dist[i] = min(min_dist[i], ||x_i - x_c||) over the
+ * centres in the DEVICE index array (first != 0: min_dist is write-only);  pick: selected_dev[step] = first arg-max of
+ * a*min_dist + b*unc (either may be NULL), then unc[selected] = 0 — so pick -> update(selected_dev + step, 1) chains on
+ * the stream without host round trips. */
+int vatl_kcenter_update(const float* emb, int64_t n, int D, const int32_t* centers_dev, int n_centers, double* min_dist, int first,
+                        void* stream);
+int vatl_kcenter_pick(const double* min_dist_or_null, double* unc_or_null, double a, double b, int32_t* selected_dev, int step,
+                      int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,3 +67,34 @@ def test_unsupported_strategies_raise():
     for bad in (dict(uncertainty="Nope"), dict(filter="Coreset"), dict(representativeness="Influence")):
         with pytest.raises(ValueError):
             ActiveLearning(_cfg(), types.SimpleNamespace(**{**base, **bad}))
+
+
+def test_query_selection_kernels_match_sklearn_restatement():
+    """influence / diversity (cosine-distance row sums) and k-center-greedy core-set on the
+    device embeddings against the reference's own sklearn calls (oracle/query.py)."""
+    import numpy as np
+    import torch
+    from active_learning import query as Q
+    from oracle import query as OQ
+    r = np.random.RandomState(7)
+    n, d = 300, 2048
+    base = np.abs(r.standard_normal((12, d))).astype(np.float32)                       # clustered, non-negative like ReLU + GAP features
+    emb = (base[r.randint(0, 12, n)] + 0.3 * np.abs(r.standard_normal((n, d)))).astype(np.float32)
+    dev = torch.device("cuda:0")
+    e = torch.from_numpy(emb).to(dev)
+    want = OQ.cosine_distance_sums(emb)
+    got = Q.cosine_distance_sums(e)
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(Q.influence_scores(e), OQ.influence_scores(emb), rtol=1e-7, atol=1e-9)
+    cand = list(range(100, 300))
+    div = Q.diversity_queries(e[100:], cand, 15)
+    order = np.argsort(OQ.cosine_distance_sums(emb[100:]), kind="stable")[:15]
+    assert div == [cand[i] for i in order]
+    unc = np.zeros(n); unlabeled = np.arange(40, n); unc[unlabeled] = r.random_sample(len(unlabeled))
+    labeled = np.arange(40)
+    for mode, moks, lam in (("moks", 0.6, 1.0), ("fixed", 0.0, 0.5), ("kcenter", 0.0, 1.0)):
+        want_q = OQ.coreset_selection(emb, labeled, unc.copy(), 25, mode, moks, lam)
+        got_q = Q.coreset_selection(e, labeled, unc.copy(), 25, mode, moks, lam)
+        assert got_q == want_q, (mode, got_q, want_q)
+    # empty labeled pool: the first pick is arg-max of the uncertainty
+    assert Q.coreset_selection(e, [], unc.copy(), 5, "moks", 0.5, 1.0) == OQ.coreset_selection(emb, [], unc.copy(), 5, "moks", 0.5, 1.0)

@@ -78,6 +78,9 @@ SIGNATURES = {
     "vatl_masked_mse_workspace_floats": (_i64, [_i64]),
     "vatl_masked_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vatl_adamw_step": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _p]),
+    "vatl_cosine_rowsum": (_i, [_p, _i64, _i, _p, _p, _p]),
+    "vatl_kcenter_update": (_i, [_p, _i64, _i, _p, _i, _p, _i, _p]),
+    "vatl_kcenter_pick": (_i, [_p, _p, _d, _d, _p, _i, _i64, _p]),
     "vatl_adam_step": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _p]),
     "vatl_sgd_step": (_i, [_p, _p, _p, _i64, _d, _d, _d, _i, _p]),
 }
@@ -265,6 +268,25 @@ def plane_entropy(hm: torch.Tensor) -> torch.Tensor:
     out = torch.empty((n, j), device=hm.device, dtype=torch.float32)
     _check(lib().vatl_plane_entropy(_ptr(hm), _ptr(out), n, j, h, w, _stream()), "vatl_plane_entropy")
     return out
+
+
+def cosine_rowsum(emb: torch.Tensor) -> torch.Tensor:
+    """(n, D) fp32 -> (n,) float64 sums of cosine distances to every row (incl. itself: 0)."""
+    n, d = emb.shape
+    out = torch.empty(n, device=emb.device, dtype=torch.float64)
+    ws = torch.empty(n + d, device=emb.device, dtype=torch.float64)
+    _check(lib().vatl_cosine_rowsum(_ptr(emb), n, d, _ptr(out, torch.float64), _ptr(ws, torch.float64), _stream()), "vatl_cosine_rowsum")
+    return out
+
+
+def kcenter_update(emb, centers: torch.Tensor, min_dist: torch.Tensor, first: bool):
+    _check(lib().vatl_kcenter_update(_ptr(emb), emb.shape[0], emb.shape[1], _ptr(centers, torch.int32), centers.numel(), _ptr(min_dist, torch.float64),
+                                     int(first), _stream()), "vatl_kcenter_update")
+
+
+def kcenter_pick(min_dist, unc, a: float, b: float, selected: torch.Tensor, step: int, n: int):
+    _check(lib().vatl_kcenter_pick(_ptr(min_dist, torch.float64), _ptr(unc, torch.float64), a, b, _ptr(selected, torch.int32), step, n, _stream()),
+           "vatl_kcenter_pick")
 
 
 def upsample_nearest_bwd(dy, yact, shift: int):
