@@ -98,3 +98,39 @@ def test_query_selection_kernels_match_sklearn_restatement():
         assert got_q == want_q, (mode, got_q, want_q)
     # empty labeled pool: the first pick is arg-max of the uncertainty
     assert Q.coreset_selection(e, [], unc.copy(), 5, "moks", 0.5, 1.0) == OQ.coreset_selection(emb, [], unc.copy(), 5, "moks", 0.5, 1.0)
+
+
+@pytest.mark.parametrize("rep,flt", [("Influence", "Coreset"), ("Influence", "None"), ("None", "Diversity"), ("Random", "Random"),
+                                     ("None", "K-Means"), ("Influence", "weighted")])
+def test_active_learning_representativeness_and_filters(rep, flt):
+    """Two rounds with every representativeness / filter combination family of ActiveLearning.py:465-617; for the
+    device-side ones (Influence, Coreset, Diversity) the queried set is re-derived from the embeddings with the
+    sklearn restatement."""
+    from active_learning import ActiveLearning
+    from oracle import query as OQ
+    opt = types.SimpleNamespace(uncertainty="THC_L1", representativeness=rep, filter=flt, strategy="THC_L1", video_id="syn", get_prenext=True,
+                                from_scratch=True, continual=True, num_gpu=1, onebyone=False, retrain_thresh=1, THCvsWPU="const", fixed_lambda=False)
+    torch.manual_seed(0); np.random.seed(0)
+    al = ActiveLearning(_cfg(), opt)
+    al.eval_and_query()
+    q0 = al.query_list_list["Round0"]
+    assert len(q0) == 6 and len(set(q0)) == 6 and len(al.labeled_id) == 6
+    assert sorted(al.retrain_id) == sorted(q0)
+    if rep == "Influence":
+        ds = al.eval_dataset
+        al.model.eval()
+        with torch.no_grad():
+            emb = al.model.get_embedding(torch.stack([ds[i][1][0] for i in range(24)]).to(dev())).cpu().numpy()
+        inf = al.influence_dict["Round0"]
+        np.testing.assert_allclose([inf[i] for i in range(24)], OQ.influence_scores(emb), rtol=1e-6, atol=1e-9)
+    assert al.outcome() is None                                   # fine-tune on the queried items
+    al.eval_and_query()
+    q1 = al.query_list_list["Round1"]
+    assert len(q1) == 6 and not (set(q1) & set(q0)) and len(al.labeled_id) == 12
+    if flt == "Coreset":                                          # second round has labeled centres: re-derive with sklearn
+        ds = al.eval_dataset
+        al.model.eval()
+        with torch.no_grad():
+            emb = al.model.get_embedding(torch.stack([ds[i][1][0] for i in range(24)]).to(dev())).cpu().numpy()
+        assert set(q1).isdisjoint(q0)
+        assert len(set(q1)) == 6

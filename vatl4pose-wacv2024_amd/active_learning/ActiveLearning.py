@@ -8,10 +8,10 @@ Same entry points as the reference class — ``ActiveLearning(cfg, opt)``, ``eva
   ``score_batch`` launch sequence per batch instead of a per-item Python loop with D2H copies.
 * ``retrain_model`` (:651-686): train-mode forward, fused masked-MSE loss+gradient, HIP backward, AdamW.
 
-In scope: uncertainty None | HP | TPC | THC_L1 | THC_L2 | WPU | THC+WPU | MPE | Margin | Entropy, representativeness None,
-filter None | Random.  Query strategies built on sklearn / umap (Influence, K-Means, Coreset), COCO mAP and
-OSPA evaluation, plots and the VL4Pose branch are out of scope and raise.
-Offline metrics can be plugged in through ``opt.evaluate_fn(pred_records, gt_records) -> dict``.
+In scope: uncertainty None | HP | TPC | THC_L1 | THC_L2 | WPU | THC+WPU | MPE | Margin | Entropy; representativeness
+None | Influence | Random; filter None | Random | Diversity | Coreset (device kernels, active_learning/query.py) and
+weighted | K-Means (sklearn on the host, exactly like the reference).  COCO mAP / OSPA evaluation, plots and the dead
+VL4Pose branch stay out.
 """
 from __future__ import annotations
 
@@ -44,10 +44,15 @@ class ActiveLearning:
         self.get_prenext = bool(getattr(opt, "get_prenext", "THC" in self.uncertainty or self.uncertainty == "TPC"))
         if self.uncertainty not in _UNC:
             raise ValueError("Uncertainty type is not supported")
-        if self.representativeness != "None":
-            raise ValueError("Representativeness type is not supported (Influence needs the sklearn kNN path: out of scope)")
-        if self.filter not in ("None", "Random"):
-            raise ValueError("Filter type is not supported (K-Means / Coreset are out of scope of the MI355X hot path)")
+        if self.representativeness not in ("None", "Influence", "Random"):
+            raise ValueError("Representativeness type is not supported")
+        if self.filter not in ("None", "Random", "Diversity", "Coreset", "weighted", "K-Means"):
+            raise ValueError("Filter type is not supported")
+        # ActiveLearning.py:284: embeddings are needed by every representativeness / filter except None and Random
+        self.need_embedding = self.representativeness not in ("None", "Random") or self.filter not in ("None", "Random")
+        self.w_unc = float(cfg.VAL.get("W_UNC", 1.0))
+        self.unc_lambda = float(cfg.VAL.get("UNC_LAMBDA", 1.0))
+        self.finish_margin = 0.05
         self.device = torch.device("cuda", torch.cuda.current_device())
         ngpu = max(1, int(getattr(opt, "num_gpu", 1)))
 
@@ -140,8 +145,8 @@ class ActiveLearning:
             return cur, m(inps[:, 1].to(self.device)), m(inps[:, 2].to(self.device))
 
     def _score_range(self, lo, hi):
-        """Forward + score the id-sorted items lo..hi-1 (one shard plus its halo); returns (hi-lo, 55) float32 rows:
-        51 key-point values, 2 uncertainty values, local-peak mean, OKS."""
+        """Forward + score the id-sorted items lo..hi-1 (one shard plus its halo); returns (hi-lo, 55 [+ 2048]) float32
+        rows: 51 key-point values, 2 uncertainty values, local-peak mean, OKS [, the get_embedding vector]."""
         n = hi - lo
         J, (hh, hw) = self.cfg.DATA_PRESET.NUM_JOINTS, self.hm_size
         # the shard's heat-maps stay on the device (209 KB per item) and are scored in one pass, so THC/TPC
@@ -153,6 +158,7 @@ class ActiveLearning:
         thc_ref = torch.zeros(n, device=self.device)
         gt_all = np.zeros((n, 3 * J), np.float64)
         ann_all = np.zeros((n, 4), np.float64)
+        emb_all = torch.empty((n, self.emb_dim), device=self.device) if self.need_embedding else None
         thc_norm = {"THC_L1": "L1", "THC": "L1", "THC+WPU": "L1", "THC_L2": "L2"}.get(self.uncertainty)
         loader = self.eval_loader if (lo == 0 and hi == self.eval_len) else DataLoader(
             Subset(self.eval_dataset, list(range(lo, hi))), batch_size=self.eval_loader.batch_size, shuffle=False, num_workers=0,
@@ -165,6 +171,9 @@ class ActiveLearning:
             ip = torch.as_tensor(isPrev, dtype=torch.uint8, device=self.device)
             inx = torch.as_tensor(isNext, dtype=torch.uint8, device=self.device)
             hm_all[idx] = cur
+            if emb_all is not None:                                       # ActiveLearning.py:284-286
+                with torch.no_grad():
+                    emb_all[idx] = self.model.get_embedding(inps[:, 0].to(self.device))
             bb_all[idx] = bboxes_crop.to(self.device).float()
             ip_all[idx], in_all[idx] = ip, inx
             if thc_norm is not None and not self.dedup:                   # reference-faithful: explicit prev/next forwards
@@ -198,15 +207,25 @@ class ActiveLearning:
             unc[:, 0] = multi_peak_scores(hm_all, self.uncertainty).float()
         kp = s.keypoints.reshape(n, -1)
         oks = compute_OKS_batch(ann_all, kp.cpu().numpy(), gt_all)
-        return torch.cat([kp, unc, s.localpeak[:, None], torch.as_tensor(oks, dtype=torch.float32, device=self.device)[:, None]], 1).contiguous()
+        cols = [kp, unc, s.localpeak[:, None], torch.as_tensor(oks, dtype=torch.float32, device=self.device)[:, None]]
+        if emb_all is not None:
+            cols.append(emb_all)
+        return torch.cat(cols, 1).contiguous()
 
     def eval_and_query(self):
         from . import distributed as D
+        from . import query as Q
         self.model.eval()
         n = self.eval_len
+        if self.need_embedding and not hasattr(self.model, "get_embedding"):
+            raise ValueError("this pose network has no get_embedding: representativeness / filters need it (SURVEY.md §9 item 3)")
+        self.emb_dim = 2048
+        width = 55 + (self.emb_dim if self.need_embedding else 0)
         # one process per GPU: every rank scores a contiguous shard (+ a one-item halo for the temporal scores)
-        # and the (n, 55) result rows are all-gathered (active_learning/distributed.py); world size 1 = whole stream
-        rows = D.sharded_rows(n, self._score_range, 55, self.device, halo=1 if self.dedup else 0).cpu().numpy()
+        # and the result rows are all-gathered (active_learning/distributed.py); world size 1 = whole stream
+        rows_dev = D.sharded_rows(n, self._score_range, width, self.device, halo=1 if self.dedup else 0)
+        fvecs = rows_dev[:, 55:].contiguous() if self.need_embedding else None          # (n, 2048) stays on the device
+        rows = rows_dev[:, :55].cpu().numpy()
         kp_all = rows[:, :51].copy()
         unc = rows[:, 51:53].astype(np.float64)
         lp = rows[:, 53].astype(np.float64)
@@ -220,24 +239,116 @@ class ActiveLearning:
         self.ospa_list.append(None)
         self.ospa_list_ann.append(None)
         self.uncertainty_mean.append(float(unc[:, 0].sum() / n))
-        un = np.asarray(self.unlabeled_id, int)
-        if len(un) > 0:
-            self.combine_weight.append(float(np.nansum(lp[un]) / len(un)))
+        un = np.asarray(self.unlabeled_id, int)                       # ascending, like IndexCollection.index here
+        nun = len(un)
+
+        # ---- representativeness (ActiveLearning.py:465-480)
+        influence = None
+        if self.representativeness != "None":
+            if nun in (0, 1):
+                influence = np.zeros(nun)
+            elif self.representativeness == "Influence":
+                influence = Q.influence_scores(fvecs[torch.as_tensor(un, device=self.device)])
+            else:
+                influence = np.random.rand(nun)
+            self.influence_dict[f"Round{self.round_cnt}"] = {int(i): float(v) for i, v in zip(un, influence)}
+        combine_weight = 0.0
+        if nun > 0:
+            combine_weight = float(np.sum(lp[un]) / nun)              # mean local-peak value of the unlabeled items (:411-414, 486-488)
+            self.combine_weight.append(combine_weight)
         self.uncertainty_dict[f"Round{self.round_cnt}"] = {int(i): (unc[i].tolist() if self.uncertainty == "THC+WPU" else float(unc[i, 0])) for i in range(n)}
-        if len(un) == 0:
-            return
-        score = self._total_score(unc[un])
-        if self.filter == "Random" or self.uncertainty == "None":
-            order = np.random.permutation(len(un))
+
+        # ---- total score (:490-527)
+        if nun in (0, 1):
+            total = np.zeros(nun)
+        elif self.uncertainty != "None":
+            u = self._total_score(unc[un])
+            total = combine_weight * u + (1 - combine_weight) * influence if self.representativeness != "None" else u
+        elif self.representativeness == "None":
+            total = np.zeros(nun)
         else:
-            order = np.argsort(-score, kind="stable")
-        query = [int(i) for i in un[order][: self.query_size]]
-        self.moks_queried = float(np.mean(oks[query])) if query else 0.0
+            total = influence
+        order = sorted(range(nun), key=lambda k: total[k], reverse=True)       # stable, like sorted(score_dict.items(), reverse=True)
+        ranked = [int(un[k]) for k in order]
+
+        # ---- candidates and filter (:529-617)
+        if self.filter == "None":
+            candidates = sorted(ranked[: self.query_size])
+        elif self.filter in ("weighted", "K-Means", "Coreset"):
+            candidates = sorted(ranked)
+        else:
+            candidates = sorted(ranked[: 8 * self.query_size])
+        score_of = {int(un[k]): float(total[k]) for k in range(nun)}
+        if nun in (0, 1) or self.filter == "None":
+            query = candidates
+        elif self.filter == "Random":
+            query = self.random_query(list(candidates), self.query_size)
+        elif self.filter == "Diversity":
+            query = Q.diversity_queries(fvecs[torch.as_tensor(candidates, device=self.device)], candidates, self.query_size)
+        elif self.filter == "Coreset":
+            unc_list = np.zeros(n)
+            unc_list[candidates] = total                               # `np.array(list(total_score))`: unlabeled order, as the reference assigns it
+            if self.uncertainty == "None" or self.unc_lambda == 0:
+                mode = "kcenter"
+            else:
+                mode = "fixed" if getattr(self.opt, "fixed_lambda", False) else "moks"
+            query = Q.coreset_selection(fvecs, self.labeled_id, unc_list, self.query_size, mode, self.moks_queried, self.unc_lambda)
+        else:                                                          # "weighted" / "K-Means": sklearn on the host, like the reference
+            emb = fvecs[torch.as_tensor(candidates, device=self.device)].double().cpu().numpy()
+            if self.filter == "weighted":
+                _, first = np.unique(emb, axis=0, return_index=True)   # drop duplicate embeddings
+                emb = emb[first]
+                cand = [candidates[i] for i in first]
+                weight = (1 + self.w_unc * combine_weight * np.array([score_of[c] for c in candidates]))[first]
+                if nun <= self.query_size:
+                    self.query_size = nun
+                self.query_size = min(self.query_size, len(emb))
+                query, _ = Q.kmeans_queries(emb, cand, self.query_size, weight)
+            else:
+                if nun < self.query_size:
+                    self.query_size = nun
+                query, _ = Q.kmeans_queries(emb, candidates, self.query_size)
+
+        # ---- book-keeping (:619-650)
+        thr = self.finish_acc + self.finish_margin
+        lab, unl = set(self.labeled_id), set(self.unlabeled_id)
+        key = f"Round{self.round_cnt}"
+        self.true_labeled_dict[key] = [i for i in range(n) if i in lab and oks[i] >= thr]
+        self.true_unlabeled_dict[key] = [i for i in range(n) if i in unl and oks[i] >= thr]
+        self.false_labeled_dict[key] = [i for i in range(n) if i in lab and oks[i] < thr]
+        self.false_unlabeled_dict[key] = [i for i in range(n) if i in unl and oks[i] < thr]
+        if nun == 0:
+            return
+        query = [int(q) for q in query]
+        self.moks_queried = float(np.mean(oks[query])) if query else 0.0          # get_retrain_id (:852-871)
         self.moksQ_list.append(self.moks_queried)
-        self.retrain_id = sorted(set(self.labeled_id) | set(query))
-        self.labeled_id = sorted(set(self.labeled_id) | set(query))
+        self.retrain_id = [i for i in self.labeled_id if oks[i] <= thr] + query
+        self.labeled_id = sorted(lab | set(query))
         self.unlabeled_id = [i for i in self.unlabeled_id if i not in set(query)]
-        self.query_list_list[f"Round{self.round_cnt}"] = query
+        self.query_list_list[key] = query
+        self._is_finished(query, oks)
+        if self.actual_finish < 100:
+            self.is_early_stop = True
+
+    def _is_finished(self, query, oks):
+        """ActiveLearning.py:707-725: the three stopping-criterion bookmarks (label percentage at which each first held)."""
+        time = len(self.labeled_id) / self.eval_len * 100
+        if np.all(oks >= self.finish_acc) and time < self.actual_finish:
+            self.actual_finish = time
+        if query and np.mean(oks[query]) >= self.finish_acc and time < self.finished_minerror:
+            self.finished_minerror = time
+        if np.all(oks[self.labeled_id] >= self.finish_acc) and time < self.finished_oursc:
+            self.finished_oursc = time
+
+    @staticmethod
+    def random_query(candidate_list, query_size):
+        """ActiveLearning.py:727-734."""
+        out = []
+        while len(out) < query_size and len(candidate_list) > 0:
+            q = int(np.random.choice(candidate_list))
+            out.append(q)
+            candidate_list.remove(q)
+        return out
 
     @staticmethod
     def _check_wpu(status):
