@@ -64,7 +64,7 @@ def test_active_learning_rounds(unc):
 def test_unsupported_strategies_raise():
     from active_learning import ActiveLearning
     base = dict(uncertainty="THC_L1", representativeness="None", filter="None", from_scratch=True)
-    for bad in (dict(uncertainty="Nope"), dict(filter="Coreset"), dict(representativeness="Influence")):
+    for bad in (dict(uncertainty="Nope"), dict(filter="Spectral"), dict(representativeness="Density")):
         with pytest.raises(ValueError):
             ActiveLearning(_cfg(), types.SimpleNamespace(**{**base, **bad}))
 
