@@ -282,3 +282,23 @@ def test_chunked_batches_are_bit_identical(vh):
     finally:
         hip_engine.MAX_CHUNK = old
     assert torch.equal(parts, whole) and torch.equal(buf, whole) and torch.equal(emb_parts, emb)
+
+
+def test_forward_with_embedding_is_bit_identical(vh):
+    """One trunk pass serving heat-maps and get_embedding (the reference runs the trunk twice)."""
+    from alphapose.models import hip_engine
+    m = _build_simplepose()
+    x = to_dev(synth.crops(3))
+    with torch.no_grad():
+        hm, emb = m(x), m.get_embedding(x)
+    out, e = torch.empty_like(hm), torch.empty_like(emb)
+    hip_engine.forward_with_embedding(m, x, out, e)
+    assert torch.equal(out, hm) and torch.equal(e, emb)
+    mf = _build({"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50})
+    with torch.no_grad():
+        hm, emb = mf(x), mf.get_embedding(x)
+    out, e = torch.empty_like(hm), torch.empty_like(emb)
+    hip_engine.forward_with_embedding(mf, x, out, e)
+    assert torch.equal(out, hm) and torch.equal(e, emb)
+    with pytest.raises(vh.VatlError):
+        hip_engine.forward_with_embedding(_build(HRNET_CFG), x, out, e)

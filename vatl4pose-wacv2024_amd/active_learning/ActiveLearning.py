@@ -135,11 +135,16 @@ class ActiveLearning:
         return ae.to(self.device).eval()
 
     # ------------------------------------------------------------------ hot loop 1
-    def _heatmaps(self, inps):
+    def _heatmaps(self, inps, emb_out=None):
         m = self.model
         x = inps[:, 0].to(self.device, non_blocking=True)
         with torch.no_grad():
-            cur = m(x)
+            if emb_out is not None:                   # heat-maps and get_embedding from one trunk pass
+                from alphapose.models import hip_engine
+                cur = torch.empty((x.shape[0], self.cfg.DATA_PRESET.NUM_JOINTS, *self.hm_size), device=self.device)
+                hip_engine.forward_with_embedding(m, x, cur, emb_out)
+            else:
+                cur = m(x)
             if not self.get_prenext or self.dedup:
                 return cur, None, None
             return cur, m(inps[:, 1].to(self.device)), m(inps[:, 2].to(self.device))
@@ -164,16 +169,16 @@ class ActiveLearning:
             Subset(self.eval_dataset, list(range(lo, hi))), batch_size=self.eval_loader.batch_size, shuffle=False, num_workers=0,
             collate_fn=self.collate_fn)
         for (idxs, inps, labels, label_masks, GTkpts, img_ids, ann_ids, bboxes_crop, bboxes_ann, isPrev, isNext) in loader:
-            cur, prev, nxt = self._heatmaps(inps)
+            emb_b = torch.empty((len(idxs), self.emb_dim), device=self.device) if emb_all is not None else None
+            cur, prev, nxt = self._heatmaps(inps, emb_b)
             assert cur.dim() == 4, "the dimension of output must be 4"
             loc = np.asarray(idxs) - lo
             idx = torch.as_tensor(loc, device=self.device)
             ip = torch.as_tensor(isPrev, dtype=torch.uint8, device=self.device)
             inx = torch.as_tensor(isNext, dtype=torch.uint8, device=self.device)
             hm_all[idx] = cur
-            if emb_all is not None:                                       # ActiveLearning.py:284-286
-                with torch.no_grad():
-                    emb_all[idx] = self.model.get_embedding(inps[:, 0].to(self.device))
+            if emb_all is not None:                                       # ActiveLearning.py:284-286, without the second trunk pass
+                emb_all[idx] = emb_b
             bb_all[idx] = bboxes_crop.to(self.device).float()
             ip_all[idx], in_all[idx] = ip, inx
             if thc_norm is not None and not self.dedup:                   # reference-faithful: explicit prev/next forwards

@@ -129,8 +129,10 @@ class _SimplePosePlan:
     def features(self, x_nchw):
         return self.trunk(x_nchw)
 
-    def __call__(self, x_nchw, out=None):
+    def __call__(self, x_nchw, out=None, emb_out=None):
         x = self.trunk(x_nchw)
+        if emb_out is not None:
+            emb_out.copy_(vh.gap_fwd(x))                # get_embedding of the same trunk pass (simplepose.py:88-91)
         for dc in self.deconvs:
             x = dc(x)
         return self.head(x, relu=False, out_nchw=True, out=out)
@@ -184,8 +186,11 @@ class _FastPosePlan:
     def features(self, x_nchw):
         return self.trunk(x_nchw)
 
-    def __call__(self, x_nchw, out=None):
-        x = vh.pixelshuffle2_fwd(self.trunk(x_nchw))
+    def __call__(self, x_nchw, out=None, emb_out=None):
+        t = self.trunk(x_nchw)
+        if emb_out is not None:
+            emb_out.copy_(vh.gap_fwd(t))                # fastpose.py:70-73
+        x = vh.pixelshuffle2_fwd(t)
         x = vh.pixelshuffle2_fwd(self.duc1(x, relu=True))
         x = vh.pixelshuffle2_fwd(self.duc2(x, relu=True))
         return self.head(x, relu=False, out_nchw=True, out=out)
@@ -356,6 +361,20 @@ def forward_into(m: nn.Module, x: torch.Tensor, out: torch.Tensor) -> torch.Tens
     for i in range(0, x.shape[0], MAX_CHUNK):
         plan(x[i:i + MAX_CHUNK], out=out[i:i + MAX_CHUNK])
     return out
+
+
+def forward_with_embedding(m: nn.Module, x: torch.Tensor, out: torch.Tensor, emb: torch.Tensor) -> None:
+    """Heat-maps into ``out`` and the get_embedding vectors (N, 2048) into ``emb`` from ONE trunk pass — the reference
+    runs the trunk twice for this (ActiveLearning.py:277, 284).  Bit-identical to
+    forward_into() + embedding(): same launches, the pooled trunk output is simply kept."""
+    if m.training:
+        raise vh.VatlError("forward_with_embedding is an inference entry point: call model.eval() first")
+    x = _prepare_input(m, x)
+    plan = _plan_for(m, x.device)
+    if not hasattr(plan, "features"):
+        raise vh.VatlError(f"{type(m).__name__} has no get_embedding")
+    for i in range(0, x.shape[0], MAX_CHUNK):
+        plan(x[i:i + MAX_CHUNK], out=out[i:i + MAX_CHUNK], emb_out=emb[i:i + MAX_CHUNK])
 
 
 def embedding(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
