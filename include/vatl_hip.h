@@ -294,6 +294,11 @@ int vatl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, doub
 int vatl_sgd_step(float* p, const float* g, float* buf, int64_t n, double lr, double momentum, double weight_decay, int step,
                   void* stream);
 
+/* compute_OKS (al_metric.py:42-69; called per item at ActiveLearning.py:309): object key-point similarity of the decoded
+ * key-points pred (N,17,3) fp32 against ground truth gt (N,51) float64 with the annotation box (N,4) xywh float64 as the
+ * object scale; invisible-everywhere items fall back to the distance from the doubled box.  out (N) float64. */
+int vatl_oks(const float* pred_kpts, const double* gt_kpts, const double* bbox_xywh, double* out, int N, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * Query selection on the (N, D) fp32 embeddings; float64 accumulation like the
  * reference's float64 fvecs_matrix.

@@ -158,3 +158,21 @@ def test_mpe_margin_entropy_criteria():
     assert fin[4] and not fin[0] and np.isnan(want_ent[5])
     assert np.array_equal(np.isnan(got_ent), np.isnan(want_ent)) and np.array_equal(np.isneginf(got_ent), np.isneginf(want_ent))
     np.testing.assert_allclose(got_ent[fin], want_ent[fin], rtol=1e-5)
+
+
+def test_oks_kernel_matches_al_metric():
+    """§8f rank 1: compute_OKS on the device vs the numpy restatement (visible / partly visible / nothing visible)."""
+    import vatl_hip as vh
+    from oracle import scorers
+    from tests.gpu_util import to_dev
+    r = np.random.RandomState(3)
+    n = 9
+    pred = (r.uniform(0, 300, (n, 17, 3))).astype(np.float32)
+    gt = pred.reshape(n, 51).astype(np.float64) + r.standard_normal((n, 51)) * 4
+    gt[:, 2::3] = (r.random_sample((n, 17)) > 0.3).astype(np.float64)
+    gt[0, 2::3] = 0.0                                        # nothing visible: distance from the doubled box
+    gt[1, 2::3] = 1.0
+    box = np.stack([r.uniform(0, 100, n), r.uniform(0, 100, n), r.uniform(40, 200, n), r.uniform(60, 260, n)], 1)
+    got = vh.oks(to_dev(pred), torch.from_numpy(gt).cuda(), torch.from_numpy(box).cuda()).cpu().numpy()
+    want = np.array([scorers.oks(box[i], pred[i].reshape(-1), gt[i]) for i in range(n)])
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)

@@ -211,8 +211,9 @@ class ActiveLearning:
         elif self.uncertainty in ("MPE", "Margin", "Entropy"):
             unc[:, 0] = multi_peak_scores(hm_all, self.uncertainty).float()
         kp = s.keypoints.reshape(n, -1)
-        oks = compute_OKS_batch(ann_all, kp.cpu().numpy(), gt_all)
-        cols = [kp, unc, s.localpeak[:, None], torch.as_tensor(oks, dtype=torch.float32, device=self.device)[:, None]]
+        # compute_OKS on the device (al_metric.py:42-69): no D2H of the key-points inside the evaluation loop
+        oks = vh.oks(s.keypoints.contiguous(), torch.as_tensor(gt_all, device=self.device), torch.as_tensor(ann_all, device=self.device))
+        cols = [kp, unc, s.localpeak[:, None], oks.float()[:, None]]
         if emb_all is not None:
             cols.append(emb_all)
         return torch.cat(cols, 1).contiguous()

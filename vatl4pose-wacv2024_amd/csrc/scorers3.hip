@@ -127,9 +127,46 @@ __global__ __launch_bounds__(256) void plane_entropy_kernel(const float* __restr
     if (threadIdx.x == 0) out[blockIdx.x] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+// compute_OKS (al_metric.py:42-69): one thread per item, float64 like the numpy original.
+__global__ void oks_kernel(const float* __restrict__ pred, const double* __restrict__ gt, const double* __restrict__ bbox_xywh,
+                           double* __restrict__ out, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double sig[17] = {.026, .025, .025, .035, .035, .079, .079, .072, .072, .062, .062, .107, .107, .087, .087, .089, .089};
+    const double bx = bbox_xywh[4 * i], by = bbox_xywh[4 * i + 1], bw = bbox_xywh[4 * i + 2], bh = bbox_xywh[4 * i + 3];
+    const double area = bw * bh + 2.220446049250313e-16;                  // np.spacing(1)
+    const float* d = pred + (long long)i * 51;
+    const double* g = gt + (long long)i * 51;
+    bool any_vis = false;
+    for (int k = 0; k < 17; ++k) any_vis |= g[3 * k + 2] > 0.0;
+    double acc = 0.0; int cnt = 0;
+    for (int k = 0; k < 17; ++k) {
+        const double xd = (double)d[3 * k], yd = (double)d[3 * k + 1];
+        double dx, dy;
+        if (any_vis) {
+            if (!(g[3 * k + 2] > 0.0)) continue;
+            dx = xd - g[3 * k]; dy = yd - g[3 * k + 1];
+        } else {
+            dx = fmax(0.0, (bx - bw) - xd) + fmax(0.0, xd - (bx + 2 * bw));
+            dy = fmax(0.0, (by - bh) - yd) + fmax(0.0, yd - (by + 2 * bh));
+        }
+        const double var = (sig[k] * 2) * (sig[k] * 2);
+        acc += exp(-((dx * dx + dy * dy) / var / area * 0.5));
+        ++cnt;
+    }
+    out[i] = acc / (double)cnt;
+}
+
 }  // namespace vatl
 
 using namespace vatl;
+
+extern "C" int vatl_oks(const float* pred_kpts, const double* gt_kpts, const double* bbox_xywh, double* out, int N, void* stream) {
+    if (N <= 0) return 0;
+    if (!pred_kpts || !gt_kpts || !bbox_xywh || !out) return fail(VATL_EINVAL, "oks: null pointer");
+    hipLaunchKernelGGL(oks_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), 0, (hipStream_t)stream, pred_kpts, gt_kpts, bbox_xywh, out, N);
+    return check_launch("oks");
+}
 
 extern "C" int vatl_peaks5(const float* hm, float* peak_val, int32_t* peak_idx, int32_t* npeaks, float* mpe, float* margin,
                            int N, int J, int H, int W, int min_distance, void* stream) {

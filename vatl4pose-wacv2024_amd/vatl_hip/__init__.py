@@ -78,6 +78,7 @@ SIGNATURES = {
     "vatl_masked_mse_workspace_floats": (_i64, [_i64]),
     "vatl_masked_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vatl_adamw_step": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _p]),
+    "vatl_oks": (_i, [_p, _p, _p, _p, _i, _p]),
     "vatl_cosine_rowsum": (_i, [_p, _i64, _i, _p, _p, _p]),
     "vatl_kcenter_update": (_i, [_p, _i64, _i, _p, _i, _p, _i, _p]),
     "vatl_kcenter_pick": (_i, [_p, _p, _d, _d, _p, _i, _i64, _p]),
@@ -267,6 +268,15 @@ def plane_entropy(hm: torch.Tensor) -> torch.Tensor:
     n, j, h, w = hm.shape
     out = torch.empty((n, j), device=hm.device, dtype=torch.float32)
     _check(lib().vatl_plane_entropy(_ptr(hm), _ptr(out), n, j, h, w, _stream()), "vatl_plane_entropy")
+    return out
+
+
+def oks(pred_kpts: torch.Tensor, gt_kpts: torch.Tensor, bbox_xywh: torch.Tensor) -> torch.Tensor:
+    """pred (N,17,3) fp32, gt (N,51) float64, boxes (N,4) xywh float64 -> (N,) float64 OKS."""
+    n = pred_kpts.shape[0]
+    out = torch.empty(n, device=pred_kpts.device, dtype=torch.float64)
+    _check(lib().vatl_oks(_ptr(pred_kpts), _ptr(gt_kpts, torch.float64), _ptr(bbox_xywh, torch.float64), _ptr(out, torch.float64), n, _stream()),
+           "vatl_oks")
     return out
 
 
