@@ -277,6 +277,14 @@ int64_t vatl_masked_mse_workspace_floats(int64_t numel);
 int vatl_masked_mse_fwd_bwd(const float* out, const float* target, const float* mask, float* grad, float* loss,
                             float* partial, int N, int J, int HW, void* stream);
 
+/* L1JointRegression (alphapose/models/criterion.py:46-94: soft-arg-max "integral" regression with the symmetric
+ * +-2 gradient of IngetralCoordinate :13-43, weighted L1, / batch when size_average): loss (1 float), grad of the
+ * loss w.r.t. the heat-maps (B,J,H,W), the predicted normalised joints pred_jts (B, 2J) in [-0.5, 0.5).
+ * gt_joints / gt_joints_vis: (B, 2J).  norm_type 0 softmax, 1 sigmoid, 2 divide_sum.  partial: B*J doubles. */
+int vatl_l1_joint_regression_fwd_bwd(const float* hm, const float* gt_joints, const float* gt_joints_vis, float* grad, float* loss,
+                                     float* pred_jts, double* partial, int B, int J, int H, int W, int norm_type, int size_average,
+                                     void* stream);
+
 /* torch.optim.AdamW step on one flat fp32 span (decoupled weight decay);
  * hyper-parameters are doubles like the Python floats torch derives its
  * per-step scalars from; `step` is the 1-based step count. */

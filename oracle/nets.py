@@ -287,3 +287,48 @@ class HRNetRef(nn.Module):
                 xs = mod(xs)
             ys = xs
         return self.final_layer(ys[0])
+
+
+# ---------------------------------------------------------------------------
+# L1JointRegression (alphapose/models/criterion.py:13-94, transforms.py:645-702)
+# ---------------------------------------------------------------------------
+
+class _IntegralCoordinate(torch.autograd.Function):
+    """criterion.py:13-43: forward multiplies by the index ramp, backward passes +-AMPLITUDE instead of the ramp."""
+
+    @staticmethod
+    def forward(ctx, inp):
+        w = torch.arange(inp.shape[-1], dtype=inp.dtype)
+        out = inp.mul(w)
+        ctx.n = inp.shape[-1]
+        ctx.save_for_backward(w, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, out = ctx.saved_tensors
+        coord = out.sum(dim=2, keepdim=True)
+        w = w[None, None, :].repeat(coord.shape[0], coord.shape[1], 1)
+        mask = torch.ones_like(w)
+        mask[w < coord] = -1
+        mask[coord.repeat(1, 1, w.shape[-1]) > ctx.n] = 1
+        return g.mul(mask * 2)
+
+
+def l1_joint_regression(preds, gt_joints, gt_vis, norm_type="softmax", size_average=True):
+    """L1JointRegression.forward (criterion.py:60-80) on (B,J,H,W) heat-maps; returns (loss, pred_jts)."""
+    b, j, h, w = preds.shape
+    p = preds.reshape(b, j, -1)
+    if norm_type == "softmax":
+        p = F.softmax(p, 2)
+    elif norm_type == "sigmoid":
+        p = p.sigmoid()
+    else:
+        p = p / p.sum(dim=2, keepdim=True)
+    p = (p / p.sum(dim=2, keepdim=True)).reshape(b, j, 1, h, w)
+    hm_x, hm_y = p.sum((2, 3)), p.sum((2, 4))
+    cx = _IntegralCoordinate.apply(hm_x).sum(dim=2, keepdim=True) / float(w) - 0.5
+    cy = _IntegralCoordinate.apply(hm_y).sum(dim=2, keepdim=True) / float(h) - 0.5
+    jts = torch.cat((cx, cy), dim=2).reshape(b, j * 2)
+    out = (torch.abs(jts - gt_joints) * gt_vis).sum()
+    return (out / b if size_average else out), jts

@@ -118,3 +118,14 @@ def gaussian_targets(n: int, seed: int = SEED, J: int = 17, hw=(64, 48), sigma: 
             t[i, j, y0:y1, x0:x1] = patch[y0 - (my - rad):y1 - (my - rad), x0 - (mx - rad):x1 - (mx - rad)]
     mask = (r.random_sample((n, J, 1, 1)) >= p_zero).astype(np.float32)
     return t, mask
+
+
+def l1_inputs(norm: str):
+    """Seeded inputs of the L1JointRegression fixtures (tools/make_golden.py gen_l1_loss and the tests)."""
+    hm = blob_heatmaps(3, seed=31) * 12.0                            # peaked after the soft-max
+    if norm == "divide_sum":
+        hm = np.abs(hm) + 0.01
+    r = np.random.RandomState(77)
+    gt = r.uniform(-0.5, 0.5, (3, 34)).astype(np.float32)
+    vis = np.repeat((r.random_sample((3, 17)) > 0.25).astype(np.float32), 2, axis=1)
+    return hm.astype(np.float32), gt, vis

@@ -67,3 +67,23 @@ def test_config_loader(tmp_path):
     p.write_text("MODEL:\n  TYPE: 'SimplePose'\n  NUM_LAYERS: 50\nVAL:\n  QUERY_RATIO: [0.05, 0.1]\n")
     cfg = update_config(str(p))
     assert cfg.MODEL.TYPE == "SimplePose" and cfg["MODEL"]["NUM_LAYERS"] == 50 and cfg.VAL.QUERY_RATIO[1] == 0.1
+
+
+def test_driver_imports_resolve():
+    """Every name scripts/Run_active_learning.py:38-46 imports from `alphapose` / `active_learning` exists with our
+    packages first on the path (third-party imports of the driver are the environment's business)."""
+    from alphapose.models import builder                                                   # noqa: F401
+    from alphapose.utils.config import update_config                                       # noqa: F401
+    from alphapose.utils.metrics import evaluate_mAP, calc_accuracy, DataLogger            # noqa: F401
+    from alphapose.utils.transforms import flip, flip_heatmap, get_func_heatmap_to_coord   # noqa: F401
+    from alphapose.utils.vis import vis_frame_fast, vis_frame
+    from active_learning import ActiveLearning                                             # noqa: F401
+    from active_learning.al_metric import plot_learning_curves, compute_alc                # noqa: F401
+    with pytest.raises(NotImplementedError):
+        vis_frame(None, None)
+    with pytest.raises(NotImplementedError):
+        vis_frame_fast(None, None)
+    for name in ("SimplePose", "FastPose", "PoseHighResolutionNet"):
+        assert builder.SPPE.get(name) is not None
+    for name in ("MSELoss", "L1JointRegression"):
+        assert builder.LOSS.get(name) is not None

@@ -185,3 +185,33 @@ def test_empty_and_ragged_batches(vh):
         for i in range(n):
             want = scorers.thc_item(hm[i], hm[i - 1] if i else None, hm[i + 1] if i + 1 < n else None, i > 0, i + 1 < n)
             np.testing.assert_allclose(got[i], want, rtol=1e-5)
+
+
+@pytest.mark.parametrize("norm", ["softmax", "sigmoid", "divide_sum"])
+def test_l1_joint_regression_loss(vh, norm):
+    """alphapose.models.criterion.L1JointRegression on MI355X (fused forward + backward) against the reference's
+    golden loss / joints / gradients and, densely, against the torch restatement."""
+    import os
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    from oracle import nets
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "l1_joint_regression.npz"))
+    hm, gt, vis = synth.l1_inputs(norm)
+    crit = builder.build_loss(edict({"TYPE": "L1JointRegression", "NORM_TYPE": norm}))
+    h = to_dev(hm).requires_grad_()
+    loss = crit(h, to_dev(gt), to_dev(vis))
+    (2.0 * loss).backward()                                               # the upstream gradient is honoured
+    np.testing.assert_allclose(float(loss.detach()), float(g[f"{norm}_loss"]), rtol=1e-5)
+    _, _, jts = vh.l1_joint_regression_fwd_bwd(to_dev(hm), to_dev(gt), to_dev(vis), norm)
+    np.testing.assert_allclose(jts.cpu().numpy(), g[f"{norm}_jts"], rtol=1e-4, atol=1e-5)
+    grad = h.grad.cpu().numpy() / 2.0
+    amax = float(g[f"{norm}_grad_absmax"])
+    np.testing.assert_allclose(grad.reshape(-1)[g[f"{norm}_grad_idx"]], g[f"{norm}_grad_val"], rtol=1e-3, atol=2e-5 * amax)
+    ht = torch.from_numpy(hm).requires_grad_()
+    lt, _ = nets.l1_joint_regression(ht, torch.from_numpy(gt), torch.from_numpy(vis), norm)
+    lt.backward()
+    e = rel_err(grad, ht.grad.numpy())
+    record("l1_joint_regression_" + norm, grad_rel=e)
+    assert e < 1e-4
+    with pytest.raises(vh.VatlError):
+        crit(torch.from_numpy(hm), torch.from_numpy(gt), torch.from_numpy(vis))

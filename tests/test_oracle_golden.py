@@ -226,3 +226,18 @@ def test_multi_peak_criteria_restatement():
     assert scorers.peak_local_max_5(q).tolist() == [[20, 20]]
     q = np.zeros((64, 48), np.float32); q[20, 20] = q[20, 25] = 1.0
     assert scorers.peak_local_max_5(q).tolist() == [[20, 20], [20, 25]]
+
+
+@pytest.mark.parametrize("norm", ["softmax", "sigmoid", "divide_sum"])
+def test_l1_joint_regression_restatement_matches_reference(norm):
+    """LOSS.TYPE L1JointRegression: loss, predicted joints and heat-map gradients against the reference module."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "l1_joint_regression.npz"))
+    hm, gt, vis = synth.l1_inputs(norm)
+    h = torch.from_numpy(hm).requires_grad_()
+    loss, jts = nets.l1_joint_regression(h, torch.from_numpy(gt), torch.from_numpy(vis), norm)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(g[f"{norm}_loss"]), rtol=1e-6)
+    np.testing.assert_allclose(jts.detach().numpy(), g[f"{norm}_jts"], rtol=1e-5, atol=1e-6)
+    got = h.grad.reshape(-1)[torch.from_numpy(g[f"{norm}_grad_idx"])].numpy()
+    np.testing.assert_allclose(got, g[f"{norm}_grad_val"], rtol=1e-4, atol=1e-6 * float(g[f"{norm}_grad_absmax"]))

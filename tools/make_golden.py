@@ -468,6 +468,29 @@ def gen_fastpose_r152(EasyDict, out: str):
     np.savez_compressed(os.path.join(out, "fastpose_r152_384.npz"), seed=np.int64(synth.SEED), **res)
 
 
+def gen_l1_loss(out: str):
+    """LOSS.TYPE L1JointRegression (criterion.py:46-94): loss value, predicted joints and sampled heat-map gradients
+    from the reference module + torch autograd, for the three NORM_TYPEs."""
+    from alphapose.models.criterion import L1JointRegression          # the reference's
+    from alphapose.utils.transforms import _integral_tensor
+    res = {}
+    for norm in ("softmax", "sigmoid", "divide_sum"):
+        hm, gt, vis = synth.l1_inputs(norm)
+        crit = L1JointRegression(NORM_TYPE=norm)
+        h = torch.from_numpy(hm).requires_grad_()
+        loss = crit(h, torch.from_numpy(gt), torch.from_numpy(vis))
+        loss.backward()
+        jts, _ = _integral_tensor(torch.from_numpy(hm), 17, False, 48, 64, 1, integral_operation=crit.integral_operation, norm_type=norm)
+        ii = _sample_idx(h.grad.numel(), "l1" + norm, 4096)
+        res[f"{norm}_loss"] = np.float64(loss.item())
+        res[f"{norm}_jts"] = jts.detach().numpy()
+        res[f"{norm}_grad_idx"] = ii
+        res[f"{norm}_grad_val"] = h.grad.reshape(-1)[ii].numpy()
+        res[f"{norm}_grad_absmax"] = np.float64(h.grad.abs().max())
+        print("l1", norm, loss.item(), float(h.grad.abs().max()))
+    np.savez_compressed(os.path.join(out, "l1_joint_regression.npz"), **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -484,6 +507,8 @@ def main():
         gen_simplepose(EasyDict, a.out)
     if a.only in ("", "nets2"):
         gen_fastpose_hrnet(EasyDict, a.out)
+    if a.only in ("", "l1"):
+        gen_l1_loss(a.out)
     if a.only in ("", "r152"):
         gen_fastpose_r152(EasyDict, a.out)
 

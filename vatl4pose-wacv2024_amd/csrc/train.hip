@@ -121,6 +121,115 @@ __global__ __launch_bounds__(256) void opt_kernel(float* __restrict__ p, const f
     }
 }
 
+// --------------------------------------------------------------------------
+// L1JointRegression (alphapose/models/criterion.py:13-94): integral (soft-arg-max) regression loss, forward and
+// backward in one pass, one block per (item, joint) plane.
+//   q = norm(h) (softmax | sigmoid | divide_sum, transforms.py:687-702);  p = q / sum(q);  px, py = marginals;
+//   c = sum_i i * p_i (IngetralCoordinate.forward);  out = c / size - 0.5;  loss = sum |out - gt| * w  (/ B)
+//   backward: dL/dc = sign(out - gt) * w / size (/ B);  IngetralCoordinate.backward replaces d c / d p_i = i by
+//   AMPLITUDE * (i < c ? -1 : +1) (criterion.py:31-43);  then through p = q / sum(q) and the normalisation.
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum4(double v, double* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+
+template <int NORM>   // 0 softmax, 1 sigmoid, 2 divide_sum
+__global__ __launch_bounds__(256) void l1_joint_regression_kernel(const float* __restrict__ hm, const float* __restrict__ gt, const float* __restrict__ vis,
+                                                                  float* __restrict__ grad, float* __restrict__ pred_jts, double* __restrict__ partial,
+                                                                  int J, int H, int W, float inv_b) {
+    extern __shared__ float q[];                       // normalised plane (before the second normalisation)
+    __shared__ double sh[4];
+    __shared__ float red[4];
+    const int HW = H * W, tid = threadIdx.x;
+    const int b = blockIdx.x / J, j = blockIdx.x - b * J;
+    const float* src = hm + (long long)blockIdx.x * HW;
+    float mx = -INFINITY;
+    if (NORM == 0) {
+        for (int i = tid; i < HW; i += 256) mx = fmaxf(mx, src[i]);
+        mx = wave_max(mx);
+        if ((tid & 63) == 0) red[tid >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+    double hs = 0.0;                                   // sum of the raw plane (divide_sum) / of exp (softmax)
+    for (int i = tid; i < HW; i += 256) {
+        const float v = src[i];
+        float t;
+        if (NORM == 0) t = expf(v - mx);
+        else if (NORM == 1) t = 1.f / (1.f + expf(-v));
+        else t = v;
+        q[i] = t;
+        hs += (double)t;
+    }
+    const double raw_sum = block_sum4(hs, sh);
+    double s = 0.0;
+    if (NORM == 1) s = raw_sum;                        // q = sigmoid(h): S = sum q
+    else {                                             // q = t / raw_sum (softmax or divide_sum); S = sum q (== 1 up to rounding)
+        const float inv = (float)(1.0 / raw_sum);
+        for (int i = tid; i < HW; i += 256) { const float t = q[i] * inv; q[i] = t; s += (double)t; }
+        s = block_sum4(s, sh);
+    }
+    // coordinates: c = sum_i i * p_i with p = q / S
+    double sx = 0.0, sy = 0.0;
+    for (int i = tid; i < HW; i += 256) { const int y = i / W, x = i - y * W; sx += (double)q[i] * x; sy += (double)q[i] * y; }
+    sx = block_sum4(sx, sh); sy = block_sum4(sy, sh);
+    const float cx = (float)(sx / s), cy = (float)(sy / s);
+    const float ox = cx / (float)W - 0.5f, oy = cy / (float)H - 0.5f;
+    const long long o2 = ((long long)b * J + j) * 2;
+    const float gx = gt[o2], gy = gt[o2 + 1], wx = vis[o2], wy = vis[o2 + 1];
+    if (tid == 0) {
+        pred_jts[o2] = ox; pred_jts[o2 + 1] = oy;
+        partial[blockIdx.x] = (double)(fabsf(ox - gx) * wx) + (double)(fabsf(oy - gy) * wy);
+    }
+    // backward
+    const float sgx = (ox > gx) ? 1.f : (ox < gx ? -1.f : 0.f), sgy = (oy > gy) ? 1.f : (oy < gy ? -1.f : 0.f);
+    const float gcx = sgx * wx * inv_b / (float)W * 2.f, gcy = sgy * wy * inv_b / (float)H * 2.f;   // AMPLITUDE = 2
+    const float fs = (float)s;
+    double pd = 0.0;                                   // sum_k p_k dP_k
+    for (int i = tid; i < HW; i += 256) {
+        const int y = i / W, x = i - y * W;
+        const float dP = gcx * ((float)x < cx ? -1.f : 1.f) + gcy * ((float)y < cy ? -1.f : 1.f);
+        pd += (double)(q[i] / fs) * dP;
+    }
+    pd = block_sum4(pd, sh);
+    // dq_i = (dP_i - pd) / S ; then through the normalisation
+    double qd = 0.0;                                   // sum_k q_k dq_k (softmax / divide_sum)
+    if (NORM != 1) {
+        for (int i = tid; i < HW; i += 256) {
+            const int y = i / W, x = i - y * W;
+            const float dP = gcx * ((float)x < cx ? -1.f : 1.f) + gcy * ((float)y < cy ? -1.f : 1.f);
+            qd += (double)q[i] * (double)((dP - (float)pd) / fs);
+        }
+        qd = block_sum4(qd, sh);
+    }
+    float* dst = grad + (long long)blockIdx.x * HW;
+    for (int i = tid; i < HW; i += 256) {
+        const int y = i / W, x = i - y * W;
+        const float dP = gcx * ((float)x < cx ? -1.f : 1.f) + gcy * ((float)y < cy ? -1.f : 1.f);
+        const float dq = (dP - (float)pd) / fs;
+        float dh;
+        if (NORM == 0) dh = q[i] * (dq - (float)qd);
+        else if (NORM == 1) dh = dq * q[i] * (1.f - q[i]);
+        else dh = (dq - (float)qd) / (float)raw_sum;
+        dst[i] = dh;
+    }
+}
+
+__global__ __launch_bounds__(256) void l1_finish_kernel(const double* __restrict__ partial, int n, float* __restrict__ loss, double scale) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = wave_sum(s);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = (float)((part[0] + part[1] + part[2] + part[3]) * scale);
+}
+
 }  // namespace vatl
 
 using namespace vatl;
@@ -191,4 +300,22 @@ extern "C" int vatl_sgd_step(float* p, const float* g, float* buf, int64_t n, do
         hipLaunchKernelGGL(opt_kernel<2>, dim3(opt_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, buf, (float*)nullptr, (long long)n,
                            (float)weight_decay, 0.f, (float)momentum, 0.f, 1.f, 0.f, (float)lr);
     return check_launch("sgd_step");
+}
+
+extern "C" int vatl_l1_joint_regression_fwd_bwd(const float* hm, const float* gt_joints, const float* gt_joints_vis, float* grad, float* loss,
+                                                float* pred_jts, double* partial, int B, int J, int H, int W, int norm_type, int size_average,
+                                                void* stream) {
+    if (!hm || !gt_joints || !gt_joints_vis || !grad || !loss || !pred_jts || !partial) return fail(VATL_EINVAL, "l1_joint_regression: null pointer");
+    if (B <= 0 || J <= 0) return fail(VATL_EINVAL, "l1_joint_regression: empty batch");
+    const size_t smem = (size_t)H * W * sizeof(float);
+    if (smem > 60 * 1024) return fail(VATL_EINVAL, "l1_joint_regression: heat-map %dx%d too large for the LDS tile", H, W);
+    hipStream_t st = (hipStream_t)stream;
+    const float inv_b = size_average ? 1.f / (float)B : 1.f;
+    const dim3 grid((unsigned)(B * J));
+    if (norm_type == 0) hipLaunchKernelGGL(l1_joint_regression_kernel<0>, grid, dim3(256), smem, st, hm, gt_joints, gt_joints_vis, grad, pred_jts, partial, J, H, W, inv_b);
+    else if (norm_type == 1) hipLaunchKernelGGL(l1_joint_regression_kernel<1>, grid, dim3(256), smem, st, hm, gt_joints, gt_joints_vis, grad, pred_jts, partial, J, H, W, inv_b);
+    else if (norm_type == 2) hipLaunchKernelGGL(l1_joint_regression_kernel<2>, grid, dim3(256), smem, st, hm, gt_joints, gt_joints_vis, grad, pred_jts, partial, J, H, W, inv_b);
+    else return fail(VATL_EINVAL, "l1_joint_regression: norm_type must be 0 (softmax), 1 (sigmoid) or 2 (divide_sum)");
+    hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(256), 0, st, partial, B * J, loss, size_average ? 1.0 / (double)B : 1.0);
+    return check_launch("l1_joint_regression");
 }

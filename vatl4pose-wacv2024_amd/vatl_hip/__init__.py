@@ -77,6 +77,7 @@ SIGNATURES = {
     "vatl_col_sum": (_i, [_p, _i64, _i, _p, _p, _p]),
     "vatl_masked_mse_workspace_floats": (_i64, [_i64]),
     "vatl_masked_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "vatl_l1_joint_regression_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_adamw_step": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _p]),
     "vatl_oks": (_i, [_p, _p, _p, _p, _i, _p]),
     "vatl_cosine_rowsum": (_i, [_p, _i64, _i, _p, _p, _p]),
@@ -638,6 +639,22 @@ def masked_mse_fwd_bwd(out: torch.Tensor, target: torch.Tensor, mask: torch.Tens
     _check(lib().vatl_masked_mse_fwd_bwd(_ptr(out), _ptr(target), _ptr(m), _ptr(grad), _ptr(loss), _ptr(ws), n, j, h * w, _stream()),
            "vatl_masked_mse_fwd_bwd")
     return loss, grad
+
+
+NORM_TYPES = {"softmax": 0, "sigmoid": 1, "divide_sum": 2}
+
+
+def l1_joint_regression_fwd_bwd(hm, gt_joints, gt_joints_vis, norm_type: str = "softmax", size_average: bool = True):
+    """-> loss (0-dim), grad (B,J,H,W), pred_jts (B,2J)."""
+    b, j, h, w = hm.shape
+    grad = torch.empty_like(hm)
+    loss = torch.empty((), device=hm.device, dtype=torch.float32)
+    jts = torch.empty((b, 2 * j), device=hm.device, dtype=torch.float32)
+    partial = torch.empty(b * j, device=hm.device, dtype=torch.float64)
+    _check(lib().vatl_l1_joint_regression_fwd_bwd(_ptr(hm), _ptr(gt_joints), _ptr(gt_joints_vis), _ptr(grad), _ptr(loss), _ptr(jts),
+                                                  _ptr(partial, torch.float64), b, j, h, w, NORM_TYPES[norm_type], int(size_average), _stream()),
+           "vatl_l1_joint_regression_fwd_bwd")
+    return loss, grad, jts
 
 
 def adam_step(p, g, m, v, step: int, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8):
