@@ -71,6 +71,16 @@ int vatl_bn_fold(const float* gamma, const float* beta, const float* mean, const
  * Replaces Conv2d+BatchNorm2d(+add)(+ReLU) chains of Bottleneck.forward
  * (Resnet.py:104-128), ResNet.forward stem (Resnet.py:171-172) and
  * SimplePose.final_layer (simplepose.py:85). */
+/* Last 1x1 conv of a bottleneck fused with the block's projection shortcut (Resnet.py:104-128 with `downsample`,
+ * :185-189): y = act(W1' a + W2' x[::stride2, ::stride2] + bias), a (N,Ho,Wo,C1), x (N,H2,W2,C2), ONE implicit GEMM over
+ * K = C1 + C2 with the A operand gathered from both tensors, so the projection output never exists in HBM.
+ * vatl_pack_conv1x1_dual_weight builds w [CoutPad][C1+C2] (folded BN scales multiplied into the rows) and bias = b1 + b2
+ * from the two (Cout,C,1,1) weights and their folded scale/bias vectors.  C1, C2 % 32 == 0, Cout >= 128. */
+int vatl_pack_conv1x1_dual_weight(const float* w1, const float* scale1, const float* bias1, const float* w2, const float* scale2,
+                                  const float* bias2, float* out, float* bias, int Cout, int C1, int C2, int CoutPad, void* stream);
+int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo,
+                          int C1, int H2, int W2, int C2, int stride2, int Cout, int CoutPad, int relu, void* stream);
+
 /* Tuning knob (benchmarks / A-B tests only; results are identical for every setting):
  * knob 0 = k-loop schedule of the conv kernel (see csrc/conv_igemm.hip), 1 = tile order, 2 = block stagger,
  * 3 = target block count of the weight-gradient launches (number of pixel splits), 4 = wgrad ablation bits,

@@ -302,3 +302,25 @@ def test_forward_with_embedding_is_bit_identical(vh):
     assert torch.equal(out, hm) and torch.equal(e, emb)
     with pytest.raises(vh.VatlError):
         hip_engine.forward_with_embedding(_build(HRNET_CFG), x, out, e)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv1x1_dual_matches_two_launches(vh, stride):
+    """conv3 + projection shortcut as one dual-source GEMM vs the two-launch form and vs float64."""
+    r = np.random.RandomState(30 + stride)
+    n, h2, w2, c1, c2, cout = 3, 12, 10, 64, 96, 256
+    ho, wo = (h2 - 1) // stride + 1, (w2 - 1) // stride + 1
+    a = r.standard_normal((n, ho, wo, c1)).astype(np.float32)
+    x = r.standard_normal((n, h2, w2, c2)).astype(np.float32)
+    w1 = (r.standard_normal((cout, c1, 1, 1)) / 8).astype(np.float32); w2_ = (r.standard_normal((cout, c2, 1, 1)) / 10).astype(np.float32)
+    s1, b1 = r.uniform(0.5, 1.5, cout).astype(np.float32), r.standard_normal(cout).astype(np.float32)
+    s2, b2 = r.uniform(0.5, 1.5, cout).astype(np.float32), r.standard_normal(cout).astype(np.float32)
+    wp, bias = vh.pack_conv1x1_dual_weight(to_dev(w1), to_dev(s1), to_dev(b1), to_dev(w2_), to_dev(s2), to_dev(b2))
+    got = vh.conv1x1_dual_fwd(to_dev(a), to_dev(x), wp, bias, cout, stride, True).cpu().numpy()
+    skip = vh.conv2d_fwd(to_dev(x), vh.pack_conv_weight(to_dev(w2_)), to_dev(s2), to_dev(b2), cout, 1, 1, stride, 0, False)
+    two = vh.conv2d_fwd(to_dev(a), vh.pack_conv_weight(to_dev(w1)), to_dev(s1), to_dev(b1), cout, 1, 1, 1, 0, True, residual=skip).cpu().numpy()
+    xs = x[:, ::stride, ::stride].astype(np.float64)
+    want = np.maximum((a.astype(np.float64) @ w1[:, :, 0, 0].T.astype(np.float64)) * s1 + b1 + (xs @ w2_[:, :, 0, 0].T.astype(np.float64)) * s2 + b2, 0)
+    e_two, e_64 = rel_err(got, two), rel_err(got, want)
+    record(f"conv1x1_dual_s{stride}", vs_two_launches=e_two, vs_fp64=e_64, two_launches_vs_fp64=rel_err(two, want))
+    assert got.shape == (n, ho, wo, cout) and e_two < 2e-6 and e_64 < 2e-6

@@ -76,16 +76,29 @@ def _d(p):
     return None if p is None else p.detach()
 
 
+# Fuse conv3 with the projection shortcut of a stage's first block into one dual-source GEMM (vatl_conv1x1_dual_fwd):
+# the projection output (3.2 GB per 1024 crops in layer 1) is never written or re-read.  VATL_FUSE_PROJ=0 = two launches.
+FUSE_PROJ = os.environ.get("VATL_FUSE_PROJ", "1") != "0"
+
+
 class _BottleneckPlan:
     def __init__(self, blk):
         self.c1 = _Conv(blk.conv1, blk.bn1)
         self.c2 = _Conv(blk.conv2, blk.bn2)
         self.c3 = _Conv(blk.conv3, blk.bn3)
         self.proj = _Conv(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+        self.dual = None
+        if (FUSE_PROJ and self.proj is not None and type(self) is _BottleneckPlan and self.proj.r == 1 and self.c3.cout >= 128
+                and blk.conv3.in_channels % 32 == 0 and blk.downsample[0].in_channels % 32 == 0):
+            w, b = vh.pack_conv1x1_dual_weight(blk.conv3.weight.detach(), self.c3.scale, self.c3.bias, blk.downsample[0].weight.detach(),
+                                               self.proj.scale, self.proj.bias)
+            self.dual = (w, b, self.proj.stride)
 
     def __call__(self, x, out=None):
         y = self.c1(x, relu=True)
         y = self.c2(y, relu=True)
+        if self.dual is not None:                                   # relu(bn3(conv3(y)) + bn_p(conv_p(x))) in one GEMM over K = C1 + C2
+            return vh.conv1x1_dual_fwd(y, x, self.dual[0], self.dual[1], self.c3.cout, self.dual[2], True, out=out)
         skip = x if self.proj is None else self.proj(x, relu=False)
         return self.c3(y, relu=True, residual=skip, out=out)        # relu(bn3(conv3) + skip)
 

@@ -59,6 +59,11 @@ struct ConvParams {
     int stagger;                      // start the second resident block of every CU half a block-time late
     int K;                            // packed K per output channel
     double* stats;                    // training: per (row block, channel) partial (sum, sum^2) of the stored tile, or NULL
+    // dual-source 1x1 (projection shortcut fused into the block's last conv): k-tiles 0..k1-1 read x (C1 = Cin channels,
+    // one row per output pixel), k-tiles k1.. read x2 (C2 channels, an H2 x W2 image sampled with stride2)
+    const float* x2;
+    int k1, C2, H2, W2, stride2;
+    unsigned x2_bytes;
     unsigned x_bytes, w_bytes, y_bytes;   // buffer extents (hardware bounds checks: OOB loads read 0, OOB stores drop)
 };
 
@@ -235,7 +240,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 //   5  LDS-DMA kernel below (buffer_load ... lds, source-side XOR swizzle): 134 — equal to VAR2, the saved
 //      ds_write pass (+5 %, ablation VAR13) is offset by its distance-1 prefetch
 // (a rotated loop that buries the tile hand-over in the last MFMA group measured equal to VAR2 and was dropped)
-template <int BM, int BN, int WM, int WN, bool STEM, int VAR>
+template <int BM, int BN, int WM, int WN, bool STEM, int VAR, bool DUAL = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                          // [2][BM][LDK]
@@ -282,11 +287,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     // vmcnt before the MFMAs in the first version of this kernel).
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? p.x2 : p.x), 0, DUAL ? p.x2_bytes : p.x_bytes, 0x00020000);
 
     // ---- per-thread gather state --------------------------------------------
     const int lrow = tid >> 3;        // 0..31
     const int kq = tid & 7;           // which float4 of the 32-wide k-tile
     int abase[LA], iy0[LA], ix0[LA];  // element offset of (b, iy0, ix0, kq*4); may be negative
+    int abase2[DUAL ? LA : 1];        // DUAL: element offset of the row's pixel in the second source
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
@@ -299,8 +306,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
             iy0[i] = oy * p.stride - pad_y;
             ix0[i] = ox * p.stride - pad_x;
             abase[i] = ((b * p.H + iy0[i]) * p.W + ix0[i]) * p.Cin + kq * 4;
+            if (DUAL) abase2[i] = ((b * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.C2 + kq * 4;
         } else {
             iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); abase[i] = 0;
+            if (DUAL) abase2[i] = 0;
         }
     }
     unsigned boff[LB];
@@ -309,9 +318,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 
     f32x4 ra[LA], rb[LB];
     int g_r = 0, g_s = 0, g_off = 0;
+    bool g_sel = false;                // DUAL: this k-tile reads the second source
     auto gtap = [&](int kt) {          // filter tap / channel offset of k-tile kt (wave-uniform)
         if (STEM) {                    // k-tile = one filter row: 8 taps x 4 channels
             g_r = kt; g_s = kq; g_off = kt * p.W * p.Cin;
+        } else if (DUAL) {             // 1x1 over [source 1 channels | source 2 channels]
+            g_sel = kt >= p.k1;
+            g_r = 0; g_s = 0; g_off = (g_sel ? kt - p.k1 : kt) * BK;
         } else {
             const int rs = kt / p.kpr;
             const int c0 = (kt - rs * p.kpr) * BK;
@@ -319,10 +332,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
             g_off = (g_r * p.W + g_s) * p.Cin + c0;
         }
     };
-    auto gloadA = [&](int i, bool live) {
+    auto a_load = [&](int i, bool live) -> f32x4 {     // the A-operand float4 of tile row lrow + 32 i for the current tap
         const bool ok = live && (unsigned)(iy0[i] + g_r) < (unsigned)p.H && (unsigned)(ix0[i] + g_s) < (unsigned)p.W;
-        ra[i] = buf_load4(xr, ok ? (unsigned)(abase[i] + g_off) << 2 : OOB);
+        if (DUAL) return buf_load4(g_sel ? xr2 : xr, ok ? (unsigned)((g_sel ? abase2[i] : abase[i]) + g_off) << 2 : OOB);
+        return buf_load4(xr, ok ? (unsigned)(abase[i] + g_off) << 2 : OOB);
     };
+    auto gloadA = [&](int i, bool live) { ra[i] = a_load(i, live); };
     auto gloadB = [&](int j, int kt, bool live) {
         rb[j] = buf_load4(wr, live ? boff[j] + (unsigned)kt * (BK * 4) : OOB);
     };
@@ -400,10 +415,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
             const bool live = kt < p.ktiles;
             gtap(kt);
 #pragma unroll
-            for (int i = 0; i < LA; ++i) {
-                const bool ok = live && (unsigned)(iy0[i] + g_r) < (unsigned)p.H && (unsigned)(ix0[i] + g_s) < (unsigned)p.W;
-                da[i] = buf_load4(xr, ok ? (unsigned)(abase[i] + g_off) << 2 : OOB);
-            }
+            for (int i = 0; i < LA; ++i) da[i] = a_load(i, live);
 #pragma unroll
             for (int j = 0; j < LB; ++j) db[j] = buf_load4(wr, live ? boff[j] + (unsigned)kt * (BK * 4) : OOB);
         };
@@ -670,9 +682,9 @@ static std::atomic<int> g_order{0};    // tile order (vatl_tune_set(1, v))
 static std::atomic<int> g_bm{0};       // tile rows (vatl_tune_set(5, v)): 0 = by grid size, 64 or 128 = forced
 static std::atomic<int> g_stagger{0};  // block stagger in percent of the k-loop time (vatl_tune_set(2, v)); 0 = off
 
-template <int BM, int BN, int WM, int WN, bool STEM, int VAR>
+template <int BM, int BN, int WM, int WN, bool STEM, int VAR, bool DUAL = false>
 static int launch(const ConvParams& p, int phases, hipStream_t st) {
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM, VAR>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM, VAR, DUAL>;
     constexpr int smem = 2 * (BM + BN) * LDK * (int)sizeof(float);
     static std::atomic<int> configured{0};
     if (!configured.load(std::memory_order_acquire)) {
@@ -861,6 +873,36 @@ extern "C" int vatl_deconv4x4s2_fwd_stats(const float* x, const float* w, float*
                                           int Cin, int Cout, int CoutPad, void* stream) {
     if (!stats || !row_blocks_used) return fail(VATL_EINVAL, "deconv4x4s2_fwd_stats: null statistics buffer");
     return deconv4x4s2_fwd_impl(x, w, nullptr, nullptr, y, N, H, W, Cin, Cout, CoutPad, 0, stats, row_blocks_used, stream);
+}
+
+// Last 1x1 conv of a bottleneck fused with the block's projection shortcut (Resnet.py:104-128 with a `downsample`):
+//   y = act( W1' a  +  W2' x[strided]  +  bias ),   a (N,Ho,Wo,C1) = output of the 3x3, x (N,H2,W2,C2) = block input,
+// one implicit GEMM over K = C1 + C2 whose A operand comes from two tensors.  w: [CoutPad][C1 + C2] with the two folded
+// BatchNorm scales already multiplied into the rows (vatl_pack_conv1x1_dual_weight); bias = bias1 + bias2.  The
+// projection's output never exists in HBM (for layer 1 of a ResNet-50 that is 3.2 GB written + read per 1024 crops).
+extern "C" int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo,
+                                     int C1, int H2, int W2, int C2, int stride2, int Cout, int CoutPad, int relu, void* stream) {
+    if (!a || !x || !w || !y || N <= 0) return fail(VATL_EINVAL, "conv1x1_dual_fwd: null pointer or empty batch");
+    if ((C1 % 32) || (C2 % 32)) return fail(VATL_EINVAL, "conv1x1_dual_fwd: channel counts %d / %d must be multiples of 32", C1, C2);
+    if (Cout < 128 || (Cout & 3)) return fail(VATL_EINVAL, "conv1x1_dual_fwd: Cout %d must be >= 128 and a multiple of 4", Cout);
+    if (stride2 < 1 || (Ho - 1) * stride2 >= H2 || (Wo - 1) * stride2 >= W2) return fail(VATL_EINVAL, "conv1x1_dual_fwd: stride %d does not map %dx%d onto %dx%d", stride2, Ho, Wo, H2, W2);
+    ConvParams p{};
+    p.x = a; p.x2 = x; p.w = w; p.scale = nullptr; p.bias = bias; p.res = nullptr; p.y = y;
+    p.N = N; p.H = Ho; p.W = Wo; p.Cin = C1; p.Cout = Cout; p.CoutPad = CoutPad;
+    p.R = 1; p.S = 1; p.stride = 1; p.pad_y = 0; p.pad_x = 0;
+    p.Ho = Ho; p.Wo = Wo; p.M = N * Ho * Wo;
+    p.OH = Ho; p.OW = Wo; p.osy = 1; p.osx = 1; p.ooy = 0; p.oox = 0;
+    p.relu = relu; p.out_nchw = 0; p.deconv = 0;
+    p.k1 = C1 / BK; p.C2 = C2; p.H2 = H2; p.W2 = W2; p.stride2 = stride2;
+    p.kpr = (C1 + C2) / BK; p.ktiles = p.kpr; p.K = C1 + C2;
+    const long long xe = (long long)p.M * C1, x2e = (long long)N * H2 * W2 * C2, ye = (long long)p.M * Cout, we = (long long)CoutPad * p.K;
+    if (xe >= (1LL << 30) || x2e >= (1LL << 30) || ye >= (1LL << 30) || we >= (1LL << 30))
+        return fail(VATL_EINVAL, "conv1x1_dual_fwd: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
+    p.x_bytes = (unsigned)(xe * 4); p.x2_bytes = (unsigned)(x2e * 4); p.y_bytes = (unsigned)(ye * 4); p.w_bytes = (unsigned)(we * 4);
+    if (CoutPad % 128) return fail(VATL_EINVAL, "conv1x1_dual_fwd: CoutPad %d must be a multiple of 128", CoutPad);
+    const int bm = tile_m_for(p, 1, 128, false);
+    if (bm == 64) return launch<64, 128, 32, 64, false, 4, true>(p, 1, (hipStream_t)stream);
+    return launch<128, 128, 64, 64, false, 4, true>(p, 1, (hipStream_t)stream);
 }
 
 // General form behind the data-gradient paths: explicit GEMM pixel grid (Ho x Wo), separate paddings and an

@@ -61,6 +61,21 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// dual-source 1x1: out[o][k] = w1[o][k] * s1[o] (k < C1) | w2[o][k - C1] * s2[o]; rows o >= Cout zero; bias = b1 + b2
+__global__ void pack_dual_weight_kernel(const float* __restrict__ w1, const float* __restrict__ s1, const float* __restrict__ b1,
+                                        const float* __restrict__ w2, const float* __restrict__ s2, const float* __restrict__ b2,
+                                        float* __restrict__ out, float* __restrict__ bias, int Cout, int C1, int C2, int CoutPad) {
+    const int K = C1 + C2;
+    const long long total = (long long)CoutPad * K;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K), o = (int)(i / K);
+        float v = 0.f;
+        if (o < Cout) v = k < C1 ? w1[(long long)o * C1 + k] * s1[o] : w2[(long long)o * C2 + (k - C1)] * s2[o];
+        out[i] = v;
+        if (k == 0 && o < Cout) bias[o] = b1[o] + b2[o];
+    }
+}
+
 __global__ void pack_deconv_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int CoutPad) {
     const long long total = 4LL * CoutPad * 4 * Cin;     // [phase][CoutPad][ty][tx][Cin]
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -342,6 +357,14 @@ extern "C" int vatl_pack_conv_weight(const float* w, float* out, int Cout, int C
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for((long long)CoutPad * R * Spad * CinPad)), dim3(256), 0, (hipStream_t)stream,
                        w, out, Cout, Cin, R, S, CoutPad, Spad, CinPad);
     return check_launch("pack_conv_weight");
+}
+
+extern "C" int vatl_pack_conv1x1_dual_weight(const float* w1, const float* scale1, const float* bias1, const float* w2, const float* scale2,
+                                             const float* bias2, float* out, float* bias, int Cout, int C1, int C2, int CoutPad, void* stream) {
+    if (!w1 || !scale1 || !bias1 || !w2 || !scale2 || !bias2 || !out || !bias || CoutPad < Cout) return fail(VATL_EINVAL, "pack_conv1x1_dual_weight: bad arguments");
+    hipLaunchKernelGGL(pack_dual_weight_kernel, dim3(grid_for((long long)CoutPad * (C1 + C2))), dim3(256), 0, (hipStream_t)stream, w1, scale1, bias1, w2,
+                       scale2, bias2, out, bias, Cout, C1, C2, CoutPad);
+    return check_launch("pack_conv1x1_dual_weight");
 }
 
 extern "C" int vatl_pack_deconv4x4s2_weight(const float* w, float* out, int Cin, int Cout, int CoutPad, void* stream) {

@@ -29,6 +29,8 @@ SIGNATURES = {
     "vatl_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vatl_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_pack_deconv4x4s2_weight": (_i, [_p, _p, _i, _i, _i, _p]),
+    "vatl_pack_conv1x1_dual_weight": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vatl_conv1x1_dual_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_bn_fold": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _i, _p]),
     "vatl_tune_set": (_i, [_i, _i]),
     "vatl_conv_cout_pad": (_i, [_i]),
@@ -168,6 +170,28 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     out = torch.empty((cpad, r, spad, cinpad), device=w.device, dtype=torch.float32)
     _check(lib().vatl_pack_conv_weight(_ptr(w.contiguous()), _ptr(out), cout, cin, r, s, cpad, spad, cinpad, _stream()), "vatl_pack_conv_weight")
     return out
+
+
+def pack_conv1x1_dual_weight(w1, scale1, bias1, w2, scale2, bias2):
+    """Two (Cout,C,1,1) weights + folded BN scale/bias -> ([CoutPad][C1+C2] scaled rows, bias1 + bias2)."""
+    cout, c1 = w1.shape[:2]
+    c2 = w2.shape[1]
+    cpad = conv_cout_pad(cout)
+    out = torch.empty((cpad, c1 + c2), device=w1.device, dtype=torch.float32)
+    bias = torch.empty(cout, device=w1.device, dtype=torch.float32)
+    _check(lib().vatl_pack_conv1x1_dual_weight(_ptr(w1.contiguous()), _ptr(scale1), _ptr(bias1), _ptr(w2.contiguous()), _ptr(scale2), _ptr(bias2),
+                                               _ptr(out), _ptr(bias), cout, c1, c2, cpad, _stream()), "vatl_pack_conv1x1_dual_weight")
+    return out, bias
+
+
+def conv1x1_dual_fwd(a, x, w_packed, bias, cout: int, stride2: int, relu: bool, out=None):
+    """relu?(W1' a + W2' x[::s, ::s] + bias): a (N,Ho,Wo,C1) and x (N,H2,W2,C2) NHWC -> (N,Ho,Wo,Cout)."""
+    n, ho, wo, c1 = a.shape
+    _, h2, w2, c2 = x.shape
+    y = out if out is not None else torch.empty((n, ho, wo, cout), device=a.device, dtype=torch.float32)
+    _check(lib().vatl_conv1x1_dual_fwd(_ptr(a), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(y), n, ho, wo, c1, h2, w2, c2, stride2, cout,
+                                       w_packed.shape[0], int(relu), _stream()), "vatl_conv1x1_dual_fwd")
+    return y
 
 
 def pack_deconv_weight(w: torch.Tensor) -> torch.Tensor:
