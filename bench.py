@@ -80,7 +80,7 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
     launch stream (torch's current stream) and relate the sum to the algorithmic FLOPs."""
     import vatl_hip as vh
     events = []
-    orig_c, orig_d = vh.conv2d_fwd, vh.deconv4x4s2_fwd
+    orig_c, orig_d, orig_u = vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd
 
     def wrap(fn):
         def inner(*a, **k):
@@ -91,12 +91,12 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
             events.append((e0, e1))
             return r
         return inner
-    vh.conv2d_fwd, vh.deconv4x4s2_fwd = wrap(orig_c), wrap(orig_d)
+    vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd = wrap(orig_c), wrap(orig_d), wrap(orig_u)
     try:
         one_step(model, x, bbox, is_prev, is_next, hm_buf)
         torch.cuda.synchronize()
     finally:
-        vh.conv2d_fwd, vh.deconv4x4s2_fwd = orig_c, orig_d
+        vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd = orig_c, orig_d, orig_u
     ms = sum(a.elapsed_time(b) for a, b in events)
     flops = GFLOP_PER_CROP * 1e9 * FRAMES
     achieved = flops / (ms * 1e-3) / 1e12
@@ -109,7 +109,7 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
-            "kernel": "conv_igemm_kernel (all conv/deconv launches of one step)", "launches": len(events),
+            "kernel": "conv_igemm_kernel (all conv/deconv launches of one step; 4 of them fuse a projection shortcut with the block's last conv)", "launches": len(events),
             "avg_launch_us": round(ms * 1e3 / len(events), 2), "flops_per_step": flops}
 
 

@@ -3,14 +3,15 @@
 
     python tools/layer_report.py gpurun_out/prof/r1_kernel_trace.csv [batch]
 
-Takes the LAST 57 conv_igemm dispatches (one forward) and pairs them, in launch
+Takes the conv_igemm dispatches of the LAST forward (57, or 53 when conv3 + projection are fused) and pairs them, in launch
 order, with the layer list of the network.
 """
 import csv
 import sys
 
 
-def layers(B):
+def layers(B, fused=False):
+    """fused: the first block of every stage runs conv3 + projection as one dual-source GEMM (K = C1 + C2)."""
     L = []
 
     def conv(name, H, W, cin, cout, k, s, res=False):
@@ -27,10 +28,15 @@ def layers(B):
             tag = f"l{si + 1}.{'0' if b == 0 else 'n'}"
             conv(tag + ".c1", H, W, cin, wd, 1, 1)
             conv(tag + ".c2", H, W, wd, wd, 3, s)
-            if b == 0:
+            if b == 0 and not fused:
                 conv(tag + ".proj", H, W, cin, 4 * wd, 1, s)
+            Hi, Wi = H, W
             H, W = H // s, W // s
-            conv(tag + ".c3", H, W, wd, 4 * wd, 1, 1, res=True)
+            if b == 0 and fused:
+                M = B * H * W
+                L.append((tag + ".c3+p", 2 * M * (wd + cin) * 4 * wd, M, 4 * wd, wd + cin, (M * (wd + cin) + M * 4 * wd + (wd + cin) * 4 * wd) * 4))
+            else:
+                conv(tag + ".c3", H, W, wd, 4 * wd, 1, 1, res=True)
             cin = 4 * wd
     for i, (ci, co) in enumerate(((2048, 256), (256, 256), (256, 256))):
         L.append((f"deconv{i + 1}", 2 * B * H * W * 16 * ci * co, B * H * W, co, 4 * ci, B * H * W * (ci + 4 * co) * 4 + 16 * ci * co * 4))
@@ -44,7 +50,9 @@ def main():
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    L = layers(B)
+    per_step = sum(1 for r in rows if "Lb1ELi0" in r["Kernel_Name"] or "true, 0" in r["Kernel_Name"])   # one stem launch per forward
+    fused = per_step > 0 and len(rows) // per_step == 53
+    L = layers(B, fused)
     last = rows[-len(L):]
     agg = {}
     for (name, fl, M, N, K, by), r in zip(L, last):
