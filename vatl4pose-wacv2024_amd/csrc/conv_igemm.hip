@@ -755,7 +755,9 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, 
         return launch<64, 64, 32, 32, false, 4>(p, phases, st);
     }
     if (stem) {
-        if (bn == 64) return launch<128, 64, 64, 32, true, 0>(p, phases, st);
+        // 7x7 stem, 1024 crops (tools/conv_bench.py): 128x64 two-phase 3.65 ms, 128x64 prefetch 3.40 ms, 64x64 prefetch 3.06 ms
+        if (bn == 64 && var == 0) return launch<128, 64, 64, 32, true, 0>(p, phases, st);
+        if (bn == 64) return launch<64, 64, 32, 32, true, 4>(p, phases, st);
         if (bn == 128) return launch<128, 128, 64, 64, true, 0>(p, phases, st);
         return launch<128, 32, 32, 32, true, 0>(p, phases, st);
     }
