@@ -396,6 +396,17 @@ def test_fused_bn_statistics_and_mask_recompute(vh):
         dz1, _, dg1, db1 = vh.bn_train_bwd(dy, y, z1, gamma, mean1, inv1)
         dz2, dg2, db2 = vh.bn_train_bwd_relu(dy, sc1, bi1, z1, gamma, mean1, inv1)
         assert torch.equal(dz1, dz2) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+    # 3-channel stem (its own tile configuration): statistics must cover every row block the chosen tile writes
+    x = vh.nchw_to_nhwc(to_dev(r.standard_normal((3, 3, 64, 48)).astype(np.float32)), 4)
+    wt = to_dev((r.standard_normal((64, 3, 7, 7)) / 12).astype(np.float32))
+    gamma, beta = to_dev(np.ones(64, np.float32)), to_dev(np.zeros(64, np.float32))
+    wp = vh.pack_conv_weight(wt)
+    z1 = vh.conv2d_fwd(x, wp, None, None, 64, 7, 7, 2, 3, False)
+    s1 = vh.bn_train_fwd_stats(z1, gamma, beta, None, None, 0.1, 1e-5)
+    out = vh.conv2d_fwd_bnstats(x, wp, 64, 7, 7, 2, 3, gamma, beta, None, None, 0.1, 1e-5)
+    assert torch.equal(out[0], z1)
+    for a, b in zip(s1, out[1:]):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-6, atol=1e-7)
     # transposed conv: four phases contribute to the same channel statistics
     x = to_dev(r.standard_normal((2, 5, 3, 64)).astype(np.float32))
     wt = to_dev((r.standard_normal((64, 128, 4, 4)) / 16).astype(np.float32))
