@@ -751,16 +751,16 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, 
     const bool stem64 = stem && bn == 64 && var != 0;     // the 7x7 stem runs the 64x64 tile (see below)
     const int bm = stem64 ? 64 : tile_m_for(p, phases, bn, stem);
     if (row_blocks) *row_blocks = (int64_t)cdiv(p.M, bm) * phases;   // what the statistics epilogue of the chosen tile writes
-    if (bm == 64) {
-        if (bn == 128) return launch<64, 128, 32, 64, false, 4>(p, phases, st);
-        return launch<64, 64, 32, 32, false, 4>(p, phases, st);
-    }
     if (stem) {
         // 7x7 stem, 1024 crops (tools/conv_bench.py): 128x64 two-phase 3.65 ms, 128x64 prefetch 3.40 ms, 64x64 prefetch 3.06 ms
         if (stem64) return launch<64, 64, 32, 32, true, 4>(p, phases, st);
         if (bn == 64) return launch<128, 64, 64, 32, true, 0>(p, phases, st);
         if (bn == 128) return launch<128, 128, 64, 64, true, 0>(p, phases, st);
         return launch<128, 32, 32, 32, true, 0>(p, phases, st);
+    }
+    if (bm == 64) {
+        if (bn == 128) return launch<64, 128, 32, 64, false, 4>(p, phases, st);
+        return launch<64, 64, 32, 32, false, 4>(p, phases, st);
     }
     if (bn == 128 && var == 5) return launch_dma<128, 128, 64, 64>(p, phases, st);
     if (bn == 64 && var == 5) return launch_dma<128, 64, 64, 32>(p, phases, st);
