@@ -50,7 +50,9 @@ def main():
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    per_step = sum(1 for r in rows if "Lb1ELi0" in r["Kernel_Name"] or "true, 0" in r["Kernel_Name"])   # one stem launch per forward
+    import re
+    is_stem = lambda name: bool(re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, true", name))
+    per_step = sum(1 for r in rows if is_stem(r["Kernel_Name"]))                                     # one stem launch per forward
     fused = per_step > 0 and len(rows) // per_step == 53
     L = layers(B, fused)
     last = rows[-len(L):]
