@@ -81,10 +81,11 @@ int vatl_pack_conv1x1_dual_weight(const float* w1, const float* scale1, const fl
 int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo,
                           int C1, int H2, int W2, int C2, int stride2, int Cout, int CoutPad, int relu, void* stream);
 
-/* Tuning knob (benchmarks / A-B tests only; results are identical for every setting):
- * knob 0 = k-loop schedule of the conv kernel (see csrc/conv_igemm.hip), 1 = tile order, 2 = block stagger,
- * 3 = target block count of the weight-gradient launches (number of pixel splits), 4 = wgrad ablation bits,
- * 5 = rows of the conv block tile (0 = chosen from the grid size, 64, 128). */
+/* Tuning knobs (benchmarks / A-B tests only).  Results are identical for every setting of
+ * knob 0 = k-loop schedule of the conv kernel, values 0, 2, 4, 5 (see csrc/conv_igemm.hip), 1 = tile order, 2 = block
+ * stagger, 3 = target block count of the weight-gradient launches (number of pixel splits), 5 = rows of the conv block
+ * tile (0 = chosen from the grid size, 64, 128).  Knob 0 values 10..13 and knob 4 (wgrad ablation bits) are profiling
+ * ablations that compute WRONG results; they are refused unless the environment has VATL_ALLOW_ABLATION=1. */
 int vatl_tune_set(int knob, int value);
 /* CoutPad the packer must use for a given Cout (multiple of the kernel's N tile). */
 int vatl_conv_cout_pad(int Cout);

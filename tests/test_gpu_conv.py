@@ -324,3 +324,12 @@ def test_conv1x1_dual_matches_two_launches(vh, stride):
     e_two, e_64 = rel_err(got, two), rel_err(got, want)
     record(f"conv1x1_dual_s{stride}", vs_two_launches=e_two, vs_fp64=e_64, two_launches_vs_fp64=rel_err(two, want))
     assert got.shape == (n, ho, wo, cout) and e_two < 2e-6 and e_64 < 2e-6
+
+
+def test_ablation_knobs_are_refused(vh):
+    import os
+    assert os.environ.get("VATL_ALLOW_ABLATION") != "1"
+    for knob, value in ((0, 10), (0, 13), (4, 1)):
+        with pytest.raises(vh.VatlError):
+            vh.tune_set(knob, value)
+    vh.tune_set(0, 4); vh.tune_set(4, 0); vh.tune_set(5, 0)

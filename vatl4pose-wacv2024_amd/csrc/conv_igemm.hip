@@ -36,6 +36,7 @@
 #include "common.h"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace vatl {
 
@@ -791,6 +792,13 @@ using namespace vatl;
 extern "C" int vatl_tune_wgrad_blocks(int blocks);
 
 extern "C" int vatl_tune_set(int knob, int value) {
+    // Ablation settings (schedule variants 10..13, wgrad ablation bits) produce WRONG results by construction; they exist
+    // for the profiling notes only and are refused unless the process opted in.
+    const bool ablation = (knob == 0 && value >= 10) || (knob == 4 && value != 0);
+    if (ablation) {
+        const char* ok = getenv("VATL_ALLOW_ABLATION");
+        if (!ok || ok[0] != '1') return fail(VATL_EINVAL, "tune_set: knob %d value %d is a profiling ablation (wrong results); set VATL_ALLOW_ABLATION=1", knob, value);
+    }
     if (knob == 3 && vatl_tune_wgrad_blocks(value) == 0) return 0;
     if (knob == 5 && (value == 0 || value == 64 || value == 128)) { g_bm.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
