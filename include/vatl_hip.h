@@ -143,8 +143,10 @@ int vatl_thc_combine(const float* pair, const uint8_t* is_prev, const uint8_t* i
 
 /* localpeak_mean (local_peak.py:5-22): per item the mean of 3x3 zero-padded
  * local maxima >= order * largest local maximum, pooled over joints (nan when
- * none).  count (N,J) int32 kept peaks per joint (may be NULL). */
-int vatl_localpeak_mean(const float* hm, float* mean, int32_t* count, int N, int J, int H, int W, float order, void* stream);
+ * none).  count (N,J) int32 kept peaks per joint (may be NULL).  workspace: 2*N*J doubles (per-plane sum and count;
+ * one block per plane, the per-item mean is formed in joint order by a second launch). */
+int vatl_localpeak_mean(const float* hm, float* mean, int32_t* count, double* workspace, int N, int J, int H, int W, float order,
+                        void* stream);
 
 /* compute_hybrid + WholeBodyAE + MSELoss (hybrid_feature.py:14-59,
  * AutoEncoder.py:13-39, ActiveLearning.py:364-386).  kpts (N,17,3) (x,y,score)

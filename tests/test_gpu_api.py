@@ -136,6 +136,7 @@ def test_mpe_margin_entropy_criteria():
     hm[3, 0] = 0.0; hm[3, 0, 4, 10] = 2.0; hm[3, 0, 5, 10] = 1.0; hm[3, 0, 40, 5] = 0.5         # a border maximum is dropped but still shadows (5,10); (40,5) is the first non-border column
     hm[4] = np.abs(hm[4]) + 1e-3                              # non-negative item: finite entropy
     hm[5, 2] = 0.0                                            # zero plane: entropy nan, no peaks
+    hm[0, 1] = 0.0; hm[0, 1, 30, 20] = -1.0                   # a plateau of thousands of equal candidates (list overflow path)
     d = to_dev(hm)
     val, idx, cnt, mpe, mar = vh.peaks5(d, 5)
     val, idx, cnt = val.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy()

@@ -45,12 +45,14 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
                                                          float* __restrict__ coords, float* __restrict__ scores, int J, int H, int W) {
     const int item = blockIdx.x / J;
     const int HW = H * W;
-    const float* src = hm + (long long)blockIdx.x * HW;
+    const float* gsrc = hm + (long long)blockIdx.x * HW;
     const int tid = threadIdx.x;
+    extern __shared__ float plane[];                   // the plane is read from HBM once
     __shared__ float red[4];
     __shared__ double dred[3][4];
     float mx = -INFINITY;
-    for (int q = tid; q < HW; q += 256) mx = fmaxf(mx, src[q]);
+    for (int q = tid; q < HW; q += 256) { const float v = gsrc[q]; plane[q] = v; mx = fmaxf(mx, v); }
+    const float* src = plane;                          // each thread re-reads only what it wrote
     mx = wave_max(mx);
     if ((tid & 63) == 0) red[tid >> 6] = mx;
     __syncthreads();
@@ -205,9 +207,11 @@ extern "C" int vatl_decode_softargmax(const float* hm, const float* bbox, float*
     if (N <= 0) return 0;
     if (!hm || !bbox || !coords || !scores) return fail(VATL_EINVAL, "decode_softargmax: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (norm_type == 0) hipLaunchKernelGGL(softargmax_kernel<0>, dim3(N * J), dim3(256), 0, st, hm, bbox, coords, scores, J, H, W);
-    else if (norm_type == 1) hipLaunchKernelGGL(softargmax_kernel<1>, dim3(N * J), dim3(256), 0, st, hm, bbox, coords, scores, J, H, W);
-    else if (norm_type == 2) hipLaunchKernelGGL(softargmax_kernel<2>, dim3(N * J), dim3(256), 0, st, hm, bbox, coords, scores, J, H, W);
+    const size_t smem = (size_t)H * W * sizeof(float);
+    if (smem > 60 * 1024) return fail(VATL_EINVAL, "decode_softargmax: heat-map %dx%d too large for the LDS tile", H, W);
+    if (norm_type == 0) hipLaunchKernelGGL(softargmax_kernel<0>, dim3(N * J), dim3(256), smem, st, hm, bbox, coords, scores, J, H, W);
+    else if (norm_type == 1) hipLaunchKernelGGL(softargmax_kernel<1>, dim3(N * J), dim3(256), smem, st, hm, bbox, coords, scores, J, H, W);
+    else if (norm_type == 2) hipLaunchKernelGGL(softargmax_kernel<2>, dim3(N * J), dim3(256), smem, st, hm, bbox, coords, scores, J, H, W);
     else return fail(VATL_EINVAL, "decode_softargmax: norm_type must be 0 (softmax), 1 (sigmoid) or 2 (divide_sum)");
     return check_launch("decode_softargmax");
 }

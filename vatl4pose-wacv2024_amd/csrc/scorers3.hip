@@ -67,20 +67,61 @@ __global__ __launch_bounds__(256) void peaks5_kernel(const float* __restrict__ h
         img[i] = (inside && v == m && v > mn) ? v : -INFINITY;     // each thread rewrites only what it alone reads
     }
     __syncthreads();
+    // Candidates are few (a handful per plane): compact them into a list and let the greedy selection run over the
+    // list; a plateau-ridden plane with more than CAP candidates falls back to arg-max passes over the whole plane.
+    constexpr int CAP = 256;
+    __shared__ float cval[CAP]; __shared__ int cidx[CAP]; __shared__ int ccount;
+    if (threadIdx.x == 0) ccount = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float v = img[i];
+        if (v != -INFINITY) { const int slot = atomicAdd(&ccount, 1); if (slot < CAP) { cval[slot] = v; cidx[slot] = i; } }
+    }
+    __syncthreads();
+    const int nc = ccount;
     float pv[5]; int pi[5]; int n = 0;
-    for (int k = 0; k < 5; ++k) {
-        float bv;
-        const int bi = block_argmax(img, HW, sval, sidx, bv);
-        if (bi < 0) break;
-        pv[n] = bv; pi[n] = bi; ++n;
-        const int by = bi / W, bx = bi - by * W;
-        // reject everything at Chebyshev distance < D (the accepted peak itself included)
-        const int side = 2 * D - 1;
-        for (int t = threadIdx.x; t < side * side; t += 256) {
-            const int yy = by - (D - 1) + t / side, xx = bx - (D - 1) + t % side;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) img[yy * W + xx] = -INFINITY;
+    if (nc <= CAP) {
+        for (int k = 0; k < 5; ++k) {                            // block_argmax orders by (value desc, flat index asc): slot order is irrelevant
+            float bv = -INFINITY; int bi = 0x7FFFFFFF;
+            for (int t = threadIdx.x; t < nc; t += 256) {
+                const float x = cval[t]; const int xi = cidx[t];
+                if (x > bv || (x == bv && xi < bi)) { bv = x; bi = xi; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if ((threadIdx.x & 63) == 0) { sval[threadIdx.x >> 6] = bv; sidx[threadIdx.x >> 6] = bi; }
+            __syncthreads();
+            bv = sval[0]; bi = sidx[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w)
+                if (sval[w] > bv || (sval[w] == bv && sidx[w] < bi)) { bv = sval[w]; bi = sidx[w]; }
+            __syncthreads();
+            if (bv == -INFINITY) break;
+            pv[n] = bv; pi[n] = bi; ++n;
+            const int by = bi / W, bx = bi - by * W;
+            for (int t = threadIdx.x; t < nc; t += 256) {        // reject everything at Chebyshev distance < D (itself included)
+                const int yy = cidx[t] / W, xx = cidx[t] - yy * W;
+                if (abs(yy - by) < D && abs(xx - bx) < D) cval[t] = -INFINITY;
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    } else {
+        for (int k = 0; k < 5; ++k) {
+            float bv;
+            const int bi = block_argmax(img, HW, sval, sidx, bv);
+            if (bi < 0) break;
+            pv[n] = bv; pi[n] = bi; ++n;
+            const int by = bi / W, bx = bi - by * W;
+            const int side = 2 * D - 1;
+            for (int t = threadIdx.x; t < side * side; t += 256) {
+                const int yy = by - (D - 1) + t / side, xx = bx - (D - 1) + t % side;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) img[yy * W + xx] = -INFINITY;
+            }
+            __syncthreads();
+        }
     }
     if (threadIdx.x == 0) {
         const long long o = (long long)blockIdx.x;
@@ -102,10 +143,12 @@ __global__ __launch_bounds__(256) void peaks5_kernel(const float* __restrict__ h
 // scipy.stats.entropy(plane.flatten()): p = h / sum(h); sum of entr(p) with entr(p) = -p ln p (p > 0), 0 (p == 0),
 // -inf (p < 0); a zero sum gives nan like numpy's 0/0 and x/0.
 __global__ __launch_bounds__(256) void plane_entropy_kernel(const float* __restrict__ hm, float* __restrict__ out, int HW) {
-    const float* src = hm + (long long)blockIdx.x * HW;
+    const float* gsrc = hm + (long long)blockIdx.x * HW;
+    extern __shared__ float plane[];                   // read from HBM once; each thread re-reads only what it wrote
     __shared__ double sh[4];
     double s = 0.0;
-    for (int i = threadIdx.x; i < HW; i += 256) s += (double)src[i];
+    for (int i = threadIdx.x; i < HW; i += 256) { const float v = gsrc[i]; plane[i] = v; s += (double)v; }
+    const float* src = plane;
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -182,6 +225,8 @@ extern "C" int vatl_peaks5(const float* hm, float* peak_val, int32_t* peak_idx, 
 extern "C" int vatl_plane_entropy(const float* hm, float* out, int N, int J, int H, int W, void* stream) {
     if (N <= 0) return 0;
     if (!hm || !out) return fail(VATL_EINVAL, "plane_entropy: null pointer");
-    hipLaunchKernelGGL(plane_entropy_kernel, dim3((unsigned)(N * J)), dim3(256), 0, (hipStream_t)stream, hm, out, H * W);
+    const size_t smem = (size_t)H * W * sizeof(float);
+    if (smem > 60 * 1024) return fail(VATL_EINVAL, "plane_entropy: heat-map %dx%d too large for the LDS tile", H, W);
+    hipLaunchKernelGGL(plane_entropy_kernel, dim3((unsigned)(N * J)), dim3(256), smem, (hipStream_t)stream, hm, out, H * W);
     return check_launch("plane_entropy");
 }

@@ -46,7 +46,7 @@ SIGNATURES = {
     "vatl_decode_argmax_affine": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_thc_pairs": (_i, [_p, _p, _i64, _i64, _p, _i, _i, _i, _i, _p]),
     "vatl_thc_combine": (_i, [_p, _p, _p, _p, _i, _p]),
-    "vatl_localpeak_mean": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "vatl_localpeak_mean": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "vatl_hybrid_ae_wpu": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i, _p]),
     "vatl_tpc_stream": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "vatl_decode_softargmax": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -381,7 +381,9 @@ def localpeak_mean(hm: torch.Tensor, order: float = 0.5):
     n, j, h, w = hm.shape
     mean = torch.empty(n, device=hm.device, dtype=torch.float32)
     cnt = torch.empty((n, j), device=hm.device, dtype=torch.int32)
-    _check(lib().vatl_localpeak_mean(_ptr(hm), _ptr(mean), _ptr(cnt, torch.int32), n, j, h, w, order, _stream()), "vatl_localpeak_mean")
+    ws = torch.empty(2 * n * j, device=hm.device, dtype=torch.float64)
+    _check(lib().vatl_localpeak_mean(_ptr(hm), _ptr(mean), _ptr(cnt, torch.int32), _ptr(ws, torch.float64), n, j, h, w, order, _stream()),
+           "vatl_localpeak_mean")
     return mean, cnt
 
 
