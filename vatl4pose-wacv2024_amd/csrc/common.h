@@ -46,4 +46,8 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// q / w for 0 <= q < 2^20, 1 <= w <= 4096 without an integer division: (q + 0.5) / w is at least 0.5 / w away from
+// every integer, far more than the float32 rounding error of the product, so the truncation is exact.
+__device__ __forceinline__ int fast_div(int q, float inv_w) { return (int)(((float)q + 0.5f) * inv_w); }
+
 }  // namespace vatl

@@ -125,31 +125,45 @@ __global__ void thc_combine_kernel(const float* __restrict__ pair, const uint8_t
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void localpeak_plane_kernel(const float* __restrict__ hm, double* __restrict__ ws, int32_t* __restrict__ count_out,
                                                               int H, int W, float order) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];        // (H+2) x (W+2)
+    extern __shared__ __attribute__((aligned(16))) float tile[];        // (H+2) x (W+2), zero halo = mode='constant', cval=0
     __shared__ float wmax[4];
     __shared__ int wcnt[4];
     __shared__ double wsum[4];
     const int tid = threadIdx.x;
-    const int HW = H * W, PW = W + 2, PN = (H + 2) * PW;
+    const int HW = H * W, PW = W + 2;
+    const float inv_w = 1.0f / (float)W;
     const float* src = hm + (long long)blockIdx.x * HW;
-    for (int q = tid; q < PN; q += 256) {
-        const int y = q / PW - 1, x = q % PW - 1;
-        tile[q] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? src[y * W + x] : 0.f;   // mode='constant', cval=0
+    // interior: 16-byte global loads (W % 4 == 0: a float4 never straddles rows); halo: zeros
+    const int n4 = HW >> 2, W4 = W >> 2;
+    const float inv_w4 = 1.0f / (float)W4;
+    for (int q = tid; q < n4; q += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q);
+        const int y = fast_div(q, inv_w4), x = 4 * (q - y * W4);
+        float* d = tile + (y + 1) * PW + x + 1;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
     }
+    for (int q = tid; q < PW; q += 256) { tile[q] = 0.f; tile[(H + 1) * PW + q] = 0.f; }
+    for (int q = tid; q < H; q += 256) { tile[(q + 1) * PW] = 0.f; tile[(q + 1) * PW + W + 1] = 0.f; }
     __syncthreads();
-    // pass 1: largest local maximum (pixel equal to its 3x3 zero-padded max); the peak flag is kept in the sign of a
-    // per-thread bit set so that pass 2 does not redo the nine reads
+    // pass 1: local maxima (pixel equal to its 3x3 zero-padded max) and the largest of them.  Each thread owns 1x4
+    // strips: 18 LDS reads serve four pixels.  Peak flags are kept in a per-thread bit set for pass 2.
     float pmax = -INFINITY;
-    unsigned long long flags = 0ull;                           // element q = tid + 256 k  ->  bit k  (HW <= 64 * 256)
+    unsigned long long flags = 0ull;                           // strip k of this thread, pixel e  ->  bit 4k + e   (n4 <= 16 * 256)
     int k = 0;
-    for (int q = tid; q < HW; q += 256, ++k) {
-        const int y = q / W, x = q - y * W;
+    for (int q = tid; q < n4; q += 256, ++k) {
+        const int y = fast_div(q, inv_w4), x = 4 * (q - y * W4);
         const float* c = tile + (y + 1) * PW + (x + 1);
-        const float v = c[0];
-        float m = fmaxf(fmaxf(c[-PW - 1], c[-PW]), c[-PW + 1]);
-        m = fmaxf(m, fmaxf(c[-1], c[1]));
-        m = fmaxf(m, fmaxf(fmaxf(c[PW - 1], c[PW]), c[PW + 1]));
-        if (v >= m) { pmax = fmaxf(pmax, v); flags |= 1ull << k; }
+        float up[6], mid[6], dn[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) { up[e] = c[-PW - 1 + e]; mid[e] = c[-1 + e]; dn[e] = c[PW - 1 + e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = mid[e + 1];
+            float m = fmaxf(fmaxf(up[e], up[e + 1]), up[e + 2]);
+            m = fmaxf(m, fmaxf(mid[e], mid[e + 2]));
+            m = fmaxf(m, fmaxf(fmaxf(dn[e], dn[e + 1]), dn[e + 2]));
+            if (v >= m) { pmax = fmaxf(pmax, v); flags |= 1ull << (4 * k + e); }
+        }
     }
     pmax = wave_max(pmax);
     if ((tid & 63) == 0) wmax[tid >> 6] = pmax;
@@ -159,15 +173,19 @@ __global__ __launch_bounds__(256) void localpeak_plane_kernel(const float* __res
     const float thr = pmax * order;
     float s = 0.f;
     int cnt = 0;
-    if (pmax > -INFINITY) {
+    if (pmax > -INFINITY && flags) {
         k = 0;
-        for (int q = tid; q < HW; q += 256, ++k) {
-            if (!((flags >> k) & 1ull)) continue;
-            const int y = q / W, x = q - y * W;
-            const float v = tile[(y + 1) * PW + (x + 1)];
-            if (v >= thr) { s += v; ++cnt; }
+        for (int q = tid; q < n4; q += 256, ++k) {
+            const unsigned f = (unsigned)(flags >> (4 * k)) & 15u;
+            if (!f) continue;
+            const int y = fast_div(q, inv_w4), x = 4 * (q - y * W4);
+            const float* c = tile + (y + 1) * PW + (x + 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if ((f >> e) & 1u) { const float v = c[e]; if (v >= thr) { s += v; ++cnt; } }
         }
     }
+    (void)inv_w;
     const double ds = wave_sum((double)s);
     cnt = wave_sum(cnt);
     if ((tid & 63) == 0) { wsum[tid >> 6] = ds; wcnt[tid >> 6] = cnt; }
@@ -310,6 +328,7 @@ extern "C" int vatl_localpeak_mean(const float* hm, float* mean, int32_t* count,
     if (!hm || !mean || !workspace) return fail(VATL_EINVAL, "localpeak_mean: null pointer");
     const size_t smem = (size_t)(H + 2) * (W + 2) * sizeof(float);
     if (smem > 60 * 1024 || (long long)H * W > 64 * 256) return fail(VATL_EINVAL, "localpeak_mean: heat-map %dx%d too large for the LDS tile", H, W);
+    if (W & 3) return fail(VATL_EINVAL, "localpeak_mean: heat-map width %d must be a multiple of 4", W);
     hipLaunchKernelGGL(localpeak_plane_kernel, dim3((unsigned)(N * J)), dim3(256), smem, (hipStream_t)stream, hm, workspace, count, H, W, order);
     hipLaunchKernelGGL(localpeak_finish_kernel, dim3(cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, workspace, mean, N, J);
     return check_launch("localpeak_mean");

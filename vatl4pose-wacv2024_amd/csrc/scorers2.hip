@@ -58,13 +58,14 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     double s = 0.0, sx = 0.0, sy = 0.0;
+    const float inv_w = 1.0f / (float)W;
     for (int q = tid; q < HW; q += 256) {
         const float v = src[q];
         float p;
         if (NORM == 0) p = expf(v - mx);
         else if (NORM == 1) p = 1.f / (1.f + expf(-v));
         else p = v;
-        const int y = q / W, x = q - y * W;
+        const int y = fast_div(q, inv_w), x = q - y * W;
         s += p; sx += (double)p * x; sy += (double)p * y;
     }
     s = wave_sum(s); sx = wave_sum(sx); sy = wave_sum(sy);

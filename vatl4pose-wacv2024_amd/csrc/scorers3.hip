@@ -49,22 +49,44 @@ __global__ __launch_bounds__(256) void peaks5_kernel(const float* __restrict__ h
     __syncthreads();
     mn = fminf(fminf(sval[0], sval[1]), fminf(sval[2], sval[3]));
     __syncthreads();
-    for (int i = threadIdx.x; i < HW; i += 256) {
-        const int y = i / W, x = i - y * W;
-        const int x0 = max(x - D, 0), x1 = min(x + D, W - 1);
-        float m = img[y * W + x0];
-        for (int xx = x0 + 1; xx <= x1; ++xx) m = fmaxf(m, img[y * W + xx]);
-        tmp[i] = m;
+    // separable (2D+1)^2 maximum filter with replicated edges (= maximum over the in-range part of the window).
+    // Row pass: each thread produces 4 consecutive outputs from one sliding window (4 + 2D reads instead of 4 (2D+1)).
+    const float inv_w = 1.0f / (float)W;
+    const int W4 = (W + 3) >> 2;
+    const float inv_w4 = 1.0f / (float)W4;
+    for (int q = threadIdx.x; q < H * W4; q += 256) {
+        const int y = fast_div(q, inv_w4), x = 4 * (q - y * W4);
+        const float* row = img + y * W;
+        float core = -INFINITY;                                   // columns x+3-D .. x+D are common to all four windows
+        for (int xx = max(x + 3 - D, 0); xx <= min(x + D, W - 1); ++xx) core = fmaxf(core, row[xx]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (x + e >= W) break;
+            float m = core;
+            for (int xx = max(x + e - D, 0); xx < max(x + 3 - D, 0); ++xx) m = fmaxf(m, row[xx]);          // left extras
+            for (int xx = min(x + D, W - 1) + 1; xx <= min(x + e + D, W - 1); ++xx) m = fmaxf(m, row[xx]);   // right extras
+            tmp[y * W + x + e] = m;
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < HW; i += 256) {
-        const int y = i / W, x = i - y * W;
-        const int y0 = max(y - D, 0), y1 = min(y + D, H - 1);
-        float m = tmp[y0 * W + x];
-        for (int yy = y0 + 1; yy <= y1; ++yy) m = fmaxf(m, tmp[yy * W + x]);
-        const float v = img[i];
-        const bool inside = y >= D && y < H - D && x >= D && x < W - D;
-        img[i] = (inside && v == m && v > mn) ? v : -INFINITY;     // each thread rewrites only what it alone reads
+    // Column pass, same sliding scheme over 4 consecutive rows of one column
+    const int H4 = (H + 3) >> 2;
+    for (int q = threadIdx.x; q < H4 * W; q += 256) {
+        const int yb = fast_div(q, inv_w), x = q - yb * W;
+        const int y = 4 * yb;
+        float core = -INFINITY;
+        for (int yy = max(y + 3 - D, 0); yy <= min(y + D, H - 1); ++yy) core = fmaxf(core, tmp[yy * W + x]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int yo = y + e;
+            if (yo >= H) break;
+            float m = core;
+            for (int yy = max(yo - D, 0); yy < max(y + 3 - D, 0); ++yy) m = fmaxf(m, tmp[yy * W + x]);
+            for (int yy = min(y + D, H - 1) + 1; yy <= min(yo + D, H - 1); ++yy) m = fmaxf(m, tmp[yy * W + x]);
+            const float v = img[yo * W + x];
+            const bool inside = yo >= D && yo < H - D && x >= D && x < W - D;
+            img[yo * W + x] = (inside && v == m && v > mn) ? v : -INFINITY;     // each thread rewrites only what it alone reads
+        }
     }
     __syncthreads();
     // Candidates are few (a handful per plane): compact them into a list and let the greedy selection run over the
@@ -103,7 +125,7 @@ __global__ __launch_bounds__(256) void peaks5_kernel(const float* __restrict__ h
             pv[n] = bv; pi[n] = bi; ++n;
             const int by = bi / W, bx = bi - by * W;
             for (int t = threadIdx.x; t < nc; t += 256) {        // reject everything at Chebyshev distance < D (itself included)
-                const int yy = cidx[t] / W, xx = cidx[t] - yy * W;
+                const int yy = fast_div(cidx[t], inv_w), xx = cidx[t] - yy * W;
                 if (abs(yy - by) < D && abs(xx - bx) < D) cval[t] = -INFINITY;
             }
             __syncthreads();
