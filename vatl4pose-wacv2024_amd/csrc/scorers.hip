@@ -198,6 +198,64 @@ __global__ __launch_bounds__(256) void localpeak_plane_kernel(const float* __res
     }
 }
 
+// any width (the per-item API accepts arbitrary planes): scalar loads, one pixel per thread step
+__global__ __launch_bounds__(256) void localpeak_plane_generic_kernel(const float* __restrict__ hm, double* __restrict__ ws, int32_t* __restrict__ count_out,
+                                                              int H, int W, float order) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];        // (H+2) x (W+2)
+    __shared__ float wmax[4];
+    __shared__ int wcnt[4];
+    __shared__ double wsum[4];
+    const int tid = threadIdx.x;
+    const int HW = H * W, PW = W + 2, PN = (H + 2) * PW;
+    const float* src = hm + (long long)blockIdx.x * HW;
+    for (int q = tid; q < PN; q += 256) {
+        const int y = q / PW - 1, x = q % PW - 1;
+        tile[q] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? src[y * W + x] : 0.f;   // mode='constant', cval=0
+    }
+    __syncthreads();
+    // pass 1: largest local maximum (pixel equal to its 3x3 zero-padded max); the peak flag is kept in the sign of a
+    // per-thread bit set so that pass 2 does not redo the nine reads
+    float pmax = -INFINITY;
+    unsigned long long flags = 0ull;                           // element q = tid + 256 k  ->  bit k  (HW <= 64 * 256)
+    int k = 0;
+    for (int q = tid; q < HW; q += 256, ++k) {
+        const int y = q / W, x = q - y * W;
+        const float* c = tile + (y + 1) * PW + (x + 1);
+        const float v = c[0];
+        float m = fmaxf(fmaxf(c[-PW - 1], c[-PW]), c[-PW + 1]);
+        m = fmaxf(m, fmaxf(c[-1], c[1]));
+        m = fmaxf(m, fmaxf(fmaxf(c[PW - 1], c[PW]), c[PW + 1]));
+        if (v >= m) { pmax = fmaxf(pmax, v); flags |= 1ull << k; }
+    }
+    pmax = wave_max(pmax);
+    if ((tid & 63) == 0) wmax[tid >> 6] = pmax;
+    __syncthreads();
+    pmax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    // pass 2: keep peaks >= order * largest peak
+    const float thr = pmax * order;
+    float s = 0.f;
+    int cnt = 0;
+    if (pmax > -INFINITY) {
+        k = 0;
+        for (int q = tid; q < HW; q += 256, ++k) {
+            if (!((flags >> k) & 1ull)) continue;
+            const int y = q / W, x = q - y * W;
+            const float v = tile[(y + 1) * PW + (x + 1)];
+            if (v >= thr) { s += v; ++cnt; }
+        }
+    }
+    const double ds = wave_sum((double)s);
+    cnt = wave_sum(cnt);
+    if ((tid & 63) == 0) { wsum[tid >> 6] = ds; wcnt[tid >> 6] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        const int c = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        ws[2 * (long long)blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        ws[2 * (long long)blockIdx.x + 1] = (double)c;
+        if (count_out) count_out[blockIdx.x] = c;
+    }
+}
+
 __global__ void localpeak_finish_kernel(const double* __restrict__ ws, float* __restrict__ mean_out, int N, int J) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -328,8 +386,8 @@ extern "C" int vatl_localpeak_mean(const float* hm, float* mean, int32_t* count,
     if (!hm || !mean || !workspace) return fail(VATL_EINVAL, "localpeak_mean: null pointer");
     const size_t smem = (size_t)(H + 2) * (W + 2) * sizeof(float);
     if (smem > 60 * 1024 || (long long)H * W > 64 * 256) return fail(VATL_EINVAL, "localpeak_mean: heat-map %dx%d too large for the LDS tile", H, W);
-    if (W & 3) return fail(VATL_EINVAL, "localpeak_mean: heat-map width %d must be a multiple of 4", W);
-    hipLaunchKernelGGL(localpeak_plane_kernel, dim3((unsigned)(N * J)), dim3(256), smem, (hipStream_t)stream, hm, workspace, count, H, W, order);
+    if (W & 3) hipLaunchKernelGGL(localpeak_plane_generic_kernel, dim3((unsigned)(N * J)), dim3(256), smem, (hipStream_t)stream, hm, workspace, count, H, W, order);
+    else       hipLaunchKernelGGL(localpeak_plane_kernel, dim3((unsigned)(N * J)), dim3(256), smem, (hipStream_t)stream, hm, workspace, count, H, W, order);
     hipLaunchKernelGGL(localpeak_finish_kernel, dim3(cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, workspace, mean, N, J);
     return check_launch("localpeak_mean");
 }
