@@ -47,11 +47,20 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
     const int HW = H * W;
     const float* gsrc = hm + (long long)blockIdx.x * HW;
     const int tid = threadIdx.x;
-    extern __shared__ float plane[];                   // the plane is read from HBM once
+    extern __shared__ __attribute__((aligned(16))) float plane[];   // the plane is read from HBM once
     __shared__ float red[4];
     __shared__ double dred[3][4];
     float mx = -INFINITY;
-    for (int q = tid; q < HW; q += 256) { const float v = gsrc[q]; plane[q] = v; mx = fmaxf(mx, v); }
+    const int step = (HW & 3) == 0 ? 4 : 1;            // 16-byte loads when the plane allows it
+    if (step == 4) {
+        for (int q = tid; q < (HW >> 2); q += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(gsrc + 4 * q);
+            *reinterpret_cast<f32x4*>(plane + 4 * q) = v;
+            mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+        }
+    } else {
+        for (int q = tid; q < HW; q += 256) { const float v = gsrc[q]; plane[q] = v; mx = fmaxf(mx, v); }
+    }
     const float* src = plane;                          // each thread re-reads only what it wrote
     mx = wave_max(mx);
     if ((tid & 63) == 0) red[tid >> 6] = mx;
@@ -59,14 +68,16 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     double s = 0.0, sx = 0.0, sy = 0.0;
     const float inv_w = 1.0f / (float)W;
-    for (int q = tid; q < HW; q += 256) {
-        const float v = src[q];
-        float p;
-        if (NORM == 0) p = expf(v - mx);
-        else if (NORM == 1) p = 1.f / (1.f + expf(-v));
-        else p = v;
-        const int y = fast_div(q, inv_w), x = q - y * W;
-        s += p; sx += (double)p * x; sy += (double)p * y;
+    for (int q0 = tid * step; q0 < HW; q0 += 256 * step) {
+        for (int q = q0; q < q0 + step; ++q) {
+            const float v = src[q];
+            float p;
+            if (NORM == 0) p = expf(v - mx);
+            else if (NORM == 1) p = 1.f / (1.f + expf(-v));
+            else p = v;
+            const int y = fast_div(q, inv_w), x = q - y * W;
+            s += p; sx += (double)p * x; sy += (double)p * y;
+        }
     }
     s = wave_sum(s); sx = wave_sum(sx); sy = wave_sum(sy);
     if ((tid & 63) == 0) { dred[0][tid >> 6] = s; dred[1][tid >> 6] = sx; dred[2][tid >> 6] = sy; }

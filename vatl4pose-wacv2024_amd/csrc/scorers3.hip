@@ -166,25 +166,36 @@ __global__ __launch_bounds__(256) void peaks5_kernel(const float* __restrict__ h
 // -inf (p < 0); a zero sum gives nan like numpy's 0/0 and x/0.
 __global__ __launch_bounds__(256) void plane_entropy_kernel(const float* __restrict__ hm, float* __restrict__ out, int HW) {
     const float* gsrc = hm + (long long)blockIdx.x * HW;
-    extern __shared__ float plane[];                   // read from HBM once; each thread re-reads only what it wrote
+    extern __shared__ __attribute__((aligned(16))) float plane[];   // read from HBM once; each thread re-reads only what it wrote
     __shared__ double sh[4];
     double s = 0.0;
-    for (int i = threadIdx.x; i < HW; i += 256) { const float v = gsrc[i]; plane[i] = v; s += (double)v; }
+    if ((HW & 3) == 0) {                               // 16-byte loads
+        for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(gsrc + 4 * i);
+            *reinterpret_cast<f32x4*>(plane + 4 * i) = v;
+            s += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 256) { const float v = gsrc[i]; plane[i] = v; s += (double)v; }
+    }
     const float* src = plane;
+    const int step = (HW & 3) == 0 ? 4 : 1;            // pass 2 walks the elements this thread staged
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
     const float total = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
     __syncthreads();
     double e = 0.0;
-    for (int i = threadIdx.x; i < HW; i += 256) {
-        const float p = src[i] / total;
-        float t;
-        if (p > 0.f) t = -p * logf(p);
-        else if (p == 0.f) t = 0.f;
-        else if (p < 0.f) t = -INFINITY;
-        else t = p;                                             // nan
-        e += (double)t;
+    for (int i0 = threadIdx.x * step; i0 < HW; i0 += 256 * step) {
+        for (int i = i0; i < i0 + step; ++i) {
+            const float p = src[i] / total;
+            float t;
+            if (p > 0.f) t = -p * logf(p);
+            else if (p == 0.f) t = 0.f;
+            else if (p < 0.f) t = -INFINITY;
+            else t = p;                                         // nan
+            e += (double)t;
+        }
     }
     e = wave_sum(e);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = e;
