@@ -333,3 +333,30 @@ def test_ablation_knobs_are_refused(vh):
         with pytest.raises(vh.VatlError):
             vh.tune_set(knob, value)
     vh.tune_set(0, 4); vh.tune_set(4, 0); vh.tune_set(5, 0)
+
+
+def test_launches_from_several_host_threads(vh):
+    """SURVEY.md §8b threading: DataParallel drives one host thread per replica — the library keeps no per-call
+    global state, so concurrent launches on different streams give the single-thread results bit for bit."""
+    import threading
+    m = _build_simplepose()
+    xs = [to_dev(synth.crops(2, seed=100 + i)) for i in range(4)]
+    with torch.no_grad():
+        want = [m(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    got, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s), torch.no_grad():
+                for _ in range(3):
+                    got[i] = m(xs[i])
+            s.synchronize()
+        except Exception as e:                                       # pragma: no cover
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
