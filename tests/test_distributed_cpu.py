@@ -43,6 +43,10 @@ def _worker(rank, world, port, n, q):
     got = D.sharded_rows(n, lambda lo, hi: torch.from_numpy(_rows(hm, bb, is_prev, is_next, lo, hi)), 53, torch.device("cpu"))
     g = [torch.ones(5) * (rank + 1), torch.ones(3) * 10 * (rank + 1)]
     D.allreduce_mean_(g)
+    bn = torch.nn.BatchNorm2d(4)                                   # per-rank running statistics -> rank 0's survive
+    bn.running_mean.fill_(float(rank + 1)); bn.running_var.fill_(float(10 * (rank + 1)))
+    D.broadcast_buffers_(bn)
+    assert float(bn.running_mean[0]) == 1.0 and float(bn.running_var[0]) == 10.0, (rank, bn.running_mean)
     if rank == 0:
         q.put((got.numpy(), [t.numpy() for t in g]))
     dist.barrier()
