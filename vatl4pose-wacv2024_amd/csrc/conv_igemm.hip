@@ -89,7 +89,7 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned by
 
 // Epilogue shared by the conv kernels: scale/bias in registers, tile staged through LDS, then full-row 16-byte
 // stores with the residual read the same way (or per-element stores for NCHW / odd channel counts).
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NT = 256>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[WM / 32][WN / 32], float* smem, int m0, int n0,
                                               int ooy, int oox, int wm, int wn, int tid, int lane, int HoWo) {
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -106,7 +106,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     const bool plain = !p.deconv && p.osy == 1 && p.osx == 1 && p.OH == p.Ho && p.OW == p.Wo;   // NHWC output row index == m
     const bool vec = !p.out_nchw && (p.Cout & 3) == 0;
     constexpr int C4 = BN / 4;                         // float4 columns per tile row
-    constexpr int RPP = 256 / C4;                      // tile rows per pass
+    constexpr int RPP = NT / C4;                       // tile rows per pass
     constexpr int NP = BM / RPP;                       // passes
     unsigned offv[NP];
     f32x4 rsv[NP];
@@ -175,13 +175,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             // bn_train_finalize_kernel reduces in a fixed order (deterministic, no atomics).
             __syncthreads();                               // every thread is done reading Cs
             f32x4* sh = reinterpret_cast<f32x4*>(smem);
-            sh[tid] = ssum; sh[256 + tid] = ssq;
+            sh[tid] = ssum; sh[NT + tid] = ssq;
             __syncthreads();
             if (tid < C4) {
                 double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
 #pragma unroll 2                                           // (full unrolling cost the 128x32 kernel 256 VGPRs and spills)
                 for (int k = 0; k < RPP; ++k) {
-                    const f32x4 a = sh[k * C4 + tid], b = sh[256 + k * C4 + tid];
+                    const f32x4 a = sh[k * C4 + tid], b = sh[NT + k * C4 + tid];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { ds[c] += a[c]; dq[c] += b[c]; }
                 }
@@ -199,7 +199,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     } else {
         // NCHW output (heat-map head) or a channel count that is not a multiple of 4:
         // one tile row per thread, lanes run along pixels (contiguous in NCHW)
-        constexpr int CPP = 256 / BM;                  // tile columns per pass
+        constexpr int CPP = NT / BM;                   // tile columns per pass
         const int row = tid % BM, cl0 = tid / BM;
         const int m = m0 + row;
         const bool mv = m < p.M;
@@ -241,16 +241,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 //   5  LDS-DMA kernel below (buffer_load ... lds, source-side XOR swizzle): 134 — equal to VAR2, the saved
 //      ds_write pass (+5 %, ablation VAR13) is offset by its distance-1 prefetch
 // (a rotated loop that buries the tile hand-over in the last MFMA group measured equal to VAR2 and was dropped)
-template <int BM, int BN, int WM, int WN, bool STEM, int VAR, bool DUAL = false>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
+template <int BM, int BN, int WM, int WN, bool STEM, int VAR, bool DUAL = false, int NT = 256>
+__global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                          // [2][BM][LDK]
     float* Bs = smem + 2 * BM * LDK;           // [2][BN][LDK]
 
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    constexpr int LA = BM / 32, LB = BN / 32;  // 16-byte loads per thread per k-tile
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    constexpr int RP = NT / 8;                 // tile rows staged per pass (8 threads x 16 bytes cover the 32-wide k-tile)
+    constexpr int LA = BM / RP, LB = BN / RP;  // 16-byte loads per thread per k-tile
+    static_assert((BM / WM) * (BN / WN) == NT / 64, "one wave per wave tile");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -291,14 +292,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DUAL ? p.x2 : p.x), 0, DUAL ? p.x2_bytes : p.x_bytes, 0x00020000);
 
     // ---- per-thread gather state --------------------------------------------
-    const int lrow = tid >> 3;        // 0..31
+    const int lrow = tid >> 3;        // 0..RP-1
     const int kq = tid & 7;           // which float4 of the 32-wide k-tile
     int abase[LA], iy0[LA], ix0[LA];  // element offset of (b, iy0, ix0, kq*4); may be negative
     int abase2[DUAL ? LA : 1];        // DUAL: element offset of the row's pixel in the second source
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int m = m0 + lrow + RP * i;
         if (m < p.M) {
             const int b = m / HoWo;
             const int rem = m - b * HoWo;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     }
     unsigned boff[LB];
 #pragma unroll
-    for (int j = 0; j < LB; ++j) boff[j] = (unsigned)(((n0 + lrow + 32 * j) * p.K + kq * 4) * 4);
+    for (int j = 0; j < LB; ++j) boff[j] = (unsigned)(((n0 + lrow + RP * j) * p.K + kq * 4) * 4);
 
     f32x4 ra[LA], rb[LB];
     int g_r = 0, g_s = 0, g_off = 0;
@@ -352,10 +353,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < LA; ++i)
-            *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + 32 * i) * LDK + kq * 4]) = ra[i];
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + RP * i) * LDK + kq * 4]) = ra[i];
 #pragma unroll
         for (int j = 0; j < LB; ++j)
-            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + 32 * j) * LDK + kq * 4]) = rb[j];
+            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + RP * j) * LDK + kq * 4]) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -422,9 +423,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
         };
         auto stash = [&](const f32x4 (&da)[LA], const f32x4 (&db)[LB], int buf) {
 #pragma unroll
-            for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + 32 * i) * LDK + kq * 4]) = da[i];
+            for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + RP * i) * LDK + kq * 4]) = da[i];
 #pragma unroll
-            for (int j = 0; j < LB; ++j) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + 32 * j) * LDK + kq * 4]) = db[j];
+            for (int j = 0; j < LB; ++j) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + RP * j) * LDK + kq * 4]) = db[j];
         };
         issue(sa[0], sb[0], 1);
         for (int kt = 0; kt < p.ktiles; kt += 2) {
@@ -683,9 +684,9 @@ static std::atomic<int> g_order{0};    // tile order (vatl_tune_set(1, v))
 static std::atomic<int> g_bm{0};       // tile rows (vatl_tune_set(5, v)): 0 = by grid size, 64 or 128 = forced
 static std::atomic<int> g_stagger{0};  // block stagger in percent of the k-loop time (vatl_tune_set(2, v)); 0 = off
 
-template <int BM, int BN, int WM, int WN, bool STEM, int VAR, bool DUAL = false>
+template <int BM, int BN, int WM, int WN, bool STEM, int VAR, bool DUAL = false, int NT = 256>
 static int launch(const ConvParams& p, int phases, hipStream_t st) {
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM, VAR, DUAL>;
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM, VAR, DUAL, NT>;
     constexpr int smem = 2 * (BM + BN) * LDK * (int)sizeof(float);
     static std::atomic<int> configured{0};
     if (!configured.load(std::memory_order_acquire)) {
@@ -703,7 +704,7 @@ static int launch(const ConvParams& p, int phases, hipStream_t st) {
     static_assert(2 * (BM + BN) * LDK >= BM * (BN + 4), "epilogue tile must fit in the staging buffers");
     const int m_tiles = cdiv(p.M, BM);
     dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), smem, st, q);
     return check_launch("conv_igemm");
 }
 
