@@ -298,6 +298,13 @@ int vatl_l1_joint_regression_fwd_bwd(const float* hm, const float* gt_joints, co
                                      float* pred_jts, double* partial, int B, int J, int H, int W, int norm_type, int size_average,
                                      void* stream);
 
+/* One fine-tune step of the WholeBodyAE (ActiveLearning.py:905-925: AE forward, MSELoss(output, input), backward,
+ * torch.optim.Adam) on a mini-batch feat (B, D), B <= 12 (the reference uses 10), in one launch.  ae / m / v: the packed parameters
+ * (state-dict order W0,b0,...,W7,b7 = what vatl_hybrid_ae_wpu reads) and the Adam moments, updated in place;
+ * `step` is the 1-based Adam step; loss (1 float, before the update) may be NULL. */
+int vatl_ae_train_step(float* ae, float* m, float* v, const float* feat, int B, int D, int z, double lr, double beta1, double beta2,
+                       double eps, int step, float* loss_or_null, void* stream);
+
 /* torch.optim.AdamW step on one flat fp32 span (decoupled weight decay);
  * hyper-parameters are doubles like the Python floats torch derives its
  * per-step scalars from; `step` is the 1-based step count. */

@@ -19,7 +19,7 @@ def _cfg():
         "DATA_PRESET": {"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]},
         "MODEL": {"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50},
         "LOSS": {"TYPE": "MSELoss"},
-        "AE": {"Z_DIM": 4, "INPUT_DIM": 42, "PRETRAINED": ""},
+        "AE": {"Z_DIM": 4, "INPUT_DIM": 42, "PRETRAINED": "", "EPOCH": 2, "LR": 1e-3},
         "RETRAIN": {"BATCH_SIZE": 8, "BASE": 1, "OPTIMIZER": "AdamW", "LR": 2.5e-4, "ALPHA": 2, "WEIGHT_DECAY": 0.7, "LR_GAMMA": 0.99},
         "VAL": {"BATCH_SIZE": 10, "W_UNC": 0.01, "UNC_LAMBDA": 0.01, "QUERY_RATIO": [0.25, 0.5, 1.0]},
     })
@@ -55,6 +55,8 @@ def test_active_learning_rounds(unc):
         rounds += 1
         if result is None:
             assert np.isfinite(al.last_train_loss)
+            if "WPU" in unc:                                   # the AE was re-initialised and fine-tuned on the labeled poses
+                assert np.isfinite(al.last_ae_loss) and al.last_ae_loss > 0
             al.eval_and_query()
     assert result is not None and len(result) == 20                                            # the reference's 20-tuple
     assert len(al.unlabeled_id) == 0 and sorted(al.labeled_id) == list(range(24))

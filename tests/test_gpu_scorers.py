@@ -215,3 +215,46 @@ def test_l1_joint_regression_loss(vh, norm):
     assert e < 1e-4
     with pytest.raises(vh.VatlError):
         crit(torch.from_numpy(hm), torch.from_numpy(gt), torch.from_numpy(vis))
+
+
+def test_autoencoder_finetune_steps_match_torch_adam(vh):
+    """retrain_AE (ActiveLearning.py:905-925) on the device: three Adam steps on mini-batches of 10 against the torch
+    restatement (oracle.nets.WholeBodyAERef + torch.optim.Adam) — loss per step and every parameter."""
+    from active_learning.Whole_body_AE.AutoEncoder import WholeBodyAE, fit_autoencoder
+    from oracle import nets
+    r = np.random.RandomState(8)
+    for d, z in ((42, 4), (38, 2)):
+        ref = nets.WholeBodyAERef(z_dim=z, input_dim=d)
+        sd = {k: torch.from_numpy(synth.tensor_for("ae." + k, v.shape)) for k, v in ref.state_dict().items()}
+        ref.load_state_dict(sd)
+        ae = WholeBodyAE(z_dim=z, input_dim=d)
+        ae.load_state_dict(sd)
+        ae = ae.to(dev())
+        flat = vh.pack_ae(ae.state_dict(), dev()).clone()
+        m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+        opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+        for step in range(1, 4):
+            x = r.uniform(0, 1, (10 if step < 3 else 7, d)).astype(np.float32)
+            xt = torch.from_numpy(x)
+            loss_t = torch.nn.MSELoss()(ref(xt), xt)
+            opt.zero_grad(); loss_t.backward(); opt.step()
+            loss = vh.ae_train_step(flat, m, v, to_dev(x), d, z, step, 1e-2)
+            np.testing.assert_allclose(float(loss), loss_t.item(), rtol=1e-5)
+        vh.unpack_ae(flat, ae)
+        worst = 0.0
+        for (k, p), (_, q) in zip(ae.state_dict().items(), ref.state_dict().items()):
+            worst = max(worst, float((p.cpu() - q).abs().max() / (q.abs().max() + 1e-12)))
+            np.testing.assert_allclose(p.cpu().numpy(), q.numpy(), rtol=2e-4, atol=2e-6)
+        record(f"ae_train_d{d}", worst_param_rel=worst)
+    # the epoch driver: loss goes down on a fixed feature set and the module's parameters are the trained ones
+    feats = to_dev(r.uniform(0.2, 0.8, (33, 42)).astype(np.float32))
+    ae = WholeBodyAE(z_dim=4, input_dim=42).to(dev())
+    with torch.no_grad():
+        before = float(((ae(feats) - feats) ** 2).mean())
+    g = torch.Generator(); g.manual_seed(0)
+    mean_loss = fit_autoencoder(ae, feats, epochs=30, lr=1e-2, generator=g)
+    with torch.no_grad():
+        after = float(((ae(feats) - feats) ** 2).mean())
+    assert after < before and np.isfinite(mean_loss)
+    with pytest.raises(vh.VatlError):
+        vh.ae_train_step(flat, m, v, to_dev(np.zeros((13, 38), np.float32)), 38, 2, 1, 1e-2)        # batch above the kernel's 12

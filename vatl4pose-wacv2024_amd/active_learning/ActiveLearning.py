@@ -406,6 +406,32 @@ class ActiveLearning:
             self.scheduler.step()
         D.broadcast_buffers_(self.model)           # BN statistics are per rank; rank 0's survive (DataParallel semantics)
         self.last_train_loss, self.last_train_acc = loss_logger.avg, acc_logger.avg
+        if "WPU" in self.uncertainty:              # ActiveLearning.py:680-684: a fresh AE is fine-tuned on the labeled poses
+            self.AE = self.initialize_AE()
+            self.last_ae_loss = self.retrain_AE()
+
+    def retrain_AE(self):
+        """ActiveLearning.py:905-925.  The reference reads the hybrid features of the labeled people from its `Wholebody`
+        annotation dataset; here they are computed on the device from the ground-truth key-points and annotation boxes of
+        the labeled items (`compute_hybrid`, hybrid_feature.py:14-59), people without a visible key-point skipped like
+        Whole_body_hybrid.py:54-55."""
+        from .Whole_body_AE.AutoEncoder import fit_autoencoder
+        epochs = int(self.cfg.AE.get("EPOCH", 0))
+        if epochs <= 0 or not self.labeled_id:
+            return 0.0
+        gts, boxes = [], []
+        for i in self.labeled_id:
+            item = self.eval_dataset[i]
+            gt = np.asarray(item[4], np.float64).reshape(-1)
+            if gt[2::3].sum() == 0:
+                continue
+            gts.append(gt)
+            boxes.append(bbox_xyxy_to_xywh(np.asarray(item[8], np.float64).tolist()))
+        if not gts:
+            return 0.0
+        feat, status = vh.hybrid_feature_f64(torch.as_tensor(np.stack(gts), device=self.device), torch.as_tensor(np.asarray(boxes, np.float64), device=self.device))
+        feat = feat[status == 0].float()[:, :self.AE.input_dim].contiguous()
+        return fit_autoencoder(self.AE, feat, epochs, float(self.cfg.AE.get("LR", 1e-3)))
 
     # ------------------------------------------------------------------ round logic (ActiveLearning.py:166-205)
     def outcome(self):

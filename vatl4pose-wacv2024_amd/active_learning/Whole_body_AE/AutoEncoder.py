@@ -39,3 +39,27 @@ class WholeBodyAE(nn.Module):
         flat = x.detach().float().reshape(-1, self.input_dim).contiguous()
         recon, _ = vh.ae_forward(flat, self.packed(), self.input_dim, self.z_dim)
         return recon.reshape(x.shape)
+
+
+def fit_autoencoder(ae: WholeBodyAE, features: torch.Tensor, epochs: int, lr: float, batch_size: int = 10, generator=None):
+    """retrain_AE (ActiveLearning.py:905-925): ``epochs`` passes of shuffled mini-batches (batch 10 in the reference),
+    AE forward + MSELoss(output, input) + backward + torch.optim.Adam(lr) — every mini-batch is ONE
+    ``vatl_ae_train_step`` launch on the packed parameters.  Returns the mean loss over all steps."""
+    if not features.is_cuda:
+        raise vh.VatlError("the auto-encoder trains on MI355X only (no CPU fallback)")
+    feats = features.detach().float().reshape(-1, ae.input_dim).contiguous()
+    n = feats.shape[0]
+    if n == 0 or epochs <= 0:
+        return 0.0
+    flat = vh.pack_ae(ae.state_dict(), feats.device).clone()
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    losses, step = [], 0
+    for _ in range(int(epochs)):
+        perm = torch.randperm(n, generator=generator, device="cpu").to(feats.device)
+        for i in range(0, n, batch_size):
+            step += 1
+            losses.append(vh.ae_train_step(flat, m, v, feats[perm[i:i + batch_size]].contiguous(), ae.input_dim, ae.z_dim, step, lr))
+    vh.unpack_ae(flat, ae)
+    for p in ae.parameters():                                   # in-place update through the C ABI: bump the version counters
+        torch.autograd.graph.increment_version(p)
+    return float(torch.stack(losses).mean())

@@ -230,6 +230,82 @@ __global__ __launch_bounds__(256) void l1_finish_kernel(const double* __restrict
     if (threadIdx.x == 0) *loss = (float)((part[0] + part[1] + part[2] + part[3]) * scale);
 }
 
+// --------------------------------------------------------------------------
+// WholeBodyAE fine-tune step (ActiveLearning.py:905-925: forward, MSELoss(output, input), backward, torch.optim.Adam)
+// for one mini-batch, the whole step in ONE block: the 8-layer MLP has ~3 k parameters (AutoEncoder.py:13-32), they
+// and the batch activations live in LDS.  Parameter layout = vatl_pack_ae order (W0,b0,...,W7,b7).
+// --------------------------------------------------------------------------
+constexpr int AE_MAXB = 12, AE_MAXW = 64, AE_MAXP = 2 * (64 * 24 + 24 * 12 + 12 * 7 + 7 * 64) + 2 * (24 + 12 + 7) + 64 + 64;
+
+__global__ __launch_bounds__(256) void ae_train_step_kernel(float* __restrict__ ae, float* __restrict__ am, float* __restrict__ av,
+                                                            const float* __restrict__ feat, int B, int D, int z, float step_size, float b1,
+                                                            float b2, float bc2s, float eps, float* __restrict__ loss_out) {
+    __shared__ float W[AE_MAXP];                     // stays at the pre-step values until every delta is formed
+    __shared__ float act[9][AE_MAXB][AE_MAXW];
+    __shared__ float delta[2][AE_MAXB][AE_MAXW];
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int dims[9] = {D, 24, 12, 7, z, 7, 12, 24, D};
+    int offw[8], offb[8], P = 0;
+    for (int l = 0; l < 8; ++l) { offw[l] = P; P += dims[l + 1] * dims[l]; offb[l] = P; P += dims[l + 1]; }
+    for (int i = tid; i < P; i += 256) W[i] = ae[i];
+    for (int i = tid; i < B * D; i += 256) act[0][i / D][i % D] = feat[i];
+    __syncthreads();
+    // forward
+    for (int l = 0; l < 8; ++l) {
+        const int ni = dims[l], no = dims[l + 1];
+        for (int idx = tid; idx < B * no; idx += 256) {
+            const int b = idx / no, o = idx - b * no;
+            float acc = W[offb[l] + o];
+            for (int i = 0; i < ni; ++i) acc = fmaf(W[offw[l] + o * ni + i], act[l][b][i], acc);
+            if (l == 7) acc = 1.f / (1.f + expf(-acc));
+            else if (l != 3) acc = fmaxf(acc, 0.f);
+            act[l + 1][b][o] = acc;
+        }
+        __syncthreads();
+    }
+    // loss and output delta (through the sigmoid)
+    const float inv = 1.f / (float)(B * D);
+    float ls = 0.f;
+    for (int idx = tid; idx < B * D; idx += 256) {
+        const int b = idx / D, o = idx - b * D;
+        const float y = act[8][b][o], d = y - act[0][b][o];
+        ls += d * d;
+        delta[0][b][o] = 2.f * d * inv * y * (1.f - y);
+    }
+    ls = wave_sum(ls);
+    if ((tid & 63) == 0) red[tid >> 6] = ls;
+    __syncthreads();
+    if (tid == 0 && loss_out) *loss_out = (red[0] + red[1] + red[2] + red[3]) * inv;
+    // backward
+    int cur = 0;
+    for (int l = 7; l >= 0; --l) {
+        const int ni = dims[l], no = dims[l + 1];
+        for (int idx = tid; idx < no * ni + no; idx += 256) {
+            float g = 0.f;
+            int pi;
+            if (idx < no * ni) { const int o = idx / ni, i = idx - o * ni; for (int b = 0; b < B; ++b) g = fmaf(delta[cur][b][o], act[l][b][i], g); pi = offw[l] + idx; }
+            else { const int o = idx - no * ni; for (int b = 0; b < B; ++b) g += delta[cur][b][o]; pi = offb[l] + o; }
+            // torch.optim.Adam (no weight decay); the updated value goes to global memory, W keeps the old one
+            const float m = am[pi] + (g - am[pi]) * (1.f - b1);
+            const float v = av[pi] * b2 + g * g * (1.f - b2);
+            am[pi] = m; av[pi] = v;
+            ae[pi] = W[pi] - step_size * (m / (sqrtf(v) / bc2s + eps));
+        }
+        if (l > 0) {
+            for (int idx = tid; idx < B * ni; idx += 256) {
+                const int b = idx / ni, i = idx - b * ni;
+                float d = 0.f;
+                for (int o = 0; o < no; ++o) d = fmaf(W[offw[l] + o * ni + i], delta[cur][b][o], d);
+                if (l != 4) d = act[l][b][i] > 0.f ? d : 0.f;              // act[l] is the ReLU output of layer l-1 (act[4] = z: linear)
+                delta[cur ^ 1][b][i] = d;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 }  // namespace vatl
 
 using namespace vatl;
@@ -318,4 +394,16 @@ extern "C" int vatl_l1_joint_regression_fwd_bwd(const float* hm, const float* gt
     else return fail(VATL_EINVAL, "l1_joint_regression: norm_type must be 0 (softmax), 1 (sigmoid) or 2 (divide_sum)");
     hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(256), 0, st, partial, B * J, loss, size_average ? 1.0 / (double)B : 1.0);
     return check_launch("l1_joint_regression");
+}
+
+extern "C" int vatl_ae_train_step(float* ae, float* m, float* v, const float* feat, int B, int D, int z, double lr, double beta1, double beta2,
+                                  double eps, int step, float* loss_or_null, void* stream) {
+    if (!ae || !m || !v || !feat) return fail(VATL_EINVAL, "ae_train_step: null pointer");
+    if (B < 1 || B > AE_MAXB) return fail(VATL_EINVAL, "ae_train_step: batch %d must be in 1..%d (the reference trains with 10)", B, AE_MAXB);
+    if (D < 1 || D > AE_MAXW || z < 1 || z > AE_MAXW) return fail(VATL_EINVAL, "ae_train_step: widths must be in 1..64 (D=%d z=%d)", D, z);
+    if (step < 1) return fail(VATL_EINVAL, "ae_train_step: step is 1-based");
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    hipLaunchKernelGGL(ae_train_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ae, m, v, feat, B, D, z, (float)(lr / bc1), (float)beta1,
+                       (float)beta2, (float)sqrt(bc2), (float)eps, loss_or_null);
+    return check_launch("ae_train_step");
 }

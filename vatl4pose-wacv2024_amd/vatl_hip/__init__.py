@@ -80,6 +80,7 @@ SIGNATURES = {
     "vatl_masked_mse_workspace_floats": (_i64, [_i64]),
     "vatl_masked_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vatl_l1_joint_regression_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "vatl_ae_train_step": (_i, [_p, _p, _p, _p, _i, _i, _i, _d, _d, _d, _d, _i, _p, _p]),
     "vatl_adamw_step": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _p]),
     "vatl_oks": (_i, [_p, _p, _p, _p, _i, _p]),
     "vatl_cosine_rowsum": (_i, [_p, _i64, _i, _p, _p, _p]),
@@ -681,6 +682,25 @@ def l1_joint_regression_fwd_bwd(hm, gt_joints, gt_joints_vis, norm_type: str = "
                                                   _ptr(partial, torch.float64), b, j, h, w, NORM_TYPES[norm_type], int(size_average), _stream()),
            "vatl_l1_joint_regression_fwd_bwd")
     return loss, grad, jts
+
+
+def ae_train_step(ae_flat, m, v, feat, d: int, z: int, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8):
+    """One Adam step of the packed WholeBodyAE on the mini-batch feat (B, d); returns the loss (0-dim tensor)."""
+    loss = torch.empty((), device=feat.device, dtype=torch.float32)
+    _check(lib().vatl_ae_train_step(_ptr(ae_flat), _ptr(m), _ptr(v), _ptr(feat), feat.shape[0], d, z, lr, betas[0], betas[1], eps, step,
+                                    _ptr(loss), _stream()), "vatl_ae_train_step")
+    return loss
+
+
+def unpack_ae(flat: torch.Tensor, module) -> None:
+    """Inverse of pack_ae: copy the packed parameters back into the encoder / decoder Linear layers."""
+    off = 0
+    with torch.no_grad():
+        for half in (module.encoder, module.decoder):
+            for i in (0, 2, 4, 6):
+                for t in (half[i].weight, half[i].bias):
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
 
 
 def adam_step(p, g, m, v, step: int, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8):
