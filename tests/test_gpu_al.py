@@ -26,9 +26,9 @@ def _cfg():
 
 
 @pytest.mark.parametrize("unc", ["THC+WPU", "TPC", "HP"])
-def test_active_learning_rounds(unc):
+def test_active_learning_rounds(unc, tmp_path):
     from active_learning import ActiveLearning
-    opt = types.SimpleNamespace(uncertainty=unc, representativeness="None", filter="None", strategy=unc, video_id="syn", get_prenext=True,
+    opt = types.SimpleNamespace(work_dir=str(tmp_path), uncertainty=unc, representativeness="None", filter="None", strategy=unc, video_id="syn", get_prenext=True,
                                 from_scratch=True, continual=True, num_gpu=1, onebyone=False, retrain_thresh=1, THCvsWPU="const")
     torch.manual_seed(0)
     al = ActiveLearning(_cfg(), opt)
@@ -43,6 +43,15 @@ def test_active_learning_rounds(unc):
         d = scorers.decode_heatmaps(hm[i], ds.bbox[i])
         np.testing.assert_allclose(al.keypoints[i].reshape(17, 3)[:, :2], d["coords"], rtol=1e-4, atol=1e-4)
     assert len(al.labeled_id) == 6 and len(al.unlabeled_id) == 18
+    # result records (ActiveLearning.py:310-327): COCO-style dicts, written where the driver expects them
+    import json, os
+    recs = json.load(open(os.path.join(opt.work_dir, "predicted_kpt.json")))
+    assert len(recs) == 24 and set(recs[0]) == {"bbox", "image_id", "id", "score", "category_id", "keypoints", "GT_keypoints", "OKS"}
+    np.testing.assert_allclose(recs[3]["keypoints"], al.keypoints[3], rtol=1e-6)
+    sc = np.asarray(recs[3]["keypoints"])[2::3]
+    np.testing.assert_allclose(recs[3]["score"], sc.mean() + 1.25 * sc.max(), rtol=1e-5)
+    assert recs[5]["id"] == int(ds[5][6]) and recs[5]["image_id"] == int(ds[5][5])
+    assert os.path.exists(os.path.join(opt.work_dir, "GT_kpt.json")) and os.path.exists(os.path.join(opt.work_dir, "predicted_kpt_ann.json"))
     if unc != "HP":
         u = al.uncertainty_dict["Round0"]
         picked = al.query_list_list["Round0"]

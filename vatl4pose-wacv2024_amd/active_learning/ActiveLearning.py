@@ -163,6 +163,7 @@ class ActiveLearning:
         thc_ref = torch.zeros(n, device=self.device)
         gt_all = np.zeros((n, 3 * J), np.float64)
         ann_all = np.zeros((n, 4), np.float64)
+        ids_all = np.zeros((n, 2), np.float64)                            # image id, annotation id (exact in float64)
         emb_all = torch.empty((n, self.emb_dim), device=self.device) if self.need_embedding else None
         thc_norm = {"THC_L1": "L1", "THC": "L1", "THC+WPU": "L1", "THC_L2": "L2"}.get(self.uncertainty)
         loader = self.eval_loader if (lo == 0 and hi == self.eval_len) else DataLoader(
@@ -186,6 +187,7 @@ class ActiveLearning:
                 one = (ip ^ inx).float()
                 thc_ref[idx] = (tp * ip + tn * inx) * (1 + one)
             gt_all[loc] = GTkpts.reshape(len(idxs), -1).numpy()
+            ids_all[loc, 0], ids_all[loc, 1] = np.asarray(img_ids, np.float64), np.asarray(ann_ids, np.float64)
             ann_all[loc] = np.asarray([bbox_xyxy_to_xywh(b.tolist()) for b in bboxes_ann])
         ae_flat = self.AE.packed() if self.AE is not None else None
         s = score_batch(hm_all, bb_all, ip_all, in_all, thc_norm=thc_norm if self.dedup else None, ae_flat=ae_flat,
@@ -213,6 +215,8 @@ class ActiveLearning:
         kp = s.keypoints.reshape(n, -1)
         # compute_OKS on the device (al_metric.py:42-69): no D2H of the key-points inside the evaluation loop
         oks = vh.oks(s.keypoints.contiguous(), torch.as_tensor(gt_all, device=self.device), torch.as_tensor(ann_all, device=self.device))
+        # float64 side rows for the result records (ActiveLearning.py:310-327): ids, annotation box (xywh), ground truth
+        self._side = (lo, hi, torch.as_tensor(np.concatenate([ids_all, ann_all, gt_all], 1), device=self.device))
         cols = [kp, unc, s.localpeak[:, None], oks.float()[:, None]]
         if emb_all is not None:
             cols.append(emb_all)
@@ -231,12 +235,19 @@ class ActiveLearning:
         # and the result rows are all-gathered (active_learning/distributed.py); world size 1 = whole stream
         rows_dev = D.sharded_rows(n, self._score_range, width, self.device, halo=1 if self.dedup else 0)
         fvecs = rows_dev[:, 55:].contiguous() if self.need_embedding else None          # (n, 2048) stays on the device
+
+        def side_rows(lo, hi):                     # the rows _score_range stashed for exactly this range
+            assert self._side[0] == lo and self._side[1] == hi
+            return self._side[2]
+        side = D.sharded_rows(n, side_rows, 2 + 4 + 3 * self.cfg.DATA_PRESET.NUM_JOINTS, self.device, halo=1 if self.dedup else 0).cpu().numpy()
+        self._side = None
         rows = rows_dev[:, :55].cpu().numpy()
         kp_all = rows[:, :51].copy()
         unc = rows[:, 51:53].astype(np.float64)
         lp = rows[:, 53].astype(np.float64)
         oks = rows[:, 54].astype(np.float64)
         self.keypoints, self.oks = kp_all, oks
+        self._write_records(kp_all, oks, side)
         evaluate = getattr(self.opt, "evaluate_fn", None)
         res = evaluate(kp_all, self) if evaluate else {"AP": None, "mOKS": float(oks.mean())}
         self.percentage.append(len(self.labeled_id) / n * 100)
@@ -335,6 +346,33 @@ class ActiveLearning:
         self._is_finished(query, oks)
         if self.actual_finish < 100:
             self.is_early_stop = True
+
+    def _write_records(self, kp_all, oks, side):
+        """The reference's result records (ActiveLearning.py:310-327, 438-447): one COCO-style dict per item in
+        ``self.kpt_json`` (predictions), ``self.kpt_json_ann`` (labeled items carry their ground truth) and ``self.GT_json``;
+        written as predicted_kpt.json / predicted_kpt_ann.json / GT_kpt.json when ``opt.work_dir`` is set, so the
+        third-party evaluate_mAP / ospa_for_loc tools can be run on them (they stay outside this package)."""
+        labeled = set(self.labeled_id)
+        self.kpt_json, self.kpt_json_ann, self.GT_json = [], [], []
+        for i in range(len(kp_all)):
+            kp = kp_all[i].astype(np.float32)
+            scores = kp[2::3]
+            gt = side[i, 6:].tolist()
+            rec = {"bbox": side[i, 2:6].tolist(), "image_id": int(side[i, 0]), "id": int(side[i, 1]),
+                   "score": float(np.mean(scores) + 1.25 * np.max(scores)), "category_id": 1, "keypoints": [float(x) for x in kp],
+                   "GT_keypoints": gt, "OKS": float(oks[i])}
+            self.kpt_json.append(rec)
+            self.kpt_json_ann.append(dict(rec, keypoints=gt) if i in labeled else dict(rec))
+            self.GT_json.append(dict(rec, keypoints=gt))
+        work_dir = getattr(self.opt, "work_dir", None)
+        from . import distributed as D
+        if work_dir and D.is_main():
+            import json
+            import os
+            os.makedirs(work_dir, exist_ok=True)
+            for name, data in (("predicted_kpt.json", self.kpt_json), ("predicted_kpt_ann.json", self.kpt_json_ann), ("GT_kpt.json", self.GT_json)):
+                with open(os.path.join(work_dir, name), "w") as f:
+                    json.dump(data, f)
 
     def _is_finished(self, query, oks):
         """ActiveLearning.py:707-725: the three stopping-criterion bookmarks (label percentage at which each first held)."""

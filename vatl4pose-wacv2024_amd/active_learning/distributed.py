@@ -28,8 +28,8 @@ def halo_bounds(n: int, lo: int, hi: int, halo: int = 1):
 
 
 def sharded_rows(n: int, score_fn, row_width: int, device, halo: int = 1) -> torch.Tensor:
-    """Every rank scores its shard (+halo) with ``score_fn(lo_ext, hi_ext) -> (hi_ext-lo_ext, row_width)`` float32
-    rows on ``device``; returns the (n, row_width) result rows of the whole stream on every rank."""
+    """Every rank scores its shard (+halo) with ``score_fn(lo_ext, hi_ext) -> (hi_ext-lo_ext, row_width)`` rows (any
+    one dtype) on ``device``; returns the (n, row_width) result rows of the whole stream on every rank."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     lo, hi = shard_bounds(n, rank, world)
@@ -41,7 +41,7 @@ def sharded_rows(n: int, score_fn, row_width: int, device, halo: int = 1) -> tor
         return rows
     sizes = [shard_bounds(n, r, world) for r in range(world)]
     pad = max(h - l for l, h in sizes)
-    buf = torch.zeros((pad, row_width), device=device, dtype=torch.float32)
+    buf = torch.zeros((pad, row_width), device=device, dtype=rows.dtype)
     buf[:hi - lo] = rows
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
@@ -69,3 +69,7 @@ def broadcast_buffers_(module, src: int = 0):
         return
     for b in module.buffers():
         dist.broadcast(b, src=src)
+
+
+def is_main() -> bool:
+    return not dist.is_initialized() or dist.get_rank() == 0
