@@ -1,0 +1,72 @@
+"""The N > 1 path on real kernels: two ranks (gloo, both on cuda:0 — the box has one GPU) run the sharded
+evaluation and one data-parallel fine-tune step; results must equal the single-process run."""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make_al(filter_="None", rep="None"):
+    from active_learning import ActiveLearning
+    from tests.test_gpu_al import _cfg
+    opt = types.SimpleNamespace(uncertainty="THC+WPU", representativeness=rep, filter=filter_, strategy="THC+WPU", video_id="syn", get_prenext=True,
+                                from_scratch=True, continual=True, num_gpu=1, onebyone=False, retrain_thresh=1, THCvsWPU="const", fixed_lambda=False)
+    torch.manual_seed(0); np.random.seed(0)
+    return ActiveLearning(_cfg(), opt)
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "vatl4pose-wacv2024_amd")]
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    al = _make_al("Coreset", "Influence")
+    al.eval_and_query()
+    out = {"kp": al.keypoints.copy(), "oks": al.oks.copy(), "unc": al.uncertainty_dict["Round0"], "query": al.query_list_list["Round0"],
+           "influence": al.influence_dict["Round0"]}
+    # one data-parallel fine-tune pass: parameters must stay identical across ranks (same averaged gradients)
+    al.outcome()
+    flat = torch.cat([p.detach().reshape(-1) for p in al.model.parameters()]).double()
+    out["param_sum"] = float(flat.sum()); out["param_abs"] = float(flat.abs().sum())
+    out["bn_mean"] = al.model.preact.bn1.running_mean.cpu().numpy().copy()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process():
+    single = _make_al("Coreset", "Influence")
+    single.eval_and_query()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        # sharded evaluation (12 + 12 items, one-item halo) == whole stream: bit-identical key-points, scores, queries
+        assert np.array_equal(res[r]["kp"], single.keypoints) and np.array_equal(res[r]["oks"], single.oks)
+        assert res[r]["unc"] == single.uncertainty_dict["Round0"]
+        assert res[r]["query"] == single.query_list_list["Round0"]
+        assert res[r]["influence"] == single.influence_dict["Round0"]
+    # data-parallel step: both ranks hold the same parameters afterwards; BN statistics are rank 0's
+    assert res[0]["param_sum"] == res[1]["param_sum"] and res[0]["param_abs"] == res[1]["param_abs"]
+    assert np.array_equal(res[0]["bn_mean"], res[1]["bn_mean"])
