@@ -43,6 +43,10 @@ def _worker(rank, world, port, q):
     flat = torch.cat([p.detach().reshape(-1) for p in al.model.parameters()]).double()
     out["param_sum"] = float(flat.sum()); out["param_abs"] = float(flat.abs().sum())
     out["bn_mean"] = al.model.preact.bn1.running_mean.cpu().numpy().copy()
+    out["ae_sum"] = float(torch.cat([p.detach().reshape(-1) for p in al.AE.parameters()]).double().sum())
+    out["train_loss"] = al.last_train_loss
+    al.eval_and_query()                                               # second round on the fine-tuned replicas
+    out["kp2"] = al.keypoints.copy(); out["unc2"] = al.uncertainty_dict["Round1"]
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -70,3 +74,6 @@ def test_two_ranks_match_single_process():
     # data-parallel step: both ranks hold the same parameters afterwards; BN statistics are rank 0's
     assert res[0]["param_sum"] == res[1]["param_sum"] and res[0]["param_abs"] == res[1]["param_abs"]
     assert np.array_equal(res[0]["bn_mean"], res[1]["bn_mean"])
+    assert res[0]["ae_sum"] == res[1]["ae_sum"]                        # the re-trained auto-encoder is rank 0's everywhere
+    assert np.isfinite(res[0]["train_loss"]) and np.isfinite(res[1]["train_loss"])
+    assert np.array_equal(res[0]["kp2"], res[1]["kp2"]) and res[0]["unc2"] == res[1]["unc2"]

@@ -124,6 +124,8 @@ class ActiveLearning:
         else:
             raise ValueError("Optimizer not supported!")
         scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=cfg.RETRAIN.LR_GAMMA)
+        from . import distributed as D
+        D.broadcast_module_(model)                 # identical replicas on every rank (random init / checkpoint of rank 0)
         return model, optimizer, scheduler
 
     def initialize_AE(self):
@@ -132,7 +134,10 @@ class ActiveLearning:
         path = self.cfg.AE.get("PRETRAINED", "")
         if path:
             ae.load_state_dict(torch.load(path, map_location="cpu"))
-        return ae.to(self.device).eval()
+        ae = ae.to(self.device).eval()
+        from . import distributed as D
+        D.broadcast_module_(ae)
+        return ae
 
     # ------------------------------------------------------------------ hot loop 1
     def _heatmaps(self, inps, emb_out=None):
@@ -422,31 +427,48 @@ class ActiveLearning:
         loss_logger, acc_logger = DataLogger(), DataLogger()
         subset = Subset(self.train_dataset, self.retrain_id)
         ngpu = max(1, int(getattr(self.opt, "num_gpu", 1)))
+        # Data parallel like the reference's nn.DataParallel (ActiveLearning.py:233, 667): every rank sees the same shuffled
+        # mini-batches (shared seed) and takes its contiguous slice; the slice gradients are weighted by slice size and
+        # all-reduced, which is the gradient of the mean loss over the whole mini-batch.  World size 1: the whole batch.
+        world, rank = D.world_rank()
+        gen = torch.Generator()
+        gen.manual_seed(D.shared_seed())
         loader = DataLoader(subset, batch_size=self.cfg.RETRAIN.BATCH_SIZE * ngpu, shuffle=True, num_workers=0, drop_last=False,
-                            collate_fn=self.collate_fn)
+                            collate_fn=self.collate_fn, generator=gen)
         self.model.train()
         trainer = hip_train.trainer_for(self.model)
+        params = [p for p in self.model.parameters() if p.requires_grad]
         for _ in range(self.retrain_epoch):
             for (idxs, inps, labels, label_masks, *_rest) in loader:
-                x = inps[:, 0].to(self.device).float().contiguous()
-                labels, label_masks = labels.to(self.device).float().contiguous(), label_masks.to(self.device).float()
-                with torch.no_grad():
-                    out = trainer.forward(x)
-                    loss, dout = vh.masked_mse_fwd_bwd(out, labels, label_masks)          # 0.5 * MSE(out*m, label*m) and its gradient
-                    grads = trainer.backward(dout)
-                    D.allreduce_mean_(list(grads.values()))                # data-parallel ranks: one flat fp32 all-reduce per step
-                    for p, g in grads.items():
-                        p.grad = g
+                nb = len(idxs)
+                lo, hi = D.shard_bounds(nb, rank, world)
+                if hi > lo:
+                    x = inps[lo:hi, 0].to(self.device).float().contiguous()
+                    lab, msk = labels[lo:hi].to(self.device).float().contiguous(), label_masks[lo:hi].to(self.device).float()
+                    with torch.no_grad():
+                        out = trainer.forward(x)
+                        loss, dout = vh.masked_mse_fwd_bwd(out, lab, msk)              # 0.5 * MSE(out*m, label*m) and its gradient
+                        grads = trainer.backward(dout)
+                        if world > 1:
+                            for g in grads.values():
+                                g.mul_((hi - lo) * world / nb)
+                    loss_logger.update(float(loss), hi - lo)
+                    m = msk.reshape(msk.shape[0], -1, 1, 1)
+                    acc_logger.update(calc_accuracy(out * m, lab * m), hi - lo)
+                else:                                                                  # fewer items than ranks: contribute zeros
+                    grads = {p: torch.zeros_like(p) for p in params}
+                glist = [grads[p] for p in params]
+                D.allreduce_mean_(glist)                   # one flat fp32 all-reduce per step (136 MB for SimplePose-R50)
+                for p, g in zip(params, glist):
+                    p.grad = g
                 self.optimizer.step()
-                loss_logger.update(float(loss), x.size(0))
-                m = label_masks.reshape(label_masks.shape[0], -1, 1, 1)
-                acc_logger.update(calc_accuracy(out * m, labels * m), x.size(0))
             self.scheduler.step()
         D.broadcast_buffers_(self.model)           # BN statistics are per rank; rank 0's survive (DataParallel semantics)
         self.last_train_loss, self.last_train_acc = loss_logger.avg, acc_logger.avg
         if "WPU" in self.uncertainty:              # ActiveLearning.py:680-684: a fresh AE is fine-tuned on the labeled poses
             self.AE = self.initialize_AE()
             self.last_ae_loss = self.retrain_AE()
+            D.broadcast_module_(self.AE)           # the fit shuffles with the rank's own RNG: rank 0's AE is the one every shard scores with
 
     def retrain_AE(self):
         """ActiveLearning.py:905-925.  The reference reads the hybrid features of the labeled people from its `Wholebody`

@@ -73,3 +73,28 @@ def broadcast_buffers_(module, src: int = 0):
 
 def is_main() -> bool:
     return not dist.is_initialized() or dist.get_rank() == 0
+
+
+def world_rank():
+    return (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
+
+
+def shared_seed() -> int:
+    """One random seed agreed by all ranks (rank 0's): the ranks must shuffle the fine-tune set identically before
+    each takes its slice of every mini-batch."""
+    seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        seed = seed.to(dev)
+        dist.broadcast(seed, src=0)
+    return int(seed.item())
+
+
+def broadcast_module_(module, src: int = 0):
+    """Parameters and buffers of rank ``src`` to every rank (after a random initialisation or a rank-local fit, so
+    that the replicas start identical — what nn.DataParallel's per-forward replicate does for the reference)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)
+        torch.autograd.graph.increment_version(t)
