@@ -298,6 +298,14 @@ int vatl_l1_joint_regression_fwd_bwd(const float* hm, const float* gt_joints, co
                                      float* pred_jts, double* partial, int B, int J, int H, int W, int norm_type, int size_average,
                                      void* stream);
 
+/* SimpleTransform._target_generator (alphapose/utils/presets/simple_transform.py:122-158) for a batch: joints_xy (N,J,2)
+ * input-pixel coordinates, vis (N,J) -> target (N,J,H,W) with an un-normalised Gaussian (sigma, radius 3 sigma, clipped
+ * at the borders) centred on int(x / stride + 0.5), weight (N,J) = vis, zeroed when the patch misses the map; the
+ * patch is drawn only for weight > 0.5.  Like the reference (:130-131) x is divided by in_h / H and y by in_w / W — the
+ * two strides are equal (4) for every preset. */
+int vatl_gaussian_targets(const float* joints_xy, const float* vis, float* target, float* weight, int N, int J, int H, int W,
+                          int in_h, int in_w, float sigma, void* stream);
+
 /* One fine-tune step of the WholeBodyAE (ActiveLearning.py:905-925: AE forward, MSELoss(output, input), backward,
  * torch.optim.Adam) on a mini-batch feat (B, D), B <= 12 (the reference uses 10), in one launch.  ae / m / v: the packed parameters
  * (state-dict order W0,b0,...,W7,b7 = what vatl_hybrid_ae_wpu reads) and the Adam moments, updated in place;

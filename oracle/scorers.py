@@ -384,6 +384,44 @@ def sgd_step(p, g, buf, step: int, lr: float, momentum: float = 0.9, wd: float =
 
 
 # --------------------------------------------------------------------------
+# §8f rank 2 (part): Gaussian heat-map targets        simple_transform.py:122-158
+# --------------------------------------------------------------------------
+
+def target_generator(joints_xy: np.ndarray, vis: np.ndarray, hm_hw=(64, 48), in_hw=(256, 192), sigma: float = 2.0):
+    """SimpleTransform._target_generator for one person: joints_xy (J,2) float32 input-pixel coordinates, vis (J,)
+    -> target (J,H,W) float32, target_weight (J,1,1) float32."""
+    H, W = hm_hw
+    J = joints_xy.shape[0]
+    # _feat_stride = input_size / heatmap_size with both (H, W); the reference applies index 0 to x and index 1 to y
+    # (simple_transform.py:130-131) — the two are equal (4.0) for every preset
+    stride = np.array(in_hw, np.float64) / np.array(hm_hw, np.float64)
+    weight = np.ones((J, 1), np.float32)
+    weight[:, 0] = vis
+    target = np.zeros((J, H, W), np.float32)
+    tmp = sigma * 3
+    for i in range(J):
+        mu_x = int(joints_xy[i, 0] / stride[0] + 0.5)
+        mu_y = int(joints_xy[i, 1] / stride[1] + 0.5)
+        ul = [int(mu_x - tmp), int(mu_y - tmp)]
+        br = [int(mu_x + tmp + 1), int(mu_y + tmp + 1)]
+        if ul[0] >= W or ul[1] >= H or br[0] < 0 or br[1] < 0:
+            weight[i] = 0
+            continue
+        size = 2 * tmp + 1
+        x = np.arange(0, size, 1, np.float32)
+        y = x[:, np.newaxis]
+        x0 = y0 = size // 2
+        g = np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * (sigma ** 2)))
+        g_x = max(0, -ul[0]), min(br[0], W) - ul[0]
+        g_y = max(0, -ul[1]), min(br[1], H) - ul[1]
+        img_x = max(0, ul[0]), min(br[0], W)
+        img_y = max(0, ul[1]), min(br[1], H)
+        if weight[i] > 0.5:
+            target[i, img_y[0]:img_y[1], img_x[0]:img_x[1]] = g[g_y[0]:g_y[1], g_x[0]:g_x[1]]
+    return target, np.expand_dims(weight, -1)
+
+
+# --------------------------------------------------------------------------
 # a13: MPE / Margin / Entropy          ActiveLearning.py:387-396, 762-796
 # --------------------------------------------------------------------------
 # `peak_local_max` is scikit-image's (pinned scikit-image==0.24.0, requirements.txt:172); the package is ABSENT from

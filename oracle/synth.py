@@ -129,3 +129,13 @@ def l1_inputs(norm: str):
     gt = r.uniform(-0.5, 0.5, (3, 34)).astype(np.float32)
     vis = np.repeat((r.random_sample((3, 17)) > 0.25).astype(np.float32), 2, axis=1)
     return hm.astype(np.float32), gt, vis
+
+
+def target_joints(n: int, hm_hw, in_hw, seed: int = 41, J: int = 17):
+    """Seeded joint positions (input-pixel coordinates) and visibility flags for the target-generator fixtures: most
+    inside the crop, some on / beyond the borders (patch clipped or missed entirely), ~20 % invisible."""
+    r = _rs(seed, f"tjoints{n}x{hm_hw}")
+    xy = np.stack([r.uniform(-40, in_hw[1] + 40, (n, J)), r.uniform(-40, in_hw[0] + 40, (n, J))], 2).astype(np.float32)
+    xy[0, 0] = [0.0, 0.0]; xy[0, 1] = [in_hw[1] - 1, in_hw[0] - 1]; xy[0, 2] = [-30.0, 10.0]; xy[0, 3] = [in_hw[1] + 27.9, 5.0]
+    vis = (r.random_sample((n, J)) >= 0.2).astype(np.float32)
+    return xy, vis

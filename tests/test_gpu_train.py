@@ -418,3 +418,18 @@ def test_fused_bn_statistics_and_mask_recompute(vh):
     assert torch.equal(out[0], z1)
     for a, b in zip(s1, out[1:]):
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag,hm_hw,in_hw,sigma", [("a", (64, 48), (256, 192), 2.0), ("b", (96, 72), (384, 288), 1.5)])
+def test_gaussian_targets_vs_reference_golden(vh, tag, hm_hw, in_hw, sigma):
+    """SimpleTransform._target_generator on the device: patch positions, clipping and weights exact (the support of
+    every map is identical), values within float32 exp rounding."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "targets.npz"))
+    joints, vis = synth.target_joints(6, hm_hw, in_hw, seed=41)
+    t, w = vh.gaussian_targets(to_dev(joints), to_dev(vis), hm_hw, in_hw, sigma)
+    t, w = t.cpu().numpy(), w.cpu().numpy()
+    want_t, want_w = g[f"{tag}_target"], g[f"{tag}_weight"]
+    assert np.array_equal(w.reshape(6, 17), want_w.reshape(6, 17))
+    assert np.array_equal(t != 0, want_t != 0)
+    np.testing.assert_allclose(t, want_t, rtol=2e-6, atol=1e-12)

@@ -241,3 +241,13 @@ def test_l1_joint_regression_restatement_matches_reference(norm):
     np.testing.assert_allclose(jts.detach().numpy(), g[f"{norm}_jts"], rtol=1e-5, atol=1e-6)
     got = h.grad.reshape(-1)[torch.from_numpy(g[f"{norm}_grad_idx"])].numpy()
     np.testing.assert_allclose(got, g[f"{norm}_grad_val"], rtol=1e-4, atol=1e-6 * float(g[f"{norm}_grad_absmax"]))
+
+
+@pytest.mark.parametrize("tag,hm_hw,in_hw,sigma", [("a", (64, 48), (256, 192), 2), ("b", (96, 72), (384, 288), 1.5)])
+def test_target_generator_restatement_matches_reference(tag, hm_hw, in_hw, sigma):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "targets.npz"))
+    joints, vis = synth.target_joints(6, hm_hw, in_hw, seed=41)
+    for n in range(6):
+        t, w = scorers.target_generator(joints[n], vis[n], hm_hw, in_hw, sigma)
+        assert np.array_equal(t, g[f"{tag}_target"][n]) and np.array_equal(w, g[f"{tag}_weight"][n])

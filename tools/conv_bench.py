@@ -24,6 +24,7 @@ SHAPES = {  # name: (H, W, Cin, Cout, k, stride, residual)
     "l3.c1": (16, 12, 1024, 256, 1, 1, False), "l3.c2": (16, 12, 256, 256, 3, 1, False), "l3.c3": (16, 12, 256, 1024, 1, 1, True),
     "l4.c1": (8, 6, 2048, 512, 1, 1, False), "l4.c2": (8, 6, 512, 512, 3, 1, False), "l4.c3": (8, 6, 512, 2048, 1, 1, True),
     "l3.c2s2": (32, 24, 256, 256, 3, 2, False),
+    "l2.c3nr": (32, 24, 128, 512, 1, 1, False), "l3.c3nr": (16, 12, 256, 1024, 1, 1, False), "l1.c3nr": (64, 48, 64, 256, 1, 1, False),
     "deconv1": (8, 6, 2048, 256, 0, 0, False), "deconv3": (32, 24, 256, 256, 0, 0, False),
     "head": (64, 48, 256, 17, 1, 1, False),
     # HRNet-W32 branches (basic blocks: 3x3, residual on the second conv), the 1x1 up paths and the 32->17 head
@@ -62,7 +63,7 @@ def main():
 
 def run(a):
     dev = torch.device("cuda:0")
-    names = a.layers.split(",") if a.layers else [n for n in SHAPES if not n.startswith("hr.")]
+    names = a.layers.split(",") if a.layers else [n for n in SHAPES if not n.startswith("hr.") and not n.endswith("nr")]
     if a.layers == "hrnet":
         names = [n for n in SHAPES if n.startswith("hr.")]
     tot_f = tot_t = 0.0

@@ -491,6 +491,29 @@ def gen_l1_loss(out: str):
     np.savez_compressed(os.path.join(out, "l1_joint_regression.npz"), **res)
 
 
+def gen_targets(out: str):
+    """SimpleTransform._target_generator (simple_transform.py:122-158) called unbound on seeded joints, incl. joints on
+    and beyond the borders, invisible joints and a non-integer sigma."""
+    from alphapose.utils.presets.simple_transform import SimpleTransform          # the reference's
+    res = {}
+    for tag, hm_hw, in_hw, sigma in (("a", (64, 48), (256, 192), 2), ("b", (96, 72), (384, 288), 1.5)):
+        joints, vis = synth.target_joints(6, hm_hw, in_hw, seed=41)
+        me = types.SimpleNamespace(_heatmap_size=np.array(hm_hw), _sigma=sigma,
+                                   _feat_stride=np.array([in_hw[0], in_hw[1]]) / np.array(hm_hw))
+        # the reference computes _feat_stride = input_size / heatmap_size with both given as (H, W); index 0 is applied to x,
+        # index 1 to y (both are 4.0 for every shipped preset)
+        tg, tw = [], []
+        for n in range(joints.shape[0]):
+            j3 = np.zeros((17, 3, 2), np.float32)
+            j3[:, 0, 0], j3[:, 1, 0] = joints[n, :, 0], joints[n, :, 1]
+            j3[:, 0, 1] = j3[:, 1, 1] = vis[n]
+            t, w = SimpleTransform._target_generator(me, j3, 17)
+            tg.append(t); tw.append(w)
+        res[f"{tag}_target"] = np.stack(tg); res[f"{tag}_weight"] = np.stack(tw)
+        print("targets", tag, res[f"{tag}_target"].shape, float(res[f"{tag}_target"].sum()), float(res[f"{tag}_weight"].sum()))
+    np.savez_compressed(os.path.join(out, "targets.npz"), **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -507,6 +530,8 @@ def main():
         gen_simplepose(EasyDict, a.out)
     if a.only in ("", "nets2"):
         gen_fastpose_hrnet(EasyDict, a.out)
+    if a.only in ("", "targets"):
+        gen_targets(a.out)
     if a.only in ("", "l1"):
         gen_l1_loss(a.out)
     if a.only in ("", "r152"):

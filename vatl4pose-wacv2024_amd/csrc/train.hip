@@ -306,6 +306,35 @@ __global__ __launch_bounds__(256) void ae_train_step_kernel(float* __restrict__ 
     }
 }
 
+// --------------------------------------------------------------------------
+// Gaussian heat-map targets (simple_transform.py:122-158): one block per (person, joint) plane
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gaussian_target_kernel(const float* __restrict__ joints, const float* __restrict__ vis, float* __restrict__ target,
+                                                              float* __restrict__ weight, int H, int W, double stride_x, double stride_y, float sigma) {
+    const float jx = joints[2 * (long long)blockIdx.x], jy = joints[2 * (long long)blockIdx.x + 1];
+    const int mu_x = (int)((double)jx / stride_x + 0.5), mu_y = (int)((double)jy / stride_y + 0.5);     // int(): truncation toward zero
+    const double tmp = (double)sigma * 3.0;
+    const int ulx = (int)(mu_x - tmp), uly = (int)(mu_y - tmp), brx = (int)(mu_x + tmp + 1), bry = (int)(mu_y + tmp + 1);
+    float w = vis[blockIdx.x];
+    const bool outside = ulx >= W || uly >= H || brx < 0 || bry < 0;
+    if (outside) w = 0.f;
+    if (threadIdx.x == 0) weight[blockIdx.x] = w;
+    const bool draw = !outside && w > 0.5f;
+    const int half = (int)(2 * tmp + 1) / 2;                      // size // 2 with size = 2*tmp + 1 (a float in the reference)
+    const float inv = 1.f / (2.f * sigma * sigma);
+    float* dst = target + (long long)blockIdx.x * H * W;
+    const float inv_w = 1.0f / (float)W;
+    for (int i = threadIdx.x; i < H * W; i += 256) {
+        const int y = fast_div(i, inv_w), x = i - y * W;
+        float v = 0.f;
+        if (draw && x >= ulx && x < brx && y >= uly && y < bry) {
+            const float dx = (float)(x - ulx - half), dy = (float)(y - uly - half);
+            v = expf(-(dx * dx + dy * dy) * inv);
+        }
+        dst[i] = v;
+    }
+}
+
 }  // namespace vatl
 
 using namespace vatl;
@@ -406,4 +435,13 @@ extern "C" int vatl_ae_train_step(float* ae, float* m, float* v, const float* fe
     hipLaunchKernelGGL(ae_train_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ae, m, v, feat, B, D, z, (float)(lr / bc1), (float)beta1,
                        (float)beta2, (float)sqrt(bc2), (float)eps, loss_or_null);
     return check_launch("ae_train_step");
+}
+
+extern "C" int vatl_gaussian_targets(const float* joints_xy, const float* vis, float* target, float* weight, int N, int J, int H, int W,
+                                     int in_h, int in_w, float sigma, void* stream) {
+    if (N <= 0) return 0;
+    if (!joints_xy || !vis || !target || !weight || J <= 0 || sigma <= 0.f) return fail(VATL_EINVAL, "gaussian_targets: bad arguments");
+    hipLaunchKernelGGL(gaussian_target_kernel, dim3((unsigned)(N * J)), dim3(256), 0, (hipStream_t)stream, joints_xy, vis, target, weight, H, W,
+                       (double)in_h / (double)H, (double)in_w / (double)W, sigma);   // the reference divides x by stride[0] = in_h / H (:130)
+    return check_launch("gaussian_targets");
 }

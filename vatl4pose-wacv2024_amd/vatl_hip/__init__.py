@@ -80,6 +80,7 @@ SIGNATURES = {
     "vatl_masked_mse_workspace_floats": (_i64, [_i64]),
     "vatl_masked_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vatl_l1_joint_regression_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "vatl_gaussian_targets": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "vatl_ae_train_step": (_i, [_p, _p, _p, _p, _i, _i, _i, _d, _d, _d, _d, _i, _p, _p]),
     "vatl_adamw_step": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _p]),
     "vatl_oks": (_i, [_p, _p, _p, _p, _i, _p]),
@@ -682,6 +683,16 @@ def l1_joint_regression_fwd_bwd(hm, gt_joints, gt_joints_vis, norm_type: str = "
                                                   _ptr(partial, torch.float64), b, j, h, w, NORM_TYPES[norm_type], int(size_average), _stream()),
            "vatl_l1_joint_regression_fwd_bwd")
     return loss, grad, jts
+
+
+def gaussian_targets(joints_xy, vis, hm_hw=(64, 48), in_hw=(256, 192), sigma: float = 2.0):
+    """joints (N,J,2) input-pixel coordinates, vis (N,J) -> target (N,J,H,W), weight (N,J,1,1)  [_target_generator]."""
+    n, j, _ = joints_xy.shape
+    target = torch.empty((n, j, hm_hw[0], hm_hw[1]), device=joints_xy.device, dtype=torch.float32)
+    weight = torch.empty((n, j), device=joints_xy.device, dtype=torch.float32)
+    _check(lib().vatl_gaussian_targets(_ptr(joints_xy.contiguous()), _ptr(vis.contiguous()), _ptr(target), _ptr(weight), n, j, hm_hw[0], hm_hw[1],
+                                       in_hw[0], in_hw[1], sigma, _stream()), "vatl_gaussian_targets")
+    return target, weight.reshape(n, j, 1, 1)
 
 
 def ae_train_step(ae_flat, m, v, feat, d: int, z: int, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8):
