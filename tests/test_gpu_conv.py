@@ -360,3 +360,27 @@ def test_launches_from_several_host_threads(vh):
     assert not errs, errs
     for g, w in zip(got, want):
         assert torch.equal(g, w)
+
+
+def test_every_tile_and_schedule_gives_identical_bits(vh):
+    """The tuning knobs change the block tile (64 / 128 rows), the k-loop schedule (two-phase, interleaved, distance-2
+    prefetch, LDS-DMA) and the tile order — never the per-output reduction order: results are bit-identical."""
+    r = np.random.RandomState(77)
+    for (n, h, w, cin, cout, k, stride) in ((3, 16, 12, 128, 128, 3, 1), (5, 8, 6, 256, 512, 1, 1), (2, 16, 12, 64, 64, 3, 2)):
+        x = to_dev(r.standard_normal((n, h, w, cin)).astype(np.float32))
+        wt = to_dev((r.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32))
+        sc, bi = to_dev(r.uniform(0.5, 1.5, cout).astype(np.float32)), to_dev(r.standard_normal(cout).astype(np.float32))
+        ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+        res = to_dev(r.standard_normal((n, ho, wo, cout)).astype(np.float32))
+        wp = vh.pack_conv_weight(wt)
+        outs = []
+        try:
+            for var in (4, 0, 2, 5):
+                for bm in (0, 64, 128):
+                    for order in (0, 1):
+                        vh.tune_set(0, var); vh.tune_set(5, bm); vh.tune_set(1, order)
+                        outs.append(vh.conv2d_fwd(x, wp, sc, bi, cout, k, k, stride, k // 2, True, residual=res).clone())
+        finally:
+            vh.tune_set(0, 4); vh.tune_set(5, 0); vh.tune_set(1, 0)
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
