@@ -167,13 +167,33 @@ def cfg5(dev):
                       "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)
 
 
+def fastpose_infer(dev):
+    """FastPose inference (not one of BASELINE.json's configs; here to keep an eye on the SE / DUC path)."""
+    from active_learning.scoring import score_batch
+    from alphapose.models import hip_engine
+    for layers, hw, n, gflop in ((50, (256, 192), 1024, 11.774), (152, (384, 288), 256, 59.192)):
+        m = build({"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": layers}, hw, dev).eval()
+        vx, bbox, ip, inx = video(dev, n, hw)
+        hm = torch.empty((n, 17, hw[0] // 4, hw[1] // 4), device=dev)
+
+        def run():
+            with torch.no_grad():
+                hip_engine.forward_into(m, vx, hm)
+                return score_batch(hm, bbox, ip, inx, thc_norm="L1")
+        dt = timed(run, 3, 1)
+        print(json.dumps({"config": f"FastPose-R{layers} {hw[0]}x{hw[1]} inference + THC-L1, {n} frames", "frames_per_s": round(n / dt, 1),
+                          "conv_tflops": round(gflop * 1e9 * n / dt / 1e12, 2)}), flush=True)
+        del m, vx, hm
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="cfg3,cfg4,cfg5")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     for name in a.only.split(","):
-        {"cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}[name](dev)
+        {"cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5, "fastpose": fastpose_infer}[name](dev)
         torch.cuda.empty_cache()
 
 
