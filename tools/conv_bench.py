@@ -40,8 +40,16 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--layers", default="")
     ap.add_argument("--vars", default="", help="comma list of k-loop schedule variants to A/B (vatl_tune_set knob 0)")
+    ap.add_argument("--ablate", default="", help="comma list of conv ablation bit sets (vatl_tune_set knob 6; needs VATL_ALLOW_ABLATION=1)")
     ap.add_argument("--bm", default="", help="comma list of block-tile row counts to A/B (vatl_tune_set knob 5: 0 auto, 64, 128)")
     a = ap.parse_args()
+    if a.ablate:
+        for v in a.ablate.split(","):
+            print(f"--- ablation bits {v} (1 = no epilogue, 2 = one k-tile)")
+            vh.tune_set(6, int(v))
+            run(a)
+        vh.tune_set(6, 0)
+        return
     if a.bm:
         for v in a.bm.split(","):
             print(f"--- block tile rows {v}")

@@ -65,6 +65,7 @@ struct ConvParams {
     const float* x2;
     int k1, C2, H2, W2, stride2;
     unsigned x2_bytes;
+    int ablate;                       // profiling only (vatl_tune_set(6, bits), wrong results): 1 = no epilogue
     unsigned x_bytes, w_bytes, y_bytes;   // buffer extents (hardware bounds checks: OOB loads read 0, OOB stores drop)
 };
 
@@ -520,7 +521,18 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
         if (NO_BAR) __syncthreads();
     }
 
-    conv_epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, ooy, oox, wm, wn, tid, lane, HoWo);
+    if (p.ablate & 1) {                // profiling only: keep the accumulators alive, skip the write-out
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+        if (s == 12345.678f) p.y[0] = s;
+        return;
+    }
+    conv_epilogue<BM, BN, WM, WN, NT>(p, acc, smem, m0, n0, ooy, oox, wm, wn, tid, lane, HoWo);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -681,6 +693,7 @@ static int launch_dma(const ConvParams& p, int phases, hipStream_t st);
 
 static std::atomic<int> g_var{4};      // k-loop schedule (vatl_tune_set(0, v)); 4 = shipped default
 static std::atomic<int> g_order{0};    // tile order (vatl_tune_set(1, v))
+static std::atomic<int> g_ablate{0};   // vatl_tune_set(6, bits): 1 = no epilogue, 2 = one k-tile only (profiling ablations, wrong results)
 static std::atomic<int> g_bm{0};       // tile rows (vatl_tune_set(5, v)): 0 = by grid size, 64 or 128 = forced
 static std::atomic<int> g_stagger{0};  // block stagger in percent of the k-loop time (vatl_tune_set(2, v)); 0 = off
 
@@ -699,6 +712,8 @@ static int launch(const ConvParams& p, int phases, hipStream_t st) {
     q.n_tiles = p.CoutPad / BN;
     q.m_tiles = cdiv(p.M, BM);
     q.order = g_order.load(std::memory_order_relaxed);
+    q.ablate = g_ablate.load(std::memory_order_relaxed);
+    if ((q.ablate & 2) && q.ktiles > 1) q.ktiles = 1;
     // one s_sleep(127) = 8128 cycles; a k-tile costs ~8192 cycles when two blocks share the SIMDs
     q.stagger = (int)((long long)g_stagger.load(std::memory_order_relaxed) * p.ktiles / 100);
     static_assert(2 * (BM + BN) * LDK >= BM * (BN + 4), "epilogue tile must fit in the staging buffers");
@@ -795,13 +810,14 @@ extern "C" int vatl_tune_wgrad_blocks(int blocks);
 extern "C" int vatl_tune_set(int knob, int value) {
     // Ablation settings (schedule variants 10..13, wgrad ablation bits) produce WRONG results by construction; they exist
     // for the profiling notes only and are refused unless the process opted in.
-    const bool ablation = (knob == 0 && value >= 10) || (knob == 4 && value != 0);
+    const bool ablation = (knob == 0 && value >= 10) || ((knob == 4 || knob == 6) && value != 0);
     if (ablation) {
         const char* ok = getenv("VATL_ALLOW_ABLATION");
         if (!ok || ok[0] != '1') return fail(VATL_EINVAL, "tune_set: knob %d value %d is a profiling ablation (wrong results); set VATL_ALLOW_ABLATION=1", knob, value);
     }
     if (knob == 3 && vatl_tune_wgrad_blocks(value) == 0) return 0;
     if (knob == 5 && (value == 0 || value == 64 || value == 128)) { g_bm.store(value, std::memory_order_relaxed); return 0; }
+    if (knob == 6 && value >= 0 && value <= 3) { g_ablate.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
     if (knob == 0 && value >= 0 && value <= 13) { g_var.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }
