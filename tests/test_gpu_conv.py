@@ -384,3 +384,21 @@ def test_every_tile_and_schedule_gives_identical_bits(vh):
             vh.tune_set(0, 4); vh.tune_set(5, 0); vh.tune_set(1, 0)
         for o in outs[1:]:
             assert torch.equal(o, outs[0])
+
+
+def test_persistent_1x1_kernel_is_bit_identical(vh):
+    """The persistent GEMM kernel for short-K 1x1 layers (several tiles per block, next tile prefetched during the
+    epilogue) against the one-tile-per-block kernel: identical bits, with residual / ReLU / tails / several runs."""
+    r = np.random.RandomState(91)
+    for (n, h, w, cin, cout, res) in ((40, 16, 12, 64, 256, True), (9, 16, 12, 128, 512, True), (33, 8, 6, 256, 1024, False), (7, 13, 11, 512, 128, False)):
+        x = to_dev(r.standard_normal((n, h, w, cin)).astype(np.float32))
+        wp = vh.pack_conv_weight(to_dev((r.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)))
+        sc, bi = to_dev(r.uniform(0.5, 1.5, cout).astype(np.float32)), to_dev(r.standard_normal(cout).astype(np.float32))
+        rs = to_dev(r.standard_normal((n, h, w, cout)).astype(np.float32)) if res else None
+        try:
+            vh.tune_set(5, 128)                                        # whole 128-row tiles on both paths
+            vh.tune_set(7, 0); a = vh.conv2d_fwd(x, wp, sc, bi, cout, 1, 1, 1, 0, True, residual=rs).clone()
+            vh.tune_set(7, 4); b = vh.conv2d_fwd(x, wp, sc, bi, cout, 1, 1, 1, 0, True, residual=rs).clone()
+        finally:
+            vh.tune_set(5, 0); vh.tune_set(7, 1)
+        assert torch.equal(a, b), (n, cin, cout)

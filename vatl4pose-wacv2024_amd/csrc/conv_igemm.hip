@@ -536,6 +536,131 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// Persistent 1x1 / stride-1 kernel (a plain GEMM Y[M][N] = A[M][K] W[N][K]^T with the conv epilogue).
+// The short-K 1x1 layers (conv3 / conv1 of the bottlenecks, K = 64..512) spend as long in the prologue (first
+// operand loads with nothing to overlap) and in the tile write-out as in their 2-16 k-tiles (profiles/r01_notes.md,
+// ablation knob 6).  Here a block stays resident, walks a run of tiles and requests the NEXT tile's first operand
+// tile before the current tile's epilogue, so that latency and the write-out overlap.  Same LDS layout, fragment
+// mapping, MFMA order and epilogue as conv_igemm_kernel: results are bit-identical.
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void gemm1x1_persistent_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                          // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;           // [2][BN][LDK]
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int LA = BM / 32, LB = BN / 32;
+    constexpr int NG = BK / 8, MPG = 4 * TM * TN;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lrow = tid >> 3, kq = tid & 7;
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+
+    // XCD-aware runs: XCD x (= block id mod 8) owns tiles [x*per, (x+1)*per) in n-fastest order; its blocks walk the run
+    // with a stride of (blocks per XCD), so the blocks that share an activation panel are on the same L2 at the same time
+    const int total = p.m_tiles * p.n_tiles;
+    const int per = (total + 7) >> 3, bpx = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int run_end = min((xcd + 1) * per, total);
+    int t = xcd * per + loc;
+    if (t >= run_end) return;
+
+    unsigned aoff[LA], boff[LB];               // byte offsets of this thread's float4s at k-tile 0
+    int m0, n0;
+    auto setup = [&](int tile, unsigned (&ao)[LA], unsigned (&bo)[LB], int& mm0, int& nn0) {
+        const int m_tile = tile / p.n_tiles, n_tile = tile - m_tile * p.n_tiles;
+        mm0 = m_tile * BM; nn0 = n_tile * BN;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) ao[i] = (unsigned)(((mm0 + lrow + 32 * i) * p.K + kq * 4) * 4);   // rows >= M: past the descriptor -> zeros
+#pragma unroll
+        for (int j = 0; j < LB; ++j) bo[j] = (unsigned)(((nn0 + lrow + 32 * j) * p.K + kq * 4) * 4);
+    };
+    f32x4 ra[LA], rb[LB];
+    auto gload = [&](const unsigned (&ao)[LA], const unsigned (&bo)[LB], int kt, bool live) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) ra[i] = buf_load4(xr, live ? ao[i] + (unsigned)kt * (BK * 4) : OOB);
+#pragma unroll
+        for (int j = 0; j < LB; ++j) rb[j] = buf_load4(wr, live ? bo[j] + (unsigned)kt * (BK * 4) : OOB);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + 32 * i) * LDK + kq * 4]) = ra[i];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + 32 * j) * LDK + kq * 4]) = rb[j];
+    };
+    auto frag_read = [&](f32x4 (&af)[TM], f32x4 (&bf)[TN], int buf, int g) {
+        const float* Ab = As + (buf * BM + wm * WM + frow) * LDK + fk + g * 8;
+        const float* Bb = Bs + (buf * BN + wn * WN + frow) * LDK + fk + g * 8;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);
+    };
+
+    setup(t, aoff, boff, m0, n0);
+    gload(aoff, boff, 0, true);
+    lstore(0);
+    __syncthreads();
+    const int HoWo = p.Ho * p.Wo;
+    for (;;) {
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        f32x4 af[2][TM], bf[2][TN];
+        for (int kt = 0; kt < p.ktiles; ++kt) {
+            const int buf = kt & 1;
+            const bool live = kt + 1 < p.ktiles;
+            frag_read(af[0], bf[0], buf, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) frag_read(af[(g + 1) & 1], bf[(g + 1) & 1], buf, g + 1);
+                if (g == 0) gload(aoff, boff, kt + 1, live);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][tt], bf[g & 1][j][tt], acc[i][j], 0, 0, 0);
+                if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+                for (int q = 0; q < MPG; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x016, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (live) lstore(buf ^ 1);
+            __syncthreads();
+        }
+        // request the next tile's first operand tile: in flight during this tile's epilogue
+        const int tn = t + bpx;
+        const bool more = tn < run_end;
+        unsigned aoffn[LA], boffn[LB];
+        int m0n = 0, n0n = 0;
+        if (more) { setup(tn, aoffn, boffn, m0n, n0n); gload(aoffn, boffn, 0, true); }
+        conv_epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, 0, 0, wm, wn, tid, lane, HoWo);
+        if (!more) break;
+        __syncthreads();                       // every thread is done with the epilogue's LDS tile
+        lstore(0);
+        __syncthreads();
+        t = tn; m0 = m0n; n0 = n0n;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) aoff[i] = aoffn[i];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) boff[j] = boffn[j];
+    }
+}
+
 // LDS-DMA variant (VAR 5): operand tiles go HBM/L2 -> LDS directly (buffer_load ... lds, 1 KiB per wave
 // instruction, no staging VGPRs, no ds_write pass).  The DMA destination is lane-linear (base + lane*16 B), so
 // the LDS rows are unpadded 32-float rows and bank conflicts are avoided by an XOR swizzle applied on the
@@ -744,6 +869,28 @@ static int launch_dma(const ConvParams& p, int phases, hipStream_t st) {
     return check_launch("conv_igemm_dma");
 }
 
+template <int BM, int BN, int WM, int WN>
+static int launch_persistent(const ConvParams& p, hipStream_t st) {
+    auto kern = gemm1x1_persistent_kernel<BM, BN, WM, WN>;
+    constexpr int smem = 2 * (BM + BN) * LDK * (int)sizeof(float);
+    static std::atomic<int> configured{0};
+    if (!configured.load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return fail(VATL_ELAUNCH, "hipFuncSetAttribute(gemm1x1_persistent): %s", hipGetErrorString(e));
+        configured.store(1, std::memory_order_release);
+    }
+    ConvParams q = p;
+    q.n_tiles = p.CoutPad / BN;
+    q.m_tiles = cdiv(p.M, BM);
+    const int total = q.m_tiles * q.n_tiles;
+    int grid = 512;                            // two resident blocks per CU
+    if (grid > total) grid = (total + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, st, q);
+    return check_launch("gemm1x1_persistent");
+}
+
+static std::atomic<int> g_persist{1};  // vatl_tune_set(7, v): 1 = persistent kernel for the short-K 1x1 layers, 0 = off
+
 // CoutPad granularity the packer must honour for a given Cout.
 static int tile_n_for(int Cout) { return Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128); }
 
@@ -779,6 +926,12 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, 
         if (bn == 128) return launch<64, 128, 32, 64, false, 4>(p, phases, st);
         return launch<64, 64, 32, 32, false, 4>(p, phases, st);
     }
+    // short-K 1x1 / stride-1 layers on whole 128x128 tiles: the persistent GEMM kernel
+    const int pk = g_persist.load(std::memory_order_relaxed);
+    if (pk && bn == 128 && var == 4 && phases == 1 && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad_y == 0 && !p.out_nchw && !p.deconv &&
+        p.osy == 1 && p.osx == 1 && p.OH == p.Ho && p.OW == p.Wo && (p.Cout & 3) == 0 && p.ktiles <= pk * 16 && !p.x2 &&
+        (long long)(p.M + 128) * p.K < (1LL << 30))
+        return launch_persistent<128, 128, 64, 64>(p, st);
     if (bn == 128 && var == 5) return launch_dma<128, 128, 64, 64>(p, phases, st);
     if (bn == 64 && var == 5) return launch_dma<128, 64, 64, 32>(p, phases, st);
     if (bn == 128) {
@@ -818,6 +971,7 @@ extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 3 && vatl_tune_wgrad_blocks(value) == 0) return 0;
     if (knob == 5 && (value == 0 || value == 64 || value == 128)) { g_bm.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 6 && value >= 0 && value <= 3) { g_ablate.store(value, std::memory_order_relaxed); return 0; }
+    if (knob == 7 && value >= 0 && value <= 64) { g_persist.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
     if (knob == 0 && value >= 0 && value <= 13) { g_var.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }
