@@ -84,7 +84,7 @@ int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float* w, const 
 /* Tuning knobs (benchmarks / A-B tests only).  Results are identical for every setting of
  * knob 0 = k-loop schedule of the conv kernel, values 0, 2, 4, 5 (see csrc/conv_igemm.hip), 1 = tile order, 2 = block
  * stagger, 3 = target block count of the weight-gradient launches (number of pixel splits), 5 = rows of the conv block
- * tile (0 = chosen from the grid size, 64, 128).  Knob 0 values 10..13, knob 4 (wgrad ablation bits) and knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) are profiling
+ * tile (0 = chosen from the grid size, 64, 128), 7 = persistent 1x1 kernel for K <= 256 v (0 = off, default 1).  Knob 0 values 10..13, knob 4 (wgrad ablation bits) and knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) are profiling
  * ablations that compute WRONG results; they are refused unless the environment has VATL_ALLOW_ABLATION=1. */
 int vatl_tune_set(int knob, int value);
 /* CoutPad the packer must use for a given Cout (multiple of the kernel's N tile). */

@@ -889,7 +889,7 @@ static int launch_persistent(const ConvParams& p, hipStream_t st) {
     return check_launch("gemm1x1_persistent");
 }
 
-static std::atomic<int> g_persist{1};  // vatl_tune_set(7, v): 1 = persistent kernel for the short-K 1x1 layers, 0 = off
+static std::atomic<int> g_persist{1};  // vatl_tune_set(7, v): persistent kernel for 1x1 layers with K <= 256 v (0 = off)
 
 // CoutPad granularity the packer must honour for a given Cout.
 static int tile_n_for(int Cout) { return Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128); }
@@ -929,7 +929,7 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, 
     // short-K 1x1 / stride-1 layers on whole 128x128 tiles: the persistent GEMM kernel
     const int pk = g_persist.load(std::memory_order_relaxed);
     if (pk && bn == 128 && var == 4 && phases == 1 && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad_y == 0 && !p.out_nchw && !p.deconv &&
-        p.osy == 1 && p.osx == 1 && p.OH == p.Ho && p.OW == p.Wo && (p.Cout & 3) == 0 && p.ktiles <= pk * 16 && !p.x2 &&
+        p.osy == 1 && p.osx == 1 && p.OH == p.Ho && p.OW == p.Wo && (p.Cout & 3) == 0 && p.ktiles <= pk * 8 && !p.x2 &&
         (long long)(p.M + 128) * p.K < (1LL << 30))
         return launch_persistent<128, 128, 64, 64>(p, st);
     if (bn == 128 && var == 5) return launch_dma<128, 128, 64, 64>(p, phases, st);
