@@ -1,32 +1,34 @@
-"""Registries and build helpers (reference: alphapose/models/builder.py:4-42)."""
+"""The three registries of the plugin surface and the constructors the reference's drivers call on them
+(alphapose/models/builder.py:4-42): ``build_sppe(cfg.MODEL, preset_cfg=cfg.DATA_PRESET)``, ``build_loss(cfg.LOSS)``,
+``build_dataset(cfg.DATASET.X, preset_cfg=..., train=..., get_prenext=...)`` and ``retrieve_dataset``.
+
+A config node names its class in ``TYPE``; every other key becomes a constructor keyword, joined by the caller's
+extras (``PRESET`` = the data preset).  A list of nodes yields an ``nn.Sequential`` of the built objects.
+"""
 import importlib
 
 from torch import nn
 
 from alphapose.utils import Registry, build_from_cfg, retrieve_from_cfg
 
-SPPE = Registry("sppe")
-LOSS = Registry("loss")
-DATASET = Registry("dataset")
+SPPE, LOSS, DATASET = Registry("sppe"), Registry("loss"), Registry("dataset")
 
 
 def build(cfg, registry, default_args=None):
-    if isinstance(cfg, list):
-        return nn.Sequential(*[build_from_cfg(c, registry, default_args) for c in cfg])
-    return build_from_cfg(cfg, registry, default_args)
+    if not isinstance(cfg, list):
+        return build_from_cfg(cfg, registry, default_args)
+    return nn.Sequential(*(build_from_cfg(node, registry, default_args) for node in cfg))
 
 
-def build_sppe(cfg, preset_cfg, **kwargs):
-    return build(cfg, SPPE, default_args={"PRESET": preset_cfg, **kwargs})
+def _with_preset(preset_cfg, extras):
+    merged = dict(extras)
+    merged["PRESET"] = preset_cfg
+    return merged
 
 
-def build_loss(cfg):
-    return build(cfg, LOSS)
-
-
-def _import_dataset(type_name):
-    # datasets are host-side I/O outside the hot path; they
-    # register themselves on import when a datasets package is installed beside us.
+def _ensure_dataset_registered(type_name):
+    """Dataset classes register themselves when ``alphapose.datasets`` is imported; the COCO-json datasets of the
+    reference are host-side I/O outside the MI355X path and may be installed beside this package."""
     try:
         importlib.import_module("alphapose.datasets")
     except ImportError:
@@ -35,11 +37,19 @@ def _import_dataset(type_name):
         raise KeyError(f"{type_name} is not in the {DATASET.name} registry")
 
 
+def build_loss(cfg):
+    return build(cfg, LOSS)
+
+
+def build_sppe(cfg, preset_cfg, **kwargs):
+    return build(cfg, SPPE, default_args=_with_preset(preset_cfg, kwargs))
+
+
 def build_dataset(cfg, preset_cfg, **kwargs):
-    _import_dataset(cfg["TYPE"])
-    return build(cfg, DATASET, default_args={"PRESET": preset_cfg, **kwargs})
+    _ensure_dataset_registered(cfg["TYPE"])
+    return build(cfg, DATASET, default_args=_with_preset(preset_cfg, kwargs))
 
 
 def retrieve_dataset(cfg):
-    _import_dataset(cfg["TYPE"])
+    _ensure_dataset_registered(cfg["TYPE"])
     return retrieve_from_cfg(cfg, DATASET)

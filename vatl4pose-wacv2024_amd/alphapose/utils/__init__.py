@@ -1,3 +1,7 @@
-from .registry import Registry, build_from_cfg, retrieve_from_cfg
+"""Registry helpers under the names the reference's packages import from ``alphapose.utils``
+(the builder and the dataset modules do ``from alphapose.utils import Registry, build_from_cfg``)."""
+from . import registry as _registry
 
-__all__ = ["Registry", "build_from_cfg", "retrieve_from_cfg"]
+Registry = _registry.Registry
+build_from_cfg = _registry.build_from_cfg
+retrieve_from_cfg = _registry.retrieve_from_cfg
