@@ -109,7 +109,7 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
-            "kernel": "conv_igemm_kernel (all conv/deconv launches of one step; 4 of them fuse a projection shortcut with the block's last conv)", "launches": len(events),
+            "kernel": "conv_igemm_kernel + gemm1x1_persistent_kernel (all conv/deconv launches of one step; 4 of them fuse a projection shortcut with the block's last conv)", "launches": len(events),
             "avg_launch_us": round(ms * 1e3 / len(events), 2), "flops_per_step": flops,
             # the step's conv launches have different shapes: `achieved` is sum(flops) / sum(duration); per-launch averages for reference
             "flops_per_launch": flops / len(events), "traffic_per_launch": (traffic / len(events)) if traffic else None,
