@@ -304,9 +304,13 @@ extern "C" int vatl_conv2d_wgrad(const float* x, const float* dz, float* dw, flo
     p.g_bytes = (unsigned)(ge * 4); p.x_bytes = (unsigned)(xe * 4);
     hipStream_t st = (hipStream_t)stream;
     const int64_t wsn = vatl_conv2d_wgrad_workspace_floats(Cout, Cin, R, S);
-    if (hipMemsetAsync(workspace, 0, wsn * sizeof(float), st) != hipSuccess) return fail(VATL_ELAUNCH, "conv2d_wgrad: memset failed");
+    // 1x1: the packed gradient [Cout][1][Cin] IS the OIHW tensor — accumulate straight into dw, no unpack pass
+    const bool direct = !stem && R == 1 && S == 1;
+    float* acc = direct ? dw : workspace;
+    if (hipMemsetAsync(acc, 0, wsn * sizeof(float), st) != hipSuccess) return fail(VATL_ELAUNCH, "conv2d_wgrad: memset failed");
     int rc;
     WgradParams q = p;
+    q.dw = acc;
     q.Gs = CoutG;                                         // row stride of dz; channels Cout..CoutG-1 are padding
     if (stem) rc = launch_wgrad<64, 32, 32, 32, true>(q, st);
     else if (Cout >= 128 && Cx >= 128) rc = launch_wgrad<128, 128, 64, 64, false>(q, st);
@@ -315,6 +319,7 @@ extern "C" int vatl_conv2d_wgrad(const float* x, const float* dz, float* dw, flo
     else if (Cout > 32) rc = launch_wgrad<64, 64, 32, 32, false>(q, st);
     else rc = launch_wgrad<32, 128, 32, 32, false>(q, st);
     if (rc) return rc;
+    if (direct) return 0;
     const long long total = (long long)Cout * Cin * R * S;
     long long gsz = (total + 255) / 256; if (gsz > 4096) gsz = 4096;
     hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3((unsigned)gsz), dim3(256), 0, st, workspace, dw, Cout, Cin, R, S, stem ? 8 : S, Cx);

@@ -168,6 +168,8 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     """(Cout,Cin,R,S) -> [CoutPad][R][Spad][CinPad]; the 3-channel stem is padded to 4 channels x 8 taps."""
     cout, cin, r, s = w.shape
     cpad = conv_cout_pad(cout)
+    if r == 1 and s == 1 and cpad == cout and cin != 3 and w.is_contiguous() and w.dtype == torch.float32:
+        return w.detach().view(cout, 1, 1, cin)              # (Cout,Cin,1,1) already is the packed [Cout][1][1][Cin]: no copy
     spad, cinpad = (8, 4) if cin == 3 else (s, cin)
     out = torch.empty((cpad, r, spad, cinpad), device=w.device, dtype=torch.float32)
     _check(lib().vatl_pack_conv_weight(_ptr(w.contiguous()), _ptr(out), cout, cin, r, s, cpad, spad, cinpad, _stream()), "vatl_pack_conv_weight")
