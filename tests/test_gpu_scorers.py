@@ -261,3 +261,25 @@ def test_autoencoder_finetune_steps_match_torch_adam(vh):
     assert after < before and np.isfinite(mean_loss)
     with pytest.raises(vh.VatlError):
         vh.ae_train_step(flat, m, v, to_dev(np.zeros((13, 38), np.float32)), 38, 2, 1, 1e-2)        # batch above the kernel's 12
+
+
+def test_decode_with_nan_and_inf_entries(vh):
+    """Null handling like numpy's: a NaN is the arg-max (the first one), its score is NaN and `maxval > 0` is False, so
+    the joint decodes to the (0, 0) heat-map corner; +inf is an ordinary maximum."""
+    hm = synth.blob_heatmaps(2, seed=13)
+    hm[0, 2, 10, 7] = np.nan; hm[0, 2, 40, 30] = np.nan          # two NaNs: the first (row-major) wins
+    hm[0, 5, 33, 21] = np.inf
+    hm[1, 0, :, :] = np.nan                                      # whole plane NaN -> index 0
+    hm[1, 4, 63, 47] = np.nan                                    # NaN in the last element, every thread has seen real values
+    bb = synth.bboxes(2)
+    c, m, i = vh.decode(to_dev(hm), to_dev(bb))
+    c, m, i = c.cpu().numpy(), m.cpu().numpy(), i.cpu().numpy()
+    for n in range(2):
+        with np.errstate(all="ignore"):
+            d = scorers.decode_heatmaps(hm[n], bb[n])
+        assert np.array_equal(i[n], d["idx"].astype(np.int32))
+        assert np.array_equal(np.isnan(m[n]), np.isnan(d["maxvals"][:, 0]))
+        ok = ~np.isnan(d["maxvals"][:, 0])
+        assert np.array_equal(m[n][ok], d["maxvals"][ok, 0])
+        np.testing.assert_allclose(c[n], d["coords"], rtol=1e-6, atol=1e-4)
+    assert i[0, 2] == 10 * 48 + 7 and i[0, 5] == 33 * 48 + 21 and i[1, 0] == 0 and i[1, 4] == 63 * 48 + 47

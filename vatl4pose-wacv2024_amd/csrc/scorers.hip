@@ -10,8 +10,9 @@ namespace vatl {
 // --------------------------------------------------------------------------
 // decode: one 256-thread block per (item, joint)
 // --------------------------------------------------------------------------
+// np.argmax ordering: larger value first, equal values by lower index, and NaN is the maximum (the FIRST NaN wins)
 __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi) {
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    if (ov > v || (ov == v && oi < i) || (ov != ov && (v == v || oi < i))) { v = ov; i = oi; }
 }
 
 __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ hm, const float* __restrict__ bbox,
@@ -32,12 +33,12 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
             const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (v[e] > best || bidx == 0x7fffffff) { best = v[e]; bidx = 4 * q + e; }
+                if (v[e] > best || bidx == 0x7fffffff || (v[e] != v[e] && best == best)) { best = v[e]; bidx = 4 * q + e; }
         }
     } else {
         for (int q = tid; q < HW; q += 256) {
             const float v = src[q];
-            if (v > best || bidx == 0x7fffffff) { best = v; bidx = q; }
+            if (v > best || bidx == 0x7fffffff || (v != v && best == best)) { best = v; bidx = q; }
         }
     }
 #pragma unroll
