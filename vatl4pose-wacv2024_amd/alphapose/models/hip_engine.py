@@ -307,6 +307,14 @@ class _NchwAdapter:
         return vh.nhwc_to_nchw(self.inner(vh.nchw_to_nhwc(x_nchw)))
 
 
+def _chunks(n: int):
+    """Balanced chunk bounds: 1080 crops (the reference's evaluation batch) become 2 x 540, not 1024 + 56 — a small last
+    chunk would run every layer on a nearly empty grid.  Results do not depend on the chunking (bit-identical)."""
+    k = max(1, -(-n // MAX_CHUNK))
+    size = -(-n // k)
+    return [(i, min(i + size, n)) for i in range(0, n, size)]
+
+
 def _version_key(m: nn.Module, device):
     v = 0
     for t in list(m.parameters()) + list(m.buffers()):
@@ -361,7 +369,7 @@ def run_module_nchw(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
     plan = _plan_for(m, x.device)
     if x.shape[0] <= MAX_CHUNK:
         return plan(x)
-    return torch.cat([plan(c) for c in x.split(MAX_CHUNK)], 0)
+    return torch.cat([plan(x[a:b]) for a, b in _chunks(x.shape[0])], 0)
 
 
 def forward_into(m: nn.Module, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
@@ -371,8 +379,8 @@ def forward_into(m: nn.Module, x: torch.Tensor, out: torch.Tensor) -> torch.Tens
         raise vh.VatlError("forward_into is an inference entry point: call model.eval() first")
     x = _prepare_input(m, x)
     plan = _plan_for(m, x.device)
-    for i in range(0, x.shape[0], MAX_CHUNK):
-        plan(x[i:i + MAX_CHUNK], out=out[i:i + MAX_CHUNK])
+    for a, b in _chunks(x.shape[0]):
+        plan(x[a:b], out=out[a:b])
     return out
 
 
@@ -386,8 +394,8 @@ def forward_with_embedding(m: nn.Module, x: torch.Tensor, out: torch.Tensor, emb
     plan = _plan_for(m, x.device)
     if not hasattr(plan, "features"):
         raise vh.VatlError(f"{type(m).__name__} has no get_embedding")
-    for i in range(0, x.shape[0], MAX_CHUNK):
-        plan(x[i:i + MAX_CHUNK], out=out[i:i + MAX_CHUNK], emb_out=emb[i:i + MAX_CHUNK])
+    for a, b in _chunks(x.shape[0]):
+        plan(x[a:b], out=out[a:b], emb_out=emb[a:b])
 
 
 def embedding(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
@@ -396,4 +404,4 @@ def embedding(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
         raise vh.VatlError("get_embedding is used in evaluation only (ActiveLearning.py:259,284): call model.eval() first")
     x = _prepare_input(m, x)
     plan = _plan_for(m, x.device)
-    return torch.cat([vh.gap_fwd(plan.features(c)) for c in x.split(MAX_CHUNK)], 0)
+    return torch.cat([vh.gap_fwd(plan.features(x[a:b])) for a, b in _chunks(x.shape[0])], 0)
