@@ -433,3 +433,41 @@ def test_gaussian_targets_vs_reference_golden(vh, tag, hm_hw, in_hw, sigma):
     assert np.array_equal(w.reshape(6, 17), want_w.reshape(6, 17))
     assert np.array_equal(t != 0, want_t != 0)
     np.testing.assert_allclose(t, want_t, rtol=2e-6, atol=1e-12)
+
+
+def test_simplepose_step_well_conditioned_batch(vh):
+    """The same fine-tune step on a better-conditioned problem (12 crops of 128x96: >= 576 samples per channel in the
+    last stage instead of 96): the whole-network gradients sit within ~1e-3 of float64 autograd, i.e. the 1e-2-level
+    spread of the 2-crop golden steps is conditioning (ReLU / BN sign flips), not kernel error.  The fp32 oracle
+    graph's own distance to float64 is recorded next to ours."""
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    from oracle import nets
+    hw = (128, 96)
+    cfg = edict({"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50})
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": list(hw), "HEATMAP_SIZE": [hw[0] // 4, hw[1] // 4]})
+    m = builder.build_sppe(cfg, preset_cfg=preset)
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    m = m.to(dev()).train()
+    n = 12
+    x = synth.crops(n, hw=hw)
+    labels, masks = synth.gaussian_targets(n, seed=5, hw=(hw[0] // 4, hw[1] // 4))
+    out = m(to_dev(x))
+    (0.5 * torch.nn.MSELoss()(out.mul(to_dev(masks)), to_dev(labels).mul(to_dev(masks)))).backward()
+    grads = {}
+    for dt in (torch.float64, torch.float32):
+        ref = nets.SimplePoseRef(50)
+        ref.load_state_dict(synth.state_dict_for(ref), strict=True)
+        ref = ref.to(dt).train()
+        o = ref(torch.from_numpy(x).to(dt))
+        (0.5 * torch.nn.MSELoss()(o * torch.from_numpy(masks).to(dt), torch.from_numpy(labels).to(dt) * torch.from_numpy(masks).to(dt))).backward()
+        grads[dt] = {k: p.grad.double().numpy() for k, p in ref.named_parameters()}
+    ours, ref32 = [], []
+    for k, p in m.named_parameters():
+        ex = grads[torch.float64][k]
+        den = max(np.linalg.norm(ex), 1e-30)
+        ours.append(float(np.linalg.norm(p.grad.cpu().double().numpy() - ex) / den))
+        ref32.append(float(np.linalg.norm(grads[torch.float32][k] - ex) / den))
+    record("train_step_well_conditioned", tensors=len(ours), ours_worst_l2=max(ours), ours_median_l2=float(np.median(ours)),
+           torch_fp32_worst_l2=max(ref32), torch_fp32_median_l2=float(np.median(ref32)))
+    assert np.median(ours) < 1e-3 and max(ours) < 3 * max(max(ref32), 2e-3)
