@@ -436,10 +436,11 @@ def test_gaussian_targets_vs_reference_golden(vh, tag, hm_hw, in_hw, sigma):
 
 
 def test_simplepose_step_well_conditioned_batch(vh):
-    """The same fine-tune step on a better-conditioned problem (12 crops of 128x96: >= 576 samples per channel in the
-    last stage instead of 96): the whole-network gradients sit within ~1e-3 of float64 autograd, i.e. the 1e-2-level
-    spread of the 2-crop golden steps is conditioning (ReLU / BN sign flips), not kernel error.  The fp32 oracle
-    graph's own distance to float64 is recorded next to ours."""
+    """The same fine-tune step on a larger batch (12 crops of 128x96: 576 samples per channel in the last stage instead
+    of 96), every one of the 170 parameter tensors against float64 autograd, with torch's own fp32 run of the same graph
+    as the yardstick: measured on MI355X ours / torch-fp32 = 4.6e-3 / 4.5e-3 (median L2) and 1.48e-2 / 1.50e-2 (worst) —
+    the distance to float64 is the fp32 conditioning of a 53-BatchNorm network with synthetic weights, and the HIP path
+    sits exactly where fp32 PyTorch sits."""
     from alphapose.models import builder
     from alphapose.utils.config import edict
     from oracle import nets
@@ -470,4 +471,4 @@ def test_simplepose_step_well_conditioned_batch(vh):
         ref32.append(float(np.linalg.norm(grads[torch.float32][k] - ex) / den))
     record("train_step_well_conditioned", tensors=len(ours), ours_worst_l2=max(ours), ours_median_l2=float(np.median(ours)),
            torch_fp32_worst_l2=max(ref32), torch_fp32_median_l2=float(np.median(ref32)))
-    assert np.median(ours) < 1e-3 and max(ours) < 3 * max(max(ref32), 2e-3)
+    assert np.median(ours) < 1.5 * np.median(ref32) + 1e-4 and max(ours) < 2 * max(ref32) + 1e-3
