@@ -402,20 +402,3 @@ def test_persistent_1x1_kernel_is_bit_identical(vh):
         finally:
             vh.tune_set(5, 0); vh.tune_set(7, 1)
         assert torch.equal(a, b), (n, cin, cout)
-
-
-def test_weights_stationary_kernel_is_bit_identical(vh):
-    """<= 32 output channels, K <= 320: the kernel that keeps the weights in registers against the generic 128x32 tile."""
-    r = np.random.RandomState(92)
-    for (n, h, w, cin, cout, k, res) in ((30, 64, 48, 32, 32, 3, True), (12, 64, 48, 64, 32, 1, False), (11, 64, 48, 128, 32, 1, False),
-                                         (9, 64, 48, 256, 32, 1, True), (25, 64, 48, 32, 24, 3, False)):
-        x = to_dev(r.standard_normal((n, h, w, cin)).astype(np.float32))
-        wp = vh.pack_conv_weight(to_dev((r.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)))
-        sc, bi = to_dev(r.uniform(0.5, 1.5, cout).astype(np.float32)), to_dev(r.standard_normal(cout).astype(np.float32))
-        rs = to_dev(r.standard_normal((n, h, w, cout)).astype(np.float32)) if res else None
-        try:
-            vh.tune_set(8, 0); a = vh.conv2d_fwd(x, wp, sc, bi, cout, k, k, 1, k // 2, True, residual=rs).clone()
-            vh.tune_set(8, 1); b = vh.conv2d_fwd(x, wp, sc, bi, cout, k, k, 1, k // 2, True, residual=rs).clone()
-        finally:
-            vh.tune_set(8, 1)
-        assert torch.equal(a, b), (n, cin, cout, k)

@@ -661,111 +661,6 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_persistent_kernel(ConvParams p
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Weights-stationary kernel for <= 32 output channels and a short reduction (K = R*S*Cin <= 320: the 3x3 convs of
-// HRNet's 32-channel branch, K = 288, and its 1x1 fusion convs).  With a 128x32 block tile every wave re-reads the
-// SAME 32x32 weight fragment from LDS for its own 32 rows: half of the LDS traffic, and three resident blocks run the
-// LDS pipe at ~75 % — the limit of the generic kernel on these layers (~80 TFLOP/s).  Here each wave keeps the whole
-// weight matrix of its 32 columns in registers (K/2 MFMA k-steps = 144 VGPRs for K = 288), only activations go through
-// LDS, and the block is persistent over row tiles (next tile's first operands requested before the epilogue).
-// Same fragment mapping, MFMA order and epilogue as conv_igemm_kernel<128,32,32,32>: bit-identical results.
-// ---------------------------------------------------------------------------------------------------------
-template <int KT>
-__global__ __launch_bounds__(256, 2) void conv_ws32_kernel(ConvParams p) {
-    constexpr int BM = 128, BN = 32, WM = 32, WN = 32, LA = 4, NG = BK / 8;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                          // [2][BM][LDK]; the epilogue's 128 x 36 tile reuses it
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave, wn = 0;
-    const int lrow = tid >> 3, kq = tid & 7;
-    const int frow = lane & 31, fk = (lane >> 5) * 4;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
-
-    // the wave's B fragments for the whole reduction, straight from the packed weights [32][K]
-    f32x4 bw[KT][NG];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int g = 0; g < NG; ++g) bw[kt][g] = buf_load4(wr, (unsigned)((frow * p.K + kt * BK + g * 8 + fk) * 4));
-
-    const int HoWo = p.Ho * p.Wo;
-    int abase[LA], iy0[LA], ix0[LA];
-    auto setup = [&](int m_tile, int (&ab)[LA], int (&y0)[LA], int (&x0)[LA]) {
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const int m = m_tile * BM + lrow + 32 * i;
-            if (m < p.M) {
-                const int b = m / HoWo;
-                const int rem = m - b * HoWo;
-                const int oy = rem / p.Wo;
-                const int ox = rem - oy * p.Wo;
-                y0[i] = oy * p.stride - p.pad_y;
-                x0[i] = ox * p.stride - p.pad_x;
-                ab[i] = ((b * p.H + y0[i]) * p.W + x0[i]) * p.Cin + kq * 4;
-            } else {
-                y0[i] = -(1 << 20); x0[i] = -(1 << 20); ab[i] = 0;
-            }
-        }
-    };
-    f32x4 ra[LA];
-    auto gload = [&](const int (&ab)[LA], const int (&y0)[LA], const int (&x0)[LA], int kt) {
-        const int rs = kt / p.kpr;
-        const int c0 = (kt - rs * p.kpr) * BK;
-        const int g_r = rs / p.S, g_s = rs - g_r * p.S;
-        const int g_off = (g_r * p.W + g_s) * p.Cin + c0;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const bool ok = (unsigned)(y0[i] + g_r) < (unsigned)p.H && (unsigned)(x0[i] + g_s) < (unsigned)p.W;
-            ra[i] = buf_load4(xr, ok ? (unsigned)(ab[i] + g_off) << 2 : OOB);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + 32 * i) * LDK + kq * 4]) = ra[i];
-    };
-
-    int m_tile = blockIdx.x;
-    if (m_tile >= p.m_tiles) return;
-    setup(m_tile, abase, iy0, ix0);
-    gload(abase, iy0, ix0, 0);
-    lstore(0);
-    __syncthreads();
-    for (;;) {
-        f32x16 acc[1][1];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            const int buf = kt & 1;
-            if (kt + 1 < KT) gload(abase, iy0, ix0, kt + 1);
-            const float* Ab = As + (buf * BM + wm * WM + frow) * LDK + fk;
-            f32x4 af[NG];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) af[g] = *reinterpret_cast<const f32x4*>(Ab + g * 8);
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][tt], bw[kt][g][tt], acc[0][0], 0, 0, 0);
-            if (kt + 1 < KT) lstore(buf ^ 1);
-            __syncthreads();
-        }
-        const int next = m_tile + gridDim.x;
-        const bool more = next < p.m_tiles;
-        int abn[LA], y0n[LA], x0n[LA];
-        if (more) { setup(next, abn, y0n, x0n); gload(abn, y0n, x0n, 0); }
-        conv_epilogue<BM, BN, WM, WN>(p, acc, smem, m_tile * BM, 0, 0, 0, wm, wn, tid, lane, HoWo);
-        if (!more) break;
-        __syncthreads();
-        lstore(0);
-        __syncthreads();
-        m_tile = next;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) { abase[i] = abn[i]; iy0[i] = y0n[i]; ix0[i] = x0n[i]; }
-    }
-}
-
 // LDS-DMA variant (VAR 5): operand tiles go HBM/L2 -> LDS directly (buffer_load ... lds, 1 KiB per wave
 // instruction, no staging VGPRs, no ds_write pass).  The DMA destination is lane-linear (base + lane*16 B), so
 // the LDS rows are unpadded 32-float rows and bank conflicts are avoided by an XOR swizzle applied on the
@@ -994,20 +889,6 @@ static int launch_persistent(const ConvParams& p, hipStream_t st) {
     return check_launch("gemm1x1_persistent");
 }
 
-template <int KT>
-static int launch_ws32(const ConvParams& p, hipStream_t st) {
-    auto kern = conv_ws32_kernel<KT>;
-    constexpr int smem = 2 * 128 * LDK * (int)sizeof(float);     // 36 KB: activations only (and the 128 x 36 epilogue tile)
-    ConvParams q = p;
-    q.n_tiles = 1;
-    q.m_tiles = cdiv(p.M, 128);
-    int grid = 512;                                              // two resident blocks per CU (register-bound: the weights live in VGPRs)
-    if (grid > q.m_tiles) grid = q.m_tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, st, q);
-    return check_launch("conv_ws32");
-}
-
-static std::atomic<int> g_ws32{1};     // vatl_tune_set(8, v): weights-stationary kernel for <= 32 output channels (0 = off)
 static std::atomic<int> g_persist{1};  // vatl_tune_set(7, v): persistent kernel for 1x1 layers with K <= 256 v (0 = off)
 
 // CoutPad granularity the packer must honour for a given Cout.
@@ -1044,17 +925,6 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, 
     if (bm == 64) {
         if (bn == 128) return launch<64, 128, 32, 64, false, 4>(p, phases, st);
         return launch<64, 64, 32, 32, false, 4>(p, phases, st);
-    }
-    // <= 32 output channels with a short reduction: weights held in registers (HRNet's 32-channel branch)
-    if (bn == 32 && var == 4 && g_ws32.load(std::memory_order_relaxed) && phases == 1 && p.CoutPad == 32 && !p.deconv && !p.out_nchw &&
-        (p.Cout & 3) == 0 && !p.x2 && p.kpr * BK == p.Cin && p.M >= 128 * 512) {
-        switch (p.ktiles) {
-            case 2: return launch_ws32<2>(p, st);
-            case 4: return launch_ws32<4>(p, st);
-            case 8: return launch_ws32<8>(p, st);
-            case 9: return launch_ws32<9>(p, st);
-            default: break;
-        }
     }
     // short-K 1x1 / stride-1 layers on whole 128x128 tiles: the persistent GEMM kernel
     const int pk = g_persist.load(std::memory_order_relaxed);
@@ -1102,7 +972,6 @@ extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 5 && (value == 0 || value == 64 || value == 128)) { g_bm.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 6 && value >= 0 && value <= 3) { g_ablate.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 7 && value >= 0 && value <= 64) { g_persist.store(value, std::memory_order_relaxed); return 0; }
-    if (knob == 8 && value >= 0 && value <= 1) { g_ws32.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
     if (knob == 0 && value >= 0 && value <= 13) { g_var.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }
