@@ -319,6 +319,12 @@ int vatl_ae_train_step(float* ae, float* m, float* v, const float* feat, int B, 
 int vatl_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                     double eps, double weight_decay, int step, void* stream);
 
+/* The same update for a whole parameter group in one launch: table_dev = n_tensors rows of {p, g, m, v, numel} (device
+ * pointers and the element count as int64, resident on the device); every tensor shares the hyper-parameters and the
+ * step count.  Arithmetic per element identical to vatl_adamw_step. */
+int vatl_adamw_step_multi(const int64_t* table_dev, int n_tensors, int64_t max_numel, double lr, double beta1, double beta2, double eps,
+                          double weight_decay, int step, void* stream);
+
 /* torch.optim.Adam step (ActiveLearning.py:222-223): like AdamW but `weight_decay`
  * is an L2 term added to the gradient (the reference passes none: 0). */
 int vatl_adam_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,

@@ -283,3 +283,24 @@ def test_decode_with_nan_and_inf_entries(vh):
         assert np.array_equal(m[n][ok], d["maxvals"][ok, 0])
         np.testing.assert_allclose(c[n], d["coords"], rtol=1e-6, atol=1e-4)
     assert i[0, 2] == 10 * 48 + 7 and i[0, 5] == 33 * 48 + 21 and i[1, 0] == 0 and i[1, 4] == 63 * 48 + 47
+
+
+def test_multi_tensor_adamw_equals_per_tensor(vh):
+    """One launch per parameter group (`vatl_adamw_step_multi`) against the per-tensor kernel: same bits, odd sizes and
+    unaligned tails included; the optimizer class uses it and bumps every parameter's version counter."""
+    from active_learning.optim import AdamW
+    r = np.random.RandomState(17)
+    sizes = [(64,), (17,), (256, 64, 3, 3), (1001,), (5, 7), (2048, 512, 1, 1)]
+    ps = [torch.nn.Parameter(to_dev(r.standard_normal(s).astype(np.float32))) for s in sizes]
+    qs = [p.detach().clone() for p in ps]
+    ms, vs = [torch.zeros_like(q) for q in qs], [torch.zeros_like(q) for q in qs]
+    opt = AdamW([{"params": ps[:2], "lr": 2.5e-3}, {"params": ps[2:], "lr": 2.5e-4}], weight_decay=0.7)
+    for step in range(1, 4):
+        gs = [to_dev(r.standard_normal(s).astype(np.float32)) for s in sizes]
+        for p, g in zip(ps, gs):
+            p.grad = g
+        opt.step()
+        for k, (q, g, m, v) in enumerate(zip(qs, gs, ms, vs)):
+            vh.adamw_step(q, g, m, v, step, 2.5e-3 if k < 2 else 2.5e-4, 0.7)
+    for p, q in zip(ps, qs):
+        assert torch.equal(p.detach(), q) and p._version > 0

@@ -335,6 +335,46 @@ __global__ __launch_bounds__(256) void gaussian_target_kernel(const float* __res
     }
 }
 
+// Multi-tensor AdamW: one launch per parameter group instead of one per tensor (161 tensors for SimplePose-R50).
+// table[t] = {p, g, m, v, n} (device pointers / element count as int64); blockIdx.y = tensor, blocks stride over it.
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const long long* __restrict__ table, float decay, float omb1, float b2, float omb2,
+                                                          float bc2s, float eps, float step_size) {
+    const long long* row = table + 5 * (long long)blockIdx.y;
+    float* __restrict__ p = reinterpret_cast<float*>(row[0]);
+    const float* __restrict__ g = reinterpret_cast<const float*>(row[1]);
+    float* __restrict__ m = reinterpret_cast<float*>(row[2]);
+    float* __restrict__ v = reinterpret_cast<float*>(row[3]);
+    const long long n = row[4];
+    const bool vec = ((row[0] | row[1] | row[2] | row[3]) & 15) == 0;
+    const long long n4 = vec ? n >> 2 : 0;
+    for (long long q = blockIdx.x * 256LL + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        f32x4 P = *reinterpret_cast<f32x4*>(p + 4 * q);
+        const f32x4 G = *reinterpret_cast<const f32x4*>(g + 4 * q);
+        f32x4 M = *reinterpret_cast<f32x4*>(m + 4 * q);
+        f32x4 V = *reinterpret_cast<f32x4*>(v + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            P[e] = P[e] * decay;
+            M[e] = M[e] + (G[e] - M[e]) * omb1;
+            V[e] = V[e] * b2 + G[e] * G[e] * omb2;
+            P[e] = P[e] - step_size * (M[e] / (sqrtf(V[e]) / bc2s + eps));
+        }
+        *reinterpret_cast<f32x4*>(p + 4 * q) = P;
+        *reinterpret_cast<f32x4*>(m + 4 * q) = M;
+        *reinterpret_cast<f32x4*>(v + 4 * q) = V;
+    }
+    if (blockIdx.x == 0) {
+        for (long long i = 4 * n4 + threadIdx.x; i < n; i += 256) {
+            float P = p[i] * decay;
+            const float G = g[i];
+            const float M = m[i] + (G - m[i]) * omb1;
+            const float V = v[i] * b2 + G * G * omb2;
+            P = P - step_size * (M / (sqrtf(V) / bc2s + eps));
+            p[i] = P; m[i] = M; v[i] = V;
+        }
+    }
+}
+
 }  // namespace vatl
 
 using namespace vatl;
@@ -444,4 +484,19 @@ extern "C" int vatl_gaussian_targets(const float* joints_xy, const float* vis, f
     hipLaunchKernelGGL(gaussian_target_kernel, dim3((unsigned)(N * J)), dim3(256), 0, (hipStream_t)stream, joints_xy, vis, target, weight, H, W,
                        (double)in_h / (double)H, (double)in_w / (double)W, sigma);   // the reference divides x by stride[0] = in_h / H (:130)
     return check_launch("gaussian_targets");
+}
+
+extern "C" int vatl_adamw_step_multi(const int64_t* table_dev, int n_tensors, int64_t max_numel, double lr, double beta1, double beta2, double eps,
+                                     double weight_decay, int step, void* stream) {
+    if (n_tensors <= 0) return 0;
+    if (!table_dev) return fail(VATL_EINVAL, "adamw_step_multi: null table");
+    if (step < 1) return fail(VATL_EINVAL, "adamw_step_multi: step is 1-based");
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    long long bx = (max_numel / 4 + 255) / 256;
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)bx, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(table_dev), (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps, (float)(lr / bc1));
+    return check_launch("adamw_step_multi");
 }

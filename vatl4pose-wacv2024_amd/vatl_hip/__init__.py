@@ -87,6 +87,7 @@ SIGNATURES = {
     "vatl_cosine_rowsum": (_i, [_p, _i64, _i, _p, _p, _p]),
     "vatl_kcenter_update": (_i, [_p, _i64, _i, _p, _i, _p, _i, _p]),
     "vatl_kcenter_pick": (_i, [_p, _p, _d, _d, _p, _i, _i64, _p]),
+    "vatl_adamw_step_multi": (_i, [_p, _i, _i64, _d, _d, _d, _d, _d, _i, _p]),
     "vatl_adam_step": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _p]),
     "vatl_sgd_step": (_i, [_p, _p, _p, _i64, _d, _d, _d, _i, _p]),
 }
@@ -714,6 +715,21 @@ def unpack_ae(flat: torch.Tensor, module) -> None:
                 for t in (half[i].weight, half[i].bias):
                     t.copy_(flat[off:off + t.numel()].view_as(t))
                     off += t.numel()
+
+
+def adamw_step_multi(params, grads, ms, vs, step: int, lr: float, weight_decay: float, betas=(0.9, 0.999), eps: float = 1e-8):
+    """One launch for a list of tensors sharing hyper-parameters and step count."""
+    if not params:
+        return
+    rows = []
+    for p_, g_, m_, v_ in zip(params, grads, ms, vs):
+        for t in (p_, g_, m_, v_):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise VatlError("adamw_step_multi needs contiguous fp32 device tensors")
+        rows.append((p_.data_ptr(), g_.data_ptr(), m_.data_ptr(), v_.data_ptr(), p_.numel()))
+    table = torch.tensor(rows, dtype=torch.int64).to(params[0].device, non_blocking=False)
+    _check(lib().vatl_adamw_step_multi(_ptr(table, torch.int64), len(rows), max(r[4] for r in rows), lr, betas[0], betas[1], eps, weight_decay, step,
+                                       _stream()), "vatl_adamw_step_multi")
 
 
 def adam_step(p, g, m, v, step: int, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8):
