@@ -213,13 +213,14 @@ int vatl_pack_dgrad_weight(const float* w_oihw, float* out, int Cout, int Cin, i
                            int ntaps, const int* tap_r, const int* tap_s, void* stream);
 /* Weight gradient of nn.Conv2d: dw (Cout,Cin,R,S) = sum over pixels of dz (x) x.  x NHWC (N,H,W,Cin)
  * (Cin = 3 means the 4-channel padded stem input), dz NHWC (N,Ho,Wo,CoutG) with channel stride
- * CoutG >= Cout; workspace: vatl_conv2d_wgrad_workspace_floats floats.  fp32 MFMA, split over pixels,
- * fp32 atomics (summation order across splits not fixed). */
-int64_t vatl_conv2d_wgrad_workspace_floats(int Cout, int Cin, int R, int S);
+ * CoutG >= Cout.  fp32 MFMA; the pixel range is split over blocks, every split writes a partial gradient into its slice
+ * of the workspace (vatl_conv2d_wgrad_workspace_floats(Cout, Cin, R, S, M = N*Ho*Wo) floats) and one pass sums the slices
+ * in split order while restoring the OIHW layout: no atomics, bitwise reproducible. */
+int64_t vatl_conv2d_wgrad_workspace_floats(int Cout, int Cin, int R, int S, int64_t M);
 int vatl_conv2d_wgrad(const float* x, const float* dz, float* dw, float* workspace, int N, int H, int W, int Cin,
                       int Cout, int CoutG, int R, int S, int stride, int pad, void* stream);
 /* Weight gradient of nn.ConvTranspose2d(4,2,1): dw (Cin,Cout,4,4); x NHWC (N,H,W,Cin), dy NHWC (N,2H,2W,Cout). */
-int64_t vatl_deconv4x4s2_wgrad_workspace_floats(int Cin, int Cout);
+int64_t vatl_deconv4x4s2_wgrad_workspace_floats(int Cin, int Cout, int64_t M /* = N*H*W input pixels */);
 int vatl_deconv4x4s2_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int H, int W, int Cin,
                            int Cout, void* stream);
 

@@ -472,3 +472,29 @@ def test_simplepose_step_well_conditioned_batch(vh):
     record("train_step_well_conditioned", tensors=len(ours), ours_worst_l2=max(ours), ours_median_l2=float(np.median(ours)),
            torch_fp32_worst_l2=max(ref32), torch_fp32_median_l2=float(np.median(ref32)))
     assert np.median(ours) < 1.5 * np.median(ref32) + 1e-4 and max(ours) < 2 * max(ref32) + 1e-3
+
+
+def test_fine_tune_step_is_bitwise_reproducible(vh):
+    """No atomics anywhere in the step (weight gradients are reduced over pixel splits in a fixed order, BN statistics
+    and the loss through ordered partials): two runs of forward + backward give identical bits for every gradient."""
+    from alphapose.models import builder, hip_train
+    from alphapose.utils.config import edict
+    cfg = edict({"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50})
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    m = builder.build_sppe(cfg, preset_cfg=preset)
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    m = m.to(dev()).train()
+    x = to_dev(synth.crops(5))
+    labels, masks = synth.gaussian_targets(5, seed=11)
+    labels, masks = to_dev(labels), to_dev(masks)
+    runs = []
+    for _ in range(2):
+        tr = hip_train.trainer_for(m)
+        with torch.no_grad():
+            out = tr.forward(x)
+            loss, dout = vh.masked_mse_fwd_bwd(out, labels, masks)
+            grads = tr.backward(dout)
+        runs.append((out.clone(), float(loss), {k: v.clone() for k, v in grads.items()}))
+    assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    for p in runs[0][2]:
+        assert torch.equal(runs[0][2][p], runs[1][2][p])

@@ -33,7 +33,8 @@ struct WgradParams {
     int d_oy, d_ox;      // (row, column) advance of a 32-pixel step: 32 = d_b*Ho*Wo + d_oy*Wo + d_ox
     int adv, adv_cx, adv_cy;   // element-offset advance of the gathered operand for that step / a column carry / a row carry
     unsigned g_bytes, x_bytes;
-    int ablate;          // benchmarks only (vatl_tune_set(4, bits)): 1 = skip the atomic epilogue (wrong results)
+    int ablate;          // benchmarks only (vatl_tune_set(4, bits)): 1 = skip the epilogue (wrong results)
+    long long slice;     // floats between the partial gradients of consecutive M-splits in the workspace
 };
 
 constexpr unsigned WG_OOB = 0xFFFFFFFFu;
@@ -199,8 +200,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     }
 
     if (p.ablate & 1) return;
-    // D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)] -> n,  [col = lane&31] -> channel: coalesced fp32 atomics
+    // D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)] -> n,  [col = lane&31] -> channel: coalesced stores of this split's partial
+    // tile into its own slice of the workspace (no atomics: the reduction over splits runs in a fixed order afterwards)
     const int Kp = (STEM ? p.R * 8 : p.R * p.S) * p.Cx;
+    float* __restrict__ part = p.dw + (long long)split * p.slice;
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + wn * WN + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                if (cv && n < p.Cn) atomicAdd(p.dw + (long long)n * Kp + col, acc[i][j][e]);
+                if (cv && n < p.Cn) part[(long long)n * Kp + col] = acc[i][j][e];
             }
         }
 }
@@ -219,32 +222,60 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
 static std::atomic<int> g_wgrad_blocks{1024};
 static std::atomic<int> g_wgrad_ablate{0};   // vatl_tune_set(3, v)
 
+// tile configuration of a weight-gradient GEMM: rows n (Cn), columns (tap, channel of Cx)
+struct WgradCfg { int bn, bj; bool stem; };
+static WgradCfg wgrad_cfg(int Cn, int Cx, bool stem) {
+    if (stem) return {64, 32, true};
+    if (Cn >= 128 && Cx >= 128) return {128, 128, false};
+    if (Cn >= 128) return {128, 64, false};
+    if (Cn > 32 && Cx >= 128) return {64, 128, false};
+    if (Cn > 32) return {64, 64, false};
+    return {32, 128, false};
+}
+
+// number of M-splits: at most ~g_wgrad_blocks blocks (two per CU resident: 512 per wave), at least 4 k-tiles each
+struct WgradPlan { int tiles, splits, kt_per_split; };
+static WgradPlan wgrad_plan(const WgradCfg& c, int Cn, int Cx, int R, int S, long long M) {
+    const int n_tiles = cdiv(Cn, c.bn), taps = c.stem ? R : R * S, j_tiles = c.stem ? 1 : cdiv(Cx, c.bj);
+    const int tiles = n_tiles * taps * j_tiles;
+    const int ktiles = cdiv(M, 32);
+    int splits = g_wgrad_blocks.load(std::memory_order_relaxed) / tiles;      // floor: stay within a whole number of 512-block waves
+    const int max_splits = (ktiles + 3) / 4;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const int kps = (ktiles + splits - 1) / splits;
+    return {tiles, (ktiles + kps - 1) / kps, kps};                           // every split owns >= 1 k-tile
+}
+
 template <int BN, int BJ, int WN, int WJ, bool STEM>
-static int launch_wgrad(WgradParams p, hipStream_t st) {
+static int launch_wgrad_t(WgradParams p, const WgradPlan& plan, hipStream_t st) {
     p.n_tiles = cdiv(p.Cn, BN);
     p.taps = STEM ? p.R : p.R * p.S;
     p.j_tiles_per_tap = STEM ? 1 : cdiv(p.Cx, BJ);
-    const int tiles = p.n_tiles * p.taps * p.j_tiles_per_tap;
     const int hw = p.Ho * p.Wo, rem = 32 % hw;
     p.d_oy = rem / p.Wo; p.d_ox = rem % p.Wo;
     p.adv = ((32 / hw) * p.H * p.W + p.d_oy * p.stride * p.W + p.d_ox * p.stride) * p.Cx;
     p.adv_cx = (p.stride * p.W - p.Wo * p.stride) * p.Cx;
     p.adv_cy = (p.H * p.W - p.Ho * p.stride * p.W) * p.Cx;
-    // M-splits for at most ~g_wgrad_blocks blocks (two per CU resident: 512 per wave), at least 4 k-tiles each
-    const int target = g_wgrad_blocks.load(std::memory_order_relaxed);
     p.ablate = g_wgrad_ablate.load(std::memory_order_relaxed);
-    int splits = target / tiles;                           // floor: stay within a whole number of 512-block waves
-    const int max_splits = (p.ktiles + 3) / 4;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    p.kt_per_split = (p.ktiles + splits - 1) / splits;
-    splits = (p.ktiles + p.kt_per_split - 1) / p.kt_per_split;
-    hipLaunchKernelGGL((conv_wgrad_kernel<BN, BJ, WN, WJ, STEM>), dim3((unsigned)(tiles * splits)), dim3(256), 0, st, p);
+    p.kt_per_split = plan.kt_per_split;
+    hipLaunchKernelGGL((conv_wgrad_kernel<BN, BJ, WN, WJ, STEM>), dim3((unsigned)(plan.tiles * plan.splits)), dim3(256), 0, st, p);
     return check_launch("conv_wgrad");
 }
 
+static int launch_wgrad(const WgradParams& p, const WgradCfg& c, const WgradPlan& plan, hipStream_t st) {
+    if (c.stem) return launch_wgrad_t<64, 32, 32, 32, true>(p, plan, st);
+    if (c.bn == 128 && c.bj == 128) return launch_wgrad_t<128, 128, 64, 64, false>(p, plan, st);
+    if (c.bn == 128) return launch_wgrad_t<128, 64, 64, 32, false>(p, plan, st);
+    if (c.bn == 64 && c.bj == 128) return launch_wgrad_t<64, 128, 32, 64, false>(p, plan, st);
+    if (c.bn == 64) return launch_wgrad_t<64, 64, 32, 32, false>(p, plan, st);
+    return launch_wgrad_t<32, 128, 32, 32, false>(p, plan, st);
+}
+
 // out (Cout,Cin,R,S) <- packed [Cout][R][Spad][CinPad]   (inverse of pack_conv_weight, drops the padding)
-__global__ void unpack_conv_grad_kernel(const float* __restrict__ packed, float* __restrict__ out, int Cout, int Cin, int R, int S, int Spad, int CinPad) {
+// ... summed over the M-splits in split order (deterministic)
+__global__ void unpack_conv_grad_kernel(const float* __restrict__ packed, float* __restrict__ out, int Cout, int Cin, int R, int S, int Spad, int CinPad,
+                                        int splits, long long slice) {
     const long long total = (long long)Cout * Cin * R * S;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int s = (int)(i % S);
@@ -252,19 +283,25 @@ __global__ void unpack_conv_grad_kernel(const float* __restrict__ packed, float*
         const int r = (int)(t % R); t /= R;
         const int c = (int)(t % Cin);
         const int o = (int)(t / Cin);
-        out[i] = packed[(((long long)o * R + r) * Spad + s) * CinPad + c];
+        const float* src = packed + (((long long)o * R + r) * Spad + s) * CinPad + c;
+        float acc = 0.f;
+        for (int k = 0; k < splits; ++k) acc += src[(long long)k * slice];
+        out[i] = acc;
     }
 }
 
 // out (Cin,Cout,4,4) <- packed [Cin][ky][kx][Cout]
-__global__ void unpack_deconv_grad_kernel(const float* __restrict__ packed, float* __restrict__ out, int Cin, int Cout) {
+__global__ void unpack_deconv_grad_kernel(const float* __restrict__ packed, float* __restrict__ out, int Cin, int Cout, int splits, long long slice) {
     const long long total = (long long)Cin * Cout * 16;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int k = (int)(i % 16);
         long long t = i / 16;
         const int o = (int)(t % Cout);
         const int c = (int)(t / Cout);
-        out[i] = packed[((long long)c * 16 + k) * Cout + o];
+        const float* src = packed + ((long long)c * 16 + k) * Cout + o;
+        float acc = 0.f;
+        for (int q = 0; q < splits; ++q) acc += src[(long long)q * slice];
+        out[i] = acc;
     }
 }
 
@@ -279,12 +316,19 @@ extern "C" int vatl_tune_wgrad_blocks(int blocks) {       // reached through vat
     return 0;
 }
 
-extern "C" int64_t vatl_conv2d_wgrad_workspace_floats(int Cout, int Cin, int R, int S) {
-    return Cin == 3 ? (int64_t)Cout * R * 8 * 4 : (int64_t)Cout * R * S * Cin;
+static int64_t conv_packed_floats(int Cout, int Cin, int R, int S) { return Cin == 3 ? (int64_t)Cout * R * 8 * 4 : (int64_t)Cout * R * S * Cin; }
+
+extern "C" int64_t vatl_conv2d_wgrad_workspace_floats(int Cout, int Cin, int R, int S, int64_t M) {
+    const bool stem = (Cin == 3);
+    const int Cx = stem ? 4 : Cin;
+    const WgradPlan plan = wgrad_plan(wgrad_cfg(Cout, Cx, stem), Cout, Cx, R, S, M);
+    return conv_packed_floats(Cout, Cin, R, S) * plan.splits;
 }
 
 // dw (Cout,Cin,R,S) = sum over pixels of dz (x) gathered input.  x NHWC (N,H,W,Cin) (Cin = 4 padded for the
-// 3-channel stem), dz NHWC (N,Ho,Wo,CoutG) where CoutG >= Cout is the channel stride of dz.
+// 3-channel stem), dz NHWC (N,Ho,Wo,CoutG) where CoutG >= Cout is the channel stride of dz.  The pixel range is split
+// over blocks; every split writes its partial gradient into its own slice of the workspace and one pass sums the slices
+// in split order while it restores the OIHW layout: no atomics, bitwise reproducible.
 extern "C" int vatl_conv2d_wgrad(const float* x, const float* dz, float* dw, float* workspace, int N, int H, int W, int Cin,
                                  int Cout, int CoutG, int R, int S, int stride, int pad, void* stream) {
     if (!x || !dz || !dw || !workspace) return fail(VATL_EINVAL, "conv2d_wgrad: null pointer");
@@ -299,34 +343,27 @@ extern "C" int vatl_conv2d_wgrad(const float* x, const float* dz, float* dw, flo
     p.Ho = (H + 2 * pad - R) / stride + 1; p.Wo = (W + 2 * pad - S) / stride + 1;
     p.M = N * p.Ho * p.Wo; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.ktiles = cdiv(p.M, 32);
+    p.Gs = CoutG;                                         // row stride of dz; channels Cout..CoutG-1 are padding
     const long long ge = (long long)p.M * CoutG, xe = (long long)N * H * W * Cx;
     if (ge + 64LL * CoutG >= (1LL << 30) || xe >= (1LL << 30)) return fail(VATL_EINVAL, "conv2d_wgrad: a tensor exceeds 2^30 elements; split the batch");
     p.g_bytes = (unsigned)(ge * 4); p.x_bytes = (unsigned)(xe * 4);
     hipStream_t st = (hipStream_t)stream;
-    const int64_t wsn = vatl_conv2d_wgrad_workspace_floats(Cout, Cin, R, S);
-    // 1x1: the packed gradient [Cout][1][Cin] IS the OIHW tensor — accumulate straight into dw, no unpack pass
-    const bool direct = !stem && R == 1 && S == 1;
-    float* acc = direct ? dw : workspace;
-    if (hipMemsetAsync(acc, 0, wsn * sizeof(float), st) != hipSuccess) return fail(VATL_ELAUNCH, "conv2d_wgrad: memset failed");
-    int rc;
-    WgradParams q = p;
-    q.dw = acc;
-    q.Gs = CoutG;                                         // row stride of dz; channels Cout..CoutG-1 are padding
-    if (stem) rc = launch_wgrad<64, 32, 32, 32, true>(q, st);
-    else if (Cout >= 128 && Cx >= 128) rc = launch_wgrad<128, 128, 64, 64, false>(q, st);
-    else if (Cout >= 128) rc = launch_wgrad<128, 64, 64, 32, false>(q, st);
-    else if (Cout > 32 && Cx >= 128) rc = launch_wgrad<64, 128, 32, 64, false>(q, st);
-    else if (Cout > 32) rc = launch_wgrad<64, 64, 32, 32, false>(q, st);
-    else rc = launch_wgrad<32, 128, 32, 32, false>(q, st);
+    const WgradCfg cfg = wgrad_cfg(Cout, Cx, stem);
+    const WgradPlan plan = wgrad_plan(cfg, Cout, Cx, R, S, p.M);
+    p.slice = conv_packed_floats(Cout, Cin, R, S);
+    const int rc = launch_wgrad(p, cfg, plan, st);
     if (rc) return rc;
-    if (direct) return 0;
     const long long total = (long long)Cout * Cin * R * S;
     long long gsz = (total + 255) / 256; if (gsz > 4096) gsz = 4096;
-    hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3((unsigned)gsz), dim3(256), 0, st, workspace, dw, Cout, Cin, R, S, stem ? 8 : S, Cx);
+    hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3((unsigned)gsz), dim3(256), 0, st, workspace, dw, Cout, Cin, R, S, stem ? 8 : S, Cx, plan.splits,
+                       p.slice);
     return check_launch("conv2d_wgrad");
 }
 
-extern "C" int64_t vatl_deconv4x4s2_wgrad_workspace_floats(int Cin, int Cout) { return (int64_t)Cin * 16 * Cout; }
+extern "C" int64_t vatl_deconv4x4s2_wgrad_workspace_floats(int Cin, int Cout, int64_t M) {
+    const WgradPlan plan = wgrad_plan(wgrad_cfg(Cin, Cout, false), Cin, Cout, 4, 4, M);
+    return (int64_t)Cin * 16 * Cout * plan.splits;
+}
 
 // dw (Cin,Cout,4,4) of ConvTranspose2d(4,2,1): x NHWC (N,H,W,Cin) layer input, dy NHWC (N,2H,2W,Cout).
 extern "C" int vatl_deconv4x4s2_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int H, int W, int Cin,
@@ -343,15 +380,13 @@ extern "C" int vatl_deconv4x4s2_wgrad(const float* x, const float* dy, float* dw
     if (ge + 64LL * Cin >= (1LL << 30) || xe >= (1LL << 30)) return fail(VATL_EINVAL, "deconv4x4s2_wgrad: a tensor exceeds 2^30 elements; split the batch");
     p.g_bytes = (unsigned)(ge * 4); p.x_bytes = (unsigned)(xe * 4);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, (size_t)Cin * 16 * Cout * sizeof(float), st) != hipSuccess) return fail(VATL_ELAUNCH, "deconv4x4s2_wgrad: memset failed");
-    int rc;
-    if (Cin >= 128 && Cout >= 128) rc = launch_wgrad<128, 128, 64, 64, false>(p, st);
-    else if (Cin >= 128) rc = launch_wgrad<128, 64, 64, 32, false>(p, st);
-    else if (Cout >= 128) rc = launch_wgrad<64, 128, 32, 64, false>(p, st);
-    else rc = launch_wgrad<64, 64, 32, 32, false>(p, st);
+    const WgradCfg cfg = wgrad_cfg(Cin, Cout, false);
+    const WgradPlan plan = wgrad_plan(cfg, Cin, Cout, 4, 4, p.M);
+    p.slice = (long long)Cin * 16 * Cout;
+    const int rc = launch_wgrad(p, cfg, plan, st);
     if (rc) return rc;
     const long long total = (long long)Cin * Cout * 16;
     long long gsz = (total + 255) / 256; if (gsz > 4096) gsz = 4096;
-    hipLaunchKernelGGL(unpack_deconv_grad_kernel, dim3((unsigned)gsz), dim3(256), 0, st, workspace, dw, Cin, Cout);
+    hipLaunchKernelGGL(unpack_deconv_grad_kernel, dim3((unsigned)gsz), dim3(256), 0, st, workspace, dw, Cin, Cout, plan.splits, p.slice);
     return check_launch("deconv4x4s2_wgrad");
 }

@@ -57,9 +57,9 @@ SIGNATURES = {
     "vatl_plane_entropy": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vatl_conv2d_fwd_ex": (_i, [_p] * 6 + [_i] * 20 + [_p]),
     "vatl_pack_dgrad_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
-    "vatl_conv2d_wgrad_workspace_floats": (_i64, [_i, _i, _i, _i]),
+    "vatl_conv2d_wgrad_workspace_floats": (_i64, [_i, _i, _i, _i, _i64]),
     "vatl_conv2d_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "vatl_deconv4x4s2_wgrad_workspace_floats": (_i64, [_i, _i]),
+    "vatl_deconv4x4s2_wgrad_workspace_floats": (_i64, [_i, _i, _i64]),
     "vatl_deconv4x4s2_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vatl_col_reduce_workspace_doubles": (_i64, [_i64, _i]),
     "vatl_bn_train_fwd_stats": (_i, [_p, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
@@ -499,7 +499,8 @@ def conv2d_wgrad(x, dz, cout: int, cin: int, r: int, s: int, stride: int, pad: i
     """x NHWC (N,H,W,Cin or 4 for the stem), dz NHWC (N,Ho,Wo,CoutG) -> dw (Cout,Cin,R,S)."""
     n, h, w, _ = x.shape
     dw = torch.empty((cout, cin, r, s), device=x.device, dtype=torch.float32)
-    ws = torch.empty(int(lib().vatl_conv2d_wgrad_workspace_floats(cout, cin, r, s)), device=x.device, dtype=torch.float32)
+    m = n * dz.shape[1] * dz.shape[2]
+    ws = torch.empty(int(lib().vatl_conv2d_wgrad_workspace_floats(cout, cin, r, s, m)), device=x.device, dtype=torch.float32)
     _check(lib().vatl_conv2d_wgrad(_ptr(x), _ptr(dz), _ptr(dw), _ptr(ws), n, h, w, cin, cout, dz.shape[3], r, s, stride, pad, _stream()),
            "vatl_conv2d_wgrad")
     return dw
@@ -509,7 +510,7 @@ def deconv4x4s2_wgrad(x, dy) -> torch.Tensor:
     n, h, w, cin = x.shape
     cout = dy.shape[3]
     dw = torch.empty((cin, cout, 4, 4), device=x.device, dtype=torch.float32)
-    ws = torch.empty(int(lib().vatl_deconv4x4s2_wgrad_workspace_floats(cin, cout)), device=x.device, dtype=torch.float32)
+    ws = torch.empty(int(lib().vatl_deconv4x4s2_wgrad_workspace_floats(cin, cout, n * h * w)), device=x.device, dtype=torch.float32)
     _check(lib().vatl_deconv4x4s2_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), n, h, w, cin, cout, _stream()), "vatl_deconv4x4s2_wgrad")
     return dw
 
