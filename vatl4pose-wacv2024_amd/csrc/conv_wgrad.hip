@@ -49,6 +49,7 @@ template <int BN, int BJ, int WN, int WJ, bool STEM>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     constexpr int NWN = BN / WN, NWJ = BJ / WJ, NWK = 4 / (NWN * NWJ);
     static_assert(NWN * NWJ * NWK == 4 && NWK >= 1, "4 waves");
+    static_assert(NWK == (STEM ? 2 : 1), "wgrad_cfg().nwk must match the waves that split the k-steps");
     constexpr int TN = WN / 32, TJ = WJ / 32;
     constexpr int LG = BN / 32, LX = BJ / 32;            // float4 loads per thread per k-tile (32 rows each)
     __shared__ __attribute__((aligned(16))) float Gs[2][32][BN];
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     // D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)] -> n,  [col = lane&31] -> channel: coalesced stores of this split's partial
     // tile into its own slice of the workspace (no atomics: the reduction over splits runs in a fixed order afterwards)
     const int Kp = (STEM ? p.R * 8 : p.R * p.S) * p.Cx;
-    float* __restrict__ part = p.dw + (long long)split * p.slice;
+    float* __restrict__ part = p.dw + ((long long)split * NWK + wk) * p.slice;      // waves that share a tile and split its k-steps own a slice each
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -223,18 +224,18 @@ static std::atomic<int> g_wgrad_blocks{1024};
 static std::atomic<int> g_wgrad_ablate{0};   // vatl_tune_set(3, v)
 
 // tile configuration of a weight-gradient GEMM: rows n (Cn), columns (tap, channel of Cx)
-struct WgradCfg { int bn, bj; bool stem; };
+struct WgradCfg { int bn, bj; bool stem; int nwk; };      // nwk: waves of a block that split the k-steps of one tile (one slice each)
 static WgradCfg wgrad_cfg(int Cn, int Cx, bool stem) {
-    if (stem) return {64, 32, true};
-    if (Cn >= 128 && Cx >= 128) return {128, 128, false};
-    if (Cn >= 128) return {128, 64, false};
-    if (Cn > 32 && Cx >= 128) return {64, 128, false};
-    if (Cn > 32) return {64, 64, false};
-    return {32, 128, false};
+    if (stem) return {64, 32, true, 2};
+    if (Cn >= 128 && Cx >= 128) return {128, 128, false, 1};
+    if (Cn >= 128) return {128, 64, false, 1};
+    if (Cn > 32 && Cx >= 128) return {64, 128, false, 1};
+    if (Cn > 32) return {64, 64, false, 1};
+    return {32, 128, false, 1};
 }
 
 // number of M-splits: at most ~g_wgrad_blocks blocks (two per CU resident: 512 per wave), at least 4 k-tiles each
-struct WgradPlan { int tiles, splits, kt_per_split; };
+struct WgradPlan { int tiles, splits, kt_per_split, slices; };   // slices = splits * nwk partial gradients to sum
 static WgradPlan wgrad_plan(const WgradCfg& c, int Cn, int Cx, int R, int S, long long M) {
     const int n_tiles = cdiv(Cn, c.bn), taps = c.stem ? R : R * S, j_tiles = c.stem ? 1 : cdiv(Cx, c.bj);
     const int tiles = n_tiles * taps * j_tiles;
@@ -244,7 +245,8 @@ static WgradPlan wgrad_plan(const WgradCfg& c, int Cn, int Cx, int R, int S, lon
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     const int kps = (ktiles + splits - 1) / splits;
-    return {tiles, (ktiles + kps - 1) / kps, kps};                           // every split owns >= 1 k-tile
+    const int sp = (ktiles + kps - 1) / kps;                                  // every split owns >= 1 k-tile
+    return {tiles, sp, kps, sp * c.nwk};
 }
 
 template <int BN, int BJ, int WN, int WJ, bool STEM>
@@ -272,36 +274,37 @@ static int launch_wgrad(const WgradParams& p, const WgradCfg& c, const WgradPlan
     return launch_wgrad_t<32, 128, 32, 32, false>(p, plan, st);
 }
 
-// out (Cout,Cin,R,S) <- packed [Cout][R][Spad][CinPad]   (inverse of pack_conv_weight, drops the padding)
-// ... summed over the M-splits in split order (deterministic)
-__global__ void unpack_conv_grad_kernel(const float* __restrict__ packed, float* __restrict__ out, int Cout, int Cin, int R, int S, int Spad, int CinPad,
-                                        int splits, long long slice) {
-    const long long total = (long long)Cout * Cin * R * S;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int s = (int)(i % S);
-        long long t = i / S;
-        const int r = (int)(t % R); t /= R;
-        const int c = (int)(t % Cin);
-        const int o = (int)(t / Cin);
-        const float* src = packed + (((long long)o * R + r) * Spad + s) * CinPad + c;
-        float acc = 0.f;
-        for (int k = 0; k < splits; ++k) acc += src[(long long)k * slice];
-        out[i] = acc;
-    }
-}
-
-// out (Cin,Cout,4,4) <- packed [Cin][ky][kx][Cout]
-__global__ void unpack_deconv_grad_kernel(const float* __restrict__ packed, float* __restrict__ out, int Cin, int Cout, int splits, long long slice) {
-    const long long total = (long long)Cin * Cout * 16;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % 16);
-        long long t = i / 16;
-        const int o = (int)(t % Cout);
-        const int c = (int)(t / Cout);
-        const float* src = packed + ((long long)c * 16 + k) * Cout + o;
-        float acc = 0.f;
-        for (int q = 0; q < splits; ++q) acc += src[(long long)q * slice];
-        out[i] = acc;
+// Sum of the per-split partial gradients (fixed order: four split lanes accumulate strided splits, then lane 0..3 are added
+// in order) while the packed layout goes back to the tensor's own layout.  Threads run along the PACKED index so that every
+// slice is read with coalesced 256-byte rows; block = 64 packed elements x 4 split lanes.
+//   MODE 0: conv     packed [Cout][R][Spad][CinPad] -> out (Cout,Cin,R,S)
+//   MODE 1: deconv   packed [Cin][16][Cout]         -> out (Cin,Cout,4,4)
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ packed, float* __restrict__ out, int A, int B, int R, int S,
+                                                           int Spad, int CinPad, int slices, long long slice, long long packed_total) {
+    __shared__ float part[4][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long long j = (long long)blockIdx.x * 64 + e;
+    float acc = 0.f;
+    if (j < packed_total)
+        for (int k = q; k < slices; k += 4) acc += packed[(long long)k * slice + j];
+    part[q][e] = acc;
+    __syncthreads();
+    if (q != 0 || j >= packed_total) return;
+    const float v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+    if (MODE == 0) {                                   // A = Cout, B = Cin
+        const int c = (int)(j % CinPad);
+        long long t = j / CinPad;
+        const int s = (int)(t % Spad); t /= Spad;
+        const int r = (int)(t % R);
+        const int o = (int)(t / R);
+        if (c < B && s < S) out[(((long long)o * B + c) * R + r) * S + s] = v;
+    } else {                                           // A = Cin, B = Cout
+        const int o = (int)(j % B);
+        long long t = j / B;
+        const int k = (int)(t % 16);
+        const int c = (int)(t / 16);
+        out[((long long)c * B + o) * 16 + k] = v;
     }
 }
 
@@ -322,7 +325,7 @@ extern "C" int64_t vatl_conv2d_wgrad_workspace_floats(int Cout, int Cin, int R, 
     const bool stem = (Cin == 3);
     const int Cx = stem ? 4 : Cin;
     const WgradPlan plan = wgrad_plan(wgrad_cfg(Cout, Cx, stem), Cout, Cx, R, S, M);
-    return conv_packed_floats(Cout, Cin, R, S) * plan.splits;
+    return conv_packed_floats(Cout, Cin, R, S) * plan.slices;
 }
 
 // dw (Cout,Cin,R,S) = sum over pixels of dz (x) gathered input.  x NHWC (N,H,W,Cin) (Cin = 4 padded for the
@@ -353,16 +356,14 @@ extern "C" int vatl_conv2d_wgrad(const float* x, const float* dz, float* dw, flo
     p.slice = conv_packed_floats(Cout, Cin, R, S);
     const int rc = launch_wgrad(p, cfg, plan, st);
     if (rc) return rc;
-    const long long total = (long long)Cout * Cin * R * S;
-    long long gsz = (total + 255) / 256; if (gsz > 4096) gsz = 4096;
-    hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3((unsigned)gsz), dim3(256), 0, st, workspace, dw, Cout, Cin, R, S, stem ? 8 : S, Cx, plan.splits,
-                       p.slice);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3((unsigned)((p.slice + 63) / 64)), dim3(256), 0, st, workspace, dw, Cout, Cin, R, S, stem ? 8 : S, Cx,
+                       plan.slices, p.slice, p.slice);
     return check_launch("conv2d_wgrad");
 }
 
 extern "C" int64_t vatl_deconv4x4s2_wgrad_workspace_floats(int Cin, int Cout, int64_t M) {
     const WgradPlan plan = wgrad_plan(wgrad_cfg(Cin, Cout, false), Cin, Cout, 4, 4, M);
-    return (int64_t)Cin * 16 * Cout * plan.splits;
+    return (int64_t)Cin * 16 * Cout * plan.slices;
 }
 
 // dw (Cin,Cout,4,4) of ConvTranspose2d(4,2,1): x NHWC (N,H,W,Cin) layer input, dy NHWC (N,2H,2W,Cout).
@@ -385,8 +386,7 @@ extern "C" int vatl_deconv4x4s2_wgrad(const float* x, const float* dy, float* dw
     p.slice = (long long)Cin * 16 * Cout;
     const int rc = launch_wgrad(p, cfg, plan, st);
     if (rc) return rc;
-    const long long total = (long long)Cin * Cout * 16;
-    long long gsz = (total + 255) / 256; if (gsz > 4096) gsz = 4096;
-    hipLaunchKernelGGL(unpack_deconv_grad_kernel, dim3((unsigned)gsz), dim3(256), 0, st, workspace, dw, Cin, Cout, plan.splits, p.slice);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((p.slice + 63) / 64)), dim3(256), 0, st, workspace, dw, Cin, Cout, 4, 4, 4, Cout,
+                       plan.slices, p.slice, p.slice);
     return check_launch("deconv4x4s2_wgrad");
 }
