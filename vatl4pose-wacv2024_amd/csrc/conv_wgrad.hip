@@ -7,9 +7,9 @@
 //   t = (r, s)      filter tap, pix(m)+t = (oy*stride - pad + r, ox*stride - pad + s), zero outside
 //
 // GEMM shape: rows n (Cn), cols j = (t, c) (R*S*Cx), reduction over the M pixels — the long axis —
-// so the launch is split along M and partial tiles are combined with fp32 atomics into the packed
-// gradient [Cn][R*S][Cx] (zeroed first; summation order across splits is not fixed: ~1e-7 relative
-// run-to-run noise, documented in DESIGN.md).  Both operands are staged K-major ([m][n] / [m][c], the
+// so the launch is split along M: every split writes its partial tile into its own slice of a workspace
+// (packed layout [Cn][R*S][Cx] per slice) and wgrad_reduce_kernel sums the slices in a fixed order while it
+// restores the tensor layout — no atomics, bitwise reproducible.  Both operands are staged K-major ([m][n] / [m][c], the
 // natural NHWC layout), so one ds_read_b32 per operand tile feeds an MFMA k-step (lanes 0-31 take
 // pixel 2s, lanes 32-63 pixel 2s+1).  v_mfma_f32_32x32x2_f32, exact fp32.
 #include "common.h"
@@ -274,24 +274,33 @@ static int launch_wgrad(const WgradParams& p, const WgradCfg& c, const WgradPlan
     return launch_wgrad_t<32, 128, 32, 32, false>(p, plan, st);
 }
 
-// Sum of the per-split partial gradients (fixed order: four split lanes accumulate strided splits, then lane 0..3 are added
-// in order) while the packed layout goes back to the tensor's own layout.  Threads run along the PACKED index so that every
-// slice is read with coalesced 256-byte rows; block = 64 packed elements x 4 split lanes.
+// Sum of the per-split partial gradients (fixed order: eight split lanes accumulate strided splits, four interleaved chains each,
+// then the lanes are added in order) while the packed layout goes back to the tensor's own layout.  Threads run along the PACKED
+// index so that every slice is read with coalesced 128-byte rows; block = 32 packed elements x 8 split lanes.
 //   MODE 0: conv     packed [Cout][R][Spad][CinPad] -> out (Cout,Cin,R,S)
 //   MODE 1: deconv   packed [Cin][16][Cout]         -> out (Cin,Cout,4,4)
 template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ packed, float* __restrict__ out, int A, int B, int R, int S,
                                                            int Spad, int CinPad, int slices, long long slice, long long packed_total) {
-    __shared__ float part[4][64];
-    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const long long j = (long long)blockIdx.x * 64 + e;
-    float acc = 0.f;
-    if (j < packed_total)
-        for (int k = q; k < slices; k += 4) acc += packed[(long long)k * slice + j];
-    part[q][e] = acc;
+    __shared__ float part[8][32];
+    const int e = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const long long j = (long long)blockIdx.x * 32 + e;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four independent chains: the loads of one lane overlap
+    if (j < packed_total) {
+        const float* src = packed + j;
+        int k = q;
+        for (; k + 24 < slices; k += 32) {
+            a0 += src[(long long)k * slice]; a1 += src[(long long)(k + 8) * slice];
+            a2 += src[(long long)(k + 16) * slice]; a3 += src[(long long)(k + 24) * slice];
+        }
+        for (; k < slices; k += 8) a0 += src[(long long)k * slice];
+    }
+    part[q][e] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (q != 0 || j >= packed_total) return;
-    const float v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+    float v = part[0][e];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) v += part[t][e];
     if (MODE == 0) {                                   // A = Cout, B = Cin
         const int c = (int)(j % CinPad);
         long long t = j / CinPad;
@@ -356,7 +365,7 @@ extern "C" int vatl_conv2d_wgrad(const float* x, const float* dz, float* dw, flo
     p.slice = conv_packed_floats(Cout, Cin, R, S);
     const int rc = launch_wgrad(p, cfg, plan, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3((unsigned)((p.slice + 63) / 64)), dim3(256), 0, st, workspace, dw, Cout, Cin, R, S, stem ? 8 : S, Cx,
+    hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3((unsigned)((p.slice + 31) / 32)), dim3(256), 0, st, workspace, dw, Cout, Cin, R, S, stem ? 8 : S, Cx,
                        plan.slices, p.slice, p.slice);
     return check_launch("conv2d_wgrad");
 }
@@ -386,7 +395,7 @@ extern "C" int vatl_deconv4x4s2_wgrad(const float* x, const float* dy, float* dw
     p.slice = (long long)Cin * 16 * Cout;
     const int rc = launch_wgrad(p, cfg, plan, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((p.slice + 63) / 64)), dim3(256), 0, st, workspace, dw, Cin, Cout, 4, 4, 4, Cout,
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((p.slice + 31) / 32)), dim3(256), 0, st, workspace, dw, Cin, Cout, 4, 4, 4, Cout,
                        plan.slices, p.slice, p.slice);
     return check_launch("deconv4x4s2_wgrad");
 }
