@@ -87,3 +87,16 @@ def test_driver_imports_resolve():
         assert builder.SPPE.get(name) is not None
     for name in ("MSELoss", "L1JointRegression"):
         assert builder.LOSS.get(name) is not None
+
+
+def test_engine_chunking_respects_the_32bit_offset_limit():
+    """Batches are cut so that no tensor of a launch reaches 2^30 elements, in balanced chunks."""
+    from alphapose.models import hip_engine as h
+    assert h._chunk_limit((256, 192)) == h.MAX_CHUNK == 1024
+    lim = h._chunk_limit((384, 288))
+    assert lim * 192 * 144 * 64 < 2 ** 30 <= (lim + 1) * 192 * 144 * 64 and lim == 606
+    assert h._chunks(1080, (256, 192)) == [(0, 540), (540, 1080)]
+    assert h._chunks(1024, (384, 288)) == [(0, 512), (512, 1024)]
+    assert h._chunks(5, (256, 192)) == [(0, 5)]
+    cuts = h._chunks(2000, (384, 288))
+    assert cuts[0][0] == 0 and cuts[-1][1] == 2000 and all(b - a <= lim for a, b in cuts) and all(x[1] == y[0] for x, y in zip(cuts, cuts[1:]))

@@ -307,10 +307,19 @@ class _NchwAdapter:
         return vh.nhwc_to_nchw(self.inner(vh.nchw_to_nhwc(x_nchw)))
 
 
-def _chunks(n: int):
+def _chunk_limit(hw) -> int:
+    """Largest batch one launch sequence may take: MAX_CHUNK, and every tensor below 2^30 elements (the kernels use 32-bit
+    buffer byte offsets) — the largest per-crop tensor of all three networks is the stride-2 stem output (H/2 x W/2 x 64):
+    1365 crops at 256x192, 606 at 384x288."""
+    per_crop = (hw[0] // 2) * (hw[1] // 2) * 64
+    return max(1, min(MAX_CHUNK, ((1 << 30) - 1) // max(per_crop, 1)))
+
+
+def _chunks(n: int, hw=(256, 192)):
     """Balanced chunk bounds: 1080 crops (the reference's evaluation batch) become 2 x 540, not 1024 + 56 — a small last
     chunk would run every layer on a nearly empty grid.  Results do not depend on the chunking (bit-identical)."""
-    k = max(1, -(-n // MAX_CHUNK))
+    lim = _chunk_limit(hw)
+    k = max(1, -(-n // lim))
     size = -(-n // k)
     return [(i, min(i + size, n)) for i in range(0, n, size)]
 
@@ -367,9 +376,9 @@ def run_module_nchw(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
         return hip_train.forward_train(m, x)
     x = _prepare_input(m, x)
     plan = _plan_for(m, x.device)
-    if x.shape[0] <= MAX_CHUNK:
+    if x.shape[0] <= _chunk_limit(x.shape[2:]):
         return plan(x)
-    return torch.cat([plan(x[a:b]) for a, b in _chunks(x.shape[0])], 0)
+    return torch.cat([plan(x[a:b]) for a, b in _chunks(x.shape[0], x.shape[2:])], 0)
 
 
 def forward_into(m: nn.Module, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
@@ -379,7 +388,7 @@ def forward_into(m: nn.Module, x: torch.Tensor, out: torch.Tensor) -> torch.Tens
         raise vh.VatlError("forward_into is an inference entry point: call model.eval() first")
     x = _prepare_input(m, x)
     plan = _plan_for(m, x.device)
-    for a, b in _chunks(x.shape[0]):
+    for a, b in _chunks(x.shape[0], x.shape[2:]):
         plan(x[a:b], out=out[a:b])
     return out
 
@@ -394,7 +403,7 @@ def forward_with_embedding(m: nn.Module, x: torch.Tensor, out: torch.Tensor, emb
     plan = _plan_for(m, x.device)
     if not hasattr(plan, "features"):
         raise vh.VatlError(f"{type(m).__name__} has no get_embedding")
-    for a, b in _chunks(x.shape[0]):
+    for a, b in _chunks(x.shape[0], x.shape[2:]):
         plan(x[a:b], out=out[a:b], emb_out=emb[a:b])
 
 
@@ -404,4 +413,4 @@ def embedding(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
         raise vh.VatlError("get_embedding is used in evaluation only (ActiveLearning.py:259,284): call model.eval() first")
     x = _prepare_input(m, x)
     plan = _plan_for(m, x.device)
-    return torch.cat([vh.gap_fwd(plan.features(x[a:b])) for a, b in _chunks(x.shape[0])], 0)
+    return torch.cat([vh.gap_fwd(plan.features(x[a:b])) for a, b in _chunks(x.shape[0], x.shape[2:])], 0)
