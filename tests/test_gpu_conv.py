@@ -402,3 +402,24 @@ def test_persistent_1x1_kernel_is_bit_identical(vh):
         finally:
             vh.tune_set(5, 0); vh.tune_set(7, 1)
         assert torch.equal(a, b), (n, cin, cout)
+
+
+def test_large_384x288_batch_is_chunked_below_the_offset_limit(vh):
+    """610 crops of 384x288 would put 2^30+ elements into the stem output: the engine cuts the batch (2 x 305) and the
+    results equal those of the same crops in a small batch."""
+    from alphapose.models import builder, hip_engine
+    from alphapose.utils.config import edict
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [384, 288], "HEATMAP_SIZE": [96, 72]})
+    cfg = edict({"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50})
+    m = builder.build_sppe(cfg, preset_cfg=preset)
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    m = m.to(dev()).eval()
+    n = 610
+    assert hip_engine._chunk_limit((384, 288)) < n
+    g = torch.Generator(device=dev()); g.manual_seed(3)
+    x = torch.rand((n, 3, 384, 288), device=dev(), generator=g) - 0.45
+    with torch.no_grad():
+        hm = m(x)
+        pick = torch.tensor([0, 304, 305, 609], device=dev())
+        small = m(x[pick])
+    assert hm.shape == (n, 17, 96, 72) and torch.equal(hm[pick], small)
