@@ -177,3 +177,43 @@ def test_oks_kernel_matches_al_metric():
     got = vh.oks(to_dev(pred), torch.from_numpy(gt).cuda(), torch.from_numpy(box).cuda()).cpu().numpy()
     want = np.array([scorers.oks(box[i], pred[i].reshape(-1), gt[i]) for i in range(n)])
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
+
+
+def test_config1_validate_harness_batch4():
+    """BASELINE.json configs[0] (scripts/poseestimator_eval.py:47-79): SimpleBaseline-R50, batch of 4 crops, `m.eval()`
+    forward, per-crop `heatmap_to_coord` with the crop box, record score = mean + 1.25 max of the joint scores — the
+    reference's own per-item calls on our modules against the CPU restatement (pinned to the reference's golden outputs)."""
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    from alphapose.utils.transforms import get_func_heatmap_to_coord
+    from oracle import nets, scorers, synth
+    from tests.gpu_util import dev, record, rel_err, to_dev
+    cfg = edict({"MODEL": {"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50},
+                 "DATA_PRESET": {"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]},
+                 "LOSS": {"TYPE": "MSELoss"}})
+    m = builder.build_sppe(cfg.MODEL, preset_cfg=cfg.DATA_PRESET)
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    m = m.to(dev()).eval()
+    x = synth.crops(4, seed=23)
+    bb = synth.bboxes(4, seed=23)
+    heatmap_to_coord = get_func_heatmap_to_coord(cfg)
+    with torch.no_grad():
+        output = m(to_dev(x))
+    assert output.dim() == 4 and output.shape == (4, 17, 64, 48)
+    ref = nets.SimplePoseRef(50)
+    ref.load_state_dict(synth.state_dict_for(ref), strict=True)
+    ref.eval()
+    with torch.no_grad():
+        want_hm = ref(torch.from_numpy(x)).numpy()
+    record("config1_heatmaps", rel=rel_err(output.cpu().numpy(), want_hm))
+    assert rel_err(output.cpu().numpy(), want_hm) < 1e-4
+    eval_joints = list(range(17))
+    for j in range(4):
+        pose_coords, pose_scores = heatmap_to_coord(output[j][eval_joints], bb[j].tolist(), hm_shape=cfg.DATA_PRESET.HEATMAP_SIZE, norm_type=None)
+        d = scorers.decode_heatmaps(want_hm[j], bb[j])
+        assert pose_coords.shape == (17, 2) and pose_scores.shape == (17, 1) and pose_coords.dtype == np.float32
+        assert np.array_equal(np.argmax(output[j].cpu().numpy().reshape(17, -1), 1), d["idx"])
+        np.testing.assert_allclose(pose_coords, d["coords"], rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(pose_scores, d["maxvals"], rtol=1e-4)
+        score = float(np.mean(pose_scores) + 1.25 * np.max(pose_scores))
+        np.testing.assert_allclose(score, scorers.pose_score(d["maxvals"]), rtol=1e-4)
