@@ -159,7 +159,16 @@ def cpu_baseline():
             if i:
                 scorers.thc_pair(hm[i], hm[i - 1])
     post = time.perf_counter() - t0
-    return {"value": round(n / (fwd + post), 2), "unit": "frames/s", "cores": cores, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(n / (fwd + post), 2), "unit": "frames/s", "cores": cores, "cores_available": avail, "cpu_model": cpu_model, "kind": "port",
             "sample": f"{n} crops: SimplePose-R50 forward (torch CPU fp32, {cores} threads, median of 3) + numpy decode/local-peak/THC",
             "forward_s": round(fwd, 3), "scoring_s": round(post, 3)}
 
