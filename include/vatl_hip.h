@@ -87,6 +87,13 @@ int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float* w, const 
  * tile (0 = chosen from the grid size, 64, 128), 7 = persistent 1x1 kernel for K <= 256 v (0 = off, default 1).  Knob 0 values 10..13, knob 4 (wgrad ablation bits) and knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) are profiling
  * ablations that compute WRONG results; they are refused unless the environment has VATL_ALLOW_ABLATION=1. */
 int vatl_tune_set(int knob, int value);
+/* Opt-in split-K for small batches (single-frame / online inference): with a caller-owned workspace registered, conv
+ * launches of fewer than 256 blocks and >= 16 k-tiles are cut along K into ~512 blocks; every split writes a raw partial
+ * tile into its workspace slice and one pass sums the slices in order and applies scale / bias / residual / ReLU.
+ * Deterministic, but the summation order differs from the unsplit kernel: results agree to fp32 rounding, not bit for bit,
+ * and the choice depends on the batch size — so it is OFF unless a workspace is set (the evaluation path relies on
+ * batch-size-independent bits).  The workspace is shared by all streams: use from one stream at a time.  NULL disables. */
+int vatl_set_splitk_workspace(float* workspace, int64_t floats);
 /* CoutPad the packer must use for a given Cout (multiple of the kernel's N tile). */
 int vatl_conv_cout_pad(int Cout);
 int vatl_conv2d_fwd(const float* x, const float* w, const float* scale, const float* bias, const float* residual,

@@ -423,3 +423,37 @@ def test_large_384x288_batch_is_chunked_below_the_offset_limit(vh):
         pick = torch.tensor([0, 304, 305, 609], device=dev())
         small = m(x[pick])
     assert hm.shape == (n, 17, 96, 72) and torch.equal(hm[pick], small)
+
+
+def test_optin_splitk_matches_unsplit_kernel(vh):
+    """Opt-in split-K (small batches): same results as the unsplit kernel to fp32 rounding, through plain / residual /
+    ReLU / NCHW-head / transposed-conv launches and a whole batch-2 forward; off again afterwards."""
+    r = np.random.RandomState(55)
+    try:
+        cases = []
+        for (n, h, w, cin, cout, k, res, nchw) in ((2, 8, 6, 2048, 512, 1, False, False), (1, 8, 6, 512, 512, 3, True, False),
+                                                   (2, 16, 12, 1024, 256, 1, True, False), (1, 16, 12, 512, 17, 1, False, True)):
+            x = to_dev(r.standard_normal((n, h, w, cin)).astype(np.float32))
+            wp = vh.pack_conv_weight(to_dev((r.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)))
+            sc, bi = to_dev(r.uniform(0.5, 1.5, cout).astype(np.float32)), to_dev(r.standard_normal(cout).astype(np.float32))
+            rs = to_dev(r.standard_normal((n, h, w, cout)).astype(np.float32)) if res else None
+            cases.append(lambda x=x, wp=wp, sc=sc, bi=bi, cout=cout, k=k, rs=rs, nchw=nchw: vh.conv2d_fwd(x, wp, sc, bi, cout, k, k, 1, k // 2, not nchw, residual=rs, out_nchw=nchw))
+        xd = to_dev(r.standard_normal((2, 8, 6, 2048)).astype(np.float32))
+        wd = vh.pack_deconv_weight(to_dev((r.standard_normal((2048, 256, 4, 4)) / 90).astype(np.float32)))
+        sd, bd = to_dev(np.ones(256, np.float32)), to_dev(np.zeros(256, np.float32))
+        cases.append(lambda: vh.deconv4x4s2_fwd(xd, wd, sd, bd, 256, True))
+        m = _build_simplepose()
+        xm = to_dev(synth.crops(2))
+        cases.append(lambda: m(xm))
+        with torch.no_grad():
+            base = [c().clone() for c in cases]
+            vh.enable_splitk(32)
+            split = [c().clone() for c in cases]
+        for a, b in zip(base, split):
+            assert a.shape == b.shape and rel_err(b.cpu().numpy(), a.cpu().numpy()) < 2e-6
+        assert not torch.equal(base[0], split[0])                 # the split path really ran (different summation order)
+    finally:
+        vh.enable_splitk(0)
+    with torch.no_grad():
+        again = cases[0]()
+    assert torch.equal(again, base[0])

@@ -17,7 +17,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--splitk", type=int, default=0, help="megabytes of split-K workspace (vatl_hip.enable_splitk); 0 = off")
     a = ap.parse_args()
+    if a.splitk:
+        import vatl_hip as vh
+        vh.enable_splitk(a.splitk)
     from bench import build_model
     from active_learning.scoring import score_batch
     dev = torch.device("cuda:0")
@@ -37,7 +41,7 @@ def main():
         fwd()
     torch.cuda.synchronize()
     eager = (time.perf_counter() - t0) / a.iters
-    res = {"batch": a.batch, "eager_ms": round(eager * 1e3, 3)}
+    res = {"batch": a.batch, "splitk_MB": a.splitk, "eager_ms": round(eager * 1e3, 3)}
     try:
         g = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream()

@@ -35,6 +35,7 @@
 // (blockIdx.y = py*2+px): pad = (1-py, 1-px), output scattered to (2y+py, 2x+px).
 #include "common.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 
@@ -66,6 +67,11 @@ struct ConvParams {
     int k1, C2, H2, W2, stride2;
     unsigned x2_bytes;
     int ablate;                       // profiling only (vatl_tune_set(6, bits), wrong results): 1 = no epilogue
+    // opt-in split-K (small batches): blockIdx.z owns k-tiles [z*kt_per_split, ...) and writes a raw partial tile into
+    // its slice of `part` (output layout of y, NHWC); splitk_reduce_kernel sums the slices in order and applies the epilogue
+    int splits, kt_per_split;
+    float* part;
+    long long part_slice;
     unsigned x_bytes, w_bytes, y_bytes;   // buffer extents (hardware bounds checks: OOB loads read 0, OOB stores drop)
 };
 
@@ -320,9 +326,15 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
     for (int j = 0; j < LB; ++j) boff[j] = (unsigned)(((n0 + lrow + RP * j) * p.K + kq * 4) * 4);
 
     f32x4 ra[LA], rb[LB];
+    int kbase = 0;                     // split-K: first k-tile of this block's share
+    if (p.splits > 1) {
+        kbase = blockIdx.z * p.kt_per_split;
+        p.ktiles = min(p.kt_per_split, p.ktiles - kbase);
+    }
     int g_r = 0, g_s = 0, g_off = 0;
     bool g_sel = false;                // DUAL: this k-tile reads the second source
     auto gtap = [&](int kt) {          // filter tap / channel offset of k-tile kt (wave-uniform)
+        kt += kbase;
         if (STEM) {                    // k-tile = one filter row: 8 taps x 4 channels
             g_r = kt; g_s = kq; g_off = kt * p.W * p.Cin;
         } else if (DUAL) {             // 1x1 over [source 1 channels | source 2 channels]
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
     };
     auto gloadA = [&](int i, bool live) { ra[i] = a_load(i, live); };
     auto gloadB = [&](int j, int kt, bool live) {
-        rb[j] = buf_load4(wr, live ? boff[j] + (unsigned)kt * (BK * 4) : OOB);
+        rb[j] = buf_load4(wr, live ? boff[j] + (unsigned)(kt + kbase) * (BK * 4) : OOB);
     };
     auto gload = [&](int kt, bool live) {
         gtap(kt);
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
             for (int i = 0; i < LA; ++i) da[i] = a_load(i, live);
 #pragma unroll
-            for (int j = 0; j < LB; ++j) db[j] = buf_load4(wr, live ? boff[j] + (unsigned)kt * (BK * 4) : OOB);
+            for (int j = 0; j < LB; ++j) db[j] = buf_load4(wr, live ? boff[j] + (unsigned)(kt + kbase) * (BK * 4) : OOB);
         };
         auto stash = [&](const f32x4 (&da)[LA], const f32x4 (&db)[LB], int buf) {
 #pragma unroll
@@ -521,6 +533,10 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
         if (NO_BAR) __syncthreads();
     }
 
+    if (p.splits > 1) {                // raw partial sums into this split's slice; scale / bias / residual / ReLU happen in the reduction
+        p.y = p.part + (long long)blockIdx.z * p.part_slice;
+        p.scale = nullptr; p.bias = nullptr; p.res = nullptr; p.relu = 0; p.out_nchw = 0; p.stats = nullptr;
+    }
     if (p.ablate & 1) {                // profiling only: keep the accumulators alive, skip the write-out
         float s = 0.f;
 #pragma unroll
@@ -822,6 +838,30 @@ static std::atomic<int> g_ablate{0};   // vatl_tune_set(6, bits): 1 = no epilogu
 static std::atomic<int> g_bm{0};       // tile rows (vatl_tune_set(5, v)): 0 = by grid size, 64 or 128 = forced
 static std::atomic<int> g_stagger{0};  // block stagger in percent of the k-loop time (vatl_tune_set(2, v)); 0 = off
 
+// Split-K (opt-in, vatl_set_splitk_workspace): y = act(sum_z part[z] * scale + bias (+ residual)), slices summed in order.
+// One thread per four channels of one output pixel (Cout % 4 == 0) or per element.
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, long long slice, int splits, const float* __restrict__ scale,
+                                     const float* __restrict__ bias, const float* __restrict__ res, float* __restrict__ y, long long total, int Cout,
+                                     int OHW, int relu, int out_nchw) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cout);
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += part[(long long)z * slice + i];
+        v = v * (scale ? scale[c] : 1.f) + (bias ? bias[c] : 0.f);
+        long long o = i;
+        if (out_nchw) {
+            const long long pix = i / Cout;
+            const long long b = pix / OHW;
+            o = (b * Cout + c) * OHW + (pix - b * OHW);
+        }
+        if (res) v += res[o];
+        y[o] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+static std::atomic<float*> g_splitk_ws{nullptr};     // caller-owned workspace (vatl_set_splitk_workspace); NULL = split-K off
+static std::atomic<long long> g_splitk_floats{0};
+
 template <int BM, int BN, int WM, int WN, bool STEM, int VAR, bool DUAL = false, int NT = 256>
 static int launch(const ConvParams& p, int phases, hipStream_t st) {
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM, VAR, DUAL, NT>;
@@ -843,8 +883,30 @@ static int launch(const ConvParams& p, int phases, hipStream_t st) {
     q.stagger = (int)((long long)g_stagger.load(std::memory_order_relaxed) * p.ktiles / 100);
     static_assert(2 * (BM + BN) * LDK >= BM * (BN + 4), "epilogue tile must fit in the staging buffers");
     const int m_tiles = cdiv(p.M, BM);
-    dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, 1);
+    const long long blocks = (long long)m_tiles * q.n_tiles * phases;
+    float* ws = g_splitk_ws.load(std::memory_order_acquire);
+    q.splits = 1;
+    if (ws && !STEM && !DUAL && !q.stats && !q.ablate && blocks < 256 && q.ktiles >= 16) {
+        // small launch with a long reduction (single-frame / small-batch inference): cut K so that ~512 blocks are in flight
+        const long long out_elems = (long long)q.y_bytes / 4;
+        int splits = (int)std::min<long long>(q.ktiles / 8, (512 + blocks - 1) / blocks);
+        const long long fit = g_splitk_floats.load(std::memory_order_relaxed) / (out_elems > 0 ? out_elems : 1);
+        if (splits > fit) splits = (int)fit;
+        if (splits >= 2) {
+            q.kt_per_split = (q.ktiles + splits - 1) / splits;
+            q.splits = (q.ktiles + q.kt_per_split - 1) / q.kt_per_split;
+            q.part = ws;
+            q.part_slice = out_elems;
+        }
+    }
+    dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, (unsigned)q.splits);
     hipLaunchKernelGGL(kern, grid, dim3(NT), smem, st, q);
+    if (q.splits > 1) {
+        const long long total = q.part_slice;
+        long long gsz = (total + 255) / 256; if (gsz > 8192) gsz = 8192;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gsz), dim3(256), 0, st, q.part, q.part_slice, q.splits, p.scale, p.bias, p.res, p.y, total,
+                           p.Cout, p.OH * p.OW, p.relu, p.out_nchw);
+    }
     return check_launch("conv_igemm");
 }
 
@@ -977,6 +1039,13 @@ extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 2 && value >= 0 && value <= 200) { g_stagger.store(value, std::memory_order_relaxed); return 0; }
     return fail(VATL_EINVAL, "tune_set: unknown knob %d / value %d", knob, value);
+}
+
+extern "C" int vatl_set_splitk_workspace(float* workspace, int64_t floats) {
+    if (workspace && floats <= 0) return fail(VATL_EINVAL, "set_splitk_workspace: empty workspace");
+    g_splitk_floats.store(workspace ? (long long)floats : 0, std::memory_order_relaxed);
+    g_splitk_ws.store(workspace, std::memory_order_release);
+    return 0;
 }
 
 extern "C" int vatl_conv_cout_pad(int Cout) {

@@ -33,6 +33,7 @@ SIGNATURES = {
     "vatl_conv1x1_dual_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_bn_fold": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _i, _p]),
     "vatl_tune_set": (_i, [_i, _i]),
+    "vatl_set_splitk_workspace": (_i, [_p, _i64]),
     "vatl_conv_cout_pad": (_i, [_i]),
     "vatl_conv2d_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_deconv4x4s2_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -159,6 +160,20 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
 
 def tune_set(knob: int, value: int):
     _check(lib().vatl_tune_set(knob, value), "vatl_tune_set")
+
+
+_splitk_buf = None
+
+
+def enable_splitk(megabytes: int = 64, device=None):
+    """Opt-in split-K for small-batch latency (see vatl_set_splitk_workspace); ``megabytes = 0`` switches it off."""
+    global _splitk_buf
+    if megabytes <= 0:
+        _check(lib().vatl_set_splitk_workspace(None, 0), "vatl_set_splitk_workspace")
+        _splitk_buf = None
+        return
+    _splitk_buf = torch.empty(megabytes * (1 << 18), device=device or torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
+    _check(lib().vatl_set_splitk_workspace(_ptr(_splitk_buf), _splitk_buf.numel()), "vatl_set_splitk_workspace")
 
 
 def conv_cout_pad(cout: int) -> int:
