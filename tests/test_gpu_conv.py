@@ -450,7 +450,7 @@ def test_optin_splitk_matches_unsplit_kernel(vh):
             vh.enable_splitk(32)
             split = [c().clone() for c in cases]
         for a, b in zip(base, split):
-            assert a.shape == b.shape and rel_err(b.cpu().numpy(), a.cpu().numpy()) < 2e-6
+            assert a.shape == b.shape and rel_err(b.cpu().numpy(), a.cpu().numpy()) < 1e-5      # fp32 rounding of a different summation order (K up to 8192)
         assert not torch.equal(base[0], split[0])                 # the split path really ran (different summation order)
     finally:
         vh.enable_splitk(0)
