@@ -314,6 +314,18 @@ int vatl_l1_joint_regression_fwd_bwd(const float* hm, const float* gt_joints, co
 int vatl_gaussian_targets(const float* joints_xy, const float* vis, float* target, float* weight, int N, int J, int H, int W,
                           int in_h, int in_w, float sigma, void* stream);
 
+/* Crop producer, the step before the backbone (SimpleTransform.test_transform / __call__,
+ * alphapose/utils/presets/simple_transform.py:81-98, 179-251): cv2.warpAffine(img, trans, (out_w, out_h), INTER_LINEAR)
+ * [OpenCV 4.8 fixed-point bilinear, constant border 0] -> im_to_torch (alphapose/utils/transforms.py:76-91: CHW fp32,
+ * / 255 only when the crop's maximum exceeds 1) -> minus mean per channel (simple_transform.py:93-95).
+ * arena: packed uint8 frames, each (h, w, 3) row-major; per crop b: src_off[b] = byte offset of its frame in arena,
+ * src_hwf[b] = {h, w, mirror} (mirror = 1 reads the frame flipped left-right like img[:, ::-1, :], :224),
+ * minv[b] = the 6 doubles of the dst -> src map cv::warpAffine gets by inverting `trans` (source coordinates must stay
+ * below 2^20 px).  out: (B, 3, out_h, out_w) fp32.  crop_max: B int32 of workspace (holds each crop's u8 maximum on
+ * return).  B <= 65535, out_w <= 4096, out_h * out_w < 2^20. */
+int vatl_crop_warp_affine(const uint8_t* arena, const int64_t* src_off, const int32_t* src_hwf, const double* minv, float* out,
+                          int32_t* crop_max, int B, int out_h, int out_w, float mean0, float mean1, float mean2, void* stream);
+
 /* One fine-tune step of the WholeBodyAE (ActiveLearning.py:905-925: AE forward, MSELoss(output, input), backward,
  * torch.optim.Adam) on a mini-batch feat (B, D), B <= 12 (the reference uses 10), in one launch.  ae / m / v: the packed parameters
  * (state-dict order W0,b0,...,W7,b7 = what vatl_hybrid_ae_wpu reads) and the Adam moments, updated in place;

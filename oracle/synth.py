@@ -139,3 +139,27 @@ def target_joints(n: int, hm_hw, in_hw, seed: int = 41, J: int = 17):
     xy[0, 0] = [0.0, 0.0]; xy[0, 1] = [in_hw[1] - 1, in_hw[0] - 1]; xy[0, 2] = [-30.0, 10.0]; xy[0, 3] = [in_hw[1] + 27.9, 5.0]
     vis = (r.random_sample((n, J)) >= 0.2).astype(np.float32)
     return xy, vis
+
+
+def crop_cases(n: int, seed: int = 57):
+    """Seeded person boxes [xmin,ymin,xmax,ymax] (float64 python-float semantics, like annotation json) inside a 640x480
+    frame — wide, tall, tiny, partly outside the frame — plus a rotation per case (half of them 0, as at test time)."""
+    r = _rs(seed, f"cropcases{n}")
+    x0 = r.uniform(-40, 520, n); y0 = r.uniform(-30, 380, n)
+    w = r.uniform(8, 300, n); h = r.uniform(8, 420, n)
+    box = np.stack([x0, y0, x0 + w, y0 + h], 1)
+    box[0] = [100.0, 50.0, 292.0, 306.0]                     # exactly the 3:4 aspect
+    box[1] = [10.5, 20.25, 600.0, 60.0]                      # very wide
+    rot = np.where(r.random_sample(n) < 0.5, 0.0, np.clip(r.randn(n) * 40, -80, 80))
+    rot[:2] = 0.0
+    return box, rot
+
+
+def u8_frame(h: int = 480, w: int = 640, seed: int = 58) -> np.ndarray:
+    """Seeded (h,w,3) uint8 video frame: smooth colour gradients + a checker pattern + noise (exercises every sub-pixel
+    phase of the bilinear taps and the constant border)."""
+    r = _rs(seed, f"frame{h}x{w}")
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([(xx * 255 / max(w - 1, 1)), (yy * 255 / max(h - 1, 1)), ((xx // 16 + yy // 16) % 2) * 200 + 20], 2)
+    img = base + r.randint(-20, 21, (h, w, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)

@@ -100,3 +100,49 @@ def test_engine_chunking_respects_the_32bit_offset_limit():
     assert h._chunks(5, (256, 192)) == [(0, 5)]
     cuts = h._chunks(2000, (384, 288))
     assert cuts[0][0] == 0 and cuts[-1][1] == 2000 and all(b - a <= lim for a, b in cuts) and all(x[1] == y[0] for x, y in zip(cuts, cuts[1:]))
+
+
+def test_crop_geometry_host_mirror_matches_reference_fixture():
+    """The host side of the crop producer (alphapose.utils.bbox / transforms of this package) against the outputs of the
+    reference's own functions in tests/golden/crop.npz — per item and batched."""
+    import os
+    import numpy as np
+    from alphapose.utils import bbox as B, transforms as T
+    from oracle import synth
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "crop.npz"))
+    box, rot = synth.crop_cases(24)
+    for tag, (h, w) in (("a", (256, 192)), ("b", (384, 288))):
+        cb, sb = B.box_to_center_scale_batch(box, float(w) / h)
+        assert cb.dtype == np.float32 and np.array_equal(cb, g[f"{tag}_center"]) and np.array_equal(sb, g[f"{tag}_scale"])
+        tb = T.get_affine_transform_batch(cb, sb, rot, [w, h])
+        np.testing.assert_allclose(tb, g[f"{tag}_trans"], rtol=1e-13, atol=1e-11)
+        np.testing.assert_allclose(np.float32(B.center_scale_to_box_batch(cb, sb)), np.float32(g[f"{tag}_box"]), rtol=2e-7)
+        for i, (xmin, ymin, xmax, ymax) in enumerate(box.tolist()):
+            c, s = B._box_to_center_scale(xmin, ymin, xmax - xmin, ymax - ymin, float(w) / h)
+            assert np.array_equal(c, cb[i]) and np.array_equal(s, sb[i])
+            t = T.get_affine_transform(c, s, rot[i], [w, h])
+            assert np.array_equal(t, tb[i])
+            np.testing.assert_allclose(T.affine_transform(np.float32([xmin, ymax]), t), g[f"{tag}_pt"][i], rtol=1e-12, atol=1e-9)
+            np.testing.assert_allclose(np.float32(B._center_scale_to_box(c, s)), np.float32(g[f"{tag}_box"][i]), rtol=2e-7)
+        # inverse map: forward o inverse = identity
+        inv = T.invert_affine_batch(tb)
+        for f, i2 in zip(tb, inv):
+            full = np.vstack([f, [0, 0, 1]]) @ np.vstack([i2, [0, 0, 1]])
+            np.testing.assert_allclose(full, np.eye(3), atol=1e-9)
+    frame = synth.u8_frame(40, 56)
+    assert np.array_equal(T.im_to_torch(frame).numpy(), g["tensor_bright"])
+    assert np.array_equal(T.im_to_torch((frame > 250).astype(np.uint8)).numpy(), g["tensor_dark"])
+
+
+def test_simple_transform_without_gpu_fails_loudly():
+    import numpy as np
+    import pytest
+    import torch
+    import vatl_hip as vh
+    from alphapose.utils.presets import SimpleTransform
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    ds = type("D", (), {"joint_pairs": [[1, 2]]})()
+    st = SimpleTransform(ds, scale_factor=0, add_dpg=False, input_size=[256, 192], output_size=[64, 48], rot=0, sigma=2, train=False)
+    with pytest.raises(vh.VatlError):
+        st.test_transform(np.zeros((48, 64, 3), np.uint8), [4, 4, 30, 40])

@@ -251,3 +251,67 @@ def test_target_generator_restatement_matches_reference(tag, hm_hw, in_hw, sigma
     for n in range(6):
         t, w = scorers.target_generator(joints[n], vis[n], hm_hw, in_hw, sigma)
         assert np.array_equal(t, g[f"{tag}_target"][n]) and np.array_equal(w, g[f"{tag}_weight"][n])
+
+
+@pytest.mark.parametrize("tag,in_hw", [("a", (256, 192)), ("b", (384, 288))])
+def test_crop_geometry_restatement_matches_reference(tag, in_hw):
+    """Centre/scale, the 2x3 crop matrix (with rotation), the corrected box and a transformed point against the reference's
+    own _box_to_center_scale / get_affine_transform / _center_scale_to_box / affine_transform (tests/golden/crop.npz)."""
+    import os
+    from oracle import crop
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "crop.npz"))
+    box, rot = synth.crop_cases(24)
+    for i, ((xmin, ymin, xmax, ymax), r) in enumerate(zip(box.tolist(), rot.tolist())):
+        c, s = crop.box_to_center_scale(xmin, ymin, xmax - xmin, ymax - ymin, float(in_hw[1]) / in_hw[0])
+        assert c.dtype == np.float32 and np.array_equal(c, g[f"{tag}_center"][i])
+        assert s.dtype == np.float32 and np.array_equal(s, g[f"{tag}_scale"][i])
+        t = crop.affine_transform_matrix(c, s, r, [in_hw[1], in_hw[0]])
+        np.testing.assert_allclose(t, g[f"{tag}_trans"][i], rtol=1e-13, atol=1e-11)       # float64 solve, same points
+        # the fixture was produced under numpy 2 (float32 scalar arithmetic); the pinned numpy 1.23.5 computes in float64
+        np.testing.assert_allclose(np.float32(crop.center_scale_to_box(c, s)), np.float32(g[f"{tag}_box"][i]), rtol=2e-7)
+        np.testing.assert_allclose(crop.transform_point(np.float32([xmin, ymax]), t), g[f"{tag}_pt"][i], rtol=1e-12, atol=1e-9)
+
+
+def test_crop_tensor_conversion_matches_reference():
+    """im_to_torch incl. its 'only divide when max > 1' rule, then the mean shift."""
+    import os
+    from oracle import crop
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "crop.npz"))
+    frame = synth.u8_frame(40, 56)
+    dark = (frame > 250).astype(np.uint8)
+    mean = np.float32(crop.MEAN).reshape(3, 1, 1)
+    assert dark.max() == 1
+    assert np.array_equal(crop.image_to_tensor(frame), g["tensor_bright"] + (-mean))
+    assert np.array_equal(crop.image_to_tensor(dark), g["tensor_dark"] + (-mean))
+    assert g["tensor_dark"].max() == 1.0
+
+
+def test_warp_restatement_properties():
+    """cv2 is absent (parity unpinned, oracle/crop.py): the fixed-point warp is checked through properties —
+    identity and integer shifts are exact copies, the weight table sums to 2^15, the result stays within the 1/32-pixel
+    quantisation bound of an independent float64 bilinear warp, and the border is constant 0."""
+    from oracle import crop
+    tab = crop.bilinear_weight_table().astype(np.int64)
+    assert (tab.sum(1) == 1 << 15).all() and tuple(tab[0]) == (32767, 0, 0, 1) and tuple(tab[33]) == (31 * 31 * 32, 31 * 32, 31 * 32, 32)
+    f = synth.u8_frame(60, 80)
+    assert np.array_equal(crop.warp_affine_u8(f, [[1, 0, 0], [0, 1, 0]], (80, 60)), f)
+    sh = crop.warp_affine_u8(f, [[1, 0, 7], [0, 1, -3]], (80, 60))
+    assert np.array_equal(sh[:57, 7:], f[3:, :73]) and (sh[57:] == 0).all() and (sh[:, :7] == 0).all()
+    box, rot = synth.crop_cases(8)
+    big = synth.u8_frame(480, 640)
+    smooth = np.stack([big[..., 0], big[..., 1], big[..., 0] // 2 + big[..., 1] // 2], 2)     # gradients: |d/dpx| <= ~21 with noise
+    for (xmin, ymin, xmax, ymax), r in zip(box.tolist(), rot.tolist()):
+        c, s = crop.box_to_center_scale(xmin, ymin, xmax - xmin, ymax - ymin, 0.75)
+        t = crop.affine_transform_matrix(c, s, r, [192, 256])
+        got = crop.warp_affine_u8(smooth, t, (192, 256)).astype(np.float64)
+        ref = crop.float_bilinear_reference(smooth, t, (192, 256))
+        # coordinates are rounded to 1/32 px (<= 1/64 px error per axis): bound = max local gradient * 2/64 + rounding 0.5
+        grad = max(np.abs(np.diff(smooth.astype(np.float64), axis=0)).max(), np.abs(np.diff(smooth.astype(np.float64), axis=1)).max())
+        mi = crop.invert_affine(t)
+        gx, gy = np.meshgrid(np.arange(192.0), np.arange(256.0))
+        fx, fy = mi[0, 0] * gx + mi[0, 1] * gy + mi[0, 2], mi[1, 0] * gx + mi[1, 1] * gy + mi[1, 2]
+        inside = (fx > 1) & (fx < 638) & (fy > 1) & (fy < 478)                               # taps that never see the border
+        assert np.abs(got - ref)[inside].max() <= grad * (2.0 / 64) * 2 + 0.5 + 1e-9
+        assert np.abs(got - ref).max() <= 255 * (2.0 / 64) * 2 + 0.5                         # frame edge: step to the border value
+        outside = (fx < -1.1) | (fx > 640.1) | (fy < -1.1) | (fy > 480.1)
+        assert (got[outside] == 0).all()

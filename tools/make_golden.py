@@ -514,6 +514,34 @@ def gen_targets(out: str):
     np.savez_compressed(os.path.join(out, "targets.npz"), **res)
 
 
+def gen_crop(out: str):
+    """The numpy/torch pieces of the crop producer, called on the reference itself: _box_to_center_scale,
+    _center_scale_to_box (alphapose/utils/bbox.py:197-226), get_affine_transform / affine_transform
+    (alphapose/utils/transforms.py:753-792, cv2.getAffineTransform through the float64 shim) and im_to_torch (:76-91).
+    cv2.warpAffine itself cannot be run here (no cv2) — see oracle/crop.py."""
+    from alphapose.utils.bbox import _box_to_center_scale, _center_scale_to_box                 # the reference's
+    from alphapose.utils.transforms import affine_transform, get_affine_transform, im_to_torch
+    box, rot = synth.crop_cases(24)
+    res = {}
+    for tag, (inp_h, inp_w) in (("a", (256, 192)), ("b", (384, 288))):
+        cs, ss, ts, bs, ps = [], [], [], [], []
+        for (xmin, ymin, xmax, ymax), r in zip(box.tolist(), rot.tolist()):
+            c, s = _box_to_center_scale(xmin, ymin, xmax - xmin, ymax - ymin, float(inp_w) / inp_h)
+            s = s * 1.0
+            t = get_affine_transform(c, s, r, [inp_w, inp_h])
+            cs.append(c); ss.append(s); ts.append(t)
+            bs.append(np.array(_center_scale_to_box(c, s), np.float64))
+            ps.append(affine_transform(np.array([xmin, ymax], np.float32), t))
+        res[f"{tag}_center"], res[f"{tag}_scale"] = np.stack(cs), np.stack(ss)
+        res[f"{tag}_trans"], res[f"{tag}_box"], res[f"{tag}_pt"] = np.stack(ts), np.stack(bs), np.stack(ps)
+        print("crop", tag, res[f"{tag}_trans"].dtype, res[f"{tag}_center"].dtype, float(np.abs(res[f"{tag}_trans"]).sum()))
+    frame = synth.u8_frame(40, 56)
+    dark = (frame > 250).astype(np.uint8)                         # max == 1: im_to_torch must NOT divide by 255
+    res["tensor_bright"] = im_to_torch(frame.copy()).numpy()
+    res["tensor_dark"] = im_to_torch(dark.copy()).numpy()
+    np.savez_compressed(os.path.join(out, "crop.npz"), **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -534,6 +562,8 @@ def main():
         gen_targets(a.out)
     if a.only in ("", "l1"):
         gen_l1_loss(a.out)
+    if a.only in ("", "crop"):
+        gen_crop(a.out)
     if a.only in ("", "r152"):
         gen_fastpose_r152(EasyDict, a.out)
 

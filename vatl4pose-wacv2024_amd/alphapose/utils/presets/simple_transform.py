@@ -1,0 +1,201 @@
+"""Person-crop producer with the reference's ``SimpleTransform`` interface, warping on MI355X.
+
+Reference: alphapose/utils/presets/simple_transform.py — ``__init__`` :54-79, ``test_transform`` :81-98,
+``_target_generator`` :122-158, ``_integral_target_generator`` :160-177, ``__call__`` :179-251,
+``half_body_transform`` :253-304.  The per-item methods keep their signatures and results; the pixel work
+(cv2.warpAffine + im_to_torch + mean shift, Gaussian targets) is one ``libvatl_hip.so`` launch each, and
+``crop_batch`` / ``targets_batch`` do a whole batch per launch.  The geometry
+(centre/scale, augmentation draws, the 2x3 matrix) stays on the host in numpy like the reference's: it is a few
+float64 operations per crop and its random draws (``np.random`` / ``random``) must consume the same streams.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+
+import vatl_hip as vh
+
+from ..bbox import (_box_to_center_scale, _center_scale_to_box, box_to_center_scale_batch, center_scale_to_box_batch)
+from ..transforms import (affine_transform, flip_joints_3d, get_affine_transform, get_affine_transform_batch, invert_affine_batch)
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise vh.VatlError("SimpleTransform crops on MI355X only (there is deliberately no CPU path)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class FrameArena:
+    """uint8 frames packed back to back in one device buffer — what ``vatl_crop_warp_affine`` reads."""
+
+    def __init__(self, frames, device=None):
+        dev = device or _device()
+        frames = [np.ascontiguousarray(f) for f in frames]
+        for f in frames:
+            if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3:
+                raise ValueError(f"frames must be (h, w, 3) uint8, got {f.dtype} {f.shape}")
+        sizes = np.array([f.size for f in frames], np.int64)
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        self.hw = np.array([f.shape[:2] for f in frames], np.int32).reshape(-1, 2)
+        host = torch.from_numpy(np.concatenate([f.reshape(-1) for f in frames])) if frames else torch.empty(0, dtype=torch.uint8)
+        self.data = host.to(dev, non_blocking=False)
+
+
+class SimpleTransform(object):
+    """Generation of cropped input person and pose heat-maps (constructor arguments as the reference's, :54)."""
+
+    def __init__(self, dataset, scale_factor, add_dpg, input_size, output_size, rot, sigma, train, gpu_device=None, loss_type="MSELoss"):
+        self._joint_pairs = dataset.joint_pairs
+        self._scale_factor = scale_factor
+        self._rot = rot
+        self._add_dpg = add_dpg
+        self._gpu_device = gpu_device
+        self._input_size = input_size
+        self._heatmap_size = output_size
+        self._sigma = sigma
+        self._train = train
+        self._loss_type = loss_type
+        self._aspect_ratio = float(input_size[1]) / input_size[0]  # w / h
+        self._feat_stride = np.array(input_size) / np.array(output_size)
+        self.pixel_std = 1
+        if train:
+            self.num_joints_half_body = dataset.num_joints_half_body
+            self.prob_half_body = dataset.prob_half_body
+            self.upper_body_ids = dataset.upper_body_ids
+            self.lower_body_ids = dataset.lower_body_ids
+
+    # ------------------------------------------------------------------ batched fast path
+    def crop_batch(self, arena: FrameArena, frame_index, centers, scales, rots=0.0, mirror=None, out=None):
+        """Warp B crops in one launch: crop b reads frame ``frame_index[b]`` of ``arena`` through the matrix
+        get_affine_transform(centers[b], scales[b], rots[b], [inp_w, inp_h]) -> (B,3,inp_h,inp_w) fp32 device tensor."""
+        inp_h, inp_w = int(self._input_size[0]), int(self._input_size[1])
+        fi = np.asarray(frame_index, np.int64).reshape(-1)
+        n = fi.shape[0]
+        trans = get_affine_transform_batch(centers, scales, rots, [inp_w, inp_h])
+        minv = invert_affine_batch(trans)
+        hwf = np.zeros((n, 3), np.int32)
+        hwf[:, :2] = arena.hw[fi]
+        if mirror is not None:
+            hwf[:, 2] = np.asarray(mirror).astype(np.int32)
+        dev = arena.data.device
+        crops, _ = vh.crop_warp_affine(arena.data, torch.from_numpy(arena.offsets[fi]).to(dev), torch.from_numpy(hwf).to(dev),
+                                       torch.from_numpy(np.ascontiguousarray(minv)).to(dev), (inp_h, inp_w), out=out)
+        return crops, trans
+
+    def test_transform_batch(self, arena: FrameArena, frame_index, boxes_xyxy):
+        """``test_transform`` (:81-98) for B (frame, box) pairs -> crops (B,3,H,W) on device, boxes (B,4) float32 tensor."""
+        centers, scales = box_to_center_scale_batch(boxes_xyxy, self._aspect_ratio)
+        crops, _ = self.crop_batch(arena, frame_index, centers, scales, 0.0)
+        return crops, torch.from_numpy(center_scale_to_box_batch(centers, scales).astype(np.float32))
+
+    def targets_batch(self, joints_xy, vis):
+        """``_target_generator`` (:122-158) for (B,J,2) input-pixel joints, (B,J) visibility -> target (B,J,h,w), weight (B,J,1,1)."""
+        dev = _device()
+        j = torch.as_tensor(np.ascontiguousarray(joints_xy, np.float32)).to(dev)
+        v = torch.as_tensor(np.ascontiguousarray(vis, np.float32)).to(dev)
+        return vh.gaussian_targets(j, v, tuple(int(s) for s in self._heatmap_size), tuple(int(s) for s in self._input_size), float(self._sigma))
+
+    # ------------------------------------------------------------------ reference per-item interface
+    def test_transform(self, img, bbox):
+        xmin, ymin, xmax, ymax = bbox
+        center, scale = _box_to_center_scale(xmin, ymin, xmax - xmin, ymax - ymin, self._aspect_ratio)
+        scale = scale * 1.0
+        arena = FrameArena([img])
+        crops, _ = self.crop_batch(arena, [0], center[None], scale[None], 0.0)
+        return crops[0], torch.tensor(_center_scale_to_box(center, scale))
+
+    def _target_generator(self, joints_3d, num_joints):
+        target, weight = self.targets_batch(joints_3d[None, :, 0:2, 0], joints_3d[None, :, 0, 1])
+        return target[0], weight[0]
+
+    def _integral_target_generator(self, joints_3d, num_joints, patch_height, patch_width):
+        target_weight = np.ones((num_joints, 2), dtype=np.float32)
+        target_weight[:, 0] = joints_3d[:, 0, 1]
+        target_weight[:, 1] = joints_3d[:, 0, 1]
+        head = {136: 26, 133: 23, 68: 26}.get(num_joints)
+        if head:
+            target_weight[:head, :] = target_weight[:head, :] * 2
+        target = np.zeros((num_joints, 2), dtype=np.float32)
+        target[:, 0] = joints_3d[:, 0, 0] / patch_width - 0.5
+        target[:, 1] = joints_3d[:, 1, 0] / patch_height - 0.5
+        return target.reshape((-1)), target_weight.reshape((-1))
+
+    def __call__(self, img, label):
+        bbox = list(label["bbox"])
+        xmin, ymin, xmax, ymax = bbox
+        center, scale = _box_to_center_scale(xmin, ymin, xmax - xmin, ymax - ymin, self._aspect_ratio)
+        if self._add_dpg and self._train:
+            raise NotImplementedError("DPG box jitter is broken in the reference itself (simple_transform.py:184-185 reads imgwidth "
+                                      "before it is assigned) and no shipped config enables it")
+        imgwidth, imght = label["width"], label["height"]
+        assert imgwidth == img.shape[1] and imght == img.shape[0]
+        gt_joints = label["joints_3d"]
+        self.num_joints = gt_joints.shape[0]
+        joints_vis = np.zeros((self.num_joints, 1), dtype=np.float32)
+        joints_vis[:, 0] = gt_joints[:, 0, 1]
+
+        # the random draws below are made in the reference's order so a seeded run selects the same augmentations
+        if self._train and (np.sum(joints_vis[:, 0]) > self.num_joints_half_body and np.random.rand() < self.prob_half_body):
+            c_half_body, s_half_body = self.half_body_transform(gt_joints[:, :, 0], joints_vis)
+            if c_half_body is not None and s_half_body is not None:
+                center, scale = c_half_body, s_half_body
+        if self._train:
+            sf = self._scale_factor
+            scale = (scale * np.float32(np.clip(np.random.randn() * sf + 1, 1 - sf, 1 + sf))).astype(np.float32)
+        else:
+            scale = scale * 1.0
+        if self._train:
+            rf = self._rot
+            r = np.clip(np.random.randn() * rf, -rf * 2, rf * 2) if random.random() <= 0.6 else 0
+        else:
+            r = 0
+        joints = gt_joints
+        mirror = False
+        if random.random() > 0.5 and self._train:
+            assert img.shape[2] == 3
+            mirror = True                                   # the kernel reads the frame right-to-left instead of copying it
+            joints = flip_joints_3d(joints, imgwidth, self._joint_pairs)
+            center[0] = imgwidth - center[0] - 1
+
+        inp_h, inp_w = self._input_size
+        arena = FrameArena([img])
+        crops, trans = self.crop_batch(arena, [0], center[None], scale[None], r, mirror=[mirror])
+        trans = trans[0]
+        for i in range(self.num_joints):
+            if joints[i, 0, 1] > 0.0:
+                joints[i, 0:2, 0] = affine_transform(joints[i, 0:2, 0], trans)
+        if self._loss_type == "MSELoss":
+            target, target_weight = self._target_generator(joints, self.num_joints)
+        elif "JointRegression" in self._loss_type:
+            target, target_weight = self._integral_target_generator(joints, self.num_joints, inp_h, inp_w)
+            target, target_weight = torch.from_numpy(target), torch.from_numpy(target_weight)
+        else:
+            raise NotImplementedError(self._loss_type)
+        bbox = _center_scale_to_box(center, scale)
+        return crops[0], target, target_weight, torch.Tensor(bbox)
+
+    def half_body_transform(self, joints, joints_vis):
+        upper_joints, lower_joints = [], []
+        for joint_id in range(self.num_joints):
+            if joints_vis[joint_id][0] > 0:
+                (upper_joints if joint_id in self.upper_body_ids else lower_joints).append(joints[joint_id])
+        if np.random.randn() < 0.5 and len(upper_joints) > 2:
+            selected_joints = upper_joints
+        else:
+            selected_joints = lower_joints if len(lower_joints) > 2 else upper_joints
+        if len(selected_joints) < 2:
+            return None, None
+        selected_joints = np.array(selected_joints, dtype=np.float32)
+        center = selected_joints.mean(axis=0)[:2]
+        left_top = np.amin(selected_joints, axis=0)
+        right_bottom = np.amax(selected_joints, axis=0)
+        w = right_bottom[0] - left_top[0]
+        h = right_bottom[1] - left_top[1]
+        if w > self._aspect_ratio * h:
+            h = w * 1.0 / self._aspect_ratio
+        elif w < self._aspect_ratio * h:
+            w = h * self._aspect_ratio
+        scale = np.array([w * 1.0 / self.pixel_std, h * 1.0 / self.pixel_std], dtype=np.float32)
+        return center, scale * 1.5

@@ -5,8 +5,11 @@ heatmap_to_coord_simple_regress :586-642, get_max_pred :710-727,
 get_max_pred_batch :730-749, get_func_heatmap_to_coord :946-954.
 The per-item functions keep their signatures and results (numpy in, numpy out) but
 execute one libvatl_hip.so launch; the batched variants avoid the per-item D2H sync.
-Crop / flip / SMPL helpers of the reference file are host-side data preparation and
-out of scope.
+The crop geometry of the same file (get_affine_transform :753-786, affine_transform
+:789-792, flip_joints_3d :521-547, im_to_torch :76-91) is kept as host numpy, batched:
+it is O(crops) float64 work whose result (one 2x3 matrix per crop) feeds the warp
+kernel (``vatl_hip.crop_warp_affine``).  SMPL helpers are out of
+scope.
 """
 from __future__ import annotations
 
@@ -105,3 +108,78 @@ def flip_heatmap(heatmap, joint_pairs, shift=False):
     if shift:
         out[:, :, :, 1:] = out[:, :, :, 0:-1].clone()
     return out.squeeze(0) if ndim == 3 else out
+
+
+# ---------------------------------------------------------------------------------------------
+# crop geometry (host, float64 like the reference's numpy / cv2.getAffineTransform arithmetic)
+# ---------------------------------------------------------------------------------------------
+def get_affine_transform_batch(centers, scales, rots, output_size, inv=False):
+    """transforms.py:753-786 for B crops at once: centers/scales (B,2) float32, rots (B,) degrees, output_size
+    [w, h] -> (B,2,3) float64.  The three point pairs are rounded to float32 exactly where the reference stores
+    them in float32 arrays; the 3-point system is then solved in float64 (cv2.getAffineTransform)."""
+    c = np.asarray(centers, np.float32).reshape(-1, 2)
+    sc = np.asarray(scales, np.float32).reshape(-1, 2)
+    n = c.shape[0]
+    rad = np.pi * np.broadcast_to(np.asarray(rots, np.float64), (n,)) / 180
+    sn, cs = np.sin(rad), np.cos(rad)
+    half = sc[:, 0].astype(np.float64) * -0.5
+    src_dir = np.stack([0.0 * cs - half * sn, 0.0 * sn + half * cs], 1)
+    dst_w, dst_h = output_size[0], output_size[1]
+    src = np.zeros((n, 3, 2), np.float32)
+    dst = np.zeros((n, 3, 2), np.float32)
+    src[:, 0] = c
+    src[:, 1] = c.astype(np.float64) + src_dir
+    dst[:, 0] = [dst_w * 0.5, dst_h * 0.5]
+    dst[:, 1] = [dst_w * 0.5, dst_h * 0.5 + dst_w * -0.5]
+    for pts in (src, dst):
+        d = pts[:, 0] - pts[:, 1]
+        pts[:, 2] = pts[:, 1] + np.stack([-d[:, 1], d[:, 0]], 1)
+    a, b = (dst, src) if inv else (src, dst)
+    lhs = np.concatenate([a.astype(np.float64), np.ones((n, 3, 1))], axis=2)
+    return np.transpose(np.linalg.solve(lhs, b.astype(np.float64)), (0, 2, 1))
+
+
+def get_affine_transform(center, scale, rot, output_size, shift=None, inv=0):
+    """Per-item form with the reference's signature (transforms.py:753-786); ``shift`` other than zero is unused there."""
+    if shift is not None and np.any(np.asarray(shift) != 0):
+        raise NotImplementedError("get_affine_transform: non-zero shift is not used by any caller of the reference")
+    if not isinstance(scale, (np.ndarray, list)):
+        scale = np.array([scale, scale])
+    return get_affine_transform_batch(np.asarray(center)[None], np.asarray(scale)[None], rot, output_size, bool(inv))[0]
+
+
+def affine_transform(pt, t):
+    """transforms.py:789-792."""
+    return np.dot(t, np.array([pt[0], pt[1], 1.0]).T)[:2]
+
+
+def invert_affine_batch(m):
+    """(B,2,3) forward matrices -> the dst->src maps cv::warpAffine derives from them (same float64 operation order)."""
+    m = np.array(m, np.float64).reshape(-1, 6)
+    d = m[:, 0] * m[:, 4] - m[:, 1] * m[:, 3]
+    d = np.where(d != 0, 1.0 / np.where(d != 0, d, 1.0), 0.0)
+    out = np.empty_like(m)
+    out[:, 0], out[:, 4] = m[:, 4] * d, m[:, 0] * d
+    out[:, 1], out[:, 3] = m[:, 1] * -d, m[:, 3] * -d
+    out[:, 2] = -out[:, 0] * m[:, 2] - out[:, 1] * m[:, 5]
+    out[:, 5] = -out[:, 3] * m[:, 2] - out[:, 4] * m[:, 5]
+    return out.reshape(-1, 2, 3)
+
+
+def flip_joints_3d(joints_3d, width, joint_pairs):
+    """(J,3,2) joints mirrored about the image's vertical axis with left/right swapped (transforms.py:521-547)."""
+    joints = joints_3d.copy()
+    joints[:, 0, 0] = width - joints[:, 0, 0] - 1
+    for a, b in joint_pairs:
+        joints[[a, b]] = joints[[b, a]]
+    joints[:, :, 0] *= joints[:, :, 1]
+    return joints
+
+
+def im_to_torch(img):
+    """(H,W,3) ndarray -> (3,H,W) float tensor, divided by 255 when its maximum exceeds 1 (transforms.py:76-91).
+    Layout helper for callers that hold a host image; the crop path fuses this into the warp kernel."""
+    t = torch.from_numpy(np.ascontiguousarray(np.transpose(img, (2, 0, 1)))).float()
+    if t.max() > 1:
+        t /= 255
+    return t

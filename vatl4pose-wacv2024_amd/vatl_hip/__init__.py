@@ -82,6 +82,7 @@ SIGNATURES = {
     "vatl_masked_mse_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vatl_l1_joint_regression_fwd_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_gaussian_targets": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "vatl_crop_warp_affine": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _p]),
     "vatl_ae_train_step": (_i, [_p, _p, _p, _p, _i, _i, _i, _d, _d, _d, _d, _i, _p, _p]),
     "vatl_adamw_step": (_i, [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _i, _p]),
     "vatl_oks": (_i, [_p, _p, _p, _p, _i, _p]),
@@ -712,6 +713,26 @@ def gaussian_targets(joints_xy, vis, hm_hw=(64, 48), in_hw=(256, 192), sigma: fl
     _check(lib().vatl_gaussian_targets(_ptr(joints_xy.contiguous()), _ptr(vis.contiguous()), _ptr(target), _ptr(weight), n, j, hm_hw[0], hm_hw[1],
                                        in_hw[0], in_hw[1], sigma, _stream()), "vatl_gaussian_targets")
     return target, weight.reshape(n, j, 1, 1)
+
+
+PIXEL_MEAN = (0.406, 0.457, 0.480)          # simple_transform.py:93-95
+
+
+def crop_warp_affine(arena, src_off, src_hwf, minv, out_hw=(256, 192), mean=PIXEL_MEAN, out=None):
+    """cv2.warpAffine(INTER_LINEAR) + im_to_torch + mean shift for B crops in one call  [SimpleTransform.test_transform].
+
+    arena: uint8 device tensor holding the packed (h, w, 3) frames; src_off (B,) int64 byte offsets; src_hwf (B,3) int32
+    {h, w, mirror}; minv (B,2,3) float64 dst->src maps.  Returns (B,3,out_h,out_w) fp32 and the per-crop u8 maxima."""
+    b = int(src_off.shape[0])
+    dev = arena.device
+    if out is None:
+        out = torch.empty((b, 3, out_hw[0], out_hw[1]), device=dev, dtype=torch.float32)
+    cmax = torch.empty(b, device=dev, dtype=torch.int32)
+    _check(lib().vatl_crop_warp_affine(_ptr(arena, torch.uint8), _ptr(src_off, torch.int64), _ptr(src_hwf.contiguous(), torch.int32),
+                                       _ptr(minv.contiguous(), torch.float64), _ptr(out), _ptr(cmax, torch.int32), b, out_hw[0], out_hw[1],
+                                       float(mean[0]), float(mean[1]), float(mean[2]), _stream()),
+           "vatl_crop_warp_affine")
+    return out, cmax
 
 
 def ae_train_step(ae_flat, m, v, feat, d: int, z: int, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-8):
