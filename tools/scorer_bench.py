@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--items", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", default="", help="substring of the kernel name to run alone")
     a = ap.parse_args()
     import vatl_hip as vh
     from active_learning.Whole_body_AE.AutoEncoder import WholeBodyAE
@@ -40,7 +41,22 @@ def main():
     mask = (torch.rand((n, J, 1, 1), device=dev, generator=g) > 0.2).float()
     npar = 34_000_000
     p_, g_, m_, v_ = (torch.rand(npar, device=dev) for _ in range(4))
+    # crop producer (§8f rank 2): 32 synthetic 1080p frames (199 MB), n person boxes 60-240 px wide -> (n,3,256,192) fp32
+    import numpy as np
+    from alphapose.utils.bbox import box_to_center_scale_batch
+    from alphapose.utils.transforms import get_affine_transform_batch, invert_affine_batch
+    arena = torch.randint(0, 256, (32 * 1080 * 1920 * 3,), device=dev, dtype=torch.uint8, generator=g)
+    rs = np.random.RandomState(2)
+    bw = rs.uniform(60, 240, n); bx, by = rs.uniform(0, 1600, n), rs.uniform(0, 700, n)
+    cc, ss = box_to_center_scale_batch(np.stack([bx, by, bx + bw, by + bw * 4 / 3], 1), 0.75)
+    minv = torch.from_numpy(invert_affine_batch(get_affine_transform_batch(cc, ss, 0.0, [192, 256]))).to(dev)
+    fidx = rs.randint(0, 32, n)
+    soff = torch.from_numpy(fidx.astype(np.int64) * (1080 * 1920 * 3)).to(dev)
+    hwf = torch.tensor([[1080, 1920, 0]], dtype=torch.int32, device=dev).repeat(n, 1).contiguous()
+    crop_out = torch.empty((n, 3, 256, 192), device=dev)
+    crop_bytes = int(n * 3 * 256 * 192 * 4 + (ss[:, 0].astype(np.float64) * ss[:, 1]).sum() * 3)        # output + the source window once
     cases = [
+        ("crop_warp_affine (f2: warpAffine + im_to_torch + mean)", lambda: vh.crop_warp_affine(arena, soff, hwf, minv, (256, 192), out=crop_out), crop_bytes),
         ("decode_argmax_affine (a8)", lambda: vh.decode(hm, bbox), n * (plane + 204)),
         ("thc_stream L1 (a9)", lambda: vh.thc_stream(hm, ip, inx, "L1"), n * 2 * plane),
         ("thc_pairs L1 (a9, explicit neighbour maps)", lambda: vh.thc_pairs(hm, hm2, "L1"), n * 2 * plane),
@@ -54,6 +70,8 @@ def main():
         ("adamw_step 34 M parameters (a7)", lambda: vh.adamw_step(p_, g_, m_, v_, 3, 1e-3, 0.7), npar * 28),
     ]
     for name, fn, byts in cases:
+        if a.only and a.only not in name:
+            continue
         for _ in range(2):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
