@@ -163,3 +163,27 @@ def u8_frame(h: int = 480, w: int = 640, seed: int = 58) -> np.ndarray:
     base = np.stack([(xx * 255 / max(w - 1, 1)), (yy * 255 / max(h - 1, 1)), ((xx // 16 + yy // 16) % 2) * 200 + 20], 2)
     img = base + r.randint(-20, 21, (h, w, 3))
     return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def frame_video(n_frames: int = 8, tracks: int = 2, hw=(240, 320), seed: int = 71, J: int = 17):
+    """Seeded stand-in for a decoded PoseTrack video: ``n_frames`` uint8 RGB frames and one annotation per (track, frame)
+    in the field layout the reference's loaders build (posetrack21.py:103-115): a person box drifting through the
+    frame, joints inside it, ~15 % invisible; ``id`` orders items track by track, frame by frame."""
+    r = _rs(seed, f"video{n_frames}x{tracks}")
+    frames = [u8_frame(hw[0], hw[1], seed + 1 + f) for f in range(n_frames)]
+    anns = []
+    for t in range(tracks):
+        x0, y0 = r.uniform(10, hw[1] * 0.4), r.uniform(5, hw[0] * 0.2)
+        w, h = r.uniform(50, 110), r.uniform(110, 170)
+        for f in range(n_frames):
+            bx, by = x0 + 3.5 * f + r.uniform(-1, 1), y0 + 1.25 * f + r.uniform(-1, 1)
+            j3 = np.zeros((J, 3, 2), np.float32)
+            j3[:, 0, 0] = r.uniform(bx, bx + w, J)
+            j3[:, 1, 0] = r.uniform(by, by + h, J)
+            vis = (r.random_sample(J) > 0.15).astype(np.float32)
+            j3[:, 0, 1] = j3[:, 1, 1] = vis
+            j3[:, :, 0] *= j3[:, :, 1]
+            kp = np.stack([j3[:, 0, 0], j3[:, 1, 0], vis], 1).reshape(-1).astype(np.float32)
+            anns.append({"bbox": (float(bx), float(by), float(bx + w), float(by + h)), "joints_3d": j3, "keypoint": kp.tolist(),
+                         "id": t * 1000 + f, "ann_id": 500000 + t * 1000 + f, "img_id": 9000 + f, "track_id": f"v{t}", "frame": f})
+    return frames, anns

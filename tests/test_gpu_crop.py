@@ -179,3 +179,91 @@ def test_full_batch_properties_and_errors():
     with pytest.raises(vh.VatlError):
         vh.crop_warp_affine(arena.data, torch.zeros(1, dtype=torch.int64, device=dev()), torch.zeros((1, 3), dtype=torch.int32, device=dev()),
                             torch.zeros((1, 2, 3), dtype=torch.float64, device=dev()), (256, 8192))
+
+
+def _video_cfg():
+    from alphapose.utils.config import edict
+    return edict({
+        "DATASET": {"TRAIN": {"TYPE": "FrameVideo"}, "EVAL": {"TYPE": "FrameVideo"}},
+        "DATA_PRESET": {"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]},
+        "MODEL": {"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50},
+        "LOSS": {"TYPE": "MSELoss"},
+        "AE": {"Z_DIM": 4, "INPUT_DIM": 42, "PRETRAINED": "", "EPOCH": 1, "LR": 1e-3},
+        "RETRAIN": {"BATCH_SIZE": 8, "BASE": 1, "OPTIMIZER": "AdamW", "LR": 2.5e-4, "ALPHA": 2, "WEIGHT_DECAY": 0.7, "LR_GAMMA": 0.99},
+        "VAL": {"BATCH_SIZE": 6, "W_UNC": 0.01, "UNC_LAMBDA": 0.01, "QUERY_RATIO": [0.25, 1.0]},
+    })
+
+
+def test_frame_video_items_follow_the_reference_item_contract():
+    """FrameVideo over decoded u8 frames: every field of the 11-tuple against the oracle composition, prev/next crops
+    = test_transform of the id-adjacent item of the same track, and a DataLoader batch = one launch = the same items."""
+    from torch.utils.data import DataLoader
+    from alphapose.datasets import FrameVideo
+    from oracle import crop, scorers, synth
+    frames, anns = synth.frame_video(6, 2)
+    preset = {"IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48], "SIGMA": 2}
+    ds = FrameVideo(frames, list(reversed(anns)), train=False, get_prenext=True, PRESET=preset)      # sorts by id itself
+    assert len(ds) == 12 and ds.ID_SORTED_STREAM
+    by_id = sorted(anns, key=lambda a: a["id"])
+    for i in (0, 3, 5, 6, 11):
+        a = by_id[i]
+        idx, inp, label, mask, gt, img_id, ann_id, bb_crop, bb_ann, is_prev, is_next = ds[i]
+        assert idx == i and img_id == a["img_id"] and ann_id == a["ann_id"]
+        assert (is_prev, is_next) == (i not in (0, 6), i not in (5, 11))                          # two tracks of six frames
+        ref_img, ref_bb = crop.test_transform(frames[a["frame"]], a["bbox"])
+        assert inp.shape == (3, 3, 256, 192) and np.array_equal(inp[0].cpu().numpy(), ref_img)
+        for slot, flag, step in ((1, is_prev, -1), (2, is_next, 1)):
+            if flag:
+                nb = by_id[i + step]
+                assert np.array_equal(inp[slot].cpu().numpy(), crop.test_transform(frames[nb["frame"]], nb["bbox"])[0])
+            else:
+                assert float(inp[slot].abs().sum()) == 0.0
+        assert np.array_equal(bb_crop.numpy(), np.float32(ref_bb)) and np.array_equal(bb_ann.numpy(), np.float32(a["bbox"]))
+        assert np.array_equal(gt.numpy(), np.float32(a["keypoint"]))
+        c, s = crop.box_to_center_scale(a["bbox"][0], a["bbox"][1], a["bbox"][2] - a["bbox"][0], a["bbox"][3] - a["bbox"][1], 0.75)
+        t = crop.affine_transform_matrix(c, s, 0, [192, 256])
+        jt = a["joints_3d"].copy()
+        for j in range(17):
+            if jt[j, 0, 1] > 0:
+                jt[j, 0:2, 0] = crop.transform_point(jt[j, 0:2, 0], t)
+        rt, rw = scorers.target_generator(jt[:, 0:2, 0], jt[:, 0, 1])
+        np.testing.assert_allclose(label.cpu().numpy(), rt, rtol=1e-6, atol=1e-7)
+        assert np.array_equal(mask.cpu().numpy().reshape(-1), rw.reshape(-1))
+    batch = next(iter(DataLoader(ds, batch_size=5, shuffle=False, collate_fn=ds.my_collate_fn)))
+    assert batch[1].shape == (5, 3, 3, 256, 192) and batch[1].is_cuda
+    for k in range(5):
+        assert torch.equal(batch[1][k], ds[k][1]) and torch.equal(batch[2][k], ds[k][2])
+    assert batch[9] == [False, True, True, True, True]
+
+
+def test_active_learning_round_on_decoded_frames(tmp_path):
+    """u8 frames -> device crops -> backbone -> scorers -> query -> fine-tune on augmented device crops -> next evaluation:
+    the whole loop with no host-side pixel work."""
+    import types
+    from active_learning import ActiveLearning
+    from alphapose.datasets import FrameVideo
+    from oracle import synth
+    frames, anns = synth.frame_video(8, 2)
+    preset = {"IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48], "SIGMA": 2}
+    aug = {"SCALE_FACTOR": 0.25, "ROT_FACTOR": 30, "NUM_JOINTS_HALF_BODY": 8, "PROB_HALF_BODY": 0.3}
+    ev = FrameVideo(frames, anns, train=False, get_prenext=True, PRESET=preset)
+    tr = FrameVideo(frames, anns, train=True, get_prenext=False, PRESET=preset, AUG=aug)
+    assert not tr.ID_SORTED_STREAM
+    opt = types.SimpleNamespace(work_dir=str(tmp_path), uncertainty="THC+WPU", representativeness="None", filter="None", strategy="THC+WPU", video_id="syn",
+                                get_prenext=True, from_scratch=True, continual=True, num_gpu=1, onebyone=False, retrain_thresh=1, THCvsWPU="const")
+    torch.manual_seed(0); np.random.seed(0); random.seed(0)
+    al = ActiveLearning(_video_cfg(), opt, eval_dataset=ev, train_dataset=tr)
+    assert al.dedup
+    al.eval_and_query()
+    assert len(al.labeled_id) == 4 and len(al.unlabeled_id) == 12
+    kp0 = np.array(al.keypoints[0])
+    # the scored key-points are the decode of the model's heat-map for the device-made crop
+    al.model.eval()
+    with torch.no_grad():
+        hm = al.model(ev[0][1][0][None]).cpu().numpy()
+    from oracle import scorers
+    d = scorers.decode_heatmaps(hm[0], ev[0][7].numpy())
+    np.testing.assert_allclose(kp0.reshape(17, 3)[:, :2], d["coords"], rtol=1e-4, atol=1e-4)
+    assert al.outcome() is None and np.isfinite(al.last_train_loss)
+    al.eval_and_query()
+    assert len(al.unlabeled_id) == 0

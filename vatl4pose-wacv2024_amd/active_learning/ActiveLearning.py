@@ -63,7 +63,7 @@ class ActiveLearning:
         self.collate_fn = self.eval_dataset.my_collate_fn
         workers = int(getattr(opt, "num_workers", 0))
         self.eval_loader = DataLoader(self.eval_dataset, batch_size=cfg.VAL.BATCH_SIZE * ngpu, shuffle=False, num_workers=workers,
-                                      drop_last=False, pin_memory=True, collate_fn=self.collate_fn)
+                                      drop_last=False, pin_memory=not getattr(self.eval_dataset, "DEVICE_ITEMS", False), collate_fn=self.collate_fn)
         self.eval_len = len(self.eval_dataset)
         self.dedup = bool(getattr(self.eval_dataset, "ID_SORTED_STREAM", False))
 

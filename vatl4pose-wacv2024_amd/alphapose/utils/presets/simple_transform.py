@@ -18,7 +18,7 @@ import torch
 import vatl_hip as vh
 
 from ..bbox import (_box_to_center_scale, _center_scale_to_box, box_to_center_scale_batch, center_scale_to_box_batch)
-from ..transforms import (affine_transform, flip_joints_3d, get_affine_transform, get_affine_transform_batch, invert_affine_batch)
+from ..transforms import flip_joints_3d, get_affine_transform_batch, invert_affine_batch
 
 
 def _device():
@@ -122,21 +122,21 @@ class SimpleTransform(object):
         target[:, 1] = joints_3d[:, 1, 0] / patch_height - 0.5
         return target.reshape((-1)), target_weight.reshape((-1))
 
-    def __call__(self, img, label):
+    def _draw(self, label):
+        """Host half of ``__call__`` (:179-229): centre/scale of the box and, in train mode, the augmentation draws in the
+        reference's order (half-body, scale, rotation, flip) so a seeded run selects the same augmentations.
+        -> center, scale (float32 (2,)), rotation in degrees, mirror flag, joints (J,3,2) (flipped when mirrored)."""
         bbox = list(label["bbox"])
         xmin, ymin, xmax, ymax = bbox
         center, scale = _box_to_center_scale(xmin, ymin, xmax - xmin, ymax - ymin, self._aspect_ratio)
         if self._add_dpg and self._train:
             raise NotImplementedError("DPG box jitter is broken in the reference itself (simple_transform.py:184-185 reads imgwidth "
                                       "before it is assigned) and no shipped config enables it")
-        imgwidth, imght = label["width"], label["height"]
-        assert imgwidth == img.shape[1] and imght == img.shape[0]
+        imgwidth = label["width"]
         gt_joints = label["joints_3d"]
         self.num_joints = gt_joints.shape[0]
         joints_vis = np.zeros((self.num_joints, 1), dtype=np.float32)
         joints_vis[:, 0] = gt_joints[:, 0, 1]
-
-        # the random draws below are made in the reference's order so a seeded run selects the same augmentations
         if self._train and (np.sum(joints_vis[:, 0]) > self.num_joints_half_body and np.random.rand() < self.prob_half_body):
             c_half_body, s_half_body = self.half_body_transform(gt_joints[:, :, 0], joints_vis)
             if c_half_body is not None and s_half_body is not None:
@@ -154,27 +154,42 @@ class SimpleTransform(object):
         joints = gt_joints
         mirror = False
         if random.random() > 0.5 and self._train:
-            assert img.shape[2] == 3
             mirror = True                                   # the kernel reads the frame right-to-left instead of copying it
             joints = flip_joints_3d(joints, imgwidth, self._joint_pairs)
             center[0] = imgwidth - center[0] - 1
+        return center, scale, r, mirror, joints
 
+    def call_batch(self, arena: FrameArena, frame_index, labels):
+        """``__call__`` (:179-251) for a batch: per-item draws on the host, then ONE warp launch and ONE target launch.
+        -> crops (B,3,H,W), targets, target weights, boxes (B,4) float32 (host tensor)."""
         inp_h, inp_w = self._input_size
-        arena = FrameArena([img])
-        crops, trans = self.crop_batch(arena, [0], center[None], scale[None], r, mirror=[mirror])
-        trans = trans[0]
-        for i in range(self.num_joints):
-            if joints[i, 0, 1] > 0.0:
-                joints[i, 0:2, 0] = affine_transform(joints[i, 0:2, 0], trans)
+        draws = [self._draw(lb) for lb in labels]
+        centers = np.stack([d[0] for d in draws]).astype(np.float32).reshape(-1, 2)
+        scales = np.stack([d[1] for d in draws]).astype(np.float32).reshape(-1, 2)
+        rots = np.array([d[2] for d in draws], np.float64)
+        crops, trans = self.crop_batch(arena, frame_index, centers, scales, rots, mirror=[d[3] for d in draws])
+        joints = np.stack([d[4] for d in draws]).astype(np.float32)                     # (B,J,3,2), a copy
+        xy1 = np.concatenate([joints[:, :, 0:2, 0].astype(np.float64), np.ones(joints.shape[:2] + (1,))], 2)
+        moved = np.einsum("bik,bjk->bji", trans, xy1)                                   # affine_transform (:789-792) per joint
+        vis = joints[:, :, 0, 1] > 0.0
+        joints[:, :, 0:2, 0] = np.where(vis[..., None], moved, joints[:, :, 0:2, 0])
         if self._loss_type == "MSELoss":
-            target, target_weight = self._target_generator(joints, self.num_joints)
+            target, weight = self.targets_batch(joints[:, :, 0:2, 0], joints[:, :, 0, 1])
         elif "JointRegression" in self._loss_type:
-            target, target_weight = self._integral_target_generator(joints, self.num_joints, inp_h, inp_w)
-            target, target_weight = torch.from_numpy(target), torch.from_numpy(target_weight)
+            tw = [self._integral_target_generator(j, j.shape[0], inp_h, inp_w) for j in joints]
+            target = torch.from_numpy(np.stack([t for t, _ in tw]))
+            weight = torch.from_numpy(np.stack([w for _, w in tw]))
         else:
             raise NotImplementedError(self._loss_type)
-        bbox = _center_scale_to_box(center, scale)
-        return crops[0], target, target_weight, torch.Tensor(bbox)
+        boxes = torch.from_numpy(center_scale_to_box_batch(centers, scales).astype(np.float32))
+        return crops, target, weight, boxes
+
+    def __call__(self, img, label):
+        imgwidth, imght = label["width"], label["height"]
+        assert imgwidth == img.shape[1] and imght == img.shape[0]
+        assert img.shape[2] == 3
+        crops, target, weight, boxes = self.call_batch(FrameArena([img]), [0], [label])
+        return crops[0], target[0], weight[0], torch.Tensor(boxes[0].tolist())
 
     def half_body_transform(self, joints, joints_vis):
         upper_joints, lower_joints = [], []
