@@ -108,12 +108,12 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
     except (OSError, IndexError, KeyError, ValueError):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": traffic,
+            "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": (traffic / len(events)) if traffic else None,
             "kernel": "conv_igemm_kernel + gemm1x1_persistent_kernel (all conv/deconv launches of one step; 4 of them fuse a projection shortcut with the block's last conv)", "launches": len(events),
             "avg_launch_us": round(ms * 1e3 / len(events), 2), "flops_per_step": flops,
             # the step's conv launches have different shapes: `achieved` is sum(flops) / sum(duration); per-launch averages for reference
-            "flops_per_launch": flops / len(events), "traffic_per_launch": (traffic / len(events)) if traffic else None,
-            "traffic_note": "HBM bytes of all conv launches of one step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950), from the committed profiles/*_pmc_summary.json"}
+            "flops_per_launch": flops / len(events), "traffic_per_step": traffic,
+            "traffic_note": "`traffic` = HBM bytes per launch (average over the step's conv launches, like `achieved`); source: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE x2 on gfx950), summed over the conv launches of one step in the committed profiles/*_pmc_summary.json"}
 
 
 def cpu_baseline():
