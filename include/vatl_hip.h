@@ -92,7 +92,8 @@ int vatl_tune_set(int knob, int value);
  * tile into its workspace slice and one pass sums the slices in order and applies scale / bias / residual / ReLU.
  * Deterministic, but the summation order differs from the unsplit kernel: results agree to fp32 rounding, not bit for bit,
  * and the choice depends on the batch size — so it is OFF unless a workspace is set (the evaluation path relies on
- * batch-size-independent bits).  The workspace is shared by all streams: use from one stream at a time.  NULL disables. */
+ * batch-size-independent bits).  The workspace is registered for the CURRENT device (launches on other devices never touch
+ * it) and is shared by that device's streams: use from one stream at a time.  NULL disables it for the current device. */
 int vatl_set_splitk_workspace(float* workspace, int64_t floats);
 /* CoutPad the packer must use for a given Cout (multiple of the kernel's N tile). */
 int vatl_conv_cout_pad(int Cout);

@@ -361,14 +361,13 @@ def _plan_for(m: nn.Module, device):
 
 
 _SPLITK_MB = int(os.environ.get("VATL_SPLITK_MB", "0"))   # opt-in small-batch latency mode (vatl_hip.enable_splitk); 0 = off
-_splitk_ready = False
+_splitk_ready = set()                                      # device indices whose workspace is registered
 
 
 def _prepare_input(m: nn.Module, x: torch.Tensor):
-    global _splitk_ready
-    if _SPLITK_MB > 0 and not _splitk_ready and x.is_cuda:
+    if _SPLITK_MB > 0 and x.is_cuda and x.device.index not in _splitk_ready:
         vh.enable_splitk(_SPLITK_MB, x.device)
-        _splitk_ready = True
+        _splitk_ready.add(x.device.index)
     if not x.is_cuda:
         raise vh.VatlError("the pose network runs on MI355X only: move the model and inputs to a HIP device "
                            "(there is deliberately no CPU fallback)")

@@ -1,6 +1,7 @@
 // Shared helpers for libvatl_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
@@ -16,6 +17,19 @@ int fail(int code, const char* fmt, ...);
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATL_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+// Raising a kernel's dynamic-LDS limit is a per-device setting: `done_mask` (one static per kernel instantiation) remembers
+// the devices it has been applied on, so a process that drives several devices configures each of them once.
+inline int ensure_dynamic_lds(const void* kern, int bytes, std::atomic<unsigned>& done_mask, const char* what) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return fail(VATL_ELAUNCH, "%s: no current device", what);
+    const unsigned bit = 1u << (d & 31);
+    if (done_mask.load(std::memory_order_acquire) & bit) return 0;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(VATL_ELAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+    done_mask.fetch_or(bit, std::memory_order_release);
     return 0;
 }
 

@@ -859,20 +859,27 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, long long s
     }
 }
 
-static std::atomic<float*> g_splitk_ws{nullptr};     // caller-owned workspace (vatl_set_splitk_workspace); NULL = split-K off
-static std::atomic<long long> g_splitk_floats{0};
+// caller-owned split-K workspaces (vatl_set_splitk_workspace), one slot per device: a launch only ever uses the workspace that
+// was registered while its own device was current.  All NULL = split-K off (g_splitk_any skips the device query).
+constexpr int kMaxDevices = 16;
+static std::atomic<float*> g_splitk_ws[kMaxDevices];
+static std::atomic<long long> g_splitk_floats[kMaxDevices];
+static std::atomic<int> g_splitk_any{0};
+
+static float* splitk_workspace(long long* floats) {
+    if (!g_splitk_any.load(std::memory_order_acquire)) return nullptr;
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return nullptr;
+    *floats = g_splitk_floats[d].load(std::memory_order_relaxed);
+    return g_splitk_ws[d].load(std::memory_order_acquire);
+}
 
 template <int BM, int BN, int WM, int WN, bool STEM, int VAR, bool DUAL = false, int NT = 256>
 static int launch(const ConvParams& p, int phases, hipStream_t st) {
     auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM, VAR, DUAL, NT>;
     constexpr int smem = 2 * (BM + BN) * LDK * (int)sizeof(float);
-    static std::atomic<int> configured{0};
-    if (!configured.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return fail(VATL_ELAUNCH, "hipFuncSetAttribute(conv_igemm): %s", hipGetErrorString(e));
-        configured.store(1, std::memory_order_release);
-    }
+    static std::atomic<unsigned> configured{0};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, configured, "conv_igemm")) return rc;
     ConvParams q = p;
     q.n_tiles = p.CoutPad / BN;
     q.m_tiles = cdiv(p.M, BM);
@@ -884,13 +891,14 @@ static int launch(const ConvParams& p, int phases, hipStream_t st) {
     static_assert(2 * (BM + BN) * LDK >= BM * (BN + 4), "epilogue tile must fit in the staging buffers");
     const int m_tiles = cdiv(p.M, BM);
     const long long blocks = (long long)m_tiles * q.n_tiles * phases;
-    float* ws = g_splitk_ws.load(std::memory_order_acquire);
+    long long ws_floats = 0;
+    float* ws = splitk_workspace(&ws_floats);
     q.splits = 1;
     if (ws && !STEM && !DUAL && !q.stats && !q.ablate && blocks < 256 && q.ktiles >= 16) {
         // small launch with a long reduction (single-frame / small-batch inference): cut K so that ~512 blocks are in flight
         const long long out_elems = (long long)q.y_bytes / 4;
         int splits = (int)std::min<long long>(q.ktiles / 8, (512 + blocks - 1) / blocks);
-        const long long fit = g_splitk_floats.load(std::memory_order_relaxed) / (out_elems > 0 ? out_elems : 1);
+        const long long fit = ws_floats / (out_elems > 0 ? out_elems : 1);
         if (splits > fit) splits = (int)fit;
         if (splits >= 2) {
             q.kt_per_split = (q.ktiles + splits - 1) / splits;
@@ -916,12 +924,8 @@ static int launch_dma(const ConvParams& p, int phases, hipStream_t st) {
     constexpr int stage_bytes = 2 * (BM + BN) * BK * (int)sizeof(float);
     constexpr int epi_bytes = BM * (BN + 4) * (int)sizeof(float);
     constexpr int smem = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
-    static std::atomic<int> configured{0};
-    if (!configured.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return fail(VATL_ELAUNCH, "hipFuncSetAttribute(conv_igemm_dma): %s", hipGetErrorString(e));
-        configured.store(1, std::memory_order_release);
-    }
+    static std::atomic<unsigned> configured{0};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, configured, "conv_igemm_dma")) return rc;
     ConvParams q = p;
     q.n_tiles = p.CoutPad / BN;
     q.m_tiles = cdiv(p.M, BM);
@@ -935,12 +939,8 @@ template <int BM, int BN, int WM, int WN>
 static int launch_persistent(const ConvParams& p, hipStream_t st) {
     auto kern = gemm1x1_persistent_kernel<BM, BN, WM, WN>;
     constexpr int smem = 2 * (BM + BN) * LDK * (int)sizeof(float);
-    static std::atomic<int> configured{0};
-    if (!configured.load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return fail(VATL_ELAUNCH, "hipFuncSetAttribute(gemm1x1_persistent): %s", hipGetErrorString(e));
-        configured.store(1, std::memory_order_release);
-    }
+    static std::atomic<unsigned> configured{0};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, configured, "gemm1x1_persistent")) return rc;
     ConvParams q = p;
     q.n_tiles = p.CoutPad / BN;
     q.m_tiles = cdiv(p.M, BM);
@@ -1043,8 +1043,13 @@ extern "C" int vatl_tune_set(int knob, int value) {
 
 extern "C" int vatl_set_splitk_workspace(float* workspace, int64_t floats) {
     if (workspace && floats <= 0) return fail(VATL_EINVAL, "set_splitk_workspace: empty workspace");
-    g_splitk_floats.store(workspace ? (long long)floats : 0, std::memory_order_relaxed);
-    g_splitk_ws.store(workspace, std::memory_order_release);
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return fail(VATL_EINVAL, "set_splitk_workspace: no current device (or index >= %d)", kMaxDevices);
+    g_splitk_floats[d].store(workspace ? (long long)floats : 0, std::memory_order_relaxed);
+    g_splitk_ws[d].store(workspace, std::memory_order_release);
+    int any = 0;
+    for (int i = 0; i < kMaxDevices; ++i) any |= g_splitk_ws[i].load(std::memory_order_relaxed) != nullptr;
+    g_splitk_any.store(any, std::memory_order_release);
     return 0;
 }
 

@@ -163,18 +163,22 @@ def tune_set(knob: int, value: int):
     _check(lib().vatl_tune_set(knob, value), "vatl_tune_set")
 
 
-_splitk_buf = None
+_splitk_buf = {}                                     # device index -> workspace tensor kept alive while registered
 
 
 def enable_splitk(megabytes: int = 64, device=None):
-    """Opt-in split-K for small-batch latency (see vatl_set_splitk_workspace); ``megabytes = 0`` switches it off."""
-    global _splitk_buf
-    if megabytes <= 0:
-        _check(lib().vatl_set_splitk_workspace(None, 0), "vatl_set_splitk_workspace")
-        _splitk_buf = None
-        return
-    _splitk_buf = torch.empty(megabytes * (1 << 18), device=device or torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32)
-    _check(lib().vatl_set_splitk_workspace(_ptr(_splitk_buf), _splitk_buf.numel()), "vatl_set_splitk_workspace")
+    """Opt-in split-K for small-batch latency on ``device`` (default: the current one; see vatl_set_splitk_workspace);
+    ``megabytes = 0`` switches it off for that device."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(idx):                                     # the library files the workspace under the current device
+        if megabytes <= 0:
+            _check(lib().vatl_set_splitk_workspace(None, 0), "vatl_set_splitk_workspace")
+            _splitk_buf.pop(idx, None)
+            return
+        buf = torch.empty(megabytes * (1 << 18), device=torch.device("cuda", idx), dtype=torch.float32)
+        _check(lib().vatl_set_splitk_workspace(_ptr(buf), buf.numel()), "vatl_set_splitk_workspace")
+        _splitk_buf[idx] = buf
 
 
 def conv_cout_pad(cout: int) -> int:
