@@ -17,11 +17,23 @@ constexpr int MAX_ROW_BLOCKS = 4096;     // partial sums per channel (the finali
 // loads are 16-byte and fully coalesced; threads sharing a column are combined through LDS.  Partials are doubles:
 // partial[(rb * C + c) * 2 + {0,1}].
 struct RowSplit { long long rows_per_block; int nrb; };
-static inline RowSplit row_split(long long M) {
-    long long nrb = (M + 255) / 256;                  // ~256 rows per block: thousands of blocks keep HBM busy
-    if (nrb > MAX_ROW_BLOCKS) nrb = MAX_ROW_BLOCKS;
+static inline RowSplit row_split(long long M, int C) {
+    // A block of col_reduce_kernel covers min(C/4, 256) float4 columns with 256 threads, i.e. `rstep` rows at a time.  Aim at
+    // >= ~1024 blocks (small-M layers would otherwise run on a few dozen CUs with every thread walking hundreds of rows one
+    // load at a time) while keeping >= 16 row steps per block, so that the per-block partials stay a few % of the traffic.
+    const int c4 = C >> 2 > 0 ? C >> 2 : 1;
+    const int cols = c4 < 256 ? c4 : 256, rstep = 256 / cols, gy = (c4 + 255) / 256;
+    long long rpb = 256;                               // large M: ~256 rows per block, thousands of blocks
+    const long long want = 1024 / gy > 0 ? 1024 / gy : 1;
+    if ((M + rpb - 1) / rpb < want) {
+        rpb = (M + want - 1) / want;
+        const long long floor_rows = 16LL * rstep;
+        if (rpb < floor_rows) rpb = floor_rows;
+        rpb = (rpb + rstep - 1) / rstep * rstep;
+    }
+    long long nrb = (M + rpb - 1) / rpb;
+    if (nrb > MAX_ROW_BLOCKS) { nrb = MAX_ROW_BLOCKS; rpb = (M + nrb - 1) / nrb; }
     if (nrb < 1) nrb = 1;
-    const long long rpb = (M + nrb - 1) / nrb;
     return {rpb, (int)((M + rpb - 1) / rpb)};
 }
 
@@ -47,19 +59,21 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
         f32x4 msc = {0.f, 0.f, 0.f, 0.f}, mbi = {1.f, 1.f, 1.f, 1.f};
         if (MODE == 1) { mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4); is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4); }
         if (MODE == 1 && mscale) { msc = *reinterpret_cast<const f32x4*>(mscale + c4 * 4); mbi = *reinterpret_cast<const f32x4*>(mbias + c4 * 4); }
-        for (long long r = r0 + rlane; r < r1; r += rstep) {
-            const long long o = r * C + c4 * 4;
-            f32x4 v = *reinterpret_cast<const f32x4*>(a + o);
+        const f32x4* __restrict__ a4 = reinterpret_cast<const f32x4*>(a);
+        const f32x4* __restrict__ y4 = reinterpret_cast<const f32x4*>(y);
+        const f32x4* __restrict__ z4 = reinterpret_cast<const f32x4*>(z);
+        const long long C4l = C4;
+        // rows are taken four at a time with all their loads issued first (a thread otherwise has one 16-byte load in
+        // flight per step); the accumulation order is the plain row order either way
+        auto fold = [&](f32x4 v, f32x4 yy, f32x4 zz) {
             if (MODE == 0) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
             } else {
                 if (y) {
-                    const f32x4 yy = *reinterpret_cast<const f32x4*>(y + o);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = yy[e] > 0.f ? v[e] : 0.f;
                 }
-                const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o);
                 if (mscale) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = relu_on(zz[e], msc[e], mbi[e]) ? v[e] : 0.f;
@@ -67,6 +81,24 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s[e] += v[e]; q[e] += v[e] * ((zz[e] - mu[e]) * is[e]); }
             }
+        };
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        long long r = r0 + rlane;
+        for (; r + 3LL * rstep < r1; r += 4LL * rstep) {
+            f32x4 v[4], yy[4], zz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long o = (r + (long long)u * rstep) * C4l + c4;
+                v[u] = a4[o];
+                yy[u] = (MODE == 1 && y) ? y4[o] : zero;
+                zz[u] = MODE == 1 ? z4[o] : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fold(v[u], yy[u], zz[u]);
+        }
+        for (; r < r1; r += rstep) {
+            const long long o = r * C4l + c4;
+            fold(a4[o], (MODE == 1 && y) ? y4[o] : zero, MODE == 1 ? z4[o] : zero);
         }
     }
     __shared__ float sh[2][256][4];
@@ -310,7 +342,7 @@ static inline int ew_grid(long long n) { long long g = (n + 255) / 256; if (g > 
 
 using namespace vatl;
 
-extern "C" int64_t vatl_col_reduce_workspace_doubles(int64_t M, int C) { return 2 * (int64_t)row_split(M).nrb * (int64_t)C; }
+extern "C" int64_t vatl_col_reduce_workspace_doubles(int64_t M, int C) { return 2 * (int64_t)row_split(M, C).nrb * (int64_t)C; }
 
 static void launch_col_reduce(int mode, const float* a, const float* y, const float* z, const float* mean, const float* invstd,
                               double* ws, long long M, int C, const RowSplit& rs, hipStream_t st, const float* mscale = nullptr,
@@ -329,7 +361,7 @@ extern "C" int vatl_bn_train_fwd_stats(const float* z, int64_t M, int C, const f
                                        float* running_var, float momentum, float eps, float* save_mean, float* save_invstd,
                                        float* scale, float* bias, double* workspace, void* stream) {
     if (!z || !save_mean || !save_invstd || !scale || !bias || !workspace || M <= 0) return fail(VATL_EINVAL, "bn_train_fwd_stats: bad arguments");
-    const RowSplit rs = row_split(M);
+    const RowSplit rs = row_split(M, C);
     launch_col_reduce(0, z, nullptr, nullptr, nullptr, nullptr, workspace, (long long)M, C, rs, (hipStream_t)stream);
     hipLaunchKernelGGL(bn_train_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, workspace, rs.nrb, (long long)M, C, gamma, beta,
                        running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, bias);
@@ -349,7 +381,7 @@ static int bn_train_bwd_impl(const float* dy, const float* y_or_null, const floa
                              int64_t M, int C, float* coef3C, double* workspace, void* stream) {
     if (!dy || !z || !save_mean || !save_invstd || !dz || !coef3C || !workspace || (C & 3) || M <= 0)
         return fail(VATL_EINVAL, "bn_train_bwd: bad arguments");
-    const RowSplit rs = row_split(M);
+    const RowSplit rs = row_split(M, C);
     hipStream_t st = (hipStream_t)stream;
     launch_col_reduce(1, dy, y_or_null, z, save_mean, save_invstd, workspace, (long long)M, C, rs, st, mscale, mbias);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, workspace, rs.nrb, (long long)M, C, gamma, save_mean, save_invstd,
@@ -392,7 +424,7 @@ extern "C" int vatl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx,
 
 extern "C" int vatl_col_sum(const float* x, int64_t M, int C, float* out, double* workspace, void* stream) {
     if (!x || !out || !workspace || M <= 0) return fail(VATL_EINVAL, "col_sum: bad arguments");
-    const RowSplit rs = row_split(M);
+    const RowSplit rs = row_split(M, C);
     launch_col_reduce(0, x, nullptr, nullptr, nullptr, nullptr, workspace, (long long)M, C, rs, (hipStream_t)stream);
     hipLaunchKernelGGL(col_sum_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, workspace, rs.nrb, C, out);
     return check_launch("col_sum");
