@@ -146,3 +146,27 @@ def test_simple_transform_without_gpu_fails_loudly():
     st = SimpleTransform(ds, scale_factor=0, add_dpg=False, input_size=[256, 192], output_size=[64, 48], rot=0, sigma=2, train=False)
     with pytest.raises(vh.VatlError):
         st.test_transform(np.zeros((48, 64, 3), np.uint8), [4, 4, 30, 40])
+
+
+@pytest.mark.parametrize("name,count", [("fastpose", 348), ("hrnet", 1754)])
+def test_fastpose_hrnet_state_dicts_are_checkpoint_compatible(name, count):
+    """Keys (in order) and shapes of the package's modules against those of the reference's own modules
+    (tests/golden/fastpose_hrnet.npz): a strict load_state_dict of a reference checkpoint must work."""
+    import os
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fastpose_hrnet.npz"))
+    hr = {"TYPE": "PoseHighResolutionNet", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50, "FINAL_CONV_KERNEL": 1, "PRETRAINED_LAYERS": ["*"],
+          "STAGE2": {"NUM_MODULES": 1, "NUM_BRANCHES": 2, "NUM_BLOCKS": [4, 4], "NUM_CHANNELS": [32, 64], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"},
+          "STAGE3": {"NUM_MODULES": 4, "NUM_BRANCHES": 3, "NUM_BLOCKS": [4, 4, 4], "NUM_CHANNELS": [32, 64, 128], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"},
+          "STAGE4": {"NUM_MODULES": 3, "NUM_BRANCHES": 4, "NUM_BLOCKS": [4, 4, 4, 4], "NUM_CHANNELS": [32, 64, 128, 256], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"}}
+    cfg = edict({"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50} if name == "fastpose" else hr)
+    m = builder.build_sppe(cfg, preset_cfg=_cfgs()[1])
+    sd = m.state_dict()
+    assert len(sd) == count
+    assert list(sd.keys()) == [str(k) for k in g[f"{name}_keys"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in g[f"{name}_shapes"]]
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    if name == "fastpose":
+        for attr in ("conv_out", "preact", "suffle1", "duc1", "duc2", "get_embedding", "_initialize"):
+            assert hasattr(m, attr)
