@@ -42,7 +42,23 @@ def main():
     ap.add_argument("--vars", default="", help="comma list of k-loop schedule variants to A/B (vatl_tune_set knob 0)")
     ap.add_argument("--ablate", default="", help="comma list of conv ablation bit sets (vatl_tune_set knob 6; needs VATL_ALLOW_ABLATION=1)")
     ap.add_argument("--bm", default="", help="comma list of block-tile row counts to A/B (vatl_tune_set knob 5: 0 auto, 64, 128)")
+    ap.add_argument("--persist", default="", help="comma list of persistent-1x1 settings to A/B (vatl_tune_set knob 7: 0 off, 1 = K <= 256 [default])")
     a = ap.parse_args()
+    # clock / cache warm-up: the first configuration measured in a fresh process otherwise reads 4-10 % slow, which biases every A/B
+    warm_a = torch.randn((4096, 4096), device="cuda:0")
+    t_end = torch.cuda.Event(enable_timing=True); t_beg = torch.cuda.Event(enable_timing=True)
+    t_beg.record()
+    for _ in range(200):
+        warm_a @ warm_a
+    t_end.record(); torch.cuda.synchronize()
+    del warm_a
+    if a.persist:
+        for v in a.persist.split(","):
+            print(f"--- persistent 1x1 kernel for K <= 256 * {v}")
+            vh.tune_set(7, int(v))
+            run(a)
+        vh.tune_set(7, 1)
+        return
     if a.ablate:
         for v in a.ablate.split(","):
             print(f"--- ablation bits {v} (1 = no epilogue, 2 = one k-tile)")

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         }
 }
 
-static std::atomic<int> g_wgrad_blocks{1024};
+static std::atomic<int> g_wgrad_blocks{0};    // 0 = by filter size (below); vatl_tune_set(3, v) forces a target
 static std::atomic<int> g_wgrad_ablate{0};   // vatl_tune_set(3, v)
 
 // tile configuration of a weight-gradient GEMM: rows n (Cn), columns (tap, channel of Cx)
@@ -234,13 +234,17 @@ static WgradCfg wgrad_cfg(int Cn, int Cx, bool stem) {
     return {32, 128, false, 1};
 }
 
-// number of M-splits: at most ~g_wgrad_blocks blocks (two per CU resident: 512 per wave), at least 4 k-tiles each
+// number of M-splits: at most ~target blocks (two per CU resident: 512 per wave), at least 4 k-tiles each.  Measured at
+// B = 120 (tools/wgrad_bench.py): 1x1 filters are ~10 % faster with one 512-block wave (half the partial slices to
+// write and sum), 3x3 filters want two waves.
 struct WgradPlan { int tiles, splits, kt_per_split, slices; };   // slices = splits * nwk partial gradients to sum
 static WgradPlan wgrad_plan(const WgradCfg& c, int Cn, int Cx, int R, int S, long long M) {
     const int n_tiles = cdiv(Cn, c.bn), taps = c.stem ? R : R * S, j_tiles = c.stem ? 1 : cdiv(Cx, c.bj);
     const int tiles = n_tiles * taps * j_tiles;
     const int ktiles = cdiv(M, 32);
-    int splits = g_wgrad_blocks.load(std::memory_order_relaxed) / tiles;      // floor: stay within a whole number of 512-block waves
+    int target = g_wgrad_blocks.load(std::memory_order_relaxed);
+    if (target <= 0) target = (R * S == 1) ? 512 : 1024;
+    int splits = target / tiles;                                              // floor: stay within a whole number of 512-block waves
     const int max_splits = (ktiles + 3) / 4;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
