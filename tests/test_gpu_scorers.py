@@ -104,6 +104,28 @@ def test_localpeak_random_vs_oracle(vh):
         np.testing.assert_allclose(float(mean[i]), m, rtol=1e-5)
 
 
+@pytest.mark.parametrize("hw", [(96, 72), (64, 48), (16, 8), (5, 4), (130, 96), (33, 256), (24, 18), (7, 5)])
+def test_localpeak_plane_sizes(vh, hw):
+    """Every kernel variant behind vatl_localpeak_mean (register tiles: 1, 2 and many waves per plane; LDS tile when a row
+    is wider than a wave or the plane is taller than 16 waves cover; scalar path for widths that are not a multiple of 4):
+    integer peak counts exact, means to fp32 rounding, borders / plateaus / all-negative planes included."""
+    H, W = hw
+    r = np.random.RandomState(H * 1000 + W)
+    hm = r.random_sample((3, 5, H, W)).astype(np.float32)
+    hm[0, 0] = np.round(hm[0, 0] * 4) / 4                       # plateaus (ties)
+    hm[0, 1] = -hm[0, 1] - 0.1                                   # all negative: the zero border beats every pixel
+    hm[0, 2, 0, :] = 2.0; hm[0, 2, :, -1] = 3.0                  # maxima on the borders
+    hm[1, 3] = 0.0
+    mean, cnt = vh.localpeak_mean(to_dev(hm))
+    for i in range(3):
+        c, _, m = scorers.localpeak_stats(hm[i])
+        assert np.array_equal(cnt[i].cpu().numpy(), c), (hw, i)
+        if np.isnan(m):
+            assert np.isnan(float(mean[i]))
+        else:
+            np.testing.assert_allclose(float(mean[i]), m, rtol=1e-5)
+
+
 def test_wpu_golden(vh, golden_scorers):
     g = golden_scorers
     kp = to_dev(g["kp"].reshape(-1, 17, 3))

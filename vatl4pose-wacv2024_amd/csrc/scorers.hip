@@ -199,6 +199,79 @@ __global__ __launch_bounds__(256) void localpeak_plane_kernel(const float* __res
     }
 }
 
+// Register-tile variant for W % 4 == 0 (every shipped heat-map size): the plane never touches LDS.  A thread owns a 4-column x
+// RPT-row patch: RPT + 2 float4 row loads (the two halo rows come out of L1/L2), the 3x3 maximum is a vertical max3 in registers
+// followed by a horizontal max3 whose outer columns come from the neighbouring lanes (one shuffle each way per row).  Lanes
+// are laid out [row group][float4 column] with whole row groups per wave, so a neighbour is always lane +- 1 of the same wave.
+// Zero halo (scipy mode='constant', cval=0): rows / columns outside the plane read as 0.
+template <int RPT>
+__global__ __launch_bounds__(1024) void localpeak_plane_reg_kernel(const float* __restrict__ hm, double* __restrict__ ws, int32_t* __restrict__ count_out,
+                                                                   int H, int W, float order) {
+    __shared__ float wmax[16];
+    __shared__ int wcnt[16];
+    __shared__ double wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    const int W4 = W >> 2, gpw = 64 / W4;                     // float4 columns per row, row groups per wave
+    const int g = lane / W4, c4 = lane - g * W4;
+    const bool on = g < gpw;
+    const int row0 = (wave * gpw + g) * RPT;                  // first row of this thread's patch
+    const float* src = hm + (long long)blockIdx.x * H * W + 4 * c4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[RPT + 2];
+#pragma unroll
+    for (int r = 0; r < RPT + 2; ++r) {
+        const int y = row0 - 1 + r;
+        v[r] = (on && y >= 0 && y < H) ? *reinterpret_cast<const f32x4*>(src + (long long)y * W) : zero;
+    }
+    float pmax = -INFINITY;
+    unsigned long long flags = 0ull;                          // row r, column e of the patch -> bit 4 r + e
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        f32x4 vm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vm[e] = fmaxf(fmaxf(v[r][e], v[r + 1][e]), v[r + 2][e]);
+        float left = __shfl_up(vm[3], 1, 64), right = __shfl_down(vm[0], 1, 64);
+        if (c4 == 0) left = 0.f;
+        if (c4 == W4 - 1) right = 0.f;
+        const float L[4] = {fmaxf(fmaxf(left, vm[0]), vm[1]), fmaxf(fmaxf(vm[0], vm[1]), vm[2]), fmaxf(fmaxf(vm[1], vm[2]), vm[3]),
+                            fmaxf(fmaxf(vm[2], vm[3]), right)};
+        const bool live = on && row0 + r < H;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float c = v[r + 1][e];
+            if (live && c >= L[e]) { pmax = fmaxf(pmax, c); flags |= 1ull << (4 * r + e); }
+        }
+    }
+    pmax = wave_max(pmax);
+    if (lane == 0) wmax[wave] = pmax;
+    __syncthreads();
+    pmax = wmax[0];
+    for (int w = 1; w < nw; ++w) pmax = fmaxf(pmax, wmax[w]);
+    // pass 2: keep peaks >= order * largest peak (values still in registers)
+    const float thr = pmax * order;
+    float s = 0.f;
+    int cnt = 0;
+    if (pmax > -INFINITY && flags) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if ((flags >> (4 * r + e)) & 1ull) { const float c = v[r + 1][e]; if (c >= thr) { s += c; ++cnt; } }
+    }
+    const double ds = wave_sum((double)s);
+    cnt = wave_sum(cnt);
+    if (lane == 0) { wsum[wave] = ds; wcnt[wave] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        int c = 0;
+        for (int w = 0; w < nw; ++w) { t += wsum[w]; c += wcnt[w]; }
+        ws[2 * (long long)blockIdx.x] = t;
+        ws[2 * (long long)blockIdx.x + 1] = (double)c;
+        if (count_out) count_out[blockIdx.x] = c;
+    }
+}
+
 // any width (the per-item API accepts arbitrary planes): scalar loads, one pixel per thread step
 __global__ __launch_bounds__(256) void localpeak_plane_generic_kernel(const float* __restrict__ hm, double* __restrict__ ws, int32_t* __restrict__ count_out,
                                                               int H, int W, float order) {
@@ -387,7 +460,11 @@ extern "C" int vatl_localpeak_mean(const float* hm, float* mean, int32_t* count,
     if (!hm || !mean || !workspace) return fail(VATL_EINVAL, "localpeak_mean: null pointer");
     const size_t smem = (size_t)(H + 2) * (W + 2) * sizeof(float);
     if (smem > 60 * 1024 || (long long)H * W > 64 * 256) return fail(VATL_EINVAL, "localpeak_mean: heat-map %dx%d too large for the LDS tile", H, W);
+    const int W4 = W >> 2, gpw = W4 > 0 ? 64 / W4 : 0;
+    const int reg_waves = gpw > 0 ? cdiv(H, 16 * gpw) : 1 << 30;     // register-tile kernel: 16 rows per thread, whole row groups per wave
     if (W & 3) hipLaunchKernelGGL(localpeak_plane_generic_kernel, dim3((unsigned)(N * J)), dim3(256), smem, (hipStream_t)stream, hm, workspace, count, H, W, order);
+    else if (reg_waves <= 16 && (((uintptr_t)hm) & 15) == 0)
+        hipLaunchKernelGGL(localpeak_plane_reg_kernel<16>, dim3((unsigned)(N * J)), dim3(64 * reg_waves), 0, (hipStream_t)stream, hm, workspace, count, H, W, order);
     else       hipLaunchKernelGGL(localpeak_plane_kernel, dim3((unsigned)(N * J)), dim3(256), smem, (hipStream_t)stream, hm, workspace, count, H, W, order);
     hipLaunchKernelGGL(localpeak_finish_kernel, dim3(cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, workspace, mean, N, J);
     return check_launch("localpeak_mean");
