@@ -326,3 +326,39 @@ def test_multi_tensor_adamw_equals_per_tensor(vh):
             vh.adamw_step(q, g, m, v, step, 2.5e-3 if k < 2 else 2.5e-4, 0.7)
     for p, q in zip(ps, qs):
         assert torch.equal(p.detach(), q) and p._version > 0
+
+
+@pytest.mark.parametrize("hw", [(64, 48), (96, 72), (32, 24), (10, 7)])
+@pytest.mark.parametrize("nt", ["softmax", "sigmoid", "divide_sum"])
+def test_softargmax_plane_sizes(vh, hw, nt):
+    """Both shipped heat-map sizes (wave-per-plane register kernels) and other sizes (LDS-tile kernel) against the oracle."""
+    H, W = hw
+    r = np.random.RandomState(H + W)
+    hm = (r.random_sample((5, 17, H, W)).astype(np.float32) * 6 - 1)
+    if nt == "divide_sum":
+        hm = np.abs(hm) + 1e-3
+    bb = synth.bboxes(5)
+    c, s = vh.decode_softargmax(to_dev(hm), to_dev(bb), nt)
+    c, s = c.cpu().numpy(), s.cpu().numpy()
+    for i in range(5):
+        d = scorers.softargmax_decode(hm[i], bb[i], nt)
+        np.testing.assert_allclose(c[i], d["coords"], rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(s[i], d["maxvals"][:, 0], rtol=1e-5)
+
+
+@pytest.mark.parametrize("hw", [(64, 48), (96, 72), (32, 24), (10, 7)])
+def test_entropy_plane_sizes(vh, hw):
+    H, W = hw
+    r = np.random.RandomState(3 * H + W)
+    hm = np.abs(r.standard_normal((4, 17, H, W))).astype(np.float32) + 1e-4
+    hm[1, 2] = 0.0                                              # zero plane: nan (0 / 0)
+    hm[2, 3, 0, 0] = -0.5                                       # a negative entry: -inf
+    hm[3, 4, 1:, :] = 0.0                                       # zeros contribute 0
+    got = vh.plane_entropy(to_dev(hm)).cpu().numpy()
+    from scipy.stats import entropy
+    with np.errstate(all="ignore"):
+        want = np.array([[entropy(hm[i, j].flatten()) for j in range(17)] for i in range(4)])
+    assert np.isnan(got[1, 2]) and np.isnan(want[1, 2])
+    assert got[2, 3] == -np.inf and want[2, 3] == -np.inf
+    ok = np.isfinite(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=2e-5, atol=1e-6)

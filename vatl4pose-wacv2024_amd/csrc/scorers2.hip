@@ -101,6 +101,67 @@ __global__ __launch_bounds__(256) void softargmax_kernel(const float* __restrict
     scores[blockIdx.x] = NORM == 1 ? 1.f / (1.f + expf(-mx)) : 1.f;
 }
 
+// Same arithmetic with one WAVE per plane and the plane held in registers (NV float4 per lane, all loads in flight at once, no
+// LDS, no block barrier): used when the plane is exactly 64 * NV float4 (64x48 -> NV = 12, 96x72 -> NV = 27).
+template <int NORM, int NV>
+__global__ __launch_bounds__(256) void softargmax_wave_kernel(const float* __restrict__ hm, const float* __restrict__ bbox,
+                                                              float* __restrict__ coords, float* __restrict__ scores, int planes, int J, int H, int W) {
+    const int lane = threadIdx.x & 63;
+    const long long plane = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int item = (int)(plane / J);
+    const f32x4* src = reinterpret_cast<const f32x4*>(hm + plane * (64LL * NV * 4)) + lane;
+    f32x4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = src[k * 64];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) mx = fmaxf(fmaxf(mx, fmaxf(v[k][0], v[k][1])), fmaxf(v[k][2], v[k][3]));
+    mx = wave_max(mx);
+    double s = 0.0, sx = 0.0, sy = 0.0;
+    const float inv_w = 1.0f / (float)W;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int q0 = 4 * (k * 64 + lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float val = v[k][c];
+            float p;
+            if (NORM == 0) p = expf(val - mx);
+            else if (NORM == 1) p = 1.f / (1.f + expf(-val));
+            else p = val;
+            const int q = q0 + c;
+            const int y = fast_div(q, inv_w), x = q - y * W;
+            s += p; sx += (double)p * x; sy += (double)p * y;
+        }
+    }
+    s = wave_sum(s); sx = wave_sum(sx); sy = wave_sum(sy);
+    if (lane != 0) return;
+    // expectation -> /W - 0.5 -> (c + 0.5) * W, in float32 like the reference's tensors
+    const float ex = (float)(sx / s), ey = (float)(sy / s);
+    const float u = ((ex / (float)W - 0.5f) + 0.5f) * (float)W;
+    const float vv = ((ey / (float)H - 0.5f) + 0.5f) * (float)H;
+    const double xmin = bbox[item * 4 + 0], ymin = bbox[item * 4 + 1], xmax = bbox[item * 4 + 2];
+    const double bw = xmax - xmin, bh = (double)bbox[item * 4 + 3] - ymin;
+    const double cx = xmin + bw * 0.5, cy = ymin + bh * 0.5;
+    const float cx32 = (float)cx, cy32 = (float)cy;
+    const float top32 = (float)(cy + bw * -0.5);
+    const double g = (double)(cy32 - top32) / (W * 0.5);
+    coords[plane * 2 + 0] = (float)((double)cx32 + ((double)u - W * 0.5) * g);
+    coords[plane * 2 + 1] = (float)((double)cy32 + ((double)vv - H * 0.5) * g);
+    scores[plane] = NORM == 1 ? 1.f / (1.f + expf(-mx)) : 1.f;
+}
+
+template <int NORM>
+static bool launch_softargmax_wave(const float* hm, const float* bbox, float* coords, float* scores, int N, int J, int H, int W, hipStream_t st) {
+    const long long planes = (long long)N * J;
+    if ((((uintptr_t)hm) & 15) != 0 || planes > 0x7FFFFFFF) return false;
+    if (H * W == 64 * 12 * 4) hipLaunchKernelGGL((softargmax_wave_kernel<NORM, 12>), dim3(cdiv(planes, 4)), dim3(256), 0, st, hm, bbox, coords, scores, (int)planes, J, H, W);
+    else if (H * W == 64 * 27 * 4) hipLaunchKernelGGL((softargmax_wave_kernel<NORM, 27>), dim3(cdiv(planes, 4)), dim3(256), 0, st, hm, bbox, coords, scores, (int)planes, J, H, W);
+    else return false;
+    return true;
+}
+
 // --------------------------------------------------------------------------
 // auto-encoder forward on given features: one wave per item, lane = neuron
 // --------------------------------------------------------------------------
@@ -221,6 +282,9 @@ extern "C" int vatl_decode_softargmax(const float* hm, const float* bbox, float*
     hipStream_t st = (hipStream_t)stream;
     const size_t smem = (size_t)H * W * sizeof(float);
     if (smem > 60 * 1024) return fail(VATL_EINVAL, "decode_softargmax: heat-map %dx%d too large for the LDS tile", H, W);
+    if (norm_type == 0 && launch_softargmax_wave<0>(hm, bbox, coords, scores, N, J, H, W, st)) return check_launch("decode_softargmax");
+    if (norm_type == 1 && launch_softargmax_wave<1>(hm, bbox, coords, scores, N, J, H, W, st)) return check_launch("decode_softargmax");
+    if (norm_type == 2 && launch_softargmax_wave<2>(hm, bbox, coords, scores, N, J, H, W, st)) return check_launch("decode_softargmax");
     if (norm_type == 0) hipLaunchKernelGGL(softargmax_kernel<0>, dim3(N * J), dim3(256), smem, st, hm, bbox, coords, scores, J, H, W);
     else if (norm_type == 1) hipLaunchKernelGGL(softargmax_kernel<1>, dim3(N * J), dim3(256), smem, st, hm, bbox, coords, scores, J, H, W);
     else if (norm_type == 2) hipLaunchKernelGGL(softargmax_kernel<2>, dim3(N * J), dim3(256), smem, st, hm, bbox, coords, scores, J, H, W);

@@ -203,6 +203,38 @@ __global__ __launch_bounds__(256) void plane_entropy_kernel(const float* __restr
     if (threadIdx.x == 0) out[blockIdx.x] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+// Same arithmetic with one WAVE per plane and the plane held in registers (NV float4 per lane, all loads in flight at once, no
+// LDS, no block barrier): used when the plane is exactly 64 * NV float4 (64x48 -> NV = 12, 96x72 -> NV = 27).
+template <int NV>
+__global__ __launch_bounds__(256) void plane_entropy_wave_kernel(const float* __restrict__ hm, float* __restrict__ out, int planes) {
+    const int lane = threadIdx.x & 63;
+    const long long plane = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const f32x4* src = reinterpret_cast<const f32x4*>(hm + plane * (64LL * NV * 4)) + lane;
+    f32x4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = src[k * 64];
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s += ((double)v[k][0] + (double)v[k][1]) + ((double)v[k][2] + (double)v[k][3]);
+    const float total = (float)wave_sum(s);
+    double e = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float p = v[k][c] / total;
+            float t;
+            if (p > 0.f) t = -p * logf(p);
+            else if (p == 0.f) t = 0.f;
+            else if (p < 0.f) t = -INFINITY;
+            else t = p;                                         // nan
+            e += (double)t;
+        }
+    e = wave_sum(e);
+    if (lane == 0) out[plane] = (float)e;
+}
+
 // compute_OKS (al_metric.py:42-69): one thread per item, float64 like the numpy original.
 __global__ void oks_kernel(const float* __restrict__ pred, const double* __restrict__ gt, const double* __restrict__ bbox_xywh,
                            double* __restrict__ out, int N) {
@@ -260,6 +292,10 @@ extern "C" int vatl_plane_entropy(const float* hm, float* out, int N, int J, int
     if (!hm || !out) return fail(VATL_EINVAL, "plane_entropy: null pointer");
     const size_t smem = (size_t)H * W * sizeof(float);
     if (smem > 60 * 1024) return fail(VATL_EINVAL, "plane_entropy: heat-map %dx%d too large for the LDS tile", H, W);
-    hipLaunchKernelGGL(plane_entropy_kernel, dim3((unsigned)(N * J)), dim3(256), smem, (hipStream_t)stream, hm, out, H * W);
+    const long long planes = (long long)N * J;
+    const bool aligned = (((uintptr_t)hm) & 15) == 0;
+    if (aligned && H * W == 64 * 12 * 4) hipLaunchKernelGGL(plane_entropy_wave_kernel<12>, dim3(cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream, hm, out, (int)planes);
+    else if (aligned && H * W == 64 * 27 * 4) hipLaunchKernelGGL(plane_entropy_wave_kernel<27>, dim3(cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream, hm, out, (int)planes);
+    else hipLaunchKernelGGL(plane_entropy_kernel, dim3((unsigned)(N * J)), dim3(256), smem, (hipStream_t)stream, hm, out, H * W);
     return check_launch("plane_entropy");
 }
