@@ -110,7 +110,12 @@ def run(a):
             nchw = name.endswith("head")
             fn = lambda: vh.conv2d_fwd(x, w, sc, bi, cout, k, k, stride, k // 2, True, residual=r, out_nchw=nchw)
             flops = 2.0 * B * Ho * Wo * cin * cout * k * k
+        w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0.record()
         for _ in range(2):
+            fn()
+        w1.record(); torch.cuda.synchronize()
+        for _ in range(int(min(200, 60.0 / max(w0.elapsed_time(w1) / 2, 1e-3)))):   # >= ~60 ms of the same launch: clocks ramp from the idle state
             fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
