@@ -189,9 +189,9 @@ def main():
     local = local % max(ndev, 1)                        # (a 1-GPU box can host a 2-rank smoke run: VATL_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("VATL_DIST_BACKEND", "nccl")               # "nccl" is RCCL over xGMI on MI355X
     if dist:
         import torch.distributed as td
-        backend = os.environ.get("VATL_DIST_BACKEND", "nccl")           # "nccl" is RCCL over xGMI on MI355X
         if backend == "nccl":
             td.init_process_group("nccl", device_id=dev)
         else:
@@ -205,6 +205,8 @@ def main():
         s = one_step(model, x, bbox, is_prev, is_next, hm_buf)
         if dist:                                        # the only exchange: ~290 B of results per item
             row = torch.cat([s.keypoints.reshape(FRAMES, -1), s.argmax.float(), s.hp[:, None], s.thc[:, None], s.localpeak[:, None]], 1).contiguous()
+            if backend != "nccl":                       # gloo smoke runs: all_gather is host-only there
+                row = row.cpu()
             out = [torch.empty_like(row) for _ in range(world)]
             td.all_gather(out, row)
         return s

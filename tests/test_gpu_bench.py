@@ -28,3 +28,24 @@ def test_bench_prints_one_contract_line():
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     # whole-job rate is consistent with the step time
     assert abs(d["value"] - 1024 * 1000.0 / d["ms_per_step"]) / d["value"] < 0.01
+
+
+def test_bench_two_ranks_launch_contract():
+    """The driver's N > 1 launch line (torch.distributed.run, one rank per GPU) on a 1-GPU box: two ranks share the device and
+    talk over gloo (VATL_DIST_BACKEND; RCCL refuses two ranks on one device).  Checks the rendezvous, the per-step result
+    gather, the barrier / max-over-ranks timing and that only rank 0 prints the line, with whole-job frames = 2 x 1024."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, VATL_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma"
+    assert abs(d["value"] - 2 * 1024 * 1000.0 / d["ms_per_step"]) / d["value"] < 0.01
+    assert d["config"]["parallelism"] == "frame-sharded x2"
