@@ -362,3 +362,28 @@ def test_entropy_plane_sizes(vh, hw):
     assert got[2, 3] == -np.inf and want[2, 3] == -np.inf
     ok = np.isfinite(want)
     np.testing.assert_allclose(got[ok], want[ok], rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("hw", [(64, 48), (96, 72), (32, 24), (7, 5)])
+def test_decode_plane_sizes(vh, hw):
+    """Arg-max decode on both shipped heat-map sizes (wave-per-plane register kernel) and others (block kernel): indices and
+    maxima bit-exact incl. ties (first wins), NaN (first NaN wins), non-positive maxima (coords zeroed) and border peaks."""
+    H, W = hw
+    r = np.random.RandomState(7 * H + W)
+    hm = r.standard_normal((4, 17, H, W)).astype(np.float32)
+    hm[0, 0] = np.round(hm[0, 0])                               # many ties
+    hm[0, 1] = -np.abs(hm[0, 1]) - 1                            # all negative
+    hm[0, 2, H - 1, W - 1] = 50.0                               # border peak: no quarter-pixel shift
+    hm[0, 3, H // 2, W // 2] = np.nan; hm[0, 3, H - 1, 0] = np.nan
+    hm[1, 4] = 0.0
+    hm[1, 5, 0, 0] = 9.0; hm[1, 5, H - 1, W - 1] = 9.0         # equal maxima far apart: the first wins
+    bb = synth.bboxes(4)
+    coords, maxv, idx = vh.decode(to_dev(hm), to_dev(bb))
+    coords, maxv, idx = coords.cpu().numpy(), maxv.cpu().numpy(), idx.cpu().numpy()
+    for i in range(4):
+        with np.errstate(invalid="ignore"):
+            d = scorers.decode_heatmaps(hm[i], bb[i])
+        assert np.array_equal(idx[i], d["idx"]), (hw, i)
+        assert np.array_equal(maxv[i], d["maxvals"][:, 0], equal_nan=True)
+        ok = ~np.isnan(d["maxvals"][:, 0])
+        assert np.array_equal(coords[i][ok], d["coords"][ok])

@@ -15,6 +15,35 @@ __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi)
     if (ov > v || (ov == v && oi < i) || (ov != ov && (v == v || oi < i))) { v = ov; i = oi; }
 }
 
+// quarter-pixel shift + inverse crop affine + stores of one plane's result (one thread)
+__device__ __forceinline__ void decode_finish(const float* __restrict__ src, const float* __restrict__ bbox, float* __restrict__ coords,
+                                              float* __restrict__ maxvals, int32_t* __restrict__ idx_out, long long plane, int item,
+                                              float best, int bidx, int H, int W) {
+    int px = bidx % W, py = bidx / W;
+    if (!(best > 0.f)) { px = 0; py = 0; }                      // pred_mask: maxval <= 0 zeroes the coords
+    float u = (float)px, v = (float)py;
+    if (1 < px && px < W - 1 && 1 < py && py < H - 1) {
+        const float dx = src[py * W + px + 1] - src[py * W + px - 1];
+        const float dy = src[(py + 1) * W + px] - src[(py - 1) * W + px];
+        u += (dx > 0.f ? 0.25f : (dx < 0.f ? -0.25f : 0.f));
+        v += (dy > 0.f ? 0.25f : (dy < 0.f ? -0.25f : 0.f));
+    }
+    // inverse crop affine: control points rounded to float32 like the reference's
+    // np.float32 src/dst arrays, transform itself in float64 (cv2.getAffineTransform)
+    const double xmin = bbox[item * 4 + 0], ymin = bbox[item * 4 + 1];
+    const double xmax = bbox[item * 4 + 2], ymax = bbox[item * 4 + 3];
+    const double bw = xmax - xmin, bh = ymax - ymin;
+    const double cx = xmin + bw * 0.5, cy = ymin + bh * 0.5;
+    const float cx32 = (float)cx, cy32 = (float)cy;
+    const float top32 = (float)(cy + bw * -0.5);
+    const float d32 = cy32 - top32;
+    const double g = (double)d32 / (W * 0.5);
+    coords[plane * 2 + 0] = (float)((double)cx32 + ((double)u - W * 0.5) * g);
+    coords[plane * 2 + 1] = (float)((double)cy32 + ((double)v - H * 0.5) * g);
+    maxvals[plane] = best;
+    if (idx_out) idx_out[plane] = bidx;
+}
+
 __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ hm, const float* __restrict__ bbox,
                                                      float* __restrict__ coords, float* __restrict__ maxvals,
                                                      int32_t* __restrict__ idx_out, int J, int H, int W) {
@@ -54,29 +83,37 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
     if (tid != 0) return;
     for (int w = 1; w < 4; ++w) argmax_merge(best, bidx, sv[w], si[w]);
 
-    int px = bidx % W, py = bidx / W;
-    if (!(best > 0.f)) { px = 0; py = 0; }                      // pred_mask: maxval <= 0 zeroes the coords
-    float u = (float)px, v = (float)py;
-    if (1 < px && px < W - 1 && 1 < py && py < H - 1) {
-        const float dx = src[py * W + px + 1] - src[py * W + px - 1];
-        const float dy = src[(py + 1) * W + px] - src[(py - 1) * W + px];
-        u += (dx > 0.f ? 0.25f : (dx < 0.f ? -0.25f : 0.f));
-        v += (dy > 0.f ? 0.25f : (dy < 0.f ? -0.25f : 0.f));
+    decode_finish(src, bbox, coords, maxvals, idx_out, (long long)blockIdx.x, item, best, bidx, H, W);
+}
+
+// One WAVE per plane, the plane in registers (NV float4 per lane, every load in flight at once, no LDS, no block barrier): used
+// when the plane is exactly 64 * NV float4 (64x48 -> NV = 12, 96x72 -> NV = 27).  Same ordering rules, same finish.
+template <int NV>
+__global__ __launch_bounds__(256) void decode_wave_kernel(const float* __restrict__ hm, const float* __restrict__ bbox,
+                                                          float* __restrict__ coords, float* __restrict__ maxvals,
+                                                          int32_t* __restrict__ idx_out, int planes, int J, int H, int W) {
+    const int lane = threadIdx.x & 63;
+    const long long plane = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const float* src = hm + plane * (64LL * NV * 4);
+    const f32x4* src4 = reinterpret_cast<const f32x4*>(src) + lane;
+    f32x4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = src4[k * 64];
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (v[k][e] > best || bidx == 0x7fffffff || (v[k][e] != v[k][e] && best == best)) { best = v[k][e]; bidx = 4 * (k * 64 + lane) + e; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        argmax_merge(best, bidx, ov, oi);
     }
-    // inverse crop affine: control points rounded to float32 like the reference's
-    // np.float32 src/dst arrays, transform itself in float64 (cv2.getAffineTransform)
-    const double xmin = bbox[item * 4 + 0], ymin = bbox[item * 4 + 1];
-    const double xmax = bbox[item * 4 + 2], ymax = bbox[item * 4 + 3];
-    const double bw = xmax - xmin, bh = ymax - ymin;
-    const double cx = xmin + bw * 0.5, cy = ymin + bh * 0.5;
-    const float cx32 = (float)cx, cy32 = (float)cy;
-    const float top32 = (float)(cy + bw * -0.5);
-    const float d32 = cy32 - top32;
-    const double g = (double)d32 / (W * 0.5);
-    coords[(long long)blockIdx.x * 2 + 0] = (float)((double)cx32 + ((double)u - W * 0.5) * g);
-    coords[(long long)blockIdx.x * 2 + 1] = (float)((double)cy32 + ((double)v - H * 0.5) * g);
-    maxvals[blockIdx.x] = best;
-    if (idx_out) idx_out[blockIdx.x] = bidx;
+    if (lane == 0) decode_finish(src, bbox, coords, maxvals, idx_out, plane, (int)(plane / J), best, bidx, H, W);
 }
 
 // --------------------------------------------------------------------------
@@ -431,7 +468,14 @@ extern "C" int vatl_decode_argmax_affine(const float* hm, const float* bbox, flo
                                          int N, int J, int H, int W, void* stream) {
     if (N <= 0) return 0;
     if (!hm || !bbox || !coords || !maxvals) return fail(VATL_EINVAL, "decode_argmax_affine: null pointer");
-    hipLaunchKernelGGL(decode_kernel, dim3(N * J), dim3(256), 0, (hipStream_t)stream, hm, bbox, coords, maxvals, idx, J, H, W);
+    const long long planes = (long long)N * J;
+    const bool aligned = (((uintptr_t)hm) & 15) == 0 && planes <= 0x7FFFFFFF;
+    if (aligned && H * W == 64 * 12 * 4)
+        hipLaunchKernelGGL(decode_wave_kernel<12>, dim3(cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream, hm, bbox, coords, maxvals, idx, (int)planes, J, H, W);
+    else if (aligned && H * W == 64 * 27 * 4)
+        hipLaunchKernelGGL(decode_wave_kernel<27>, dim3(cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream, hm, bbox, coords, maxvals, idx, (int)planes, J, H, W);
+    else
+        hipLaunchKernelGGL(decode_kernel, dim3(N * J), dim3(256), 0, (hipStream_t)stream, hm, bbox, coords, maxvals, idx, J, H, W);
     return check_launch("decode_argmax_affine");
 }
 
