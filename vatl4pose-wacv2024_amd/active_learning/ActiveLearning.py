@@ -62,6 +62,8 @@ class ActiveLearning:
             cfg.DATASET.TRAIN, preset_cfg=cfg.DATA_PRESET, train=True, get_prenext=False)
         self.collate_fn = self.eval_dataset.my_collate_fn
         workers = int(getattr(opt, "num_workers", 0))
+        if getattr(self.eval_dataset, "DEVICE_ITEMS", False):
+            workers = 0                                    # items are made on the device by this process: no worker processes
         self.eval_loader = DataLoader(self.eval_dataset, batch_size=cfg.VAL.BATCH_SIZE * ngpu, shuffle=False, num_workers=workers,
                                       drop_last=False, pin_memory=not getattr(self.eval_dataset, "DEVICE_ITEMS", False), collate_fn=self.collate_fn)
         self.eval_len = len(self.eval_dataset)
