@@ -187,3 +187,41 @@ def frame_video(n_frames: int = 8, tracks: int = 2, hw=(240, 320), seed: int = 7
             anns.append({"bbox": (float(bx), float(by), float(bx + w), float(by + h)), "joints_3d": j3, "keypoint": kp.tolist(),
                          "id": t * 1000 + f, "ann_id": 500000 + t * 1000 + f, "img_id": 9000 + f, "track_id": f"v{t}", "frame": f})
     return frames, anns
+
+
+def write_coco_video(root: str, n_frames: int = 4, tracks: int = 2, hw=(120, 160), seed: int = 73, fmt: str = "posetrack"):
+    """Write a tiny PoseTrack21- / JRDB-style dataset under ``root``: lossless PNG frames and one COCO-format json with the
+    fields the reference's loaders read (images: id, image_id, vid_id, file_name, width, height; annotations: id, image_id,
+    track_id, bbox xywh, keypoints).  Includes a person with a zero-area box, one without key-points and one with no
+    visible joint (all three must be dropped).  -> (annotation path relative to root, frames, expected kept annotation ids)."""
+    import json
+    import os
+    from PIL import Image
+    r = _rs(seed, f"coco{n_frames}x{tracks}{fmt}")
+    os.makedirs(os.path.join(root, "images", "vid0"), exist_ok=True)
+    frames, images, anns, kept = [], [], [], []
+    mul = 100 if fmt == "posetrack" else 1000                        # annotation id = image id * 100 (1000) + person index, as in the real files
+    for f in range(n_frames):
+        img = u8_frame(hw[0], hw[1], seed + f)
+        name = os.path.join("images", "vid0", f"{f:06d}.png")
+        Image.fromarray(img).save(os.path.join(root, name))
+        frames.append(img)
+        image_id = 1000200 + f
+        images.append({"id": image_id, "image_id": image_id, "vid_id": 7, "file_name": name, "width": hw[1], "height": hw[0]})
+        for t in range(tracks):
+            x, y, w, h = 10.0 + 30 * t + 2 * f, 8.0 + f, 40.0 + t, 70.0
+            kp = []
+            for j in range(17):
+                kp += [float(r.uniform(x, x + w)), float(r.uniform(y, y + h)), int(r.random_sample() > 0.2)]
+            kp[2] = 1
+            anns.append({"id": image_id * mul + t, "image_id": image_id, "track_id": t, "bbox": [x, y, w, h], "keypoints": kp, "category_id": 1})
+            kept.append(image_id * mul + t)
+        if f == 1:                                                  # three invalid persons
+            anns.append({"id": image_id * mul + 50, "image_id": image_id, "track_id": 50, "bbox": [5.0, 5.0, 1.0, 1.0], "keypoints": [1.0, 1.0, 1] * 17, "category_id": 1})
+            anns.append({"id": image_id * mul + 51, "image_id": image_id, "track_id": 51, "bbox": [5.0, 5.0, 20.0, 20.0], "keypoints": [0, 0, 0] * 17, "category_id": 1})
+            anns.append({"id": image_id * mul + 52, "image_id": image_id, "track_id": 52, "bbox": [5.0, 5.0, 20.0, 20.0], "keypoints": [3.0, 4.0, 0] * 17, "category_id": 1})
+    ann_path = os.path.join("annotations", "val.json")
+    os.makedirs(os.path.join(root, "annotations"), exist_ok=True)
+    with open(os.path.join(root, ann_path), "w") as fh:
+        json.dump({"images": images, "annotations": anns, "categories": [{"id": 1, "name": "person"}]}, fh)
+    return ann_path, frames, kept

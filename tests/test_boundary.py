@@ -170,3 +170,36 @@ def test_fastpose_hrnet_state_dicts_are_checkpoint_compatible(name, count):
     if name == "fastpose":
         for attr in ("conv_out", "preact", "suffle1", "duc1", "duc2", "get_embedding", "_initialize"):
             assert hasattr(m, attr)
+
+
+@pytest.mark.parametrize("name", ["Posetrack21", "JRDB2022"])
+def test_coco_video_datasets_follow_the_reference_annotation_rules(tmp_path, name):
+    """builder.build_dataset on a COCO-format json (posetrack21.py:40-129 / jrdb2022.py): invalid persons dropped, boxes
+    xywh -> xyxy (-1) and clipped, one item per person, items sorted by the reference's composite id, track ids as built there."""
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    ann, frames, kept = synth.write_coco_video(str(tmp_path), n_frames=3, tracks=2, fmt="posetrack" if name == "Posetrack21" else "jrdb")
+    cfg = edict({"TYPE": name, "ROOT": str(tmp_path), "IMG_PREFIX": "", "ANN": ann})
+    ds = builder.build_dataset(cfg, preset_cfg=_cfgs()[1], train=False, get_prenext=True)
+    if name == "JRDB2022":                                               # jrdb2022.py keeps a degenerate box (only xmax < xmin is dropped): person 50
+        assert len(ds) == 7 and ds._labels[-1]["track_id"] == 50
+        ds._labels.pop(); ds._items.pop()
+    assert len(ds) == 6 and sorted(a["ann_id"] for a in ds._labels) == kept
+    digits = 2 if name == "Posetrack21" else 3
+    ids = [a["id"] for a in ds._labels]
+    assert ids == sorted(ids) and all(a["id"] == int(str(a["ann_id"])[-digits:] + str(a["img_id"])) for a in ds._labels)
+    first = ds._labels[0]
+    assert first["track_id"] == ("70" if name == "Posetrack21" else 0)
+    x, y, w, h = 10.0, 8.0, 40.0, 70.0                                   # track 0, frame 0 in write_coco_video
+    assert first["bbox"] == (x, y, x + w - 1, y + h - 1) and first["width"] == 160 and first["height"] == 120
+    assert first["joints_3d"].shape == (17, 3, 2) and first["joints_3d"][0, 0, 1] == 1.0
+    assert ds._items[0]["path"].endswith("000000.png") and ds._items[0]["keypoint"] == first["keypoint"]
+    # the same person in consecutive frames is id-adjacent: prev / next flags follow the track
+    assert [ds._neighbour(i, -1) for i in range(6)] == [False, True, True, False, True, True]
+    arena, where = ds._frames_for([ds._labels[0]["frame"], ds._labels[1]["frame"], ds._labels[0]["frame"]]) if torch.cuda.is_available() else (None, None)
+    with pytest.raises(AssertionError):
+        import json, os
+        bad = json.load(open(os.path.join(str(tmp_path), ann)))
+        bad["categories"][0]["name"] = "cat"
+        json.dump(bad, open(os.path.join(str(tmp_path), "annotations", "bad.json"), "w"))
+        builder.build_dataset(edict({"TYPE": name, "ROOT": str(tmp_path), "IMG_PREFIX": "", "ANN": "annotations/bad.json"}), preset_cfg=_cfgs()[1], train=False)

@@ -267,3 +267,39 @@ def test_active_learning_round_on_decoded_frames(tmp_path):
     assert al.outcome() is None and np.isfinite(al.last_train_loss)
     al.eval_and_query()
     assert len(al.unlabeled_id) == 0
+
+
+def test_posetrack_json_dataset_items_and_evaluation(tmp_path):
+    """Posetrack21 from annotation json + image files: items equal the oracle composition on the decoded frames (PNG: lossless),
+    prev / next follow the tracks, and an active-learning evaluation runs on it through builder.build_dataset."""
+    import types
+    from active_learning import ActiveLearning
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    from oracle import crop, synth
+    ann, frames, kept = synth.write_coco_video(str(tmp_path), n_frames=4, tracks=2)
+    cfg = _video_cfg()
+    for split in ("TRAIN", "EVAL"):
+        cfg.DATASET[split] = edict({"TYPE": "Posetrack21", "ROOT": str(tmp_path), "IMG_PREFIX": "", "ANN": ann,
+                                    "AUG": {"SCALE_FACTOR": 0.25, "ROT_FACTOR": 30, "NUM_JOINTS_HALF_BODY": 8, "PROB_HALF_BODY": 0.3}})
+    ds = builder.build_dataset(cfg.DATASET.EVAL, preset_cfg=cfg.DATA_PRESET, train=False, get_prenext=True)
+    assert len(ds) == 8 and ds.ID_SORTED_STREAM
+    for i in (0, 3, 4, 7):
+        a = ds._labels[i]
+        f = int(a["frame"][-10:-4])
+        idx, inp, label, mask, gt, img_id, ann_id, bb_crop, bb_ann, is_prev, is_next = ds[i]
+        assert (is_prev, is_next) == (i % 4 != 0, i % 4 != 3) and ann_id in kept and img_id == 1000200 + f
+        assert np.array_equal(inp[0].cpu().numpy(), crop.test_transform(frames[f], a["bbox"])[0])
+        if is_next:
+            nb = ds._labels[i + 1]
+            assert np.array_equal(inp[2].cpu().numpy(), crop.test_transform(frames[f + 1], nb["bbox"])[0])
+    opt = types.SimpleNamespace(work_dir=str(tmp_path / "work"), uncertainty="THC+WPU", representativeness="None", filter="None", strategy="THC+WPU",
+                                video_id="vid0", get_prenext=True, from_scratch=True, continual=True, num_gpu=1, onebyone=False, retrain_thresh=1,
+                                THCvsWPU="const")
+    os_mod = __import__("os"); os_mod.makedirs(opt.work_dir, exist_ok=True)
+    torch.manual_seed(0); np.random.seed(0); random.seed(0)
+    al = ActiveLearning(cfg, opt)
+    assert type(al.eval_dataset).__name__ == "Posetrack21" and al.dedup
+    al.eval_and_query()
+    assert len(al.labeled_id) == 2 and len(al.unlabeled_id) == 6
+    assert al.outcome() is None and np.isfinite(al.last_train_loss)

@@ -64,6 +64,11 @@ class FrameVideo(Dataset):
             self._arena = FrameArena(self._frames)
         return self._arena
 
+    def _frames_for(self, keys):
+        """-> (arena, {frame key: index in that arena}) holding at least the frames ``keys``.  In-memory videos keep every
+        frame resident; file-backed subclasses decode and upload what one batch needs."""
+        return self.arena, None
+
     def _neighbour(self, i, step):
         j = i + step
         return 0 <= j < len(self._labels) and self._labels[j]["track_id"] == self._labels[i]["track_id"]
@@ -71,21 +76,25 @@ class FrameVideo(Dataset):
     def __getitems__(self, idxs):
         idxs = [int(i) for i in idxs]
         labels = [copy.deepcopy(self._labels[i]) for i in idxs]
+        is_prev = [self.get_prenext and self._neighbour(i, -1) for i in idxs]
+        is_next = [self.get_prenext and self._neighbour(i, +1) for i in idxs]
+        keys = [lb["frame"] for lb in labels]
+        keys += [self._labels[i - 1]["frame"] for i, f in zip(idxs, is_prev) if f] + [self._labels[i + 1]["frame"] for i, f in zip(idxs, is_next) if f]
+        arena, where = self._frames_for(keys)
+        at = (lambda k: k) if where is None else (lambda k: where[k])
         for lb in labels:
-            h, w = self.arena.hw[lb["frame"]]
+            h, w = arena.hw[at(lb["frame"])]
             lb.setdefault("width", int(w)); lb.setdefault("height", int(h))
         st = self.transformation
-        cur, target, weight, boxes = st.call_batch(self.arena, [lb["frame"] for lb in labels], labels)
+        cur, target, weight, boxes = st.call_batch(arena, [at(lb["frame"]) for lb in labels], labels)
         n = len(idxs)
         stacked = torch.zeros((n, 3) + tuple(cur.shape[1:]), device=cur.device)
         stacked[:, 0] = cur
-        is_prev = [self.get_prenext and self._neighbour(i, -1) for i in idxs]
-        is_next = [self.get_prenext and self._neighbour(i, +1) for i in idxs]
         for slot, flags, step in ((1, is_prev, -1), (2, is_next, +1)):               # test_transform of the neighbour (:154-178)
             rows = [k for k in range(n) if flags[k]]
             if rows:
                 nb = [self._labels[idxs[k] + step] for k in rows]
-                crops, _ = st.test_transform_batch(self.arena, [a["frame"] for a in nb], np.array([a["bbox"] for a in nb], np.float64))
+                crops, _ = st.test_transform_batch(arena, [at(a["frame"]) for a in nb], np.array([a["bbox"] for a in nb], np.float64))
                 stacked[torch.as_tensor(rows, device=cur.device), slot] = crops
         out = []
         for k, (i, lb) in enumerate(zip(idxs, labels)):

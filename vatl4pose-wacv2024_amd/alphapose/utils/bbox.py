@@ -56,3 +56,32 @@ def center_scale_to_box_batch(centers, scales):
     c, s = np.asarray(centers, np.float64), np.asarray(scales, np.float64)
     lo = c - s * 0.5
     return np.concatenate([lo, lo + s], 1)
+
+
+def bbox_xywh_to_xyxy(xywh):
+    """(x, y, w, h) -> (xmin, ymin, xmax, ymax) with the inclusive-pixel -1 (bbox.py:40-71)."""
+    if isinstance(xywh, (tuple, list)):
+        if len(xywh) != 4:
+            raise IndexError(f"Bounding boxes must have 4 elements, given {len(xywh)}")
+        w, h = np.maximum(xywh[2] - 1, 0), np.maximum(xywh[3] - 1, 0)
+        return (xywh[0], xywh[1], xywh[0] + w, xywh[1] + h)
+    if isinstance(xywh, np.ndarray):
+        if xywh.size % 4 != 0:
+            raise IndexError(f"Bounding boxes must have n * 4 elements, given {xywh.shape}")
+        return np.hstack((xywh[:, :2], xywh[:, :2] + np.maximum(0, xywh[:, 2:4] - 1)))
+    raise TypeError(f"Expect input xywh a list, tuple or numpy.ndarray, given {type(xywh)}")
+
+
+def bbox_clip_xyxy(xyxy, width, height):
+    """Clip (xmin, ymin, xmax, ymax) to the image (0, 0, width - 1, height - 1) (bbox.py:108-150)."""
+    if isinstance(xyxy, (tuple, list)):
+        if len(xyxy) != 4:
+            raise IndexError(f"Bounding boxes must have 4 elements, given {len(xyxy)}")
+        return (np.minimum(width - 1, np.maximum(0, xyxy[0])), np.minimum(height - 1, np.maximum(0, xyxy[1])),
+                np.minimum(width - 1, np.maximum(0, xyxy[2])), np.minimum(height - 1, np.maximum(0, xyxy[3])))
+    if isinstance(xyxy, np.ndarray):
+        if xyxy.size % 4 != 0:
+            raise IndexError(f"Bounding boxes must have n * 4 elements, given {xyxy.shape}")
+        lim = np.array([width - 1, height - 1, width - 1, height - 1])
+        return np.minimum(lim, np.maximum(0, xyxy))
+    raise TypeError(f"Expect input xywh a list, tuple or numpy.ndarray, given {type(xyxy)}")
