@@ -203,3 +203,29 @@ def test_coco_video_datasets_follow_the_reference_annotation_rules(tmp_path, nam
         bad["categories"][0]["name"] = "cat"
         json.dump(bad, open(os.path.join(str(tmp_path), "annotations", "bad.json"), "w"))
         builder.build_dataset(edict({"TYPE": name, "ROOT": str(tmp_path), "IMG_PREFIX": "", "ANN": "annotations/bad.json"}), preset_cfg=_cfgs()[1], train=False)
+
+
+def test_image_datasets_registered_and_parse_coco_json(tmp_path):
+    """Mscoco / Mpii: registry names, the reference's person filters (crowd, empty key-points, zero area) and the 30-image
+    SHORTEN switch of mscoco.py:53-55."""
+    import json, os
+    from PIL import Image
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "val2017")); os.makedirs(os.path.join(root, "annotations"))
+    images, anns = [], []
+    for i in range(34):
+        name = f"{i + 1:012d}.png"
+        Image.fromarray(synth.u8_frame(48, 64, 90 + i)).save(os.path.join(root, "val2017", name))
+        images.append({"id": i + 1, "coco_url": f"http://images.cocodataset.org/val2017/{name}", "file_name": name, "width": 64, "height": 48})
+        kp = [10.0, 12.0, 2] * 17
+        anns.append({"id": 100 + i, "image_id": i + 1, "category_id": 1, "iscrowd": 0, "bbox": [4.0, 5.0, 30.0, 35.0], "area": 900.0, "num_keypoints": 17, "keypoints": kp})
+    anns.append({"id": 900, "image_id": 1, "category_id": 1, "iscrowd": 1, "bbox": [4.0, 5.0, 30.0, 35.0], "area": 900.0, "num_keypoints": 17, "keypoints": [10.0, 12.0, 2] * 17})
+    anns.append({"id": 901, "image_id": 1, "category_id": 1, "iscrowd": 0, "bbox": [4.0, 5.0, 30.0, 35.0], "area": 0.0, "num_keypoints": 17, "keypoints": [10.0, 12.0, 2] * 17})
+    anns.append({"id": 902, "image_id": 2, "category_id": 1, "iscrowd": 0, "bbox": [4.0, 5.0, 30.0, 35.0], "area": 9.0, "num_keypoints": 0, "keypoints": [0, 0, 0] * 17})
+    json.dump({"images": images, "annotations": anns, "categories": [{"id": 1, "name": "person"}]}, open(os.path.join(root, "annotations", "k.json"), "w"))
+    ds = builder.build_dataset(edict({"TYPE": "Mscoco", "ROOT": root, "IMG_PREFIX": "val2017", "ANN": "annotations/k.json"}), preset_cfg=_cfgs()[1], train=False)
+    assert len(ds) == 30 and ds._labels[0]["bbox"] == (4.0, 5.0, 33.0, 39.0) and not ds.ID_SORTED_STREAM
+    assert ds._items[3]["path"].endswith(os.path.join("val2017", "000000000004.png"))
+    assert builder.DATASET.get("Mpii").num_joints == 16 and len(builder.DATASET.get("Mpii").joint_pairs) == 6

@@ -303,3 +303,46 @@ def test_posetrack_json_dataset_items_and_evaluation(tmp_path):
     al.eval_and_query()
     assert len(al.labeled_id) == 2 and len(al.unlabeled_id) == 6
     assert al.outcome() is None and np.isfinite(al.last_train_loss)
+
+
+def test_image_dataset_batch_on_device(tmp_path):
+    """Mpii-style image dataset (16 joints): a DataLoader batch of CustomDataset's 5-tuples made by one warp + one target launch,
+    equal to the oracle composition on the decoded images."""
+    import json, os
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    from oracle import crop, scorers, synth
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "images")); os.makedirs(os.path.join(root, "annot"))
+    images, anns, frames = [], [], []
+    r = np.random.RandomState(4)
+    for i in range(5):
+        name = f"{i + 1:09d}.png"
+        f = synth.u8_frame(96, 128, 40 + i); frames.append(f)
+        Image.fromarray(f).save(os.path.join(root, "images", name))
+        images.append({"id": i + 1, "file_name": name, "width": 128, "height": 96})
+        kp = []
+        for j in range(16):
+            kp += [float(r.uniform(20, 80)), float(r.uniform(10, 80)), int(r.random_sample() > 0.2)]
+        kp[2] = 1
+        anns.append({"id": 10 + i, "image_id": i + 1, "category_id": 1, "bbox": [15.0 + i, 8.0, 70.0, 80.0], "num_keypoints": 16, "keypoints": kp})
+    json.dump({"images": images, "annotations": anns, "categories": [{"id": 1, "name": "person"}]}, open(os.path.join(root, "annot", "v.json"), "w"))
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 16, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    ds = builder.build_dataset(edict({"TYPE": "Mpii", "ROOT": root, "IMG_PREFIX": "images", "ANN": "annot/v.json"}), preset_cfg=preset, train=False)
+    img, label, mask, ids, bbox = next(iter(DataLoader(ds, batch_size=5, shuffle=False, collate_fn=ds.my_collate_fn)))
+    assert img.shape == (5, 3, 256, 192) and label.shape == (5, 16, 64, 48) and mask.shape == (5, 16, 1, 1) and ids == [1, 2, 3, 4, 5]
+    for i in range(5):
+        a = ds._labels[i]
+        ref_img, ref_bb = crop.test_transform(frames[i], a["bbox"])
+        assert np.array_equal(img[i].cpu().numpy(), ref_img) and np.array_equal(bbox[i].numpy(), np.float32(ref_bb))
+        c, s = crop.box_to_center_scale(a["bbox"][0], a["bbox"][1], a["bbox"][2] - a["bbox"][0], a["bbox"][3] - a["bbox"][1], 0.75)
+        t = crop.affine_transform_matrix(c, s, 0, [192, 256])
+        jt = a["joints_3d"].copy()
+        for j in range(16):
+            if jt[j, 0, 1] > 0:
+                jt[j, 0:2, 0] = crop.transform_point(jt[j, 0:2, 0], t)
+        rt, rw = scorers.target_generator(jt[:, 0:2, 0], jt[:, 0, 1])
+        np.testing.assert_allclose(label[i].cpu().numpy(), rt, rtol=1e-6, atol=1e-7)
+        assert np.array_equal(mask[i].cpu().numpy().reshape(-1), rw.reshape(-1))

@@ -69,18 +69,28 @@ class _CocoVideo(FrameVideo):
         db = CocoIndex(self._ann_file)
         assert db.category_names() == self.CLASSES, "Incompatible category names with " + type(self).__name__
         anns = []
-        for frame in db.images_sorted():
-            path = os.path.join(self._root, frame["file_name"])
+        for count, frame in enumerate(db.images_sorted()):
+            path = self._image_path(frame)
             if not os.path.exists(path):
                 raise IOError(f"Image: {path} not exists.")
-            for person in self._persons(db, frame):
+            persons = self._persons(db, frame)
+            for person in persons:
                 person["frame"] = path
-                person["img_id"] = frame["image_id"]
+                person["img_id"] = frame.get("image_id", frame["id"])
+                person.setdefault("id", len(anns))               # image datasets keep file order
                 anns.append(person)
+            if persons and self._stop_after(count + 1):          # (the reference checks its image counter only after a labelled image)
+                break
         super().__init__(frames=[], annotations=anns, train=train, get_prenext=get_prenext, PRESET=cfg.get("PRESET"), AUG=cfg.get("AUG"))
-        self._items = [{"path": a["frame"], "img_id": a["img_id"], "ann_id": a["ann_id"], "id": a["id"], "track_id": a["track_id"],
-                        "keypoint": a["keypoint"]} for a in self._labels]
+        self._items = [{"path": a["frame"], "img_id": a["img_id"], "ann_id": a.get("ann_id"), "id": a["id"], "track_id": a.get("track_id"),
+                        "keypoint": a.get("keypoint")} for a in self._labels]
         self._decoded = OrderedDict()
+
+    def _image_path(self, frame):
+        return os.path.join(self._root, frame["file_name"])      # posetrack21.py:53-54
+
+    def _stop_after(self, n_images):
+        return False
 
     def _track_id(self, frame, obj):
         return str(frame["vid_id"]) + str(obj["track_id"])       # posetrack21.py:105
@@ -146,3 +156,81 @@ class JRDB2022(_CocoVideo):
 
     def _track_id(self, frame, obj):
         return obj["track_id"]
+
+
+class _CocoImages(_CocoVideo):
+    """Image-only key-point datasets (pre-training): items are ``CustomDataset.__getitem__``'s 5-tuple
+    (img (3,H,W), label, label_mask, img_id, bbox) (custom.py:96-113)."""
+    REQUIRE_AREA = False
+
+    def __init__(self, train=True, dpg=False, skip_empty=True, lazy_import=False, get_prenext=False, **cfg):
+        super().__init__(train=train, dpg=dpg, skip_empty=skip_empty, lazy_import=lazy_import, get_prenext=False, **cfg)
+        self.ID_SORTED_STREAM = False
+
+    def _persons(self, db, frame):
+        """``_check_load_keypoints`` of mscoco.py:60-115 / mpii.py:62-110 (``_check_centers`` is off in the reference)."""
+        width, height = frame["width"], frame["height"]
+        out = []
+        for obj in db.anns_of.get(frame["id"], []):
+            if obj.get("iscrowd", 0):
+                continue
+            if max(obj["keypoints"]) == 0:
+                continue
+            xmin, ymin, xmax, ymax = bbox_clip_xyxy(bbox_xywh_to_xyxy(obj["bbox"]), width, height)
+            if (self.REQUIRE_AREA and obj["area"] <= 0) or xmax <= xmin or ymax <= ymin:
+                continue
+            if obj["num_keypoints"] == 0:
+                continue
+            joints_3d = np.zeros((self.num_joints, 3, 2), dtype=np.float32)
+            kp = obj["keypoints"]
+            for i in range(self.num_joints):
+                joints_3d[i, 0, 0], joints_3d[i, 1, 0] = kp[i * 3 + 0], kp[i * 3 + 1]
+                joints_3d[i, :2, 1] = min(1, kp[i * 3 + 2])
+            if np.sum(joints_3d[:, 0, 1]) < 1:
+                continue
+            out.append({"bbox": (float(xmin), float(ymin), float(xmax), float(ymax)), "width": width, "height": height, "joints_3d": joints_3d})
+        if not out and not self._skip_empty:
+            out.append({"bbox": (-1.0, -1.0, 0.0, 0.0), "width": width, "height": height, "joints_3d": np.zeros((self.num_joints, 3, 2), np.float32)})
+        return out
+
+    def __getitems__(self, idxs):
+        import copy
+        idxs = [int(i) for i in idxs]
+        labels = [copy.deepcopy(self._labels[i]) for i in idxs]
+        arena, where = self._frames_for([lb["frame"] for lb in labels])
+        img, target, weight, boxes = self.transformation.call_batch(arena, [where[lb["frame"]] for lb in labels], labels)
+        ids = [int(os.path.splitext(os.path.basename(lb["frame"]))[0]) for lb in labels]      # custom.py:103
+        return [(img[k], target[k], weight[k], ids[k], boxes[k]) for k in range(len(idxs))]
+
+    @staticmethod
+    def my_collate_fn(batch):
+        import torch
+        cols = list(zip(*batch))
+        return torch.stack(cols[0]), torch.stack(cols[1]), torch.stack(cols[2]), list(cols[3]), torch.stack(cols[4])
+
+
+@DATASET.register_module
+class Mscoco(_CocoImages):
+    """COCO person key-points (mscoco.py:9-25).  ``SHORTEN`` is the reference's own switch: it stops after 30 images."""
+    EVAL_JOINTS = list(range(17))
+    joint_pairs = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
+    SHORTEN = True
+    REQUIRE_AREA = True
+
+    def _image_path(self, frame):
+        dirname, filename = frame["coco_url"].split("/")[-2:]    # mscoco.py:41-42
+        return os.path.join(self._root, dirname, filename)
+
+    def _stop_after(self, n_images):
+        return self.SHORTEN and n_images >= 30                   # mscoco.py:53-55
+
+
+@DATASET.register_module
+class Mpii(_CocoImages):
+    """MPII human pose, 16 joints (mpii.py:13-34)."""
+    num_joints = 16
+    EVAL_JOINTS = list(range(16))
+    joint_pairs = [[0, 5], [1, 4], [2, 3], [10, 15], [11, 14], [12, 13]]
+
+    def _image_path(self, frame):
+        return os.path.join(self._root, self._img_prefix, frame["file_name"])                 # mpii.py:47-48
