@@ -51,7 +51,11 @@ def test_active_learning_rounds(unc, tmp_path):
     sc = np.asarray(recs[3]["keypoints"])[2::3]
     np.testing.assert_allclose(recs[3]["score"], sc.mean() + 1.25 * sc.max(), rtol=1e-5)
     assert recs[5]["id"] == int(ds[5][6]) and recs[5]["image_id"] == int(ds[5][5])
-    assert os.path.exists(os.path.join(opt.work_dir, "GT_kpt.json")) and os.path.exists(os.path.join(opt.work_dir, "predicted_kpt_ann.json"))
+    assert os.path.exists(os.path.join(opt.work_dir, "predicted_kpt_ann.json"))
+    gt = json.load(open(os.path.join(opt.work_dir, "GT_kpt.json")))                            # COCO layout (save_GT_dict :693-705)
+    assert set(gt) == {"images", "categories", "annotations"} and len(gt["annotations"]) == 24 and gt["categories"][0]["name"] == "person"
+    assert gt["annotations"][3]["keypoints"] == recs[3]["GT_keypoints"] and {im["id"] for im in gt["images"]} == {r["image_id"] for r in recs}
+    assert al.performance[0]["AP"] is None and 0.0 <= al.performance[0]["mOKS"] <= 1.0         # no COCO API in this image: device mOKS only
     if unc != "HP":
         u = al.uncertainty_dict["Round0"]
         picked = al.query_list_list["Round0"]

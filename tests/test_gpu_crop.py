@@ -302,6 +302,9 @@ def test_posetrack_json_dataset_items_and_evaluation(tmp_path):
     assert type(al.eval_dataset).__name__ == "Posetrack21" and al.dedup
     al.eval_and_query()
     assert len(al.labeled_id) == 2 and len(al.unlabeled_id) == 6
+    import json
+    gt = json.load(open(os_mod.path.join(opt.work_dir, "GT_kpt.json")))                        # images / categories come from the annotation file
+    assert len(gt["images"]) == 4 and gt["images"][0]["file_name"].endswith("000000.png") and len(gt["annotations"]) == 8
     assert al.outcome() is None and np.isfinite(al.last_train_loss)
 
 

@@ -256,12 +256,16 @@ class ActiveLearning:
         self.keypoints, self.oks = kp_all, oks
         self._write_records(kp_all, oks, side)
         evaluate = getattr(self.opt, "evaluate_fn", None)
-        res = evaluate(kp_all, self) if evaluate else {"AP": None, "mOKS": float(oks.mean())}
+        work_dir = getattr(self.opt, "work_dir", None)
+        tp = self._third_party_scores(work_dir) if (work_dir and not evaluate and D.is_main()) else {}
+        fallback = {"AP": None, "mOKS": float(oks.mean())}         # device OKS of every item: always available
+        res = evaluate(kp_all, self) if evaluate else (dict(tp["res"], mOKS=fallback["mOKS"]) if tp.get("res") else fallback)
+        res_ann = res if (evaluate or not tp.get("res_ann")) else dict(tp["res_ann"], mOKS=fallback["mOKS"])
         self.percentage.append(len(self.labeled_id) / n * 100)
         self.performance.append(res)
-        self.performance_ann.append(res)
-        self.ospa_list.append(None)
-        self.ospa_list_ann.append(None)
+        self.performance_ann.append(res_ann)
+        self.ospa_list.append(tp.get("ospa"))
+        self.ospa_list_ann.append(tp.get("ospa_ann"))
         self.uncertainty_mean.append(float(unc[:, 0].sum() / n))
         un = np.asarray(self.unlabeled_id, int)                       # ascending, like IndexCollection.index here
         nun = len(un)
@@ -377,9 +381,44 @@ class ActiveLearning:
             import json
             import os
             os.makedirs(work_dir, exist_ok=True)
-            for name, data in (("predicted_kpt.json", self.kpt_json), ("predicted_kpt_ann.json", self.kpt_json_ann), ("GT_kpt.json", self.GT_json)):
+            for name, data in (("predicted_kpt.json", self.kpt_json), ("predicted_kpt_ann.json", self.kpt_json_ann), ("GT_kpt.json", self._gt_dict())):
                 with open(os.path.join(work_dir, name), "w") as f:
                     json.dump(data, f)
+
+    def _gt_dict(self):
+        """``save_GT_dict`` (ActiveLearning.py:693-705): the ground truth in COCO layout — ``images`` / ``categories`` copied from the
+        evaluation set's annotation file when there is one, the records of this round as ``annotations``."""
+        import json
+        import os
+        ev = self.cfg.DATASET.EVAL
+        path = os.path.join(str(ev.get("ROOT", "")), str(ev.get("ANN", ""))) if ev.get("ANN") else ""
+        if path and os.path.isfile(path):
+            with open(path) as f:
+                src = json.load(f)
+            images, cats = src.get("images", []), src.get("categories", [])
+        else:                                                      # datasets without an annotation file (synthetic / in-memory videos)
+            images = [{"id": i, "image_id": i} for i in sorted({r["image_id"] for r in self.GT_json})]
+            cats = [{"id": 1, "name": "person"}]
+        return {"images": images, "categories": cats, "annotations": self.GT_json}
+
+    def _third_party_scores(self, work_dir):
+        """mAP / OSPA of the written records through the reference's third-party tools (ActiveLearning.py:442-447) when they are
+        installed (pycocotools / halpecocotools, JRDB_toolkit); None for whatever is missing."""
+        import os
+        from alphapose.utils.metrics import evaluate_mAP
+        gt, out = os.path.join(work_dir, "GT_kpt.json"), {}
+        for key, name in (("res", "predicted_kpt.json"), ("res_ann", "predicted_kpt_ann.json")):
+            try:
+                out[key] = evaluate_mAP(os.path.join(work_dir, name), ann_type="keypoints", ann_file=gt, silence=True)
+            except NotImplementedError:
+                out[key] = None
+        try:
+            from JRDB_toolkit.pose_eval import ospa_for_loc
+            out["ospa"] = ospa_for_loc(ann_json_path=gt, pr_json_path=os.path.join(work_dir, "predicted_kpt.json"))
+            out["ospa_ann"] = ospa_for_loc(ann_json_path=gt, pr_json_path=os.path.join(work_dir, "predicted_kpt_ann.json"))
+        except ImportError:
+            out["ospa"] = out["ospa_ann"] = None
+        return out
 
     def _is_finished(self, query, oks):
         """ActiveLearning.py:707-725: the three stopping-criterion bookmarks (label percentage at which each first held)."""

@@ -4,7 +4,7 @@
 :239-245) run inside the fine-tune loop (ActiveLearning.py:670-676).  The arg-max of
 predictions and labels comes from the same HIP kernel as the decoder, so only
 (B,J) indices cross to the host instead of two (B,J,H,W) tensors.
-``evaluate_mAP`` (:65-115, pycocotools) is offline evaluation and out of scope.
+``evaluate_mAP`` (:65-115) drives the third-party COCO API when it is installed (offline evaluation, not re-implemented).
 """
 from __future__ import annotations
 
@@ -55,6 +55,28 @@ def calc_accuracy(preds, labels, thr=0.5):
     return total / cnt if cnt > 0 else 0
 
 
-def evaluate_mAP(*args, **kwargs):
-    raise NotImplementedError("COCO mAP evaluation (pycocotools) is offline evaluation outside the MI355X hot path "
-                              "(SURVEY.md §2.1 row 5); run the reference's evaluate_mAP on the produced json files")
+def evaluate_mAP(res_file, ann_type="bbox", ann_file="./data/coco/annotations/person_keypoints_val2017.json", silence=False):
+    """COCO evaluation of a result json against a ground-truth json (metrics.py:65-115) -> {'AP', 'AP .5', ..., 'AR'}.
+
+    The arithmetic is the COCO API's (``pycocotools`` / AlphaPose's ``halpecocotools`` fork), a third-party package that is
+    part of the reference's environment but not of this image; it is used when importable and never re-implemented here
+    (offline evaluation).  Without it: NotImplementedError."""
+    try:
+        from pycocotools.coco import COCO
+        from pycocotools.cocoeval import COCOeval
+    except ImportError as e:
+        raise NotImplementedError("evaluate_mAP needs the COCO API (pycocotools / halpecocotools), which is not installed; "
+                                  "the result files are written for it (predicted_kpt.json / GT_kpt.json)") from e
+    import contextlib
+    import io
+    sink = io.StringIO() if silence else None
+    with (contextlib.redirect_stdout(sink) if silence else contextlib.nullcontext()):
+        gt = COCO(ann_file)
+        ev = COCOeval(gt, gt.loadRes(res_file), ann_type)
+        ev.evaluate()
+        ev.accumulate()
+        ev.summarize()
+    if isinstance(ev.stats[0], dict):                               # Halpe full-body fork: per-part dictionaries
+        return {part: ev.stats[i][part][0] for i, part in enumerate(["body", "foot", "face", "hand", "fullbody"])}
+    names = ["AP", "AP .5", "AP .6", "AP .7", "AP .75", "AP .8", "AP .95", "AP (M)", "AP (L)", "AR"]
+    return {name: ev.stats[i] for i, name in enumerate(names)}
