@@ -498,3 +498,23 @@ def test_fine_tune_step_is_bitwise_reproducible(vh):
     assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
     for p in runs[0][2]:
         assert torch.equal(runs[0][2][p], runs[1][2][p])
+
+
+@pytest.mark.parametrize("shape", [(3, 8, 12, 64), (32, 24, 18, 256), (2, 7, 10, 96), (5, 6, 8, 2048), (4, 96, 72, 64), (1, 9, 9, 32)])
+def test_per_item_pixel_reductions_small_batches(shape):
+    """Global average pool and the SE gate gradient through both kernel families (block per (item, channel group) for small
+    batches with many pixels; thread per (item, channel) otherwise) against float64."""
+    import vatl_hip as vh
+    n, h, w, c = shape
+    g = torch.Generator(device="cuda").manual_seed(n * 1000 + c)
+    x = torch.randn(shape, device="cuda", generator=g)
+    got = vh.gap_fwd(x).cpu().double()
+    want = x.double().mean(dim=(1, 2)).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
+    dy, y, u = (torch.randn(shape, device="cuda", generator=g) for _ in range(3))
+    gate = torch.randn((n, c), device="cuda", generator=g)
+    dg = vh.se_bwd_gate(dy, y, u, gate).cpu().double()
+    sg = torch.sigmoid(gate.double())
+    want = ((dy.double() * (y > 0) * u.double()).sum(dim=(1, 2)) * sg * (1 - sg)).cpu()
+    np.testing.assert_allclose(dg.numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+    assert torch.equal(vh.gap_fwd(x), vh.gap_fwd(x))                       # fixed summation order

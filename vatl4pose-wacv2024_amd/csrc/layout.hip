@@ -145,6 +145,76 @@ __global__ void gap_kernel(const float* __restrict__ x, float* __restrict__ y, i
 }
 
 
+// Per-item reductions over the pixels of an NHWC tensor for small batches (fine-tune steps: N = 32..120, where one thread per
+// (item, channel) leaves most of the chip idle and walks thousands of pixels one load at a time).  A block owns `cols` float4
+// channel columns of one item; its 256 threads take 256 / cols pixels at a time with four pixels in flight each and combine
+// their partial sums through LDS in a fixed order (deterministic, no workspace, no atomics).
+//   MODE 0: global average pool            out[n][c] = sum_hw x / HW
+//   MODE 1: SE gate gradient               out[n][c] = sig'(gate) * sum_hw dy*[y>0]*u
+template <int MODE>
+__global__ __launch_bounds__(256) void hw_reduce_kernel(const float* __restrict__ a, const float* __restrict__ y, const float* __restrict__ u,
+                                                        const float* __restrict__ gate, float* __restrict__ out, int HW, int C, int cols) {
+    __shared__ f32x4 sh[256];
+    const int C4 = C >> 2, groups = C4 / cols;
+    const int n = blockIdx.x / groups, c4 = (blockIdx.x - n * groups) * cols + (threadIdx.x % cols);
+    const int rlane = threadIdx.x / cols, rstep = 256 / cols;
+    const long long base = (long long)n * HW * C4 + c4;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a) + base;
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(y) + base;
+    const f32x4* u4 = reinterpret_cast<const f32x4*>(u) + base;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    auto fold = [&](f32x4 v, f32x4 yy, f32x4 uu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += MODE == 0 ? v[e] : (yy[e] > 0.f ? v[e] * uu[e] : 0.f);
+    };
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    int k = rlane;
+    for (; k + 3 * rstep < HW; k += 4 * rstep) {
+        f32x4 v[4], yy[4], uu[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long o = (long long)(k + q * rstep) * C4;
+            v[q] = a4[o];
+            yy[q] = MODE == 1 ? y4[o] : zero;
+            uu[q] = MODE == 1 ? u4[o] : zero;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fold(v[q], yy[q], uu[q]);
+    }
+    for (; k < HW; k += rstep) {
+        const long long o = (long long)k * C4;
+        fold(a4[o], MODE == 1 ? y4[o] : zero, MODE == 1 ? u4[o] : zero);
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (rlane == 0) {
+        f32x4 t = sh[threadIdx.x];
+        for (int r = 1; r < rstep; ++r) {
+            const f32x4 w = sh[r * cols + threadIdx.x];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] += w[e];
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (MODE == 0) o[e] = t[e] / (float)HW;
+            else { const float sg = 1.f / (1.f + expf(-gate[(long long)n * C + c4 * 4 + e])); o[e] = t[e] * sg * (1.f - sg); }
+        }
+        *reinterpret_cast<f32x4*>(out + (long long)n * C + c4 * 4) = o;
+    }
+}
+
+// float4 columns per block for hw_reduce_kernel: the widest power of two (8 = 128-byte segments at least) that still gives >= 512
+// blocks; 0 = use the thread-per-(item, channel) kernels
+static int hw_reduce_cols(int N, int HW, int C) {
+    if ((C & 31) || HW < 64) return 0;                          // few pixels per item: the thread-per-(item, channel) kernels are fine
+    const int C4 = C >> 2;
+    if (C4 & (C4 - 1)) return 0;
+    int cols = 8;
+    while (cols * 2 <= C4 && cols * 2 <= 256 && (long long)N * (C4 / (cols * 2)) >= 512) cols *= 2;
+    return cols;
+}
+
 // PixelShuffle(2) on NHWC: out[b][2y+i][2x+j][c] = in[b][y][x][4c + 2i + j]
 // thread per (input pixel, 4 input channels = one output channel c at the 4 sub-positions)
 __global__ void pixelshuffle2_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
@@ -389,6 +459,10 @@ extern "C" int vatl_maxpool3x3s2_fwd(const float* x, float* y, int N, int H, int
 
 extern "C" int vatl_gap_fwd(const float* x, float* y, int N, int HW, int C, void* stream) {
     if (!x || !y) return fail(VATL_EINVAL, "gap_fwd: null pointer");
+    if (const int cols = hw_reduce_cols(N, HW, C)) {
+        hipLaunchKernelGGL(hw_reduce_kernel<0>, dim3((unsigned)(N * ((C >> 2) / cols))), dim3(256), 0, (hipStream_t)stream, x, x, x, (const float*)nullptr, y, HW, C, cols);
+        return check_launch("gap_fwd");
+    }
     hipLaunchKernelGGL(gap_kernel, dim3(grid_for((long long)N * C)), dim3(256), 0, (hipStream_t)stream, x, y, N, HW, C);
     return check_launch("gap_fwd");
 }
@@ -463,6 +537,9 @@ extern "C" int vatl_se_bwd(const float* dy, const float* y, const float* u, cons
     hipStream_t st = (hipStream_t)stream;
     if (dgate_or_null) {
         if (!u) return fail(VATL_EINVAL, "se_bwd: stage 1 needs u");
+        if (const int cols = hw_reduce_cols(N, HW, C))
+            hipLaunchKernelGGL(hw_reduce_kernel<1>, dim3((unsigned)(N * ((C >> 2) / cols))), dim3(256), 0, st, dy, y, u, gate, dgate_or_null, HW, C, cols);
+        else
         hipLaunchKernelGGL(se_bwd_gate_kernel, dim3(grid_for((long long)N * C)), dim3(256), 0, st, dy, y, u, gate, dgate_or_null, N, HW, C);
     }
     if (du_or_null) {
