@@ -33,6 +33,7 @@ struct WgradParams {
     int d_oy, d_ox;      // (row, column) advance of a 32-pixel step: 32 = d_b*Ho*Wo + d_oy*Wo + d_ox
     int adv, adv_cx, adv_cy;   // element-offset advance of the gathered operand for that step / a column carry / a row carry
     unsigned g_bytes, x_bytes;
+    int tpt;             // filter taps per block column tile (> 1 when Cx < BJ: a tile packs BJ / Cx taps instead of padding one tap's channels)
     int ablate;          // benchmarks only (vatl_tune_set(4, bits)): 1 = skip the epilogue (wrong results)
     long long slice;     // floats between the partial gradients of consecutive M-splits in the workspace
 };
@@ -67,7 +68,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     const int split = bid / p.taps;
     const int n0 = n_tile * BN;
     const int c0 = jt * BJ;
-    const int r = STEM ? tap : tap / p.S, s = STEM ? 0 : tap - r * p.S;
+    // the filter tap this thread gathers for: the block's tap, or (packed tiles, Cx < BJ) tap group * tpt + its column's tap
+    const int tpt = STEM ? 1 : p.tpt;
+    const int cj0 = (tid % (BJ / 4)) * 4;
+    const int my_tap = tpt > 1 ? tap * tpt + cj0 / p.Cx : tap;
+    const bool tap_ok = STEM || my_tap < p.R * p.S;
+    const int r = STEM ? tap : my_tap / p.S, s = STEM ? 0 : my_tap - r * p.S;
     const int kt0 = split * p.kt_per_split;
     const int kt1 = min(kt0 + p.kt_per_split, p.ktiles);
     if (kt0 >= kt1) return;
@@ -102,8 +108,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         xm[q] = m;
         xoy[q] = rem / p.Wo;
         xox[q] = rem - xoy[q] * p.Wo;
-        const int c = STEM ? 0 : c0 + c4 * 4;
-        xcv[q] = c < p.Cx;
+        const int c = STEM ? 0 : (tpt > 1 ? (c4 * 4) % p.Cx : c0 + c4 * 4);
+        xcv[q] = tap_ok && c < p.Cx;
         // STEM: float4 = one of the 8 taps of this filter row (4 channels): the column offset c4 rides in the offset
         xoff[q] = ((b * p.H + xoy[q] * p.stride - p.pad + r) * p.W + xox[q] * p.stride - p.pad + s + (STEM ? c4 : 0)) * p.Cx + c;
     }
@@ -210,8 +216,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int cj = wj * WJ + j * 32 + l31;                    // column inside the block tile
-            const int col = STEM ? tap * 32 + cj : tap * p.Cx + c0 + cj;
-            const bool cv = STEM ? true : (c0 + cj) < p.Cx;
+            const int col = STEM ? tap * 32 + cj : (tpt > 1 ? tap * tpt * p.Cx + cj : tap * p.Cx + c0 + cj);   // packed tiles: taps are contiguous in the layout
+            const bool cv = STEM ? true : (tpt > 1 ? col < Kp : (c0 + cj) < p.Cx);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + wn * WN + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
@@ -238,8 +244,12 @@ static WgradCfg wgrad_cfg(int Cn, int Cx, bool stem) {
 // B = 120 (tools/wgrad_bench.py): 1x1 filters are ~10 % faster with one 512-block wave (half the partial slices to
 // write and sum), 3x3 filters want two waves.
 struct WgradPlan { int tiles, splits, kt_per_split, slices; };   // slices = splits * nwk partial gradients to sum
+// taps per column tile: narrow inputs (Cx < BJ, HRNet's 32- / 64-channel branches) pack BJ / Cx taps into a tile instead of
+// multiplying zero columns (a 32-channel 3x3 filter: 3 tiles of 4 taps instead of 9 tiles that are 3/4 padding)
+static int wgrad_tpt(const WgradCfg& c, int Cx) { return (!c.stem && Cx < c.bj && c.bj % Cx == 0) ? c.bj / Cx : 1; }
 static WgradPlan wgrad_plan(const WgradCfg& c, int Cn, int Cx, int R, int S, long long M) {
-    const int n_tiles = cdiv(Cn, c.bn), taps = c.stem ? R : R * S, j_tiles = c.stem ? 1 : cdiv(Cx, c.bj);
+    const int tpt = wgrad_tpt(c, Cx);
+    const int n_tiles = cdiv(Cn, c.bn), taps = c.stem ? R : cdiv(R * S, tpt), j_tiles = c.stem ? 1 : cdiv(Cx, c.bj);
     const int tiles = n_tiles * taps * j_tiles;
     const int ktiles = cdiv(M, 32);
     int target = g_wgrad_blocks.load(std::memory_order_relaxed);
@@ -256,7 +266,8 @@ static WgradPlan wgrad_plan(const WgradCfg& c, int Cn, int Cx, int R, int S, lon
 template <int BN, int BJ, int WN, int WJ, bool STEM>
 static int launch_wgrad_t(WgradParams p, const WgradPlan& plan, hipStream_t st) {
     p.n_tiles = cdiv(p.Cn, BN);
-    p.taps = STEM ? p.R : p.R * p.S;
+    p.tpt = (!STEM && p.Cx < BJ && BJ % p.Cx == 0) ? BJ / p.Cx : 1;
+    p.taps = STEM ? p.R : cdiv(p.R * p.S, p.tpt);
     p.j_tiles_per_tap = STEM ? 1 : cdiv(p.Cx, BJ);
     const int hw = p.Ho * p.Wo, rem = 32 % hw;
     p.d_oy = rem / p.Wo; p.d_ox = rem % p.Wo;
