@@ -30,6 +30,21 @@ def _flipped_taps(r, s):
     return [(r - 1 - i, s - 1 - j) for i in range(r) for j in range(s)]
 
 
+_pending_counters = []
+
+
+def _count_batch(bn):
+    """``num_batches_tracked += 1`` of a BatchNorm layer, deferred: the trainers bump all counters of a forward pass with
+    one multi-tensor add (a 53- to 292-layer network otherwise spends a launch per layer on a one-element add)."""
+    _pending_counters.append(bn.num_batches_tracked)
+
+
+def _flush_batch_counters():
+    if _pending_counters:
+        torch._foreach_add_(_pending_counters, 1)
+        _pending_counters.clear()
+
+
 class _ConvBN:
     """Conv2d (bias-free) + BatchNorm2d(train) (+ residual) (+ ReLU)."""
 
@@ -46,7 +61,7 @@ class _ConvBN:
         # z = conv(x); the batch statistics come out of the conv epilogue (no extra pass over z)
         z, mean, invstd, scale, bias = vh.conv2d_fwd_bnstats(x, w, self.cout, self.r, self.s, self.stride, self.pad, bn.weight.detach(),
                                                              bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps)
-        bn.num_batches_tracked += 1
+        _count_batch(bn)
         y = vh.scale_bias_act(z, scale, bias, skip, relu)
         # ReLU without a skip: the backward recomputes the mask from (z, scale, bias) and never reads y
         mask = (scale, bias) if (relu and skip is None) else None
@@ -111,7 +126,7 @@ class _DeconvBN:
         bn = self.bn
         z, mean, invstd, scale, bias = vh.deconv4x4s2_fwd_bnstats(x, vh.pack_deconv_weight(self.dc.weight.detach()), self.cout, bn.weight.detach(),
                                                                   bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps)
-        bn.num_batches_tracked += 1
+        _count_batch(bn)
         y = vh.scale_bias_act(z, scale, bias, None, True)
         self.saved = (x, z, scale, bias, mean, invstd)
         return y
@@ -172,6 +187,7 @@ class SimplePoseTrainer:
         self.head_in = x
         hw = vh.pack_conv_weight(self.head.weight.detach())
         _, hb = vh.bn_fold(None, None, None, None, 0.0, self.head.bias.detach(), channels=self.head.weight.shape[0])
+        _flush_batch_counters()
         return vh.conv2d_fwd(x, hw, None, hb, self.head.weight.shape[0], 1, 1, 1, 0, False, out_nchw=True)
 
     def backward(self, dout_nchw):
@@ -277,6 +293,7 @@ class FastPoseTrainer:
         self.head_in = x
         j = self.head.weight.shape[0]
         _, hb = vh.bn_fold(None, None, None, None, 0.0, self.head.bias.detach(), channels=j)
+        _flush_batch_counters()
         return vh.conv2d_fwd(x, vh.pack_conv_weight(self.head.weight.detach()), None, hb, j, 3, 3, 1, 1, False, out_nchw=True)
 
     def backward(self, dout_nchw):
@@ -419,6 +436,7 @@ class HRNetTrainer:
         self.head_in = ys[0]
         j, _, k, _ = self.head.weight.shape
         _, hb = vh.bn_fold(None, None, None, None, 0.0, self.head.bias.detach(), channels=j)
+        _flush_batch_counters()
         return vh.conv2d_fwd(ys[0], vh.pack_conv_weight(self.head.weight.detach()), None, hb, j, k, k, 1, k // 2, False, out_nchw=True)
 
     def backward(self, dout_nchw):
