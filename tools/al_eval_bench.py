@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""End-to-end evaluation pass of the active-learning loop on decoded frames (host + device): u8 frames -> device crops ->
+SimpleBaseline-R50 -> decode / THC / WPU / local-peak -> query, through ActiveLearning.eval_and_query.
+
+    python tools/al_eval_bench.py [--items 1024] [--batch 256] [--rounds 3]
+Prints items/s of eval_and_query (wall clock, everything included) next to bench.py's device-resident figure.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "vatl4pose-wacv2024_amd")):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--items", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--uncertainty", default="THC+WPU")
+    a = ap.parse_args()
+    from active_learning import ActiveLearning
+    from alphapose.datasets import FrameVideo
+    from alphapose.utils.config import edict
+    from oracle import synth
+    tracks = 16
+    frames, anns = synth.frame_video(a.items // tracks, tracks, hw=(480, 640))
+    preset = {"IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48], "SIGMA": 2}
+    ev = FrameVideo(frames, anns, train=False, get_prenext=True, PRESET=preset)
+    tr = FrameVideo(frames, anns, train=True, get_prenext=False, PRESET=preset, AUG={"SCALE_FACTOR": 0.25, "ROT_FACTOR": 30, "NUM_JOINTS_HALF_BODY": 8, "PROB_HALF_BODY": 0.3})
+    cfg = edict({
+        "DATASET": {"TRAIN": {"TYPE": "FrameVideo"}, "EVAL": {"TYPE": "FrameVideo"}},
+        "DATA_PRESET": {"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]},
+        "MODEL": {"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50},
+        "LOSS": {"TYPE": "MSELoss"}, "AE": {"Z_DIM": 4, "INPUT_DIM": 42, "PRETRAINED": "", "EPOCH": 1, "LR": 1e-3},
+        "RETRAIN": {"BATCH_SIZE": 120, "BASE": 1, "OPTIMIZER": "AdamW", "LR": 2.5e-4, "ALPHA": 2, "WEIGHT_DECAY": 0.7, "LR_GAMMA": 0.99},
+        "VAL": {"BATCH_SIZE": a.batch, "W_UNC": 0.01, "UNC_LAMBDA": 0.01, "QUERY_RATIO": [0.05, 0.1, 1.0]}})
+    with tempfile.TemporaryDirectory() as wd:
+        opt = types.SimpleNamespace(work_dir=wd, uncertainty=a.uncertainty, representativeness="None", filter="None", strategy=a.uncertainty, video_id="syn",
+                                    get_prenext=True, from_scratch=True, continual=True, num_gpu=1, onebyone=False, retrain_thresh=1, THCvsWPU="const")
+        torch.manual_seed(0); np.random.seed(0)
+        al = ActiveLearning(cfg, opt, eval_dataset=ev, train_dataset=tr)
+        times = []
+        for _ in range(a.rounds):
+            al.unlabeled_id = list(range(len(ev))); al.labeled_id = []
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            al.eval_and_query()
+            torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+        print(json.dumps({"metric": "ActiveLearning.eval_and_query on decoded frames (wall clock)", "items": len(ev), "batch": a.batch,
+                          "seconds": [round(t, 3) for t in times], "items_per_s": round(len(ev) / min(times), 1)}))
+
+
+if __name__ == "__main__":
+    main()

@@ -194,9 +194,8 @@ class _CocoImages(_CocoVideo):
         return out
 
     def __getitems__(self, idxs):
-        import copy
         idxs = [int(i) for i in idxs]
-        labels = [copy.deepcopy(self._labels[i]) for i in idxs]
+        labels = [dict(self._labels[i]) for i in idxs]
         arena, where = self._frames_for([lb["frame"] for lb in labels])
         img, target, weight, boxes = self.transformation.call_batch(arena, [where[lb["frame"]] for lb in labels], labels)
         ids = [int(os.path.splitext(os.path.basename(lb["frame"]))[0]) for lb in labels]      # custom.py:103

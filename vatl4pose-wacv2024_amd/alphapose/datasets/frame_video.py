@@ -15,7 +15,6 @@ loop runs one forward per item.
 """
 from __future__ import annotations
 
-import copy
 
 import numpy as np
 import torch
@@ -75,7 +74,7 @@ class FrameVideo(Dataset):
 
     def __getitems__(self, idxs):
         idxs = [int(i) for i in idxs]
-        labels = [copy.deepcopy(self._labels[i]) for i in idxs]
+        labels = [dict(self._labels[i]) for i in idxs]          # shallow: the transform copies the joints it moves, nothing else is written
         is_prev = [self.get_prenext and self._neighbour(i, -1) for i in idxs]
         is_next = [self.get_prenext and self._neighbour(i, +1) for i in idxs]
         keys = [lb["frame"] for lb in labels]
