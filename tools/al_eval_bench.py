@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--uncertainty", default="THC+WPU")
+    ap.add_argument("--retrain", action="store_true", help="also time one fine-tune epoch over all items")
     a = ap.parse_args()
     from active_learning import ActiveLearning
     from alphapose.datasets import FrameVideo
@@ -55,6 +56,16 @@ def main():
             torch.cuda.synchronize(); t0 = time.perf_counter()
             al.eval_and_query()
             torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+        if a.retrain:
+            al.retrain_id = list(range(len(ev))); al.labeled_id = list(range(len(ev))); al.retrain_epoch = 1
+            rt = []
+            for _ in range(a.rounds):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                al.retrain_model()
+                torch.cuda.synchronize(); rt.append(time.perf_counter() - t0)
+            steps = -(-len(ev) // cfg.RETRAIN.BATCH_SIZE)
+            print(json.dumps({"metric": "ActiveLearning.retrain_model, one epoch over all items (wall clock; incl. the WPU auto-encoder refit)", "items": len(ev),
+                              "batch": cfg.RETRAIN.BATCH_SIZE, "steps": steps, "seconds": [round(t, 3) for t in rt], "ms_per_step": round(min(rt) / steps * 1e3, 1)}))
         print(json.dumps({"metric": "ActiveLearning.eval_and_query on decoded frames (wall clock)", "items": len(ev), "batch": a.batch,
                           "seconds": [round(t, 3) for t in times], "items_per_s": round(len(ev) / min(times), 1)}))
 

@@ -521,13 +521,18 @@ class ActiveLearning:
         if epochs <= 0 or not self.labeled_id:
             return 0.0
         gts, boxes = [], []
+        annotation_of = getattr(self.eval_dataset, "annotation_of", None)     # (GT key-points, annotation box) without making the crops
         for i in self.labeled_id:
-            item = self.eval_dataset[i]
-            gt = np.asarray(item[4], np.float64).reshape(-1)
+            if annotation_of is not None:
+                gt, box = annotation_of(i)
+            else:
+                item = self.eval_dataset[i]
+                gt, box = item[4], item[8]
+            gt = np.asarray(gt, np.float64).reshape(-1)
             if gt[2::3].sum() == 0:
                 continue
             gts.append(gt)
-            boxes.append(bbox_xyxy_to_xywh(np.asarray(item[8], np.float64).tolist()))
+            boxes.append(bbox_xyxy_to_xywh(np.asarray(box, np.float64).tolist()))
         if not gts:
             return 0.0
         feat, status = vh.hybrid_feature_f64(torch.as_tensor(np.stack(gts), device=self.device), torch.as_tensor(np.asarray(boxes, np.float64), device=self.device))

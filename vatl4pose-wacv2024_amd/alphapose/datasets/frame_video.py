@@ -104,6 +104,11 @@ class FrameVideo(Dataset):
     def __getitem__(self, i):
         return self.__getitems__([i])[0]
 
+    def annotation_of(self, i):
+        """(GT key-points (3J,), annotation box xyxy) of item i — what the auto-encoder refit reads — without touching pixels."""
+        lb = self._labels[int(i)]
+        return np.asarray(lb["keypoint"], np.float32), np.asarray(lb["bbox"], np.float32)
+
     @staticmethod
     def my_collate_fn(batch):
         cols = list(zip(*batch))
