@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--uncertainty", default="THC+WPU")
     ap.add_argument("--retrain", action="store_true", help="also time one fine-tune epoch over all items")
+    ap.add_argument("--representativeness", default="None")
+    ap.add_argument("--filter", default="None")
     a = ap.parse_args()
     from active_learning import ActiveLearning
     from alphapose.datasets import FrameVideo
@@ -46,7 +48,7 @@ def main():
         "RETRAIN": {"BATCH_SIZE": 120, "BASE": 1, "OPTIMIZER": "AdamW", "LR": 2.5e-4, "ALPHA": 2, "WEIGHT_DECAY": 0.7, "LR_GAMMA": 0.99},
         "VAL": {"BATCH_SIZE": a.batch, "W_UNC": 0.01, "UNC_LAMBDA": 0.01, "QUERY_RATIO": [0.05, 0.1, 1.0]}})
     with tempfile.TemporaryDirectory() as wd:
-        opt = types.SimpleNamespace(work_dir=wd, uncertainty=a.uncertainty, representativeness="None", filter="None", strategy=a.uncertainty, video_id="syn",
+        opt = types.SimpleNamespace(work_dir=wd, uncertainty=a.uncertainty, representativeness=a.representativeness, filter=a.filter, strategy=a.uncertainty, video_id="syn",
                                     get_prenext=True, from_scratch=True, continual=True, num_gpu=1, onebyone=False, retrain_thresh=1, THCvsWPU="const")
         torch.manual_seed(0); np.random.seed(0)
         al = ActiveLearning(cfg, opt, eval_dataset=ev, train_dataset=tr)
