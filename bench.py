@@ -9,21 +9,28 @@ ResNet-50, 256x192 crops, 17 key-points, a 1024-frame synthetic video per GPU
 Inputs are resident in HBM before the timed region.  Random-init weights of the
 named architecture, synthetic crops (no dataset / checkpoint on the box).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL); frames shard
-across ranks (weak scaling: 1024 frames per rank), per-item results are
-all-gathered; there is no other exchange on this path.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-extra] [--no-cpu-baseline]
+N > 1: one rank per GPU over RCCL.  Under torch.distributed.run the ranks are given (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_*); run bare, `--gpus N` starts the N ranks itself as fresh child processes before anything
+touches a GPU (never an exec of this process) and relays rank 0's line.  Frames shard across ranks (weak scaling:
+1024 frames per rank), per-item results are all-gathered; there is no other exchange on this path.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying
-`roofline` (conv implicit-GEMM launches timed with HIP events) and, at N = 1,
-`cpu_baseline` (the oracle restatement timed on the host cores, bounded sample).
+`roofline` (conv implicit-GEMM launches timed with HIP events), at N = 1 `cpu_baseline` (the oracle restatement
+timed on the host cores, bounded sample), and `extra`: the other BASELINE.json configurations measured in the same
+run — configs[2] SimpleBaseline-R50 fine-tune step (fwd + bwd + AdamW, B = 120 per GPU, gradient arena all-reduced over
+RCCL at N > 1), configs[3] HRNet-W32 inference + THC + WPU on a 1024-frame shard with its halo, configs[4]
+FastPose-R152 384x288 fine-tune step (B = 32 per GPU, 301 MB gradient all-reduce at N > 1).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -173,17 +180,235 @@ def cpu_baseline():
             "forward_s": round(fwd, 3), "scoring_s": round(post, 3)}
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# the other BASELINE.json configurations (reported under "extra" of the same JSON line)
+# ---------------------------------------------------------------------------------------------------------------------
+
+HRNET_W32 = {"TYPE": "PoseHighResolutionNet", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50, "FINAL_CONV_KERNEL": 1, "PRETRAINED_LAYERS": ["*"],
+             "STAGE2": {"NUM_MODULES": 1, "NUM_BRANCHES": 2, "NUM_BLOCKS": [4, 4], "NUM_CHANNELS": [32, 64], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"},
+             "STAGE3": {"NUM_MODULES": 4, "NUM_BRANCHES": 3, "NUM_BLOCKS": [4, 4, 4], "NUM_CHANNELS": [32, 64, 128], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"},
+             "STAGE4": {"NUM_MODULES": 3, "NUM_BRANCHES": 4, "NUM_BLOCKS": [4, 4, 4, 4], "NUM_CHANNELS": [32, 64, 128, 256], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"}}
+SIMPLE_R50 = {"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50}
+FAST_R152 = {"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 152}
+GFLOP_FWD = {"simplepose_r50": 10.853, "hrnet_w32": 15.290, "fastpose_r152_384": 59.192}      # per crop, SURVEY.md §8d
+
+
+def build_net(cfg, hw, dev):
+    from alphapose.models import builder
+    from alphapose.utils.config import edict
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": list(hw), "HEATMAP_SIZE": [hw[0] // 4, hw[1] // 4]})
+    torch.manual_seed(166)
+    m = builder.build_sppe(edict(cfg), preset_cfg=preset)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+    return m.to(dev)
+
+
+def _timed(fn, steps, warmup, dist_on):
+    """Barrier + synchronize on both sides, max over ranks (same bracket as the headline)."""
+    import torch.distributed as td
+    for _ in range(warmup):
+        fn()
+    if dist_on:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist_on:
+        td.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt / steps
+
+
+def finetune_step_fn(m, opt, x, labels, masks, world):
+    """One data-parallel fine-tune step as ActiveLearning.retrain_model runs it: train-mode forward, fused masked-MSE loss +
+    gradient (scaled by this rank's share of the global mini-batch), backward into the flat gradient arena whose finished
+    buckets are all-reduced over RCCL while the backward is still running, AdamW on the arena slices."""
+    import vatl_hip as vh
+    from alphapose.models import hip_train
+    tr, arena = hip_train.trainer_for(m), hip_train.arena_for(m)
+
+    def step():
+        with torch.no_grad():
+            out = tr.forward(x)
+            loss, dout = vh.masked_mse_fwd_bwd(out, labels, masks)
+            if world > 1:
+                dout.mul_(1.0 / world)
+            arena.begin()
+            tr.backward(dout, arena=arena, overlap=True)
+            arena.finish()
+            arena.attach()
+        opt.step()
+        return loss
+    return step, arena
+
+
+def _allreduce_alone_ms(arena, dist_on):
+    """The gradient all-reduce by itself (not overlapped): what the step would pay if nothing hid it."""
+    if not dist_on:
+        return None
+    import torch.distributed as td
+    for _ in range(2):
+        td.all_reduce(arena.flat)
+    torch.cuda.synchronize()
+    td.barrier()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        td.all_reduce(arena.flat)
+    torch.cuda.synchronize()
+    return round((time.perf_counter() - t0) / 5 * 1e3, 3)
+
+
+def extra_finetune(dev, name, cfg, hw, batch, gflop_fwd, groups, world, dist_on, steps=8, warmup=2):
+    from active_learning.optim import AdamW
+    m = build_net(cfg, hw, dev).train()
+    lr = 2.5e-4                                              # al_simple_posetrack.yaml:62-69: lr x{10, 1, 5}, weight decay 0.7
+    opt = AdamW(params=[{"params": getattr(m, a).parameters(), "lr": lr * f} for a, f in groups], weight_decay=0.7)
+    g = torch.Generator(device=dev)
+    g.manual_seed(166 + int(os.environ.get("RANK", "0")))
+    x = torch.rand((batch, 3, hw[0], hw[1]), device=dev, generator=g) - 0.45
+    labels = torch.rand((batch, 17, hw[0] // 4, hw[1] // 4), device=dev, generator=g) * 0.1
+    masks = (torch.rand((batch, 17, 1, 1), device=dev, generator=g) > 0.2).float()
+    step, arena = finetune_step_fn(m, opt, x, labels, masks, world)
+    dt = _timed(step, steps, warmup, dist_on)
+    tf = 3 * gflop_fwd * 1e9 * batch / dt / 1e12              # fwd + dgrad + wgrad of every conv, per GPU
+    out = {"workload": name, "batch_per_gpu": batch, "ms_per_step": round(dt * 1e3, 3), "crops_per_s": round(batch * world / dt, 1),
+           "conv_tflops_per_gpu": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA, 4),
+           "grad_bytes": arena.total * 4, "allreduce_buckets": arena.launches if dist_on else 0,
+           "allreduce_alone_ms": _allreduce_alone_ms(arena, dist_on), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    del m, opt, step, arena, x, labels, masks
+    torch.cuda.empty_cache()
+    return out
+
+
+def extra_hrnet_shard(dev, world, rank, dist_on, steps=3, warmup=1):
+    """configs[3]: HRNet-W32 inference + THC-L1 + WPU on this rank's 1024-frame shard of an id-sorted 1024 x N stream: interior
+    shard edges recompute one halo frame (no heat-map exchange), the result rows are all-gathered."""
+    import torch.distributed as td
+    from active_learning.scoring import score_batch
+    from active_learning.Whole_body_AE.AutoEncoder import WholeBodyAE
+    from alphapose.models import hip_engine
+    m = build_net(HRNET_W32, (256, 192), dev).eval()
+    ae = WholeBodyAE(z_dim=4, kp_direct=False, input_dim=42).to(dev)
+    flat = ae.packed()
+    front, back = int(rank > 0), int(rank < world - 1)
+    n = FRAMES + front + back
+    g = torch.Generator(device=dev)
+    g.manual_seed(1660 + rank)
+    x = torch.rand((n, 3, 256, 192), device=dev, generator=g) - torch.tensor([0.406, 0.457, 0.480], device=dev).view(1, 3, 1, 1)
+    w = 60 + 180 * torch.rand(n, device=dev, generator=g)
+    bbox = torch.stack([torch.full_like(w, 100.0), torch.full_like(w, 50.0), 100 + w, 50 + w * 4 / 3], 1).contiguous()
+    pos = (torch.arange(n, device=dev) - front) % (FRAMES // TRACKS)
+    ip, inx = (pos != 0).to(torch.uint8), (pos != FRAMES // TRACKS - 1).to(torch.uint8)
+    hm = torch.empty((n, 17, 64, 48), device=dev)
+    backend_nccl = dist_on and td.get_backend() == "nccl"
+
+    def run():
+        with torch.no_grad():
+            hip_engine.forward_into(m, x, hm)
+            s = score_batch(hm, bbox, ip, inx, thc_norm="L1", ae_flat=flat, ae_dims=(42, 4))
+            if dist_on:
+                row = torch.cat([s.keypoints.reshape(n, -1), s.thc[:, None], s.wpu[:, None], s.localpeak[:, None]], 1)[front:n - back].contiguous()
+                if not backend_nccl:
+                    row = row.cpu()
+                out = [torch.empty_like(row) for _ in range(world)]
+                td.all_gather(out, row)
+        return s
+
+    dt = _timed(run, steps, warmup, dist_on)
+    tf = GFLOP_FWD["hrnet_w32"] * 1e9 * n / dt / 1e12
+    out = {"workload": "HRNet-W32 256x192 inference + decode + local-peak + THC-L1 + WPU (AE 42-d, z=4), 1024-frame shard per GPU + halo",
+           "frames_per_gpu": FRAMES, "halo_frames": front + back, "ms_per_pass": round(dt * 1e3, 3), "frames_per_s": round(FRAMES * world / dt, 1),
+           "conv_tflops_per_gpu": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA, 4)}
+    del m, x, hm
+    torch.cuda.empty_cache()
+    return out
+
+
+def extra_configs(dev, world, rank, dist_on):
+    """Every rank runs these (the collectives inside need all of them); rank 0 reports."""
+    out = {}
+    out["cfg3_simplepose_r50_finetune"] = extra_finetune(
+        dev, "SimpleBaseline-R50 256x192 fine-tune step: train-mode fwd + masked MSE + bwd + AdamW(3 groups), data-parallel", SIMPLE_R50,
+        (256, 192), 120, GFLOP_FWD["simplepose_r50"], (("final_layer", 10), ("preact", 1), ("deconv_layers", 5)), world, dist_on)
+    out["cfg4_hrnet_w32_thc_wpu"] = extra_hrnet_shard(dev, world, rank, dist_on)
+    out["cfg5_fastpose_r152_384_finetune"] = extra_finetune(
+        dev, "FastPose-R152 384x288 fine-tune step: train-mode fwd + masked MSE + bwd + AdamW(4 groups), data-parallel", FAST_R152,
+        (384, 288), 32, GFLOP_FWD["fastpose_r152_384"], (("conv_out", 10), ("preact", 1), ("duc1", 5), ("duc2", 5)), world, dist_on, steps=5)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launch
+# ---------------------------------------------------------------------------------------------------------------------
+
+def launch_ranks(n: int) -> int:
+    """`bench.py --gpus N` run bare: start N fresh rank processes of this script (nothing in this process has touched a GPU:
+    importing torch and counting devices do not), relay rank 0's JSON line, fail if any rank fails."""
+    backend = os.environ.get("VATL_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < n:
+        print(f"bench.py --gpus {n}: only {ndev} GPU(s) visible (RCCL needs one device per rank)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad:                                             # one rank died: the others would wait in a collective forever
+            rc = bad[0].returncode or 1
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    reader.join(timeout=10)
+    for line in lines:
+        sys.stdout.write(line)
+    sys.stdout.flush()
+    if rc == 0 and not any(l.startswith("{") for l in lines):
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[2..4] measurements (headline line only)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run bare and let --gpus start them)")
     dist = world > 1
     ndev = torch.cuda.device_count()
     local = local % max(ndev, 1)                        # (a 1-GPU box can host a 2-rank smoke run: VATL_DIST_BACKEND=gloo)
@@ -200,15 +425,17 @@ def main():
     model = build_model(dev)
     x, bbox, is_prev, is_next = make_video(dev, 166 + rank)
     hm_buf = torch.empty((FRAMES, 17, 64, 48), device=dev)
+    gathered = torch.empty((world * FRAMES, 71), device=dev) if dist and backend == "nccl" else None
 
     def step():
         s = one_step(model, x, bbox, is_prev, is_next, hm_buf)
         if dist:                                        # the only exchange: ~290 B of results per item
             row = torch.cat([s.keypoints.reshape(FRAMES, -1), s.argmax.float(), s.hp[:, None], s.thc[:, None], s.localpeak[:, None]], 1).contiguous()
-            if backend != "nccl":                       # gloo smoke runs: all_gather is host-only there
+            if gathered is not None:
+                td.all_gather_into_tensor(gathered, row)
+            else:                                       # gloo smoke runs: all_gather is host-only there
                 row = row.cpu()
-            out = [torch.empty_like(row) for _ in range(world)]
-            td.all_gather(out, row)
+                td.all_gather([torch.empty_like(row) for _ in range(world)], row)
         return s
 
     for _ in range(a.warmup):
@@ -229,6 +456,13 @@ def main():
         dt = float(t.item())
 
     roof = conv_roofline(model, x, bbox, is_prev, is_next, hm_buf) if rank == 0 else None
+    del model, x, hm_buf
+    torch.cuda.empty_cache()
+    extra = None
+    if not a.no_extra:
+        if dist:
+            td.barrier()
+        extra = extra_configs(dev, world, rank, dist)
     if rank == 0:
         line = {
             "metric": "frames/sec pose-infer+uncertainty, 256x192 17-kp", "value": round(a.steps * FRAMES * world / dt, 1),
@@ -238,6 +472,8 @@ def main():
                        "frames_per_gpu": FRAMES, "batch": BATCH, "tracks": TRACKS, "parallelism": f"frame-sharded x{world}"},
             "roofline": roof,
         }
+        if extra is not None:
+            line["extra"] = extra
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

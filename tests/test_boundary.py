@@ -229,3 +229,145 @@ def test_image_datasets_registered_and_parse_coco_json(tmp_path):
     assert len(ds) == 30 and ds._labels[0]["bbox"] == (4.0, 5.0, 33.0, 39.0) and not ds.ID_SORTED_STREAM
     assert ds._items[3]["path"].endswith(os.path.join("val2017", "000000000004.png"))
     assert builder.DATASET.get("Mpii").num_joints == 16 and len(builder.DATASET.get("Mpii").joint_pairs) == 6
+
+
+def test_uncertainty_option_strings_follow_the_reference_dispatch():
+    """Run_active_learning.py:57 documents `HP, TPC, THC_L1, WPU_hybrid`; the reference matches by substring
+    (ActiveLearning.py:345, 364, 371) and pairs THC with WPU only under the exact name (:403, :494)."""
+    from active_learning.ActiveLearning import uncertainty_kind
+    want = {"None": "None", "HP": "HP", "TPC": "TPC", "MPE": "MPE", "Margin": "Margin", "Entropy": "Entropy",
+            "THC": "THC", "THC_L1": "THC", "THC_L2": "THC", "WPU": "WPU", "WPU_hybrid": "WPU", "WPU_raw": "WPU",
+            "THC+WPU": "THC+WPU", "THC_L1+WPU_hybrid": "THC"}
+    for name, kind in want.items():
+        assert uncertainty_kind(name) == kind, name
+    for bad in ("Nope", "VL4Pose", ""):
+        with pytest.raises(ValueError):
+            uncertainty_kind(bad)
+
+
+def _bare_al(query_ratio, n=40):
+    """An ActiveLearning object with the round state only (no GPU, no datasets): what outcome() works on."""
+    import types
+    from active_learning.ActiveLearning import ActiveLearning
+    from alphapose.utils.config import edict
+    al = object.__new__(ActiveLearning)
+    al._depth = 0
+    al.cfg = edict({"RETRAIN": {"BASE": 1, "ALPHA": 2}, "VAL": {"QUERY_RATIO": query_ratio}})
+    al.opt = types.SimpleNamespace()
+    al.query_ratio = list(query_ratio)
+    al.eval_len = n
+    al.query_sizes = [int(n * x) for x in query_ratio]
+    al.query_size = al.query_sizes[0]
+    al.round_cnt, al.is_early_stop, al.one_by_one, al.continual = 0, False, False, True
+    al.unlabeled_id, al.labeled_id, al.moks_queried = list(range(n)), [], 0.0
+    al.percentage, al.performance, al.performance_ann = [], [], []
+    al.ospa_list, al.ospa_list_ann, al.combine_weight, al.uncertainty_mean, al.moksQ_list = [], [], [], [], []
+    al.query_list_list, al.uncertainty_dict, al.influence_dict = {}, {}, {}
+    al.spearmanr_list, al.corr_list = [], []
+    al.true_labeled_dict, al.false_labeled_dict, al.true_unlabeled_dict, al.false_unlabeled_dict = {}, {}, {}, {}
+    al.actual_finish = al.finished_minerror = al.finished_oursc = 100
+    return al
+
+
+def test_outcome_pads_an_early_stopped_video_like_the_reference():
+    """ActiveLearning.py:168-178 + Run_active_learning.py:165-173, 211-244: replay do_al()'s loop with a stubbed evaluation that
+    stops early in round 1; every per-round list of the 20-tuple must have len(query_ratio)+1 entries, the percentage axis
+    must continue along the query schedule, and the un-clamped query sizes (:199-202) must be the reference's."""
+    ratio = [0.05, 0.1, 0.2, 0.3, 0.4, 1]
+    al = _bare_al(ratio)
+    trained, evals = [], []
+
+    def fake_eval():
+        k = len(evals)
+        evals.append(al.query_size)
+        q = al.unlabeled_id[:max(al.query_size, 0)]
+        al.percentage.append(len(al.labeled_id) / al.eval_len * 100)
+        al.performance.append({"AP": 0.1 * k}); al.performance_ann.append({"AP": 0.2 * k})
+        al.ospa_list.append(k); al.ospa_list_ann.append(10 + k); al.uncertainty_mean.append(1.0 / (k + 1))
+        al.combine_weight.append(0.5 + k); al.moksQ_list.append(0.9)
+        al.query_list_list[f"Round{al.round_cnt}"] = q
+        al.labeled_id = sorted(set(al.labeled_id) | set(q))
+        al.unlabeled_id = [i for i in al.unlabeled_id if i not in set(q)]
+        if k == 1:
+            al.is_early_stop, al.actual_finish = True, al.percentage[-1]
+    al.eval_and_query = fake_eval
+    al.retrain_model = lambda: trained.append(al.round_cnt)
+    result = None
+    for _ in range(20):                                              # do_al(): eval_and_query -> outcome until a result comes back
+        al.eval_and_query()
+        result = al.outcome()
+        if result is not None:
+            break
+    assert result is not None and len(result) == 20
+    assert trained == [0] and len(evals) == 2                        # one fine-tune, then the early stop ends the video
+    assert evals == [2, 4 - 2]                                       # int(40*0.05), then query_sizes[1] - len(labeled) (un-clamped)
+    full = len(ratio) + 1
+    for idx in (0, 1, 2, 5, 7, 17, 18, 19):                          # percentages, performances(_ann), mean uncertainty, combine weight, ospa(_ann), moks
+        assert len(result[idx]) == full, (idx, len(result[idx]))
+    assert result[0] == [0.0, 5.0] + [r * 100 for r in ratio[1:]]    # the evaluated points, then query_ratio[round_cnt - 1] * 100
+    assert result[1][2:] == [result[1][1]] * (full - 2) and result[18][2:] == [11] * (full - 2)
+    assert result[14] == 5.0 and al.round_cnt == len(ratio)          # actual_finish; the padding loop advances round_cnt
+    # save_result reads exactly these 20 positions (Run_active_learning.py:214-237)
+    keys = dict(percentages=0, performances=1, performances_ann=2, query_list=3, uncertaity=4, mean_uncertaity=5, influence=6, combine_weight=7,
+                spearmanr=8, corrcoef=9, true_labeled=10, true_unlabeled=11, false_labeled=12, false_unlabeled=13, actual_finish=14,
+                finished_minerror=15, finished_oursc=16, ospa=17, ospa_ann=18, moks_queried=19)
+    import json
+    json.dumps({k: result[i] for k, i in keys.items()})              # serialisable, like result.json
+
+
+def test_outcome_round_schedule_without_early_stop():
+    ratio = [0.25, 0.5, 1.0]
+    al = _bare_al(ratio, n=24)
+    sizes = []
+
+    def fake_eval():
+        sizes.append(al.query_size)
+        q = al.unlabeled_id[:al.query_size]
+        al.labeled_id = sorted(set(al.labeled_id) | set(q))
+        al.unlabeled_id = [i for i in al.unlabeled_id if i not in set(q)]
+        for lst in (al.percentage, al.performance, al.performance_ann, al.ospa_list, al.ospa_list_ann, al.uncertainty_mean, al.combine_weight, al.moksQ_list):
+            lst.append(len(al.labeled_id))
+    al.eval_and_query = fake_eval
+    al.retrain_model = lambda: None
+    result = None
+    while result is None:
+        al.eval_and_query()
+        result = al.outcome()
+    assert sizes == [6, 6, 12, 12]                                   # query_sizes[k] - labeled; then the final evaluation of the fully labeled video
+    assert len(result[1]) == len(ratio) + 1 and result[1][-1] == 24
+
+    one = _bare_al(ratio, n=24)
+    one.one_by_one = True
+    one.eval_and_query = lambda: [lst.append(0) for lst in (one.percentage, one.performance, one.performance_ann, one.ospa_list, one.ospa_list_ann,
+                                                            one.uncertainty_mean, one.combine_weight, one.moksQ_list)]
+    one.eval_and_query()
+    res = one.outcome()                                              # --onebyone: a single evaluation, padded to the full axis
+    assert res is not None and len(res[1]) == len(ratio) + 1 and res[0] == [0, 25.0, 50.0, 100.0]
+
+
+def test_host_augmentation_arithmetic_matches_reference_fixture():
+    """tests/golden/hostaug.npz = the reference's SimpleTransform.half_body_transform / _integral_target_generator on seeded
+    joints: same boxes, same number of random draws, same targets and weights (bit for bit: it is float32 numpy on the host)."""
+    import os
+    from tests.conftest import GOLDEN
+    from alphapose.utils.presets.simple_transform import SimpleTransform
+
+    class DS:
+        joint_pairs = [[1, 2]]
+        num_joints_half_body, prob_half_body = 8, 0.3
+        upper_body_ids, lower_body_ids = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10), (11, 12, 13, 14, 15, 16)
+    g = np.load(os.path.join(GOLDEN, "hostaug.npz"))
+    st = SimpleTransform(DS, scale_factor=0.3, add_dpg=False, input_size=[256, 192], output_size=[64, 48], rot=40, sigma=2, train=True)
+    st.num_joints = 17
+    assert g["hb_ok"].sum() > 20 and (~g["hb_ok"]).sum() > 3
+    for i in range(len(g["hb_ok"])):
+        np.random.seed(1000 + i)
+        c, s = st.half_body_transform(g["hb_joints"][i], g["hb_vis"][i])
+        assert np.random.rand() == g["hb_next_draw"][i]                          # exactly one draw consumed
+        if not g["hb_ok"][i]:
+            assert c is None and s is None
+        else:
+            assert np.array_equal(c, g["hb_center"][i]) and np.array_equal(s, g["hb_scale"][i]) and s.dtype == np.float32
+    for nj in (17, 136, 133, 68):
+        t, w = st._integral_target_generator(g[f"int{nj}_joints"], nj, 256, 192)
+        assert np.array_equal(t, g[f"int{nj}_target"]) and np.array_equal(w, g[f"int{nj}_weight"]) and t.dtype == w.dtype == np.float32

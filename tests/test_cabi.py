@@ -79,3 +79,16 @@ def test_cpu_tensors_are_refused(built_lib):
     import torch
     with pytest.raises(built_lib.VatlError):
         built_lib.decode(torch.zeros(1, 17, 64, 48), torch.zeros(1, 4))
+
+
+def test_product_library_has_no_wrong_result_ablations(monkeypatch):
+    """The profiling ablations (schedule variants 10..13, "no epilogue" / "one k-tile") compute wrong results by construction:
+    the shipped library does not contain them — even with VATL_ALLOW_ABLATION=1 the knobs are refused (they exist only in the
+    -DVATL_ABLATION variant, build.py --ablation)."""
+    import vatl_hip as vh
+    monkeypatch.setenv("VATL_ALLOW_ABLATION", "1")
+    lib = vh.lib()
+    for knob, value in ((0, 10), (0, 11), (0, 12), (0, 13), (4, 1), (6, 1), (6, 2)):
+        assert lib.vatl_tune_set(knob, value) != 0
+        assert b"VATL_ABLATION" in lib.vatl_last_error()
+    assert lib.vatl_tune_set(0, 4) == 0 and lib.vatl_tune_set(6, 0) == 0 and lib.vatl_tune_set(4, 0) == 0

@@ -41,8 +41,9 @@ def _worker(rank, world, port, n, q):
     bb = synth.bboxes(n, seed=3)
     is_prev, is_next = synth.video_flags(n, 2)
     got = D.sharded_rows(n, lambda lo, hi: torch.from_numpy(_rows(hm, bb, is_prev, is_next, lo, hi)), 53, torch.device("cpu"))
-    g = [torch.ones(5) * (rank + 1), torch.ones(3) * 10 * (rank + 1)]
-    D.allreduce_mean_(g)
+    flat = torch.cat([torch.ones(5) * (rank + 1), torch.ones(3) * 10 * (rank + 1)]) / world      # each rank's share, pre-scaled
+    D.allreduce_sum_(flat)
+    g = [flat[:5], flat[5:]]
     bn = torch.nn.BatchNorm2d(4)                                   # per-rank running statistics -> rank 0's survive
     bn.running_mean.fill_(float(rank + 1)); bn.running_var.fill_(float(10 * (rank + 1)))
     D.broadcast_buffers_(bn)
@@ -80,3 +81,163 @@ def test_sharded_stream_equals_single_process_world2():
     want = _rows(hm, bb, is_prev, is_next, 0, n)
     np.testing.assert_array_equal(got, want)     # the halo makes the shard boundary invisible, bit for bit
     np.testing.assert_allclose(grads[0], 1.5) ; np.testing.assert_allclose(grads[1], 15.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2: DataParallel chunking, the flat gradient arena, process-group bring-up and the worker processes
+# ---------------------------------------------------------------------------------------------------------------------
+
+def test_chunk_bounds_are_tensor_chunk_cuts():
+    """nn.DataParallel scatters a mini-batch with Tensor.chunk: the fine-tune step must cut it the same way."""
+    from active_learning import distributed as D
+    for n in (1, 3, 10, 17, 119, 120, 960, 961):
+        for rep in (1, 2, 4, 8):
+            want = [t.shape[0] for t in torch.arange(n).chunk(rep)]
+            got = D.chunk_bounds(n, rep)
+            assert [h - l for l, h in got] == want and got[0][0] == 0 and got[-1][1] == n
+    assert D.chunk_bounds(0, 8) == []
+
+
+def _arena_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "vatl4pose-wacv2024_amd")]
+    import torch.distributed as dist
+    from active_learning import distributed as D
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    params = _arena_params()
+    arena = D.GradArena(params, bucket_bytes=4 * 100)          # small buckets: several async all-reduces per step
+    for step in range(2):                                      # the arena is reused step after step
+        arena.begin()
+        filled = 0
+        for p in reversed(params):                             # the backward pass fills the arena from the top down
+            arena.view(p).copy_(_rank_grad(p, rank, step))
+            filled += p.numel()
+            arena.done_offset(arena.total - filled)
+        arena.finish()
+        arena.attach()
+        if rank == 0:
+            q.put((step, arena.launches, [p.grad.clone().numpy() for p in params], all(p.grad.data_ptr() == arena.view(p).data_ptr() for p in params)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _arena_params():
+    g = torch.Generator().manual_seed(5)
+    return [torch.nn.Parameter(torch.randn(s, generator=g)) for s in ((64, 3, 7, 7), (64,), (64,), (17, 256, 1, 1), (17,), (300,), (1,))]
+
+
+def _rank_grad(p, rank, step):
+    g = torch.Generator().manual_seed(1000 * step + 10 * rank + p.numel() % 7)
+    return torch.randn(p.shape, generator=g)
+
+
+def test_grad_arena_bucketed_allreduce_equals_single_process_sum_world2():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_arena_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    params = _arena_params()
+    for step, launches, grads, views in sorted(got, key=lambda t: t[0]):
+        assert launches >= 3 and views                         # bucketed, and p.grad IS the arena slice (no copy back)
+        for p, g in zip(params, grads):
+            want = (_rank_grad(p, 0, step) + _rank_grad(p, 1, step)).numpy()      # what one process holding both shares computes
+            np.testing.assert_array_equal(g, want)
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vatl4pose-wacv2024_amd", "active_learning", "distributed.py")).read()
+    assert "torch.cat" not in src                              # the gradient path has no concatenate / copy-back passes
+
+
+def test_grad_arena_single_process_is_a_plain_buffer():
+    from active_learning import distributed as D
+    params = _arena_params()
+    arena = D.GradArena(params)
+    assert arena.total == sum(p.numel() for p in params) and arena.flat.numel() == arena.total
+    arena.begin()
+    arena.view(params[3]).fill_(2.0)
+    arena.done_offset(0)
+    arena.finish()
+    arena.attach()
+    assert arena.launches == 0 and float(params[3].grad.sum()) == 2.0 * params[3].numel()
+    off = arena.offset[params[3]]
+    assert float(arena.flat[off:off + params[3].numel()].sum()) == 2.0 * params[3].numel() and float(arena.flat.sum()) == 2.0 * params[3].numel()
+
+
+def _run_driver(tmp_path, script, extra_env=None, timeout=180):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VATL_DIST_BACKEND="gloo", PYTHONPATH=os.pathsep.join([root, os.path.join(root, "vatl4pose-wacv2024_amd")]))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    path = tmp_path / "driver.py"
+    path.write_text(script)
+    return subprocess.run([sys.executable, str(path)], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_single_process_driver_gets_worker_ranks(tmp_path):
+    """The unchanged driver is ONE process with opt.num_gpu = N: constructing the AL object must bring up N ranks (fresh child
+    processes), every public call must run on all of them in lock-step (announced once, by the outermost call), and the workers
+    must leave when the driver does."""
+    import json
+    script = f'''
+import json, sys
+from tests.dist_stub import StubAL
+from active_learning import distributed as D
+al = StubAL({{"token": 42}}, {{"num_gpu": 2, "dir": {str(tmp_path)!r}}})
+assert al.world == 2 and D.have_workers()
+al.eval_and_query()
+al.outcome()
+al2 = StubAL({{"token": 7}}, {{"num_gpu": 2, "dir": {str(tmp_path)!r}}})       # a second object reuses the same workers
+al2.retrain_model()
+print("driver done")
+'''
+    out = _run_driver(tmp_path, script, {"VATL_WORKER_CLASS": "tests.dist_stub:StubAL"})
+    assert out.returncode == 0 and "driver done" in out.stdout, out.stderr[-3000:]
+    for r in (0, 1):
+        rows = [json.loads(l) for l in open(tmp_path / f"rank{r}.jsonl")]
+        assert [x["call"] for x in rows] == ["eval_and_query", "retrain_model", "outcome", "retrain_model"], rows
+        assert rows[0]["value"] == 3.0 and rows[0]["world"] == 2            # the all-reduce saw both ranks
+        assert rows[1]["value"] == 42 and rows[3]["value"] == 7             # rank 0's objects reached the worker
+
+
+def test_spawn_can_be_switched_off_and_torchrun_env_is_joined(tmp_path):
+    script = f'''
+from tests.dist_stub import StubAL
+from active_learning import distributed as D
+al = StubAL({{"token": 1}}, {{"num_gpu": 4, "dir": {str(tmp_path)!r}}})
+assert al.world == 1 and not D.have_workers()
+al.eval_and_query()
+print("solo ok")
+'''
+    out = _run_driver(tmp_path, script, {"VATL_SPAWN": "0"})
+    assert out.returncode == 0 and "solo ok" in out.stdout, out.stderr[-3000:]
+    # torchrun-style: two ranks both run the driver script, the constructor joins the rendezvous from the environment
+    import subprocess
+    import sys
+    script2 = f'''
+from tests.dist_stub import StubAL
+from active_learning import distributed as D
+al = StubAL({{"token": 5}}, {{"num_gpu": 1, "dir": {str(tmp_path / "tr")!r}}})
+assert al.world == 2 and not D.have_workers()
+al.eval_and_query()
+'''
+    os.makedirs(tmp_path / "tr")
+    (tmp_path / "d2.py").write_text(script2)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, VATL_DIST_BACKEND="gloo", PYTHONPATH=os.pathsep.join([root, os.path.join(root, "vatl4pose-wacv2024_amd")]),
+                   RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(tmp_path / "d2.py")], env=env))
+    assert [p.wait(timeout=180) for p in procs] == [0, 0]
+    import json
+    for r in (0, 1):
+        assert json.loads(open(tmp_path / "tr" / f"rank{r}.jsonl").readline())["value"] == 3.0

@@ -24,6 +24,14 @@ def test_bench_prints_one_contract_line():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert 0.5 < r["frac"] < 1.0 and d["value"] > 5000
+    ex = d["extra"]                                                     # configs[2..4] measured in the same run
+    assert set(ex) == {"cfg3_simplepose_r50_finetune", "cfg4_hrnet_w32_thc_wpu", "cfg5_fastpose_r152_384_finetune"}
+    for k in ("cfg3_simplepose_r50_finetune", "cfg5_fastpose_r152_384_finetune"):
+        e = ex[k]
+        assert e["ms_per_step"] > 0 and 0.2 < e["frac_of_fp32_mfma_peak"] < 1.0 and e["allreduce_alone_ms"] is None and e["allreduce_buckets"] == 0
+        assert abs(e["crops_per_s"] - e["batch_per_gpu"] * 1000.0 / e["ms_per_step"]) / e["crops_per_s"] < 0.01
+    assert 130e6 < ex["cfg3_simplepose_r50_finetune"]["grad_bytes"] < 140e6 and 295e6 < ex["cfg5_fastpose_r152_384_finetune"]["grad_bytes"] < 305e6
+    assert ex["cfg4_hrnet_w32_thc_wpu"]["frames_per_s"] > 3000 and ex["cfg4_hrnet_w32_thc_wpu"]["halo_frames"] == 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     # whole-job rate is consistent with the step time
@@ -40,7 +48,7 @@ def test_bench_two_ranks_launch_contract():
         port = s.getsockname()[1]
     env = dict(os.environ, VATL_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extra"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -49,3 +57,24 @@ def test_bench_two_ranks_launch_contract():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma"
     assert abs(d["value"] - 2 * 1024 * 1000.0 / d["ms_per_step"]) / d["value"] < 0.01
     assert d["config"]["parallelism"] == "frame-sharded x2"
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` run bare (how the driver calls it): the script itself must start two ranks as fresh child
+    processes and relay rank 0's line; the data-parallel fine-tune configurations run with the gradient arena all-reduced
+    across the ranks (gloo here: two ranks share the box's one GPU, RCCL needs a device per rank)."""
+    env = dict(os.environ, VATL_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], capture_output=True, text=True,
+                         timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "frame-sharded x2" and "cpu_baseline" not in d
+    ex = d["extra"]
+    for k in ("cfg3_simplepose_r50_finetune", "cfg5_fastpose_r152_384_finetune"):
+        assert ex[k]["allreduce_buckets"] >= 2 and ex[k]["allreduce_alone_ms"] > 0      # bucketed, overlapped with the backward pass
+        assert abs(ex[k]["crops_per_s"] - 2 * ex[k]["batch_per_gpu"] * 1000.0 / ex[k]["ms_per_step"]) / ex[k]["crops_per_s"] < 0.01
+    assert ex["cfg4_hrnet_w32_thc_wpu"]["halo_frames"] == 1                              # rank 0 of 2: one interior edge

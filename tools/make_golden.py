@@ -542,6 +542,34 @@ def gen_crop(out: str):
     np.savez_compressed(os.path.join(out, "crop.npz"), **res)
 
 
+def gen_hostaug(out: str):
+    """Host-side augmentation arithmetic of the reference's SimpleTransform, called unbound on seeded joints:
+    half_body_transform (simple_transform.py:253-304, one np.random.randn() draw each) and _integral_target_generator
+    (:160-177, incl. the doubled leading weights of the 136 / 133 / 68-joint layouts)."""
+    from alphapose.utils.presets.simple_transform import SimpleTransform          # the reference's
+    r = np.random.RandomState(77)
+    me = types.SimpleNamespace(num_joints=17, upper_body_ids=(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10), lower_body_ids=(11, 12, 13, 14, 15, 16),
+                               _aspect_ratio=192.0 / 256, pixel_std=1)
+    n = 64
+    joints = (r.rand(n, 17, 3) * 300).astype(np.float32)
+    vis = (r.rand(n, 17, 1) > r.rand(n, 1, 1)).astype(np.float32)
+    centers, scales, ok, after = np.zeros((n, 2), np.float32), np.zeros((n, 2), np.float32), np.zeros(n, bool), np.zeros(n)
+    for i in range(n):
+        np.random.seed(1000 + i)
+        c, s = SimpleTransform.half_body_transform(me, joints[i], vis[i])
+        after[i] = np.random.rand()                                              # the next value of the stream: pins the number of draws
+        if c is not None:
+            ok[i], centers[i], scales[i] = True, c, s
+    res = {"hb_joints": joints, "hb_vis": vis, "hb_ok": ok, "hb_center": centers, "hb_scale": scales, "hb_next_draw": after}
+    for nj in (17, 136, 133, 68):
+        j3 = (r.rand(nj, 3, 2) * 250).astype(np.float32)
+        j3[:, 0, 1] = j3[:, 1, 1] = (r.rand(nj) > 0.3)
+        t, w = SimpleTransform._integral_target_generator(me, j3, nj, 256, 192)
+        res[f"int{nj}_joints"], res[f"int{nj}_target"], res[f"int{nj}_weight"] = j3, t, w
+    print("hostaug", int(ok.sum()), "of", n, "half-body crops;", float(scales.sum()))
+    np.savez_compressed(os.path.join(out, "hostaug.npz"), **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -564,6 +592,8 @@ def main():
         gen_l1_loss(a.out)
     if a.only in ("", "crop"):
         gen_crop(a.out)
+    if a.only in ("", "hostaug"):
+        gen_hostaug(a.out)
     if a.only in ("", "r152"):
         gen_fastpose_r152(EasyDict, a.out)
 

@@ -8,12 +8,20 @@ Same entry points as the reference class — ``ActiveLearning(cfg, opt)``, ``eva
   ``score_batch`` launch sequence per batch instead of a per-item Python loop with D2H copies.
 * ``retrain_model`` (:651-686): train-mode forward, fused masked-MSE loss+gradient, HIP backward, AdamW.
 
-In scope: uncertainty None | HP | TPC | THC_L1 | THC_L2 | WPU | THC+WPU | MPE | Margin | Entropy; representativeness
-None | Influence | Random; filter None | Random | Diversity | Coreset (device kernels, active_learning/query.py) and
-weighted | K-Means (sklearn on the host, exactly like the reference).  COCO mAP / OSPA evaluation, plots and the dead
-VL4Pose branch stay out.
+In scope: uncertainty None | HP | TPC | THC* (THC_L1, THC_L2, ...: always the L1 norm, ActiveLearning.py:346) | *WPU* (WPU,
+WPU_hybrid, WPU_raw: the reference matches these by substring, :371, and always takes the hybrid feature, :372) | THC+WPU |
+MPE | Margin | Entropy; representativeness None | Influence | Random; filter None | Random | Diversity | Coreset (device
+kernels, active_learning/query.py) and weighted | K-Means (sklearn on the host, exactly like the reference).  COCO mAP /
+OSPA evaluation, plots and the dead VL4Pose branch stay out.
+
+Multi-GPU: one process per GPU (active_learning/distributed.py).  Under torchrun every rank runs the driver; as one plain
+process on an N-GPU node (``opt.num_gpu`` = N, Run_active_learning.py:92-94) the constructor starts N-1 worker processes
+that mirror every public call — the replacement for the reference's ``nn.DataParallel`` (ActiveLearning.py:233).
 """
 from __future__ import annotations
+
+import functools
+import os
 
 import numpy as np
 import torch
@@ -29,7 +37,37 @@ from .al_metric import compute_OKS_batch
 from .optim import SGD, Adam, AdamW
 from .scoring import multi_peak_scores, score_batch
 
-_UNC = ("None", "HP", "TPC", "THC_L1", "THC_L2", "THC", "WPU", "THC+WPU", "MPE", "Margin", "Entropy")
+
+def uncertainty_kind(name: str) -> str:
+    """The branch of the reference's per-item dispatch (ActiveLearning.py:329-401) an ``--uncertainty`` string takes.
+    Exact names first, then the substring tests in the reference's order: anything containing "THC" is THC with the L1 norm
+    (:345-346) — paired with WPU only under the exact name "THC+WPU" (:403, :494) — and anything else containing "WPU"
+    ("WPU", "WPU_hybrid", "WPU_raw": backrun_active_learning.sh:6) is the hybrid-feature WPU (:371-386)."""
+    if name in ("None", "HP", "TPC", "MPE", "Margin", "Entropy"):
+        return name
+    if name == "VL4Pose":
+        raise ValueError("Uncertainty type is not supported")          # dead branch in the reference (SURVEY.md §9 item 8)
+    if "THC" in name:
+        return "THC+WPU" if name == "THC+WPU" else "THC"
+    if "WPU" in name:
+        return "WPU"
+    raise ValueError("Uncertainty type is not supported")
+
+
+def _collective(fn):
+    """Public entry points run on every rank in lock-step.  On the driver process that owns worker processes, the outermost
+    call is announced to them first (active_learning/worker.py); under torchrun every rank calls the method itself."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        from . import distributed as D
+        if self._depth == 0 and D.have_workers():
+            D.command("call", fn.__name__)
+        self._depth += 1
+        try:
+            return fn(self, *a, **k)
+        finally:
+            self._depth -= 1
+    return wrapper
 
 
 class ActiveLearning:
@@ -41,9 +79,8 @@ class ActiveLearning:
         self.filter = getattr(opt, "filter", "None")
         self.strategy = getattr(opt, "strategy", self.uncertainty)
         self.video_id = getattr(opt, "video_id", "synthetic")
-        self.get_prenext = bool(getattr(opt, "get_prenext", "THC" in self.uncertainty or self.uncertainty == "TPC"))
-        if self.uncertainty not in _UNC:
-            raise ValueError("Uncertainty type is not supported")
+        self.get_prenext = bool(getattr(opt, "get_prenext", "THC" in self.uncertainty or "TPC" in self.uncertainty))
+        self.unc_kind = uncertainty_kind(self.uncertainty)
         if self.representativeness not in ("None", "Influence", "Random"):
             raise ValueError("Representativeness type is not supported")
         if self.filter not in ("None", "Random", "Diversity", "Coreset", "weighted", "K-Means"):
@@ -53,8 +90,19 @@ class ActiveLearning:
         self.w_unc = float(cfg.VAL.get("W_UNC", 1.0))
         self.unc_lambda = float(cfg.VAL.get("UNC_LAMBDA", 1.0))
         self.finish_margin = 0.05
-        self.device = torch.device("cuda", torch.cuda.current_device())
+        # one process per GPU: join the torchrun group, or (plain single process, opt.num_gpu > 1) start the worker ranks
+        from . import distributed as D
+        self._depth = 0
         ngpu = max(1, int(getattr(opt, "num_gpu", 1)))
+        world = D.ensure_workers(ngpu)
+        if D.have_workers() and D.is_main():
+            payload = {k: v for k, v in (("eval_dataset", eval_dataset), ("train_dataset", train_dataset)) if v is not None}
+            D.command("new", cfg, opt, D.dump_payload(payload) if payload else "")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        # the reference's DataParallel scatters every mini-batch over opt.num_gpu replicas (:233); `replicas` keeps that
+        # partition (and with it the per-replica BatchNorm statistics) whatever the number of processes actually running
+        self.replicas = max(ngpu, world)
+        per_rank = max(1, self.replicas // world)
 
         self.eval_dataset = eval_dataset if eval_dataset is not None else builder.build_dataset(
             cfg.DATASET.EVAL, preset_cfg=cfg.DATA_PRESET, train=False, get_prenext=self.get_prenext)
@@ -64,14 +112,16 @@ class ActiveLearning:
         workers = int(getattr(opt, "num_workers", 0))
         if getattr(self.eval_dataset, "DEVICE_ITEMS", False):
             workers = 0                                    # items are made on the device by this process: no worker processes
-        self.eval_loader = DataLoader(self.eval_dataset, batch_size=cfg.VAL.BATCH_SIZE * ngpu, shuffle=False, num_workers=workers,
+        self.eval_loader = DataLoader(self.eval_dataset, batch_size=cfg.VAL.BATCH_SIZE * per_rank, shuffle=False, num_workers=workers,
                                       drop_last=False, pin_memory=not getattr(self.eval_dataset, "DEVICE_ITEMS", False), collate_fn=self.collate_fn)
         self.eval_len = len(self.eval_dataset)
         self.dedup = bool(getattr(self.eval_dataset, "ID_SORTED_STREAM", False))
+        if self.dedup and hasattr(self.eval_dataset, "emit_neighbour_crops"):
+            self.eval_dataset.emit_neighbour_crops = False     # the neighbours' heat-maps come from the stream: no prev / next crops
 
         self.query_ratio = list(cfg.VAL.QUERY_RATIO)
         self.query_sizes = [int(self.eval_len * x) for x in self.query_ratio]
-        self.query_size = max(1, self.query_sizes[0])
+        self.query_size = self.query_sizes[0]
         self.unlabeled_id = list(range(self.eval_len))
         self.labeled_id = []
         self.retrain_id = []
@@ -84,6 +134,8 @@ class ActiveLearning:
         self.finish_acc = getattr(opt, "retrain_thresh", 1)
         self.is_early_stop = False
         self.one_by_one = bool(getattr(opt, "onebyone", False))
+        if self.one_by_one:
+            self.query_size = 3                            # ActiveLearning.py:117-118
         self.continual = bool(getattr(opt, "continual", True))
 
         self.retrain_epoch = cfg.RETRAIN.BASE
@@ -172,7 +224,7 @@ class ActiveLearning:
         ann_all = np.zeros((n, 4), np.float64)
         ids_all = np.zeros((n, 2), np.float64)                            # image id, annotation id (exact in float64)
         emb_all = torch.empty((n, self.emb_dim), device=self.device) if self.need_embedding else None
-        thc_norm = {"THC_L1": "L1", "THC": "L1", "THC+WPU": "L1", "THC_L2": "L2"}.get(self.uncertainty)
+        thc_norm = "L1" if self.unc_kind in ("THC", "THC+WPU") else None          # `norm_type = 'L1'` for every THC* (:346)
         loader = self.eval_loader if (lo == 0 and hi == self.eval_len) else DataLoader(
             Subset(self.eval_dataset, list(range(lo, hi))), batch_size=self.eval_loader.batch_size, shuffle=False, num_workers=0,
             collate_fn=self.collate_fn)
@@ -199,26 +251,26 @@ class ActiveLearning:
         ae_flat = self.AE.packed() if self.AE is not None else None
         s = score_batch(hm_all, bb_all, ip_all, in_all, thc_norm=thc_norm if self.dedup else None, ae_flat=ae_flat,
                         ae_dims=(self.AE.input_dim, self.AE.z_dim) if self.AE is not None else (42, 4),
-                        wpu_only38=(self.uncertainty == "WPU"))
+                        wpu_only38=(self.unc_kind == "WPU"))
         if thc_norm is not None and not self.dedup:
             s.thc = thc_ref
         unc = torch.zeros((n, 2), device=self.device)
-        if self.uncertainty == "HP":
+        if self.unc_kind == "HP":
             unc[:, 0] = s.hp
-        elif self.uncertainty == "TPC":
+        elif self.unc_kind == "TPC":
             if not self.dedup:
                 raise ValueError("TPC needs an id-sorted stream dataset in this build")
             unc[:, 0] = vh.tpc_stream(hm_all, bb_all, s.keypoints[:, :, :2].contiguous(), ip_all, in_all)
         elif thc_norm is not None:
             unc[:, 0] = s.thc
-            if self.uncertainty == "THC+WPU":
+            if self.unc_kind == "THC+WPU":
                 self._check_wpu(s.wpu_status)
                 unc[:, 1] = s.wpu
-        elif self.uncertainty == "WPU":
+        elif self.unc_kind == "WPU":
             self._check_wpu(s.wpu_status)
             unc[:, 0] = s.wpu
-        elif self.uncertainty in ("MPE", "Margin", "Entropy"):
-            unc[:, 0] = multi_peak_scores(hm_all, self.uncertainty).float()
+        elif self.unc_kind in ("MPE", "Margin", "Entropy"):
+            unc[:, 0] = multi_peak_scores(hm_all, self.unc_kind).float()
         kp = s.keypoints.reshape(n, -1)
         # compute_OKS on the device (al_metric.py:42-69): no D2H of the key-points inside the evaluation loop
         oks = vh.oks(s.keypoints.contiguous(), torch.as_tensor(gt_all, device=self.device), torch.as_tensor(ann_all, device=self.device))
@@ -229,6 +281,7 @@ class ActiveLearning:
             cols.append(emb_all)
         return torch.cat(cols, 1).contiguous()
 
+    @_collective
     def eval_and_query(self):
         from . import distributed as D
         from . import query as Q
@@ -284,7 +337,7 @@ class ActiveLearning:
         if nun > 0:
             combine_weight = float(np.sum(lp[un]) / nun)              # mean local-peak value of the unlabeled items (:411-414, 486-488)
             self.combine_weight.append(combine_weight)
-        self.uncertainty_dict[f"Round{self.round_cnt}"] = {int(i): (unc[i].tolist() if self.uncertainty == "THC+WPU" else float(unc[i, 0])) for i in range(n)}
+        self.uncertainty_dict[f"Round{self.round_cnt}"] = {int(i): (unc[i].tolist() if self.unc_kind == "THC+WPU" else float(unc[i, 0])) for i in range(n)}
 
         # ---- total score (:490-527)
         if nun in (0, 1):
@@ -336,6 +389,10 @@ class ActiveLearning:
                 if nun < self.query_size:
                     self.query_size = nun
                 query, _ = Q.kmeans_queries(emb, candidates, self.query_size)
+
+        # Random representativeness / Random filter / the first k-center pick draw from the process-local numpy RNG: every
+        # rank adopts rank 0's selection, or the ranks' labeled sets (and with them the fine-tune collectives) would diverge
+        query, self.query_size = D.broadcast_object(([int(q) for q in query], int(self.query_size)), src=0)
 
         # ---- book-keeping (:619-650)
         thr = self.finish_acc + self.finish_margin
@@ -453,7 +510,7 @@ class ActiveLearning:
             return (v - v.min()) / rng if rng > 0 else np.zeros_like(v)
         if len(u) < 2 or self.uncertainty == "None":
             return np.zeros(len(u))
-        if self.uncertainty == "THC+WPU":
+        if self.unc_kind == "THC+WPU":
             t, w = norm(u[:, 0]), norm(u[:, 1])
             mode = getattr(self.opt, "THCvsWPU", "const")
             r = len(self.labeled_id) / self.eval_len
@@ -462,54 +519,73 @@ class ActiveLearning:
         return norm(u[:, 0])
 
     # ------------------------------------------------------------------ hot loop 2
+    @_collective
     def retrain_model(self):
+        """ActiveLearning.py:651-686.  Data parallel like the reference's nn.DataParallel (:233, 667): every rank sees the same
+        shuffled mini-batches (shared seed); a mini-batch is cut into ``self.replicas`` DataParallel chunks (``Tensor.chunk``
+        sizes) and rank r takes chunks r, r + world, ... — one chunk per rank when there is a process per GPU.  Every chunk is a
+        forward/backward of its own (per-replica BatchNorm statistics, exactly DataParallel's), its loss gradient scaled by
+        the chunk's share of the mini-batch, so the SUM over chunks and ranks is the gradient of the mean loss over the whole
+        mini-batch (:669).  Gradients live in one flat arena that is all-reduced in place while the backward pass is still
+        running (active_learning/distributed.py: GradArena)."""
         from alphapose.models import hip_train
         from . import distributed as D
         loss_logger, acc_logger = DataLogger(), DataLogger()
         subset = Subset(self.train_dataset, self.retrain_id)
-        ngpu = max(1, int(getattr(self.opt, "num_gpu", 1)))
-        # Data parallel like the reference's nn.DataParallel (ActiveLearning.py:233, 667): every rank sees the same shuffled
-        # mini-batches (shared seed) and takes its contiguous slice; the slice gradients are weighted by slice size and
-        # all-reduced, which is the gradient of the mean loss over the whole mini-batch.  World size 1: the whole batch.
         world, rank = D.world_rank()
         gen = torch.Generator()
         gen.manual_seed(D.shared_seed())
-        loader = DataLoader(subset, batch_size=self.cfg.RETRAIN.BATCH_SIZE * ngpu, shuffle=True, num_workers=0, drop_last=False,
+        loader = DataLoader(subset, batch_size=self.cfg.RETRAIN.BATCH_SIZE * self.replicas, shuffle=True, num_workers=0, drop_last=False,
                             collate_fn=self.collate_fn, generator=gen)
         self.model.train()
         trainer = hip_train.trainer_for(self.model)
-        params = [p for p in self.model.parameters() if p.requires_grad]
+        arena = hip_train.arena_for(self.model)
         for _ in range(self.retrain_epoch):
             for (idxs, inps, labels, label_masks, *_rest) in loader:
                 nb = len(idxs)
-                lo, hi = D.shard_bounds(nb, rank, world)
-                if hi > lo:
+                mine = D.chunk_bounds(nb, self.replicas)[rank::world]
+                acc, kept = None, None
+                arena.begin()
+                if not mine:                                                           # fewer chunks than ranks: contribute zeros
+                    arena.flat.zero_()
+                for k, (lo, hi) in enumerate(mine):
                     x = inps[lo:hi, 0].to(self.device).float().contiguous()
                     lab, msk = labels[lo:hi].to(self.device).float().contiguous(), label_masks[lo:hi].to(self.device).float()
                     with torch.no_grad():
                         out = trainer.forward(x)
                         loss, dout = vh.masked_mse_fwd_bwd(out, lab, msk)              # 0.5 * MSE(out*m, label*m) and its gradient
-                        grads = trainer.backward(dout)
-                        if world > 1:
-                            for g in grads.values():
-                                g.mul_((hi - lo) * world / nb)
+                        if hi - lo != nb:
+                            dout.mul_((hi - lo) / nb)
+                        if len(mine) > 1 and k == 0:                                   # DataParallel keeps replica 0's BN statistics only
+                            kept = [b.clone() for b in self.model.buffers()]
+                        trainer.backward(dout, arena=arena, overlap=len(mine) == 1)
+                        if len(mine) > 1:                                              # several replicas walked on one GPU: accumulate
+                            acc = arena.flat.clone() if acc is None else acc.add_(arena.flat)
                     loss_logger.update(float(loss), hi - lo)
                     m = msk.reshape(msk.shape[0], -1, 1, 1)
                     acc_logger.update(calc_accuracy(out * m, lab * m), hi - lo)
-                else:                                                                  # fewer items than ranks: contribute zeros
-                    grads = {p: torch.zeros_like(p) for p in params}
-                glist = [grads[p] for p in params]
-                D.allreduce_mean_(glist)                   # one flat fp32 all-reduce per step (136 MB for SimplePose-R50)
-                for p, g in zip(params, glist):
-                    p.grad = g
+                if acc is not None:
+                    arena.flat.copy_(acc)
+                    with torch.no_grad():
+                        for b, kb in zip(self.model.buffers(), kept):
+                            b.copy_(kb)
+                arena.finish()
+                arena.attach()
                 self.optimizer.step()
             self.scheduler.step()
         D.broadcast_buffers_(self.model)           # BN statistics are per rank; rank 0's survive (DataParallel semantics, SURVEY.md §8e)
-        self.last_train_loss, self.last_train_acc = loss_logger.avg, acc_logger.avg
+        self.last_train_loss, self.last_train_acc = self._global_avg(loss_logger), self._global_avg(acc_logger)
         if "WPU" in self.uncertainty:              # ActiveLearning.py:680-684: a fresh AE is fine-tuned on the labeled poses
             self.AE = self.initialize_AE()
             self.last_ae_loss = self.retrain_AE()
             D.broadcast_module_(self.AE)           # the fit shuffles with the rank's own RNG: rank 0's AE is the one every shard scores with
+
+    def _global_avg(self, logger):
+        """Item-weighted average of a DataLogger over all ranks (the reference logs the loss of the gathered mini-batch)."""
+        from . import distributed as D
+        t = torch.tensor([logger.sum, logger.cnt], dtype=torch.float64, device=self.device)
+        D.allreduce_sum_(t)
+        return float(t[0] / t[1]) if float(t[1]) > 0 else 0.0
 
     def retrain_AE(self):
         """ActiveLearning.py:905-925.  The reference reads the hybrid features of the labeled people from its `Wholebody`
@@ -540,8 +616,21 @@ class ActiveLearning:
         return fit_autoencoder(self.AE, feat, epochs, float(self.cfg.AE.get("LR", 1e-3)))
 
     # ------------------------------------------------------------------ round logic (ActiveLearning.py:166-205)
+    @_collective
     def outcome(self):
         if self.is_early_stop or self.one_by_one:
+            # ActiveLearning.py:168-178: an early-stopped video still reports len(query_ratio)+1 points per curve — the last
+            # entry repeated, the label percentage advanced along the query schedule
+            while len(self.performance) <= len(self.query_ratio):
+                self.round_cnt += 1
+                self.performance.append(self.performance[-1])
+                self.performance_ann.append(self.performance_ann[-1])
+                self.ospa_list.append(self.ospa_list[-1])
+                self.ospa_list_ann.append(self.ospa_list_ann[-1])
+                self.uncertainty_mean.append(self.uncertainty_mean[-1])
+                self.percentage.append(self.query_ratio[self.round_cnt - 1] * 100)
+                self.combine_weight.append(self.combine_weight[-1])
+                self.moksQ_list.append(self.moksQ_list[-1])
             finish = True
         else:
             if not self.continual:
@@ -558,7 +647,7 @@ class ActiveLearning:
             elif self.round_cnt >= len(self.query_ratio):
                 self.query_size = len(self.unlabeled_id)
             else:
-                self.query_size = max(1, self.query_sizes[self.round_cnt] - len(self.labeled_id))
+                self.query_size = self.query_sizes[self.round_cnt] - len(self.labeled_id)
         if not finish:
             return None
         return (self.percentage, self.performance, self.performance_ann, self.query_list_list, self.uncertainty_dict, self.uncertainty_mean,

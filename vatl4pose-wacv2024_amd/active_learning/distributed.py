@@ -1,24 +1,121 @@
-"""Frame sharding of the evaluation stream across GPUs.
+"""One process per GPU around the hot path: process-group bring-up, frame sharding of the
+evaluation stream, the flat gradient arena of the data-parallel fine-tune step, and the worker processes that
+stand in for the reference's ``nn.DataParallel`` replicas (ActiveLearning.py:233).
 
-One process per GPU (torch.distributed: "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU tests).
-The id-sorted item stream is cut into contiguous shards; THC/TPC need the heat-maps of the id-adjacent
-items, so a shard is extended by a one-item halo on each interior side and the halo items are simply
-re-computed locally (two extra forwards per rank instead of any heat-map exchange).  The only
-collective is one all-gather of the per-item result rows (~290 bytes per item).  Parameters live on
-every GPU: nothing is re-broadcast per call (the reference's DataParallel re-broadcasts 136 MB per
-forward, ActiveLearning.py:233,277).
+* **Bring-up.**  ``init_from_env()`` joins the torchrun rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) before
+  the GPU is touched; backend "nccl" is RCCL over xGMI on MI355X (``VATL_DIST_BACKEND=gloo`` for CPU tests and for
+  several ranks sharing one GPU).  When the *unchanged* reference driver runs as one plain process on an N-GPU node
+  (``opt.num_gpu = torch.cuda.device_count()``, Run_active_learning.py:92-94), ``ensure_workers()`` starts N-1 fresh
+  child processes (``python -m active_learning.worker``; never an exec of this process) that mirror every
+  ``ActiveLearning`` call rank 0 makes — the package's replacement for DataParallel's replica threads.
+* **Evaluation.**  The id-sorted item stream is cut into contiguous shards; THC/TPC need the heat-maps of the id-adjacent
+  items, so a shard is extended by a one-item halo on each interior side and the halo items are simply re-computed
+  locally (two extra forwards per rank instead of any heat-map exchange).  The only collective is one all-gather of the
+  per-item result rows (~290 bytes per item).  Parameters live on every GPU: nothing is re-broadcast per call (the
+  reference's DataParallel re-broadcasts 136 MB per forward, ActiveLearning.py:233,277).
+* **Fine-tune.**  ``GradArena``: one flat fp32 buffer whose slices ARE the ``.grad`` tensors the weight-gradient
+  kernels write; it is all-reduced in place, bucket by bucket, while the backward pass is still producing the earlier
+  layers' gradients (async collectives on RCCL's own stream).  No concatenation, no copy back, no division pass (the loss
+  gradient is pre-scaled by the rank's share of the mini-batch, so SUM is the mean-loss gradient).
 """
 from __future__ import annotations
+
+import atexit
+import os
+import pickle
+import socket
+import subprocess
+import sys
+import tempfile
 
 import torch
 import torch.distributed as dist
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# process group
+# ---------------------------------------------------------------------------------------------------------------------
+
+def backend_name() -> str:
+    return os.environ.get("VATL_DIST_BACKEND", "nccl")
+
+
+def local_device_index() -> int:
+    """The GPU of this rank: LOCAL_RANK modulo the visible devices (several gloo ranks may share one GPU in tests)."""
+    ndev = max(torch.cuda.device_count(), 1)
+    return int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))) % ndev
+
+
+def init_from_env() -> bool:
+    """Join the process group described by the torchrun environment, if there is one.  Must run before this process
+    allocates on a GPU: it selects the rank's device first.  Returns True when a group with more than one rank is up."""
+    if dist.is_initialized():
+        return dist.get_world_size() > 1
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return False
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = backend_name()
+    if torch.cuda.device_count() > 0:
+        idx = local_device_index()
+        torch.cuda.set_device(idx)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", idx))
+            return True
+    dist.init_process_group(backend)
+    return True
+
+
+def is_main() -> bool:
+    return not dist.is_initialized() or dist.get_rank() == 0
+
+
+def world_rank():
+    return (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
+
+
+def _comm_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def shared_seed() -> int:
+    """One random seed agreed by all ranks (rank 0's): the ranks must shuffle the fine-tune set identically before
+    each takes its slice of every mini-batch."""
+    seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        seed = seed.to(_comm_device())
+        dist.broadcast(seed, src=0)
+    return int(seed.item())
+
+
+def broadcast_object(obj, src: int = 0):
+    """Rank ``src``'s (small, picklable) object on every rank — the query indices a round selected, for instance:
+    anything drawn from a rank-local RNG must be agreed this way before the ranks' book-keeping may depend on it."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src, device=_comm_device())
+    return box[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# evaluation: contiguous shards + halo, one all-gather of result rows
+# ---------------------------------------------------------------------------------------------------------------------
 
 def shard_bounds(n: int, rank: int, world: int):
     """Contiguous balanced shard [lo, hi) of n items."""
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def chunk_bounds(n: int, replicas: int):
+    """``torch.Tensor.chunk`` cuts of a mini-batch of n items — how nn.DataParallel scatters it over its replicas
+    (ceil(n / replicas) items each, possibly fewer chunks than replicas): [(lo, hi), ...], never empty chunks."""
+    if n <= 0:
+        return []
+    size = -(-n // max(1, replicas))
+    return [(lo, min(lo + size, n)) for lo in range(0, n, size)]
 
 
 def halo_bounds(n: int, lo: int, hi: int, halo: int = 1):
@@ -30,8 +127,7 @@ def halo_bounds(n: int, lo: int, hi: int, halo: int = 1):
 def sharded_rows(n: int, score_fn, row_width: int, device, halo: int = 1) -> torch.Tensor:
     """Every rank scores its shard (+halo) with ``score_fn(lo_ext, hi_ext) -> (hi_ext-lo_ext, row_width)`` rows (any
     one dtype) on ``device``; returns the (n, row_width) result rows of the whole stream on every rank."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
+    world, rank = world_rank()
     lo, hi = shard_bounds(n, rank, world)
     lo_e, hi_e, front, back = halo_bounds(n, lo, hi, halo)
     rows = score_fn(lo_e, hi_e)
@@ -43,23 +139,88 @@ def sharded_rows(n: int, score_fn, row_width: int, device, halo: int = 1) -> tor
     pad = max(h - l for l, h in sizes)
     buf = torch.zeros((pad, row_width), device=device, dtype=rows.dtype)
     buf[:hi - lo] = rows
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
-    return torch.cat([o[:h - l] for o, (l, h) in zip(out, sizes)], 0)
+    out = torch.empty((world * pad, row_width), device=device, dtype=rows.dtype)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, buf)
+    else:                                                  # gloo: per-rank destination views of the same buffer
+        dist.all_gather(list(out.view(world, pad, row_width).unbind(0)), buf)
+    if all(h - l == pad for l, h in sizes):
+        return out
+    keep = [r * pad + k for r, (l, h) in enumerate(sizes) for k in range(h - l)]       # drop the padding rows of the short shards
+    return out[torch.as_tensor(keep, device=device)]
 
 
-def allreduce_mean_(tensors, group=None):
-    """Gradient averaging for the data-parallel fine-tune step: one flat fp32 bucket, one all-reduce
-    (136 MB for SimplePose-R50), divided by the world size."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return
-    flat = torch.cat([t.reshape(-1) for t in tensors])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat /= dist.get_world_size()
-    off = 0
-    for t in tensors:
-        t.copy_(flat[off:off + t.numel()].view_as(t))
-        off += t.numel()
+# ---------------------------------------------------------------------------------------------------------------------
+# fine-tune: flat gradient arena, bucketed in-place all-reduce overlapped with the backward pass
+# ---------------------------------------------------------------------------------------------------------------------
+
+class GradArena:
+    """One flat fp32 buffer holding every parameter gradient of a model, in ``parameters()`` order.
+
+    ``view(p)`` is the slice the weight-gradient kernel of parameter ``p`` writes (and what becomes ``p.grad``).  The
+    backward pass produces gradients from the last layer to the first, i.e. from the high end of the arena downwards;
+    ``done_offset(o)`` tells the arena that every slice at or above element offset ``o`` is final, and whenever a bucket's worth has
+    accumulated the arena issues an asynchronous in-place SUM all-reduce of that range (on RCCL this runs on the
+    communicator's stream and overlaps the rest of the backward).  ``finish()`` reduces what is left and waits."""
+
+    def __init__(self, params, device=None, bucket_bytes: int = 32 << 20):
+        self.params = [p for p in params]
+        self.offset, off = {}, 0
+        for p in self.params:
+            self.offset[p] = off
+            off += p.numel()
+        self.total = off
+        dev = device if device is not None else (self.params[0].device if self.params else torch.device("cpu"))
+        self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.views = {p: self.flat[o:o + p.numel()].view(p.shape) for p, o in self.offset.items()}
+        self.bucket = max(1, bucket_bytes // 4)
+        self._lo = self.total
+        self._works = []
+        self._group = None
+        self._live = False
+        self.launches = 0
+
+    def view(self, p):
+        return self.views[p]
+
+    def begin(self, group=None):
+        """Start of a backward pass.  ``group`` None = the default process group (nothing to do at world size 1)."""
+        self._lo, self._works, self._group = self.total, [], group
+        self._live = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.launches = 0
+
+    def _fire(self, lo, hi):
+        if hi > lo:
+            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self._group, async_op=True))
+            self.launches += 1
+
+    def done_offset(self, off: int):
+        """Every slice at or above element offset ``off`` holds its final value for this step."""
+        if not self._live:
+            return
+        if off < self._lo and self._lo - off >= self.bucket:
+            self._fire(off, self._lo)
+            self._lo = off
+
+    def finish(self):
+        """Reduce the remaining low end of the arena and wait for every bucket (the optimizer step comes next)."""
+        if self._live:
+            self._fire(0, self._lo)
+            self._lo = 0
+            for w in self._works:
+                w.wait()
+        self._works = []
+
+    def attach(self):
+        """``p.grad`` = the arena slices (no copies)."""
+        for p, v in self.views.items():
+            p.grad = v
+
+
+def allreduce_sum_(flat: torch.Tensor, group=None):
+    """In-place SUM all-reduce of one flat buffer (no-op at world size 1)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
 
 
 def broadcast_buffers_(module, src: int = 0):
@@ -71,25 +232,6 @@ def broadcast_buffers_(module, src: int = 0):
         dist.broadcast(b, src=src)
 
 
-def is_main() -> bool:
-    return not dist.is_initialized() or dist.get_rank() == 0
-
-
-def world_rank():
-    return (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
-
-
-def shared_seed() -> int:
-    """One random seed agreed by all ranks (rank 0's): the ranks must shuffle the fine-tune set identically before
-    each takes its slice of every mini-batch."""
-    seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-        seed = seed.to(dev)
-        dist.broadcast(seed, src=0)
-    return int(seed.item())
-
-
 def broadcast_module_(module, src: int = 0):
     """Parameters and buffers of rank ``src`` to every rank (after a random initialisation or a rank-local fit, so
     that the replicas start identical — what nn.DataParallel's per-forward replicate does for the reference)."""
@@ -98,3 +240,85 @@ def broadcast_module_(module, src: int = 0):
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src)
         torch.autograd.graph.increment_version(t)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# worker processes behind the unchanged single-process driver
+# ---------------------------------------------------------------------------------------------------------------------
+
+_workers: list = []
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def ensure_workers(num_gpu: int) -> int:
+    """Called by ``ActiveLearning.__init__`` on the driver's process.  Under torchrun: join the group.  As one plain
+    process with ``opt.num_gpu`` > 1 (the reference's DataParallel case): become rank 0 of a fresh group and start the
+    other ranks as child processes running ``active_learning.worker`` (once per process; later ``ActiveLearning``
+    objects reuse them).  Returns the world size.  ``VATL_SPAWN=0`` keeps everything on this process's GPU: the
+    DataParallel replicas are then walked one after the other (same numerics, ActiveLearning.retrain_model)."""
+    if dist.is_initialized():
+        return dist.get_world_size()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        init_from_env()
+        return dist.get_world_size()
+    want = max(1, int(num_gpu))
+    if backend_name() == "nccl":
+        want = min(want, max(torch.cuda.device_count(), 1))          # RCCL refuses two ranks on one device
+    if want <= 1 or os.environ.get("VATL_SPAWN", "1") == "0":
+        return 1
+    port = _free_port()
+    pkg_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ, WORLD_SIZE=str(want), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VATL_WORKER_PARENT=str(os.getpid()))
+    base["PYTHONPATH"] = os.pathsep.join([pkg_root] + [p for p in os.environ.get("PYTHONPATH", "").split(os.pathsep) if p])
+    for r in range(1, want):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        _workers.append(subprocess.Popen([sys.executable, "-m", "active_learning.worker"], env=env, stdin=subprocess.DEVNULL))
+    os.environ.update(WORLD_SIZE=str(want), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0")
+    init_from_env()
+    atexit.register(shutdown_workers)
+    return dist.get_world_size()
+
+
+def have_workers() -> bool:
+    return bool(_workers)
+
+
+def command(*msg):
+    """Rank 0 -> workers: the next thing every rank does together."""
+    if _workers:
+        broadcast_object(msg, src=0)
+
+
+def shutdown_workers():
+    global _workers
+    if not _workers:
+        return
+    try:
+        if dist.is_initialized():
+            broadcast_object(("exit",), src=0)
+    except Exception:                                      # a worker already died: fall through to the kill below
+        pass
+    for p in _workers:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    _workers = []
+    if dist.is_initialized():
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+def dump_payload(obj) -> str:
+    """Objects too large for a broadcast (datasets handed to the constructor) go through a temp file."""
+    fd, path = tempfile.mkstemp(prefix="vatl_payload_", suffix=".pkl")
+    with os.fdopen(fd, "wb") as f:
+        pickle.dump(obj, f)
+    return path

@@ -51,6 +51,9 @@ class FrameVideo(Dataset):
                                               rot=rot, sigma=preset.get("SIGMA", 2), train=self._train, add_dpg=False,
                                               loss_type=preset.get("LOSS_TYPE", LOSS_TYPE))
         self._labels = sorted((dict(a) for a in annotations), key=lambda a: a["id"])     # posetrack21.py:71-72
+        # A consumer that takes the neighbours' heat-maps from the id-sorted stream itself (ActiveLearning with
+        # ID_SORTED_STREAM) switches the prev / next crops off: items then carry a (1,3,H,W) stack and the flags only.
+        self.emit_neighbour_crops = True
         self._frames = frames
         self._arena = None
 
@@ -78,7 +81,8 @@ class FrameVideo(Dataset):
         is_prev = [self.get_prenext and self._neighbour(i, -1) for i in idxs]
         is_next = [self.get_prenext and self._neighbour(i, +1) for i in idxs]
         keys = [lb["frame"] for lb in labels]
-        keys += [self._labels[i - 1]["frame"] for i, f in zip(idxs, is_prev) if f] + [self._labels[i + 1]["frame"] for i, f in zip(idxs, is_next) if f]
+        if self.emit_neighbour_crops:
+            keys += [self._labels[i - 1]["frame"] for i, f in zip(idxs, is_prev) if f] + [self._labels[i + 1]["frame"] for i, f in zip(idxs, is_next) if f]
         arena, where = self._frames_for(keys)
         at = (lambda k: k) if where is None else (lambda k: where[k])
         for lb in labels:
@@ -87,10 +91,12 @@ class FrameVideo(Dataset):
         st = self.transformation
         cur, target, weight, boxes = st.call_batch(arena, [at(lb["frame"]) for lb in labels], labels)
         n = len(idxs)
-        stacked = torch.zeros((n, 3) + tuple(cur.shape[1:]), device=cur.device)
-        stacked[:, 0] = cur
+        slots = 3 if self.emit_neighbour_crops else 1
+        stacked = torch.zeros((n, slots) + tuple(cur.shape[1:]), device=cur.device) if slots == 3 else cur[:, None]
+        if slots == 3:
+            stacked[:, 0] = cur
         for slot, flags, step in ((1, is_prev, -1), (2, is_next, +1)):               # test_transform of the neighbour (:154-178)
-            rows = [k for k in range(n) if flags[k]]
+            rows = [k for k in range(n) if flags[k]] if slots == 3 else []
             if rows:
                 nb = [self._labels[idxs[k] + step] for k in rows]
                 crops, _ = st.test_transform_batch(arena, [at(a["frame"]) for a in nb], np.array([a["bbox"] for a in nb], np.float64))

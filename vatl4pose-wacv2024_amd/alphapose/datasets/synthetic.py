@@ -35,6 +35,7 @@ class SyntheticVideo(Dataset):
         self.joints_hm = np.stack([r.randint(3, self.w - 3, (self.n, self.J)), r.randint(3, self.h - 3, (self.n, self.J))], 2)
         self.vis = (r.random_sample((self.n, self.J)) > 0.2).astype(np.float32)
         self.seed = SEED
+        self.emit_neighbour_crops = True       # False: (1,3,H,W) stacks — the consumer reads the neighbours from the stream
         per = self.n // self.tracks
         pos = np.arange(self.n) % per
         self.is_prev, self.is_next = pos != 0, pos != per - 1
@@ -49,9 +50,13 @@ class SyntheticVideo(Dataset):
 
     def __getitem__(self, i):
         cur = self._crop(i)
-        zero = torch.zeros_like(cur)
-        prev = self._crop(i - 1) if (self.get_prenext and self.is_prev[i]) else zero
-        nxt = self._crop(i + 1) if (self.get_prenext and self.is_next[i]) else zero
+        if self.emit_neighbour_crops:
+            zero = torch.zeros_like(cur)
+            prev = self._crop(i - 1) if (self.get_prenext and self.is_prev[i]) else zero
+            nxt = self._crop(i + 1) if (self.get_prenext and self.is_next[i]) else zero
+            stack = torch.stack([cur, prev, nxt])
+        else:
+            stack = cur[None]
         label = torch.zeros((self.J, self.h, self.w))
         rad = int(3 * self.sigma)
         gk = torch.arange(-rad, rad + 1, dtype=torch.float32)
@@ -66,7 +71,7 @@ class SyntheticVideo(Dataset):
         gx = bb[0] + (bb[2] - bb[0]) * 0.5 + (self.joints_hm[i, :, 0] - self.w / 2) * scale
         gy = bb[1] + (bb[3] - bb[1]) * 0.5 + (self.joints_hm[i, :, 1] - self.h / 2) * scale
         gt = torch.from_numpy(np.stack([gx, gy, self.vis[i]], 1).reshape(-1).astype(np.float32))
-        return (i, torch.stack([cur, prev, nxt]), label, mask, gt, 1000 + i, 100000 + i, torch.from_numpy(bb), torch.from_numpy(bb),
+        return (i, stack, label, mask, gt, 1000 + i, 100000 + i, torch.from_numpy(bb), torch.from_numpy(bb),
                 bool(self.is_prev[i]), bool(self.is_next[i]))
 
     @staticmethod

@@ -30,6 +30,37 @@ def _flipped_taps(r, s):
     return [(r - 1 - i, s - 1 - j) for i in range(r) for j in range(s)]
 
 
+class _Grads(dict):
+    """{parameter: gradient} of one backward pass.  With a ``GradArena`` (active_learning/distributed.py) every gradient
+    kernel writes straight into the parameter's slice of the flat arena (``out(p)``), and ``flush()`` — called by the
+    sequential trainers after every block — lets the arena start the all-reduce of the part that is already final while
+    the backward pass goes on.  Without an arena the gradients are fresh tensors."""
+
+    def __init__(self, arena=None, overlap=False):
+        super().__init__()
+        self.arena, self.overlap = arena, overlap and arena is not None
+        self._low, self._filled = (arena.total if arena is not None else 0), 0
+
+    def out(self, p):
+        return self.arena.views.get(p) if self.arena is not None else None
+
+    def __setitem__(self, p, t):
+        v = self.out(p)
+        if v is not None:
+            if t.data_ptr() != v.data_ptr():
+                v.copy_(t.reshape(v.shape))
+            t = v
+            if p not in self:
+                self._filled += p.numel()
+                self._low = min(self._low, self.arena.offset[p])
+        super().__setitem__(p, t)
+
+    def flush(self):
+        # everything at or above the lowest offset written so far is final once that whole range has been written
+        if self.overlap and self._filled == self.arena.total - self._low:
+            self.arena.done_offset(self._low)
+
+
 _pending_counters = []
 
 
@@ -73,17 +104,19 @@ class _ConvBN:
         """dy: gradient of the layer output.  Returns (dx, g_skip); parameter gradients go to ``grads``."""
         x, z, y, mean, invstd, had_skip, mask = self.saved
         self.saved = None
+        og, ob = grads.out(self.bn.weight), grads.out(self.bn.bias)
         if mask is not None:
-            dz, dgamma, dbeta = vh.bn_train_bwd_relu(dy, mask[0], mask[1], z, self.bn.weight.detach(), mean, invstd)
+            dz, dgamma, dbeta = vh.bn_train_bwd_relu(dy, mask[0], mask[1], z, self.bn.weight.detach(), mean, invstd, dgamma=og, dbeta=ob)
             g = None
         else:
-            dz, g, dgamma, dbeta = vh.bn_train_bwd(dy, y, z, self.bn.weight.detach(), mean, invstd, want_g=had_skip and y is not None)
+            dz, g, dgamma, dbeta = vh.bn_train_bwd(dy, y, z, self.bn.weight.detach(), mean, invstd, want_g=had_skip and y is not None,
+                                                   dgamma=og, dbeta=ob)
         if had_skip and y is None:
             g = dy                                         # no ReLU between the sum and the output: the skip gradient is dy
         grads[self.bn.weight] = dgamma
         grads[self.bn.bias] = dbeta
         cin_w = 3 if self.cin == 3 else self.cin
-        grads[self.conv.weight] = vh.conv2d_wgrad(x, dz, self.cout, cin_w, self.r, self.s, self.stride, self.pad)
+        grads[self.conv.weight] = vh.conv2d_wgrad(x, dz, self.cout, cin_w, self.r, self.s, self.stride, self.pad, out=grads.out(self.conv.weight))
         dx = self._dgrad(dz, x.shape, dx_residual) if self.need_dx else None
         return dx, g
 
@@ -134,10 +167,11 @@ class _DeconvBN:
     def backward(self, dy, grads):
         x, z, scale, bias, mean, invstd = self.saved
         self.saved = None
-        dz, dgamma, dbeta = vh.bn_train_bwd_relu(dy, scale, bias, z, self.bn.weight.detach(), mean, invstd)
+        dz, dgamma, dbeta = vh.bn_train_bwd_relu(dy, scale, bias, z, self.bn.weight.detach(), mean, invstd,
+                                                 dgamma=grads.out(self.bn.weight), dbeta=grads.out(self.bn.bias))
         grads[self.bn.weight] = dgamma
         grads[self.bn.bias] = dbeta
-        grads[self.dc.weight] = vh.deconv4x4s2_wgrad(x, dz)
+        grads[self.dc.weight] = vh.deconv4x4s2_wgrad(x, dz, out=grads.out(self.dc.weight))
         # dx[y][x][ci] = sum_{ky,kx,co} dz[2y-1+ky][2x-1+kx][co] * W[ci][co][ky][kx]: a 4x4/2 pad-1 conv whose
         # "OIHW" weight is the deconv weight itself (O = Cin, I = Cout)
         wd = vh.pack_conv_weight(self.dc.weight.detach())
@@ -190,22 +224,25 @@ class SimplePoseTrainer:
         _flush_batch_counters()
         return vh.conv2d_fwd(x, hw, None, hb, self.head.weight.shape[0], 1, 1, 1, 0, False, out_nchw=True)
 
-    def backward(self, dout_nchw):
-        """dout (B,J,H,W) NCHW -> {parameter: gradient} for every parameter of the model."""
-        grads = {}
+    def backward(self, dout_nchw, arena=None, overlap=False):
+        """dout (B,J,H,W) NCHW -> {parameter: gradient} for every parameter of the model.  With ``arena`` the gradients are
+        its slices; ``overlap`` lets the arena all-reduce finished buckets while the earlier layers are still in flight."""
+        grads = _Grads(arena, overlap)
         j = self.head.weight.shape[0]
         cin = self.head.weight.shape[1]
         dy = vh.nchw_to_nhwc(dout_nchw.contiguous(), 32)                         # 17 -> 32 channels (zeros)
         grads[self.head.bias] = vh.col_sum(dy)[:j].contiguous()
-        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, 1, 1, 1, 0)
+        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, 1, 1, 1, 0, out=grads.out(self.head.weight))
         wd = vh.pack_dgrad_weight(self.head.weight.detach(), [(0, 0)], cout_k=32)
         n, h, w, _ = self.head_in.shape
         dx = vh.conv2d_fwd_ex(dy, wd, cin, 1, 1, 1, 0, 0, h, w, h, w, 1, 1, 0, 0)
         self.head_in = None
         for d in reversed(self.deconvs):
             dx = d.backward(dx, grads)
+            grads.flush()
         for b in reversed(self.blocks):
             dx = b.backward(dx, grads)
+            grads.flush()
         dx = vh.maxpool3x3s2_bwd_idx(dx, self.pool_idx, self.pool_hw)
         self.pool_idx = None
         self.stem.backward(dx, grads)
@@ -234,7 +271,9 @@ class _LinearT:
         if self.relu:
             dy = vh.relu_bwd(dy.contiguous(), y)
         grads[self.lin.bias] = vh.col_sum(dy)
-        grads[self.lin.weight] = vh.conv2d_wgrad(x2d.reshape(b, 1, 1, self.ci), dy.reshape(b, 1, 1, self.co), self.co, self.ci, 1, 1, 1, 0).reshape(self.co, self.ci)
+        ow = grads.out(self.lin.weight)
+        grads[self.lin.weight] = vh.conv2d_wgrad(x2d.reshape(b, 1, 1, self.ci), dy.reshape(b, 1, 1, self.co), self.co, self.ci, 1, 1, 1, 0,
+                                                 out=None if ow is None else ow.view(self.co, self.ci, 1, 1)).reshape(self.co, self.ci)
         wd = vh.pack_dgrad_weight(self.lin.weight.detach().reshape(self.co, self.ci, 1, 1), [(0, 0)])
         return vh.conv2d_fwd_ex(dy.reshape(b, 1, 1, self.co), wd, self.ci, 1, 1, 1, 0, 0, 1, 1, 1, 1, 1, 1, 0, 0).reshape(b, self.ci)
 
@@ -296,21 +335,23 @@ class FastPoseTrainer:
         _flush_batch_counters()
         return vh.conv2d_fwd(x, vh.pack_conv_weight(self.head.weight.detach()), None, hb, j, 3, 3, 1, 1, False, out_nchw=True)
 
-    def backward(self, dout_nchw):
-        grads = {}
+    def backward(self, dout_nchw, arena=None, overlap=False):
+        grads = _Grads(arena, overlap)
         j, cin = self.head.weight.shape[:2]
         dy = vh.nchw_to_nhwc(dout_nchw.contiguous(), 32)
         grads[self.head.bias] = vh.col_sum(dy)[:j].contiguous()
-        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, 3, 3, 1, 1)
+        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, 3, 3, 1, 1, out=grads.out(self.head.weight))
         wd = vh.pack_dgrad_weight(self.head.weight.detach(), _flipped_taps(3, 3), cout_k=32)
         n, h, w, _ = self.head_in.shape
         dx = vh.conv2d_fwd_ex(dy, wd, cin, 3, 3, 1, 1, 1, h, w, h, w, 1, 1, 0, 0)
         self.head_in = None
         dx, _ = self.duc2.backward(vh.pixelunshuffle2(dx), grads)
         dx, _ = self.duc1.backward(vh.pixelunshuffle2(dx), grads)
+        grads.flush()
         dx = vh.pixelunshuffle2(dx)
         for b in reversed(self.blocks):
             dx = b.backward(dx, grads)
+            grads.flush()
         dx = vh.maxpool3x3s2_bwd_idx(dx, self.pool_idx, self.pool_hw)
         self.pool_idx = None
         self.stem.backward(dx, grads)
@@ -439,12 +480,12 @@ class HRNetTrainer:
         _flush_batch_counters()
         return vh.conv2d_fwd(ys[0], vh.pack_conv_weight(self.head.weight.detach()), None, hb, j, k, k, 1, k // 2, False, out_nchw=True)
 
-    def backward(self, dout_nchw):
-        grads = {}
+    def backward(self, dout_nchw, arena=None, overlap=False):
+        grads = _Grads(arena, False)                  # the branches' gradients do not complete in arena order: one reduce at the end
         j, cin, k, _ = self.head.weight.shape
         dy = vh.nchw_to_nhwc(dout_nchw.contiguous(), 32)
         grads[self.head.bias] = vh.col_sum(dy)[:j].contiguous()
-        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, k, k, 1, k // 2)
+        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, k, k, 1, k // 2, out=grads.out(self.head.weight))
         wd = vh.pack_dgrad_weight(self.head.weight.detach(), _flipped_taps(k, k), cout_k=32)
         n, h, w, _ = self.head_in.shape
         dys = [vh.conv2d_fwd_ex(dy, wd, cin, k, k, 1, k // 2, k // 2, h, w, h, w, 1, 1, 0, 0)]
@@ -502,6 +543,17 @@ def trainer_for(m: nn.Module):
             raise NotImplementedError(f"no training-mode HIP path for {type(m).__name__}")
         m.__dict__["_vatl_trainer"] = tr
     return tr
+
+
+def arena_for(m: nn.Module):
+    """The (cached) flat gradient arena of a pose network: ``p.grad`` of every trainable parameter is a slice of it."""
+    from active_learning.distributed import GradArena
+    params = [p for p in m.parameters() if p.requires_grad]
+    ar = m.__dict__.get("_vatl_arena")
+    if ar is None or len(ar.params) != len(params) or any(a is not b for a, b in zip(ar.params, params)) or ar.flat.device != params[0].device:
+        ar = GradArena(params, device=params[0].device)
+        m.__dict__["_vatl_arena"] = ar
+    return ar
 
 
 def forward_train(m: nn.Module, x: torch.Tensor) -> torch.Tensor:

@@ -47,24 +47,17 @@ class SimpleTransform(object):
     """Generation of cropped input person and pose heat-maps (constructor arguments as the reference's, :54)."""
 
     def __init__(self, dataset, scale_factor, add_dpg, input_size, output_size, rot, sigma, train, gpu_device=None, loss_type="MSELoss"):
+        inp_h, inp_w = input_size
+        self._input_size, self._heatmap_size = input_size, output_size
+        self._aspect_ratio = float(inp_w) / inp_h                       # crops are w / h = 3 / 4
+        self._feat_stride = np.asarray(input_size) / np.asarray(output_size)
+        self._train, self._loss_type, self._sigma = train, loss_type, sigma
+        self._scale_factor, self._rot, self._add_dpg, self._gpu_device = scale_factor, rot, add_dpg, gpu_device
         self._joint_pairs = dataset.joint_pairs
-        self._scale_factor = scale_factor
-        self._rot = rot
-        self._add_dpg = add_dpg
-        self._gpu_device = gpu_device
-        self._input_size = input_size
-        self._heatmap_size = output_size
-        self._sigma = sigma
-        self._train = train
-        self._loss_type = loss_type
-        self._aspect_ratio = float(input_size[1]) / input_size[0]  # w / h
-        self._feat_stride = np.array(input_size) / np.array(output_size)
         self.pixel_std = 1
-        if train:
-            self.num_joints_half_body = dataset.num_joints_half_body
-            self.prob_half_body = dataset.prob_half_body
-            self.upper_body_ids = dataset.upper_body_ids
-            self.lower_body_ids = dataset.lower_body_ids
+        if train:                                                       # what the half-body augmentation reads from the dataset (:70-75)
+            for name in ("num_joints_half_body", "prob_half_body", "upper_body_ids", "lower_body_ids"):
+                setattr(self, name, getattr(dataset, name))
 
     # ------------------------------------------------------------------ batched fast path
     def crop_batch(self, arena: FrameArena, frame_index, centers, scales, rots=0.0, mirror=None, out=None):
@@ -110,17 +103,18 @@ class SimpleTransform(object):
         target, weight = self.targets_batch(joints_3d[None, :, 0:2, 0], joints_3d[None, :, 0, 1])
         return target[0], weight[0]
 
+    # joint counts whose leading (body) joints weigh double in the integral loss (:164-169): whole-body 136 / 133, face 68
+    _DOUBLE_WEIGHT_HEAD = {136: 26, 133: 23, 68: 26}
+
     def _integral_target_generator(self, joints_3d, num_joints, patch_height, patch_width):
-        target_weight = np.ones((num_joints, 2), dtype=np.float32)
-        target_weight[:, 0] = joints_3d[:, 0, 1]
-        target_weight[:, 1] = joints_3d[:, 0, 1]
-        head = {136: 26, 133: 23, 68: 26}.get(num_joints)
-        if head:
-            target_weight[:head, :] = target_weight[:head, :] * 2
-        target = np.zeros((num_joints, 2), dtype=np.float32)
-        target[:, 0] = joints_3d[:, 0, 0] / patch_width - 0.5
-        target[:, 1] = joints_3d[:, 1, 0] / patch_height - 0.5
-        return target.reshape((-1)), target_weight.reshape((-1))
+        """Soft-arg-max regression targets (:160-177): per joint (x / W - 0.5, y / H - 0.5), interleaved; the weights are the
+        visibility flag on both coordinates, doubled for the leading joints of the whole-body layouts."""
+        j = np.asarray(joints_3d)[:num_joints]
+        boost = np.ones(num_joints, np.float32)
+        boost[:self._DOUBLE_WEIGHT_HEAD.get(num_joints, 0)] = 2
+        weight = np.repeat((j[:, 0, 1] * boost).astype(np.float32), 2)
+        target = np.stack([j[:, 0, 0] / patch_width - 0.5, j[:, 1, 0] / patch_height - 0.5], 1).astype(np.float32)
+        return target.reshape(-1), weight
 
     def _draw(self, label):
         """Host half of ``__call__`` (:179-229): centre/scale of the box and, in train mode, the augmentation draws in the
@@ -192,25 +186,26 @@ class SimpleTransform(object):
         return crops[0], target[0], weight[0], torch.Tensor(boxes[0].tolist())
 
     def half_body_transform(self, joints, joints_vis):
-        upper_joints, lower_joints = [], []
-        for joint_id in range(self.num_joints):
-            if joints_vis[joint_id][0] > 0:
-                (upper_joints if joint_id in self.upper_body_ids else lower_joints).append(joints[joint_id])
-        if np.random.randn() < 0.5 and len(upper_joints) > 2:
-            selected_joints = upper_joints
+        """Centre / scale of a box around the visible upper-body or lower-body joints (:253-304).  One normal deviate decides
+        for the upper body (drawn whatever the joint counts are, like the reference's short-circuit order); a half needs more
+        than two visible joints to be eligible, and fewer than two selected joints means "no half-body crop"."""
+        ids = np.arange(self.num_joints)
+        seen = np.asarray(joints_vis)[:self.num_joints, 0] > 0
+        upper = seen & np.isin(ids, np.asarray(self.upper_body_ids))
+        lower = seen & ~np.isin(ids, np.asarray(self.upper_body_ids))
+        prefer_upper = np.random.randn() < 0.5
+        if prefer_upper and upper.sum() > 2:
+            pick = upper
         else:
-            selected_joints = lower_joints if len(lower_joints) > 2 else upper_joints
-        if len(selected_joints) < 2:
+            pick = lower if lower.sum() > 2 else upper
+        if pick.sum() < 2:
             return None, None
-        selected_joints = np.array(selected_joints, dtype=np.float32)
-        center = selected_joints.mean(axis=0)[:2]
-        left_top = np.amin(selected_joints, axis=0)
-        right_bottom = np.amax(selected_joints, axis=0)
-        w = right_bottom[0] - left_top[0]
-        h = right_bottom[1] - left_top[1]
-        if w > self._aspect_ratio * h:
-            h = w * 1.0 / self._aspect_ratio
-        elif w < self._aspect_ratio * h:
-            w = h * self._aspect_ratio
-        scale = np.array([w * 1.0 / self.pixel_std, h * 1.0 / self.pixel_std], dtype=np.float32)
-        return center, scale * 1.5
+        pts = np.asarray(joints, dtype=np.float32)[:self.num_joints][pick]         # visible joints of the chosen half, in joint order
+        center = pts.mean(axis=0)[:2]
+        w, h = (pts.max(axis=0) - pts.min(axis=0))[:2]
+        ar = self._aspect_ratio
+        if w > ar * h:                                                             # grow the short side to the crop's aspect ratio
+            h = w * 1.0 / ar
+        elif w < ar * h:
+            w = h * ar
+        return center, np.array([w * 1.0 / self.pixel_std, h * 1.0 / self.pixel_std], dtype=np.float32) * 1.5

@@ -488,7 +488,12 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
     } else {
         // VAR 2 = fine-grained schedule with distance-1 prefetch.  VAR 10..13 are ABLATIONS for profiling only (wrong results):
         // 10 = no global loads / LDS writes, 11 = no barrier, 12 = no fragment reads in the loop.
+#ifdef VATL_ABLATION
         constexpr bool NO_GL = VAR == 10, NO_BAR = VAR == 11, NO_FRAG = VAR == 12, NO_ST = VAR == 13;   // 13 = loads kept, no LDS writes
+#else
+        static_assert(VAR < 10, "schedule variants 10..13 are profiling ablations: build with -DVATL_ABLATION (build.py --ablation)");
+        constexpr bool NO_GL = false, NO_BAR = false, NO_FRAG = false, NO_ST = false;
+#endif
         constexpr int NG = BK / 8;                          // 4 fragment groups per k-tile
         constexpr int MPG = 4 * TM * TN;                    // MFMAs per group
         f32x4 af[2][TM], bf[2][TN];
@@ -537,7 +542,8 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
         p.y = p.part + (long long)blockIdx.z * p.part_slice;
         p.scale = nullptr; p.bias = nullptr; p.res = nullptr; p.relu = 0; p.out_nchw = 0; p.stats = nullptr;
     }
-    if (p.ablate & 1) {                // profiling only: keep the accumulators alive, skip the write-out
+#ifdef VATL_ABLATION
+    if (p.ablate & 1) {                // profiling build only: keep the accumulators alive, skip the write-out
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -548,6 +554,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
         if (s == 12345.678f) p.y[0] = s;
         return;
     }
+#endif
     conv_epilogue<BM, BN, WM, WN, NT>(p, acc, smem, m0, n0, ooy, oox, wm, wn, tid, lane, HoWo);
 }
 
@@ -884,8 +891,12 @@ static int launch(const ConvParams& p, int phases, hipStream_t st) {
     q.n_tiles = p.CoutPad / BN;
     q.m_tiles = cdiv(p.M, BM);
     q.order = g_order.load(std::memory_order_relaxed);
+#ifdef VATL_ABLATION
     q.ablate = g_ablate.load(std::memory_order_relaxed);
     if ((q.ablate & 2) && q.ktiles > 1) q.ktiles = 1;
+#else
+    q.ablate = 0;
+#endif
     // one s_sleep(127) = 8128 cycles; a k-tile costs ~8192 cycles when two blocks share the SIMDs
     q.stagger = (int)((long long)g_stagger.load(std::memory_order_relaxed) * p.ktiles / 100);
     static_assert(2 * (BM + BN) * LDK >= BM * (BN + 4), "epilogue tile must fit in the staging buffers");
@@ -999,10 +1010,12 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, 
     if (bn == 128) {
         if (var == 2) return launch<128, 128, 64, 64, false, 2>(p, phases, st);
         if (var == 4) return launch<128, 128, 64, 64, false, 4>(p, phases, st);
+#ifdef VATL_ABLATION
         if (var == 10) return launch<128, 128, 64, 64, false, 10>(p, phases, st);
         if (var == 11) return launch<128, 128, 64, 64, false, 11>(p, phases, st);
         if (var == 12) return launch<128, 128, 64, 64, false, 12>(p, phases, st);
         if (var == 13) return launch<128, 128, 64, 64, false, 13>(p, phases, st);
+#endif
         if (var == 0) return launch<128, 128, 64, 64, false, 0>(p, phases, st);
         return launch<128, 128, 64, 64, false, 4>(p, phases, st);
     }
@@ -1027,8 +1040,13 @@ extern "C" int vatl_tune_set(int knob, int value) {
     // for the profiling notes only and are refused unless the process opted in.
     const bool ablation = (knob == 0 && value >= 10) || ((knob == 4 || knob == 6) && value != 0);
     if (ablation) {
+#ifdef VATL_ABLATION
         const char* ok = getenv("VATL_ALLOW_ABLATION");
         if (!ok || ok[0] != '1') return fail(VATL_EINVAL, "tune_set: knob %d value %d is a profiling ablation (wrong results); set VATL_ALLOW_ABLATION=1", knob, value);
+#else
+        return fail(VATL_EINVAL, "tune_set: knob %d value %d is a profiling ablation (wrong results by construction): not compiled into this "
+                    "library; build the profiling variant with `build.py --ablation` (-DVATL_ABLATION)", knob, value);
+#endif
     }
     if (knob == 3 && vatl_tune_wgrad_blocks(value) == 0) return 0;
     if (knob == 5 && (value == 0 || value == 64 || value == 128)) { g_bm.store(value, std::memory_order_relaxed); return 0; }

@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
         __syncthreads();
     }
 
-    if (p.ablate & 1) return;
+#ifdef VATL_ABLATION
+    if (p.ablate & 1) return;          // profiling build only
+#endif
     // D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)] -> n,  [col = lane&31] -> channel: coalesced stores of this split's partial
     // tile into its own slice of the workspace (no atomics: the reduction over splits runs in a fixed order afterwards)
     const int Kp = (STEM ? p.R * 8 : p.R * p.S) * p.Cx;
@@ -274,7 +276,11 @@ static int launch_wgrad_t(WgradParams p, const WgradPlan& plan, hipStream_t st) 
     p.adv = ((32 / hw) * p.H * p.W + p.d_oy * p.stride * p.W + p.d_ox * p.stride) * p.Cx;
     p.adv_cx = (p.stride * p.W - p.Wo * p.stride) * p.Cx;
     p.adv_cy = (p.H * p.W - p.Ho * p.stride * p.W) * p.Cx;
+#ifdef VATL_ABLATION
     p.ablate = g_wgrad_ablate.load(std::memory_order_relaxed);
+#else
+    p.ablate = 0;
+#endif
     p.kt_per_split = plan.kt_per_split;
     hipLaunchKernelGGL((conv_wgrad_kernel<BN, BJ, WN, WJ, STEM>), dim3((unsigned)(plan.tiles * plan.splits)), dim3(256), 0, st, p);
     return check_launch("conv_wgrad");

@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvatl_hip.so")
+# VATL_HIP_LIB: an explicit library path — the profiling variant (build.py --ablation) for tools/conv_bench.py --ablate
+LIB_PATH = os.environ.get("VATL_HIP_LIB") or os.path.join(_HERE, "libvatl_hip.so")
 
 _p = C.c_void_p
 _i = C.c_int
@@ -515,10 +516,13 @@ def pack_dgrad_weight(w: torch.Tensor, taps, cout_k: int | None = None) -> torch
     return out
 
 
-def conv2d_wgrad(x, dz, cout: int, cin: int, r: int, s: int, stride: int, pad: int) -> torch.Tensor:
-    """x NHWC (N,H,W,Cin or 4 for the stem), dz NHWC (N,Ho,Wo,CoutG) -> dw (Cout,Cin,R,S)."""
+def conv2d_wgrad(x, dz, cout: int, cin: int, r: int, s: int, stride: int, pad: int, out=None) -> torch.Tensor:
+    """x NHWC (N,H,W,Cin or 4 for the stem), dz NHWC (N,Ho,Wo,CoutG) -> dw (Cout,Cin,R,S) (written into ``out`` when
+    given: a slice of the flat gradient arena)."""
     n, h, w, _ = x.shape
-    dw = torch.empty((cout, cin, r, s), device=x.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty((cout, cin, r, s), device=x.device, dtype=torch.float32)
+    if dw.numel() != cout * cin * r * s:
+        raise VatlError("conv2d_wgrad: out has the wrong size")
     m = n * dz.shape[1] * dz.shape[2]
     ws = torch.empty(int(lib().vatl_conv2d_wgrad_workspace_floats(cout, cin, r, s, m)), device=x.device, dtype=torch.float32)
     _check(lib().vatl_conv2d_wgrad(_ptr(x), _ptr(dz), _ptr(dw), _ptr(ws), n, h, w, cin, cout, dz.shape[3], r, s, stride, pad, _stream()),
@@ -526,10 +530,12 @@ def conv2d_wgrad(x, dz, cout: int, cin: int, r: int, s: int, stride: int, pad: i
     return dw
 
 
-def deconv4x4s2_wgrad(x, dy) -> torch.Tensor:
+def deconv4x4s2_wgrad(x, dy, out=None) -> torch.Tensor:
     n, h, w, cin = x.shape
     cout = dy.shape[3]
-    dw = torch.empty((cin, cout, 4, 4), device=x.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty((cin, cout, 4, 4), device=x.device, dtype=torch.float32)
+    if dw.numel() != cin * cout * 16:
+        raise VatlError("deconv4x4s2_wgrad: out has the wrong size")
     ws = torch.empty(int(lib().vatl_deconv4x4s2_wgrad_workspace_floats(cin, cout, n * h * w)), device=x.device, dtype=torch.float32)
     _check(lib().vatl_deconv4x4s2_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), n, h, w, cin, cout, _stream()), "vatl_deconv4x4s2_wgrad")
     return dw
@@ -583,13 +589,13 @@ def deconv4x4s2_fwd_bnstats(x, w_packed, cout: int, gamma, beta, running_mean, r
     return [z] + _bn_finalize(stats, used.value, 4 * n * h * w, cout, (gamma, beta, running_mean, running_var, momentum, eps), x.device)
 
 
-def bn_train_bwd_relu(dy, scale, bias, z, gamma, save_mean, save_invstd):
+def bn_train_bwd_relu(dy, scale, bias, z, gamma, save_mean, save_invstd, dgamma=None, dbeta=None):
     """Backward of Conv+BN+ReLU without a skip input; the ReLU mask is recomputed from z. -> dz, dgamma, dbeta."""
     c = z.shape[-1]
     m = z.numel() // c
     dz = torch.empty_like(z)
-    dgamma = torch.empty(c, device=z.device, dtype=torch.float32)
-    dbeta = torch.empty(c, device=z.device, dtype=torch.float32)
+    dgamma = dgamma if dgamma is not None else torch.empty(c, device=z.device, dtype=torch.float32)
+    dbeta = dbeta if dbeta is not None else torch.empty(c, device=z.device, dtype=torch.float32)
     coef = torch.empty(3 * c, device=z.device, dtype=torch.float32)
     _check(lib().vatl_bn_train_bwd_relu(_ptr(dy), _ptr(scale), _ptr(bias), _ptr(z), _ptr(gamma), _ptr(save_mean), _ptr(save_invstd), _ptr(dz),
                                         _ptr(dgamma), _ptr(dbeta), m, c, _ptr(coef), _ptr(_col_ws(m, c, z.device), torch.float64), _stream()),
@@ -605,14 +611,14 @@ def scale_bias_act(z, scale, bias, residual=None, relu=True):
     return y
 
 
-def bn_train_bwd(dy, y, z, gamma, save_mean, save_invstd, want_g: bool = False):
+def bn_train_bwd(dy, y, z, gamma, save_mean, save_invstd, want_g: bool = False, dgamma=None, dbeta=None):
     """-> dz, g (or None), dgamma, dbeta."""
     c = z.shape[-1]
     m = z.numel() // c
     dz = torch.empty_like(z)
     g = torch.empty_like(z) if want_g else None
-    dgamma = torch.empty(c, device=z.device, dtype=torch.float32)
-    dbeta = torch.empty(c, device=z.device, dtype=torch.float32)
+    dgamma = dgamma if dgamma is not None else torch.empty(c, device=z.device, dtype=torch.float32)
+    dbeta = dbeta if dbeta is not None else torch.empty(c, device=z.device, dtype=torch.float32)
     coef = torch.empty(3 * c, device=z.device, dtype=torch.float32)
     _check(lib().vatl_bn_train_bwd(_ptr(dy), _ptr(y), _ptr(z), _ptr(gamma), _ptr(save_mean), _ptr(save_invstd), _ptr(dz), _ptr(g),
                                    _ptr(dgamma), _ptr(dbeta), m, c, _ptr(coef), _ptr(_col_ws(m, c, z.device), torch.float64), _stream()),
