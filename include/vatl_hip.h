@@ -216,6 +216,18 @@ int vatl_plane_entropy(const float* hm, float* out, int N, int J, int H, int W, 
 int vatl_conv2d_fwd_ex(const float* x, const float* w, const float* scale, const float* bias, const float* residual, float* y,
                        int N, int H, int W, int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad_y, int pad_x,
                        int Ho, int Wo, int OH, int OW, int osy, int osx, int ooy, int oox, int relu, void* stream);
+/* The same launch fused with the reduction pass of the BatchNorm backward of the layer whose output gradient it produces
+ * (loss.backward() through Conv2d -> BatchNorm2d -> ReLU chains, ActiveLearning.py:672; Resnet.py:104-128): y receives
+ * g = (W^T dz + residual) * mask, mask = [bn_mask_y > 0] when bn_mask_y is given (ReLU after a residual sum), else
+ * [fmaf(bn_z, bn_scale, bn_bias) > 0] when bn_scale is given (plain Conv+BN+ReLU, the mask vatl_scale_bias_act produced), else 1;
+ * `stats` receives per (row block of the implicit GEMM, channel) the double partials (sum g, sum g*xhat), xhat =
+ * (bn_z - bn_mean)*bn_invstd, in the layout of vatl_conv2d_fwd_stats (capacity vatl_conv_stats_row_blocks(N*Ho*Wo, 1) * Cout * 2
+ * doubles per launch; *row_blocks_used = HOST count actually written).  bn_z / bn_mask_y have the layout of y.  Cout % 4 == 0.
+ * vatl_bn_bwd_from_stats then finishes the BatchNorm backward with one pass: no separate reduction over (dy, z). */
+int vatl_conv2d_fwd_ex_bnbwd(const float* x, const float* w, const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
+                             int CoutPad, int R, int S, int stride, int pad_y, int pad_x, int Ho, int Wo, int OH, int OW, int osy, int osx,
+                             int ooy, int oox, const float* bn_z, const float* bn_mask_y, const float* bn_scale, const float* bn_bias,
+                             const float* bn_mean, const float* bn_invstd, double* stats, int64_t* row_blocks_used, void* stream);
 /* Data-gradient weights of nn.Conv2d (Cout,Cin,R,S): out[c][t][n] = w[n][c][tap_r[t]][tap_s[t]],
  * shape [CinPad][ntaps][CoutK] (rows c >= Cin and columns n >= Cout zero); tap_r/tap_s are HOST arrays,
  * ntaps <= 16. */
@@ -256,6 +268,13 @@ int vatl_bn_train_bwd(const float* dy, const float* y_or_null, const float* z, c
 int vatl_bn_train_bwd_relu(const float* dy, const float* scale, const float* bias, const float* z, const float* gamma,
                            const float* save_mean, const float* save_invstd, float* dz, float* dgamma, float* dbeta,
                            int64_t M, int C, float* coef3C, double* workspace, void* stream);
+/* BatchNorm backward from the partial sums vatl_conv2d_fwd_ex_bnbwd left behind: g = the masked output gradient it stored,
+ * partial / row_blocks = its statistics (several launches may have appended theirs: per-parity data gradients of a strided
+ * conv).  dgamma = sum g*xhat, dbeta = sum g, dz = gamma*invstd*(g - dbeta/M - xhat*dgamma/M) in one pass over (g, z).
+ * coef3C: 3*C floats of scratch. */
+int vatl_bn_bwd_from_stats(const double* partial, int64_t row_blocks, const float* g, const float* z, const float* gamma,
+                           const float* save_mean, const float* save_invstd, float* dz, float* dgamma, float* dbeta, int64_t M, int C,
+                           float* coef3C, void* stream);
 /* Training forward with the BatchNorm batch statistics taken in the conv epilogue (no separate pass over z):
  * the conv / deconv writes z (no affine, no ReLU) and, per 128-row block of the implicit GEMM and channel, a partial
  * (sum, sum of squares) pair into `stats` (capacity vatl_conv_stats_row_blocks(rows, phases) * Cout * 2 doubles; rows =

@@ -18,7 +18,7 @@ fi
 if [[ "$ARGS" == *" prof "* ]]; then
   echo "== rocprofv3 kernel stats"
   rm -rf gpurun_out/prof
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > gpurun_out/prof.log 2>&1
   tail -2 gpurun_out/prof.log
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f" | cut -c1-200
   find gpurun_out/prof -name "*kernel_trace*" -size +30M -delete
@@ -28,7 +28,7 @@ if [[ "$ARGS" == *" pmc "* ]]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     echo "== rocprofv3 --pmc $c"
     rm -rf gpurun_out/pmc_$c
-    timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -o r1 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_$c.log 2>&1
+    timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -o r1 -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > gpurun_out/pmc_$c.log 2>&1
     tail -1 gpurun_out/pmc_$c.log | cut -c1-300
     ls gpurun_out/pmc_$c | head
     find gpurun_out/pmc_$c -name "*kernel_trace*" -size +30M -delete

@@ -37,7 +37,8 @@ def main():
     a = ap.parse_args()
     import vatl_hip as vh
     dev = torch.device("cuda:0")
-    vh.tune_set(4, a.ablate)
+    if a.ablate:
+        vh.tune_set(4, a.ablate)
     for name, h, w, cin, cout, k, stride, pad in SHAPES:
         if a.only and a.only not in name:
             continue
@@ -47,7 +48,8 @@ def main():
         flop = 2.0 * a.batch * ho * wo * cout * cin * k * k
         row = {"shape": name, "ideal_us": round(flop / 157.3e12 * 1e6, 1)}
         for blocks in [int(b) for b in a.blocks.split(",")]:
-            vh.tune_set(3, blocks)
+            if blocks:
+                vh.tune_set(3, blocks)
             for _ in range(3):
                 vh.conv2d_wgrad(x, dz, cout, cin, k, k, stride, pad)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

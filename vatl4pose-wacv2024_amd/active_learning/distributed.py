@@ -194,6 +194,10 @@ class GradArena:
             self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self._group, async_op=True))
             self.launches += 1
 
+    def would_fire(self, off: int) -> bool:
+        """Whether ``done_offset(off)`` would start an all-reduce (callers with work on other streams join them first)."""
+        return self._live and off < self._lo and self._lo - off >= self.bucket
+
     def done_offset(self, off: int):
         """Every slice at or above element offset ``off`` holds its final value for this step."""
         if not self._live:

@@ -57,9 +57,69 @@ class _Grads(dict):
 
     def flush(self):
         # everything at or above the lowest offset written so far is final once that whole range has been written
-        if self.overlap and self._filled == self.arena.total - self._low:
+        if self.overlap and self._filled == self.arena.total - self._low and self.arena.would_fire(self._low):
+            _side.join()                                   # the bucket's weight gradients were written on the side stream
             self.arena.done_offset(self._low)
 
+
+class _SideStream:
+    """Weight gradients on a second HIP stream.  In the backward pass of a layer, dW = wgrad(x, dz) and dx = dgrad(dz) both
+    consume dz and nothing downstream needs dW before the optimizer step, so the wgrad launches run beside the critical chain
+    (BatchNorm backward -> data gradient -> previous layer): at fine-tune batch sizes every conv launch is only 1-3 rounds of
+    resident blocks, and the MFMA-bound wgrad blocks fill the tails of the dgrad launches and overlap the HBM-bound BatchNorm
+    passes.  Same kernels, same arguments: results are bit-identical to the single-stream order.  VATL_WGRAD_STREAM=0 = off."""
+
+    def __init__(self):
+        import os
+        self.enabled = os.environ.get("VATL_WGRAD_STREAM", "1") != "0"
+        self._streams = {}
+        self.used = False
+
+    def stream(self, device):
+        st = self._streams.get(device)
+        if st is None:
+            st = self._streams[device] = torch.cuda.Stream(device=device)
+        return st
+
+    def run(self, fn, *tensors):
+        """fn() on the side stream once everything queued on the current stream so far is done; ``tensors`` are its inputs
+        (kept from being recycled by the caching allocator until the side stream is through with them)."""
+        if not self.enabled:
+            return fn()
+        main = torch.cuda.current_stream()
+        side = self.stream(tensors[0].device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = fn()
+        for t in tensors:
+            t.record_stream(side)
+        self.used = True
+        return out
+
+    def join(self):
+        """The current stream waits for every side-stream launch so far (before gradients are read / all-reduced)."""
+        if self.used:
+            for st in self._streams.values():
+                torch.cuda.current_stream().wait_stream(st)
+            self.used = False
+
+
+_side = _SideStream()
+
+
+def _gout(grads, p):
+    """The arena slice a gradient kernel should write for parameter p (None: let the wrapper allocate; plain dicts are accepted
+    wherever a ``_Grads`` is)."""
+    return grads.out(p) if isinstance(grads, _Grads) else None
+
+
+import os as _os
+# BatchNorm-backward reduction inside the producing data-gradient launch (vatl_conv2d_fwd_ex_bnbwd); VATL_FUSE_BN_BWD=0 = the
+# stand-alone reduction pass (same values up to the summation order of the per-channel sums)
+_FUSE_BN_BWD = _os.environ.get("VATL_FUSE_BN_BWD", "1") != "0"
+# ... for layers with at least this many channels: on the narrow tiles (32 / 64 output channels) the statistics epilogue costs
+# more than the stand-alone reduction pass it replaces (HRNet-W32 step 63.9 -> 69.4 ms with every layer fused)
+_FUSE_BN_MIN_C = int(_os.environ.get("VATL_FUSE_BN_MINC", "128"))
 
 _pending_counters = []
 
@@ -100,12 +160,27 @@ class _ConvBN:
         return y
 
     # ---- backward ------------------------------------------------------------
-    def backward(self, dy, grads, dx_residual=None):
-        """dy: gradient of the layer output.  Returns (dx, g_skip); parameter gradients go to ``grads``."""
+    def bn_spec(self):
+        """What the launch that PRODUCES this layer's output gradient needs in order to run the reduction pass of this layer's
+        BatchNorm backward in its own epilogue (vatl_conv2d_fwd_ex_bnbwd); taken before ``backward`` consumes the tape."""
+        if not _FUSE_BN_BWD or self.cout < _FUSE_BN_MIN_C:
+            return None
+        x, z, y, mean, invstd, had_skip, mask = self.saved
+        if mask is not None:                               # ReLU, no skip: mask recomputed from z
+            return vh.BnBwdSpec(z, mean, invstd, scale=mask[0], bias=mask[1])
+        return vh.BnBwdSpec(z, mean, invstd, mask_y=y)     # ReLU after a skip sum (y saved), or no ReLU at all (y is None)
+
+    def backward(self, dy, grads, dx_residual=None, pre=None, consumer=None):
+        """dy: gradient of the layer output.  Returns (dx, g_skip); parameter gradients go to ``grads``.
+        ``pre``: the BnBwdSpec this layer handed to the producer of dy — dy is then already masked and its (sum g, sum g*xhat)
+        partials are in ``pre``.  ``consumer``: the BnBwdSpec of the layer that will receive dx."""
         x, z, y, mean, invstd, had_skip, mask = self.saved
         self.saved = None
-        og, ob = grads.out(self.bn.weight), grads.out(self.bn.bias)
-        if mask is not None:
+        og, ob = _gout(grads, self.bn.weight), _gout(grads, self.bn.bias)
+        if pre is not None:
+            dz, dgamma, dbeta = vh.bn_bwd_from_stats(pre, dy, self.bn.weight.detach(), dgamma=og, dbeta=ob)
+            g = dy if had_skip else None
+        elif mask is not None:
             dz, dgamma, dbeta = vh.bn_train_bwd_relu(dy, mask[0], mask[1], z, self.bn.weight.detach(), mean, invstd, dgamma=og, dbeta=ob)
             g = None
         else:
@@ -116,20 +191,24 @@ class _ConvBN:
         grads[self.bn.weight] = dgamma
         grads[self.bn.bias] = dbeta
         cin_w = 3 if self.cin == 3 else self.cin
-        grads[self.conv.weight] = vh.conv2d_wgrad(x, dz, self.cout, cin_w, self.r, self.s, self.stride, self.pad, out=grads.out(self.conv.weight))
-        dx = self._dgrad(dz, x.shape, dx_residual) if self.need_dx else None
+        ow = _gout(grads, self.conv.weight)
+        grads[self.conv.weight] = _side.run(lambda: vh.conv2d_wgrad(x, dz, self.cout, cin_w, self.r, self.s, self.stride, self.pad, out=ow), x, dz)
+        dx = self._dgrad(dz, x.shape, dx_residual, consumer) if self.need_dx else None
         return dx, g
 
-    def _dgrad(self, dz, xshape, residual):
+    def _dgrad(self, dz, xshape, residual, spec=None):
         n, h, w, cin = xshape
         wt = self.conv.weight.detach()
         ho, wo = dz.shape[1], dz.shape[2]
+
+        def conv(*a, **k):                                # with a consumer spec: mask + BatchNorm-backward reduction in the epilogue
+            return vh.conv2d_fwd_ex_bnbwd(*a, spec, **k) if spec is not None else vh.conv2d_fwd_ex(*a, **k)
         if self.stride == 1:
             wd = vh.pack_dgrad_weight(wt, _flipped_taps(self.r, self.s))
-            return vh.conv2d_fwd_ex(dz, wd, cin, self.r, self.s, 1, self.r - 1 - self.pad, self.s - 1 - self.pad, h, w, h, w, 1, 1, 0, 0,
-                                    residual=residual)
+            return conv(dz, wd, cin, self.r, self.s, 1, self.r - 1 - self.pad, self.s - 1 - self.pad, h, w, h, w, 1, 1, 0, 0, residual=residual)
         assert self.stride == 2 and h == 2 * ho and w == 2 * wo
         if self.r == 1:                                   # 1x1/2 projection: only even pixels receive gradient
+            assert spec is None
             dx = torch.zeros((n, h, w, cin), device=dz.device, dtype=torch.float32) if residual is None else residual.clone()
             wd = vh.pack_dgrad_weight(wt, [(0, 0)])
             res_view = None
@@ -144,7 +223,7 @@ class _ConvBN:
             for px in (0, 1):
                 cols = [1] if px == 0 else [2, 0]
                 wd = vh.pack_dgrad_weight(wt, [(a, b) for a in rows for b in cols])
-                vh.conv2d_fwd_ex(dz, wd, cin, len(rows), len(cols), 1, 0, 0, ho, wo, h, w, 2, 2, py, px, out=dx, residual=residual)
+                conv(dz, wd, cin, len(rows), len(cols), 1, 0, 0, ho, wo, h, w, 2, 2, py, px, out=dx, residual=residual)
         return dx
 
 
@@ -164,17 +243,30 @@ class _DeconvBN:
         self.saved = (x, z, scale, bias, mean, invstd)
         return y
 
-    def backward(self, dy, grads):
+    def bn_spec(self):
+        if not _FUSE_BN_BWD or self.cout < _FUSE_BN_MIN_C:
+            return None
+        x, z, scale, bias, mean, invstd = self.saved
+        return vh.BnBwdSpec(z, mean, invstd, scale=scale, bias=bias)
+
+    def backward(self, dy, grads, pre=None, consumer=None):
         x, z, scale, bias, mean, invstd = self.saved
         self.saved = None
-        dz, dgamma, dbeta = vh.bn_train_bwd_relu(dy, scale, bias, z, self.bn.weight.detach(), mean, invstd,
-                                                 dgamma=grads.out(self.bn.weight), dbeta=grads.out(self.bn.bias))
+        if pre is not None:
+            dz, dgamma, dbeta = vh.bn_bwd_from_stats(pre, dy, self.bn.weight.detach(), dgamma=_gout(grads, self.bn.weight), dbeta=_gout(grads, self.bn.bias))
+        else:
+            dz, dgamma, dbeta = vh.bn_train_bwd_relu(dy, scale, bias, z, self.bn.weight.detach(), mean, invstd,
+                                                     dgamma=_gout(grads, self.bn.weight), dbeta=_gout(grads, self.bn.bias))
         grads[self.bn.weight] = dgamma
         grads[self.bn.bias] = dbeta
-        grads[self.dc.weight] = vh.deconv4x4s2_wgrad(x, dz, out=grads.out(self.dc.weight))
+        ow = _gout(grads, self.dc.weight)
+        grads[self.dc.weight] = _side.run(lambda: vh.deconv4x4s2_wgrad(x, dz, out=ow), x, dz)
         # dx[y][x][ci] = sum_{ky,kx,co} dz[2y-1+ky][2x-1+kx][co] * W[ci][co][ky][kx]: a 4x4/2 pad-1 conv whose
         # "OIHW" weight is the deconv weight itself (O = Cin, I = Cout)
         wd = vh.pack_conv_weight(self.dc.weight.detach())
+        if consumer is not None:
+            n, h, w, _ = x.shape
+            return vh.conv2d_fwd_ex_bnbwd(dz, wd, self.cin, 4, 4, 2, 1, 1, h, w, h, w, 1, 1, 0, 0, consumer)
         return vh.conv2d_fwd(dz, wd, None, None, self.cin, 4, 4, 2, 1, False)
 
 
@@ -189,12 +281,34 @@ class _BottleneckT:
         skip = x if self.proj is None else self.proj.forward(x)
         return self.c3.forward(self.c2.forward(self.c1.forward(x)), skip=skip)
 
-    def backward(self, dy, grads):
-        db, g = self.c3.backward(dy, grads)                # g = gradient of the skip input (masked dy)
-        da, _ = self.c2.backward(db, grads)
+    def out_spec(self):
+        """BnBwdSpec of the block output (= conv3's BatchNorm; the ReLU mask comes from the saved y)."""
+        return self.c3.bn_spec()
+
+    def backward(self, dy, grads, pre=None, consumer=None):
+        s2, s1 = self.c2.bn_spec(), self.c1.bn_spec()
+        db, g = self.c3.backward(dy, grads, pre=pre, consumer=s2)        # g = gradient of the skip input (masked dy)
+        da, _ = self.c2.backward(db, grads, pre=s2, consumer=s1)
         dskip = g if self.proj is None else self.proj.backward(g, grads)[0]
-        dx, _ = self.c1.backward(da, grads, dx_residual=dskip)   # dx = dgrad(c1) + dskip in one epilogue
+        dx, _ = self.c1.backward(da, grads, dx_residual=dskip, pre=s1, consumer=consumer)   # dx = dgrad(c1) + dskip in one epilogue
         return dx
+
+
+def _chain_blocks_backward(blocks, dx, grads, pre, flush=None):
+    """Backward through a run of residual blocks, last to first.  The data-gradient launch that produces a block's input
+    gradient runs the reduction pass of the PREVIOUS block's output BatchNorm in its epilogue (``out_spec``) whenever that
+    block is a plain residual block; ``pre`` is the spec the caller already filled for the last block (or None)."""
+    for i in range(len(blocks) - 1, -1, -1):
+        if hasattr(blocks[i], "out_spec"):
+            consumer = blocks[i - 1].out_spec() if (i > 0 and hasattr(blocks[i - 1], "out_spec")) else None
+            dx = blocks[i].backward(dx, grads, pre=pre, consumer=consumer)
+            pre = consumer
+        else:                                              # SE bottleneck: gated output, its own backward kernels; plain gradient out
+            assert pre is None
+            dx = blocks[i].backward(dx, grads)
+        if flush is not None:
+            flush()
+    return dx
 
 
 class SimplePoseTrainer:
@@ -232,20 +346,23 @@ class SimplePoseTrainer:
         cin = self.head.weight.shape[1]
         dy = vh.nchw_to_nhwc(dout_nchw.contiguous(), 32)                         # 17 -> 32 channels (zeros)
         grads[self.head.bias] = vh.col_sum(dy)[:j].contiguous()
-        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, 1, 1, 1, 0, out=grads.out(self.head.weight))
+        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, 1, 1, 1, 0, out=_gout(grads, self.head.weight))
         wd = vh.pack_dgrad_weight(self.head.weight.detach(), [(0, 0)], cout_k=32)
         n, h, w, _ = self.head_in.shape
-        dx = vh.conv2d_fwd_ex(dy, wd, cin, 1, 1, 1, 0, 0, h, w, h, w, 1, 1, 0, 0)
+        pre = self.deconvs[-1].bn_spec()
+        dx = vh.conv2d_fwd_ex_bnbwd(dy, wd, cin, 1, 1, 1, 0, 0, h, w, h, w, 1, 1, 0, 0, pre) if pre is not None else \
+            vh.conv2d_fwd_ex(dy, wd, cin, 1, 1, 1, 0, 0, h, w, h, w, 1, 1, 0, 0)
         self.head_in = None
-        for d in reversed(self.deconvs):
-            dx = d.backward(dx, grads)
+        for k in range(len(self.deconvs) - 1, -1, -1):
+            consumer = self.deconvs[k - 1].bn_spec() if k > 0 else self.blocks[-1].out_spec()
+            dx = self.deconvs[k].backward(dx, grads, pre=pre, consumer=consumer)
+            pre = consumer
             grads.flush()
-        for b in reversed(self.blocks):
-            dx = b.backward(dx, grads)
-            grads.flush()
+        dx = _chain_blocks_backward(self.blocks, dx, grads, pre, grads.flush)
         dx = vh.maxpool3x3s2_bwd_idx(dx, self.pool_idx, self.pool_hw)
         self.pool_idx = None
         self.stem.backward(dx, grads)
+        _side.join()
         return grads
 
 
@@ -271,7 +388,7 @@ class _LinearT:
         if self.relu:
             dy = vh.relu_bwd(dy.contiguous(), y)
         grads[self.lin.bias] = vh.col_sum(dy)
-        ow = grads.out(self.lin.weight)
+        ow = _gout(grads, self.lin.weight)
         grads[self.lin.weight] = vh.conv2d_wgrad(x2d.reshape(b, 1, 1, self.ci), dy.reshape(b, 1, 1, self.co), self.co, self.ci, 1, 1, 1, 0,
                                                  out=None if ow is None else ow.view(self.co, self.ci, 1, 1)).reshape(self.co, self.ci)
         wd = vh.pack_dgrad_weight(self.lin.weight.detach().reshape(self.co, self.ci, 1, 1), [(0, 0)])
@@ -302,10 +419,11 @@ class _SEBottleneckT:
         dgate = vh.se_bwd_gate(dy, y, u, gate)
         dpool = self.fc1.backward(self.fc2.backward(dgate, grads), grads)
         du, gm = vh.se_bwd_apply(dy, y, gate, dpool)
-        db, _ = self.c3.backward(du, grads)
-        da, _ = self.c2.backward(db, grads)
+        s2, s1 = self.c2.bn_spec(), self.c1.bn_spec()
+        db, _ = self.c3.backward(du, grads, consumer=s2)
+        da, _ = self.c2.backward(db, grads, pre=s2, consumer=s1)
         dskip, _ = self.proj.backward(gm, grads)
-        dx, _ = self.c1.backward(da, grads, dx_residual=dskip)
+        dx, _ = self.c1.backward(da, grads, dx_residual=dskip, pre=s1)
         return dx
 
 
@@ -340,7 +458,7 @@ class FastPoseTrainer:
         j, cin = self.head.weight.shape[:2]
         dy = vh.nchw_to_nhwc(dout_nchw.contiguous(), 32)
         grads[self.head.bias] = vh.col_sum(dy)[:j].contiguous()
-        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, 3, 3, 1, 1, out=grads.out(self.head.weight))
+        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, 3, 3, 1, 1, out=_gout(grads, self.head.weight))
         wd = vh.pack_dgrad_weight(self.head.weight.detach(), _flipped_taps(3, 3), cout_k=32)
         n, h, w, _ = self.head_in.shape
         dx = vh.conv2d_fwd_ex(dy, wd, cin, 3, 3, 1, 1, 1, h, w, h, w, 1, 1, 0, 0)
@@ -349,12 +467,11 @@ class FastPoseTrainer:
         dx, _ = self.duc1.backward(vh.pixelunshuffle2(dx), grads)
         grads.flush()
         dx = vh.pixelunshuffle2(dx)
-        for b in reversed(self.blocks):
-            dx = b.backward(dx, grads)
-            grads.flush()
+        dx = _chain_blocks_backward(self.blocks, dx, grads, None, grads.flush)
         dx = vh.maxpool3x3s2_bwd_idx(dx, self.pool_idx, self.pool_hw)
         self.pool_idx = None
         self.stem.backward(dx, grads)
+        _side.join()
         return grads
 
 
@@ -370,10 +487,14 @@ class _BasicBlockT:
         skip = x if self.proj is None else self.proj.forward(x)
         return self.c2.forward(self.c1.forward(x), skip=skip)
 
-    def backward(self, dy, grads):
-        da, g = self.c2.backward(dy, grads)
+    def out_spec(self):
+        return self.c2.bn_spec()
+
+    def backward(self, dy, grads, pre=None, consumer=None):
+        s1 = self.c1.bn_spec()
+        da, g = self.c2.backward(dy, grads, pre=pre, consumer=s1)
         dskip = g if self.proj is None else self.proj.backward(g, grads)[0]
-        return self.c1.backward(da, grads, dx_residual=dskip)[0]
+        return self.c1.backward(da, grads, dx_residual=dskip, pre=s1, consumer=consumer)[0]
 
 
 def _block_t(blk):
@@ -444,8 +565,7 @@ class _HRModuleT:
         else:
             dxs = list(dys)
         for i, br in enumerate(self.branches):
-            for blk in reversed(br):
-                dxs[i] = blk.backward(dxs[i], grads)
+            dxs[i] = _chain_blocks_backward(br, dxs[i], grads, None)
         return dxs
 
 
@@ -485,7 +605,7 @@ class HRNetTrainer:
         j, cin, k, _ = self.head.weight.shape
         dy = vh.nchw_to_nhwc(dout_nchw.contiguous(), 32)
         grads[self.head.bias] = vh.col_sum(dy)[:j].contiguous()
-        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, k, k, 1, k // 2, out=grads.out(self.head.weight))
+        grads[self.head.weight] = vh.conv2d_wgrad(self.head_in, dy, j, cin, k, k, 1, k // 2, out=_gout(grads, self.head.weight))
         wd = vh.pack_dgrad_weight(self.head.weight.detach(), _flipped_taps(k, k), cout_k=32)
         n, h, w, _ = self.head_in.shape
         dys = [vh.conv2d_fwd_ex(dy, wd, cin, k, k, 1, k // 2, k // 2, h, w, h, w, 1, 1, 0, 0)]
@@ -501,11 +621,10 @@ class HRNetTrainer:
                 if t is not None:
                     prev[width - 1] = t.backward(dys[i], grads, dx_residual=prev[width - 1])
             dys = prev
-        dx = dys[0]
-        for b in reversed(self.layer1):
-            dx = b.backward(dx, grads)
+        dx = _chain_blocks_backward(self.layer1, dys[0], grads, None)
         dx, _ = self.stem2.backward(dx, grads)
         self.stem1.backward(dx, grads)
+        _side.join()
         return grads
 
 

@@ -405,6 +405,23 @@ extern "C" int vatl_bn_train_bwd_relu(const float* dy, const float* scale, const
     return bn_train_bwd_impl(dy, nullptr, scale, bias, z, gamma, save_mean, save_invstd, dz, nullptr, dgamma, dbeta, M, C, coef3C, workspace, stream);
 }
 
+// BatchNorm backward whose reduction pass already ran in the epilogue of the data-gradient launch that produced g
+// (vatl_conv2d_fwd_ex_bnbwd): g = masked output gradient, partial = its (sum g, sum g*xhat) row-block partials.
+// Finalize (dgamma, dbeta, coefficients) + ONE apply pass dz = A*g + B*z + C.
+extern "C" int vatl_bn_bwd_from_stats(const double* partial, int64_t row_blocks, const float* g, const float* z, const float* gamma,
+                                      const float* save_mean, const float* save_invstd, float* dz, float* dgamma, float* dbeta, int64_t M, int C,
+                                      float* coef3C, void* stream) {
+    if (!partial || !g || !z || !save_mean || !save_invstd || !dz || !coef3C || (C & 3) || M <= 0 || row_blocks <= 0 || row_blocks > 0x7FFFFFFF)
+        return fail(VATL_EINVAL, "bn_bwd_from_stats: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, partial, (int)row_blocks, (long long)M, C, gamma, save_mean, save_invstd,
+                       dgamma, dbeta, coef3C, coef3C + C, coef3C + 2 * C);
+    const long long n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, g, (const float*)nullptr, z, coef3C, coef3C + C, coef3C + 2 * C, dz,
+                       (float*)nullptr, n4, C / 4, (const float*)nullptr, (const float*)nullptr);
+    return check_launch("bn_bwd_from_stats");
+}
+
 extern "C" int vatl_bn_train_finalize(const double* partial, int64_t row_blocks, int64_t M, int C, const float* gamma, const float* beta,
                                       float* running_mean, float* running_var, float momentum, float eps, float* save_mean,
                                       float* save_invstd, float* scale, float* bias, void* stream) {

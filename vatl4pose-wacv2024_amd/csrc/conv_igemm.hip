@@ -21,9 +21,14 @@
 // tile's global loads are issued before the current tile's 16 k-steps of MFMAs
 // and written to the other LDS buffer after them (register staging), so HBM/L2
 // latency hides under >= 2048 cycles of matrix work per wave.
-// LDS rows are padded 32 -> 36 floats: ds_read_b128 fragment reads (16 rows at
-// one k offset per lane group) and ds_write_b128 staging writes are both
-// conflict-free (bank = (row*36 + k) mod 64).
+// LDS rows are exactly one k-tile (32 floats = 128 bytes), bank conflicts are avoided by an XOR swizzle of
+// the 16-byte chunk position: chunk c of tile row r lives at position c ^ ((r >> 1) & 7).  A ds_read_b128
+// fragment read (16 consecutive rows at one logical chunk per lane group) then touches all 16 chunk slots of
+// the 256-byte bank row, and a ds_write_b128 staging pass (8 rows x 8 chunks per wave) still covers whole
+// rows: both conflict-free.  Against the 36-float padded rows of the first version this saves 11 % of LDS:
+// the 64x128 and 128x64 tiles drop from 55 KB to 48 KB per block = THREE resident blocks per CU instead of two
+// (their 132-138 VGPRs allow three waves per SIMD), which is what small-batch launches (fine-tune steps: one to
+// three rounds of resident blocks) need to fill the chip.
 //
 // One ds_read_b128 feeds four MFMA k-steps: lanes 0-31 hold k = 8g+t, lanes
 // 32-63 hold k = 8g+4+t at step t (same permutation for A and B, so the sum
@@ -61,6 +66,16 @@ struct ConvParams {
     int stagger;                      // start the second resident block of every CU half a block-time late
     int K;                            // packed K per output channel
     double* stats;                    // training: per (row block, channel) partial (sum, sum^2) of the stored tile, or NULL
+    // BatchNorm-backward fusion (data-gradient launches of the fine-tune step): the tile being stored is dL/dy of a
+    // Conv+BN(+ReLU) layer whose conv output is bz (same NHWC layout as y).  The epilogue applies that layer's ReLU mask
+    // (bmy > 0 if given, else bz*bsc+bbi > 0 if bsc is given, else none), stores g = masked gradient and accumulates the
+    // per-channel (sum g, sum g*xhat), xhat = (bz - bmu)*bis, into `stats` — the reduction pass of the BN backward.
+    const float* bz;
+    const float* bmy;
+    const float* bsc;
+    const float* bbi;
+    const float* bmu;
+    const float* bis;
     // dual-source 1x1 (projection shortcut fused into the block's last conv): k-tiles 0..k1-1 read x (C1 = Cin channels,
     // one row per output pixel), k-tiles k1.. read x2 (C2 channels, an H2 x W2 image sampled with stride2)
     const float* x2;
@@ -76,7 +91,9 @@ struct ConvParams {
 };
 
 constexpr int BK = 32;
-constexpr int LDK = 36;               // padded LDS row (floats)
+constexpr int LDK = BK;               // LDS row = one k-tile; chunk positions XOR-swizzled (see above)
+// dynamic LDS of a BM x BN block: the two k-loop stages, or the epilogue's output tile if that is larger
+constexpr int conv_smem_floats(int BM, int BN) { return 2 * (BM + BN) * LDK > BM * (BN + 4) ? 2 * (BM + BN) * LDK : BM * (BN + 4); }
 constexpr unsigned OOB = 0xFFFFFFFFu; // byte offset guaranteed outside any descriptor below
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -96,7 +113,7 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned by
 
 // Epilogue shared by the conv kernels: scale/bias in registers, tile staged through LDS, then full-row 16-byte
 // stores with the residual read the same way (or per-element stores for NCHW / odd channel counts).
-template <int BM, int BN, int WM, int WN, int NT = 256>
+template <int BM, int BN, int WM, int WN, int NT = 256, bool BNB = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[WM / 32][WN / 32], float* smem, int m0, int n0,
                                               int ooy, int oox, int wm, int wn, int tid, int lane, int HoWo) {
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -164,6 +181,39 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     if (vec) {
         const int c4 = tid % C4, r0 = tid / C4;
         f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BNB) {
+            // BatchNorm-backward fusion (separate instantiations: the extra tile of z / mask registers must not cost the
+            // inference kernels their occupancy): mask the gradient tile with the consumer layer's ReLU, store g, reduce (g, g*xhat)
+            const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bz), 0, p.y_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bmy), 0, p.bmy ? p.y_bytes : 0u, 0x00020000);
+            const int n = n0 + c4 * 4;
+            const bool nv = n < p.Cout;                    // Cout % 4 == 0 on this path: the float4 is in range or entirely out
+            const f32x4 one = {1.f, 1.f, 1.f, 1.f}, nul = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 mu = nv ? *reinterpret_cast<const f32x4*>(p.bmu + n) : nul, is = nv ? *reinterpret_cast<const f32x4*>(p.bis + n) : nul;
+            const f32x4 msc = (nv && p.bsc) ? *reinterpret_cast<const f32x4*>(p.bsc + n) : nul;
+            const f32x4 mbi = (nv && p.bsc) ? *reinterpret_cast<const f32x4*>(p.bbi + n) : one;   // no mask: 0*z + 1 > 0
+            f32x4 zt[NP], yt[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) zt[u] = buf_load4(zr, offv[u]);
+            if (p.bmy) {
+#pragma unroll
+                for (int u = 0; u < NP; ++u) yt[u] = buf_load4(mr, offv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[(r0 + u * RPP) * LDC + c4 * 4]);
+                f32x4 g;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float d = v[c] + rsv[u][c];
+                    const bool on = p.bmy ? yt[u][c] > 0.f : fmaf(zt[u][c], msc[c], mbi[c]) > 0.f;
+                    g[c] = on ? d : 0.f;
+                    ssum[c] += g[c];
+                    ssq[c] += g[c] * ((zt[u][c] - mu[c]) * is[c]);       // rows >= M: d = 0 exactly
+                }
+                buf_store4(yr, offv[u], g);
+            }
+        } else {
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[(r0 + u * RPP) * LDC + c4 * 4]);
@@ -175,6 +225,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { ssum[c] += o[c]; ssq[c] += o[c] * o[c]; }   // rows >= M hold exact zeros
             }
+        }
         }
         if (p.stats) {
             // BatchNorm batch statistics of the tile just stored (training forward): per-thread fp32 sums over NP rows,
@@ -248,7 +299,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 //   5  LDS-DMA kernel below (buffer_load ... lds, source-side XOR swizzle): 134 — equal to VAR2, the saved
 //      ds_write pass (+5 %, ablation VAR13) is offset by its distance-1 prefetch
 // (a rotated loop that buries the tile hand-over in the last MFMA group measured equal to VAR2 and was dropped)
-template <int BM, int BN, int WM, int WN, bool STEM, int VAR, bool DUAL = false, int NT = 256>
+template <int BM, int BN, int WM, int WN, bool STEM, int VAR, bool DUAL = false, int NT = 256, bool BNB = false>
 __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                          // [2][BM][LDK]
@@ -301,6 +352,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
     // ---- per-thread gather state --------------------------------------------
     const int lrow = tid >> 3;        // 0..RP-1
     const int kq = tid & 7;           // which float4 of the 32-wide k-tile
+    const int wpos = (kq ^ ((lrow >> 1) & 7)) * 4;   // its swizzled position in the LDS row (RP is a multiple of 16: same for every pass)
     int abase[LA], iy0[LA], ix0[LA];  // element offset of (b, iy0, ix0, kq*4); may be negative
     int abase2[DUAL ? LA : 1];        // DUAL: element offset of the row's pixel in the second source
     const int HoWo = p.Ho * p.Wo;
@@ -366,10 +418,10 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < LA; ++i)
-            *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + RP * i) * LDK + kq * 4]) = ra[i];
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + RP * i) * LDK + wpos]) = ra[i];
 #pragma unroll
         for (int j = 0; j < LB; ++j)
-            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + RP * j) * LDK + kq * 4]) = rb[j];
+            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + RP * j) * LDK + wpos]) = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -380,16 +432,19 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // fragment addressing: row frow (+ 32 i), logical chunk 2g + (lane >> 5), stored at chunk ^ ((frow >> 1) & 7)
     const int frow = lane & 31;
-    const int fk = (lane >> 5) * 4;
+    int koff[BK / 8];
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) koff[g] = ((2 * g + (lane >> 5)) ^ ((frow >> 1) & 7)) * 4;
 
     gload(0, true);
     lstore(0);
     __syncthreads();
 
     auto frag_read = [&](f32x4 (&af)[TM], f32x4 (&bf)[TN], int buf, int g) {
-        const float* Ab = As + (buf * BM + wm * WM + frow) * LDK + fk + g * 8;
-        const float* Bb = Bs + (buf * BN + wn * WN + frow) * LDK + fk + g * 8;
+        const float* Ab = As + (buf * BM + wm * WM + frow) * LDK + koff[g];
+        const float* Bb = Bs + (buf * BN + wn * WN + frow) * LDK + koff[g];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);
 #pragma unroll
@@ -436,9 +491,9 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
         };
         auto stash = [&](const f32x4 (&da)[LA], const f32x4 (&db)[LB], int buf) {
 #pragma unroll
-            for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + RP * i) * LDK + kq * 4]) = da[i];
+            for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + RP * i) * LDK + wpos]) = da[i];
 #pragma unroll
-            for (int j = 0; j < LB; ++j) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + RP * j) * LDK + kq * 4]) = db[j];
+            for (int j = 0; j < LB; ++j) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + RP * j) * LDK + wpos]) = db[j];
         };
         issue(sa[0], sb[0], 1);
         for (int kt = 0; kt < p.ktiles; kt += 2) {
@@ -555,7 +610,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
         return;
     }
 #endif
-    conv_epilogue<BM, BN, WM, WN, NT>(p, acc, smem, m0, n0, ooy, oox, wm, wn, tid, lane, HoWo);
+    conv_epilogue<BM, BN, WM, WN, NT, BNB>(p, acc, smem, m0, n0, ooy, oox, wm, wn, tid, lane, HoWo);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -580,7 +635,11 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_persistent_kernel(ConvParams p
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int lrow = tid >> 3, kq = tid & 7;
-    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    const int wpos = (kq ^ ((lrow >> 1) & 7)) * 4;
+    const int frow = lane & 31;
+    int koff[BK / 8];
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) koff[g] = ((2 * g + (lane >> 5)) ^ ((frow >> 1) & 7)) * 4;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
 
@@ -612,13 +671,13 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_persistent_kernel(ConvParams p
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + 32 * i) * LDK + kq * 4]) = ra[i];
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + 32 * i) * LDK + wpos]) = ra[i];
 #pragma unroll
-        for (int j = 0; j < LB; ++j) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + 32 * j) * LDK + kq * 4]) = rb[j];
+        for (int j = 0; j < LB; ++j) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + 32 * j) * LDK + wpos]) = rb[j];
     };
     auto frag_read = [&](f32x4 (&af)[TM], f32x4 (&bf)[TN], int buf, int g) {
-        const float* Ab = As + (buf * BM + wm * WM + frow) * LDK + fk + g * 8;
-        const float* Bb = Bs + (buf * BN + wn * WN + frow) * LDK + fk + g * 8;
+        const float* Ab = As + (buf * BM + wm * WM + frow) * LDK + koff[g];
+        const float* Bb = Bs + (buf * BN + wn * WN + frow) * LDK + koff[g];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);
 #pragma unroll
@@ -881,10 +940,10 @@ static float* splitk_workspace(long long* floats) {
     return g_splitk_ws[d].load(std::memory_order_acquire);
 }
 
-template <int BM, int BN, int WM, int WN, bool STEM, int VAR, bool DUAL = false, int NT = 256>
+template <int BM, int BN, int WM, int WN, bool STEM, int VAR, bool DUAL = false, int NT = 256, bool BNB = false>
 static int launch(const ConvParams& p, int phases, hipStream_t st) {
-    auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM, VAR, DUAL, NT>;
-    constexpr int smem = 2 * (BM + BN) * LDK * (int)sizeof(float);
+    auto kern = conv_igemm_kernel<BM, BN, WM, WN, STEM, VAR, DUAL, NT, BNB>;
+    constexpr int smem = conv_smem_floats(BM, BN) * (int)sizeof(float);
     static std::atomic<unsigned> configured{0};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, configured, "conv_igemm")) return rc;
     ConvParams q = p;
@@ -899,7 +958,6 @@ static int launch(const ConvParams& p, int phases, hipStream_t st) {
 #endif
     // one s_sleep(127) = 8128 cycles; a k-tile costs ~8192 cycles when two blocks share the SIMDs
     q.stagger = (int)((long long)g_stagger.load(std::memory_order_relaxed) * p.ktiles / 100);
-    static_assert(2 * (BM + BN) * LDK >= BM * (BN + 4), "epilogue tile must fit in the staging buffers");
     const int m_tiles = cdiv(p.M, BM);
     const long long blocks = (long long)m_tiles * q.n_tiles * phases;
     long long ws_floats = 0;
@@ -949,7 +1007,7 @@ static int launch_dma(const ConvParams& p, int phases, hipStream_t st) {
 template <int BM, int BN, int WM, int WN>
 static int launch_persistent(const ConvParams& p, hipStream_t st) {
     auto kern = gemm1x1_persistent_kernel<BM, BN, WM, WN>;
-    constexpr int smem = 2 * (BM + BN) * LDK * (int)sizeof(float);
+    constexpr int smem = conv_smem_floats(BM, BN) * (int)sizeof(float);
     static std::atomic<unsigned> configured{0};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, configured, "gemm1x1_persistent")) return rc;
     ConvParams q = p;
@@ -994,6 +1052,15 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, 
         if (bn == 64) return launch<128, 64, 64, 32, true, 0>(p, phases, st);
         if (bn == 128) return launch<128, 128, 64, 64, true, 0>(p, phases, st);
         return launch<128, 32, 32, 32, true, 0>(p, phases, st);
+    }
+    if (p.bz) {
+        // data-gradient launch that also runs the reduction pass of the consumer layer's BatchNorm backward (fine-tune step)
+        if (!p.stats || (p.Cout & 3) || p.out_nchw) return fail(VATL_EINVAL, "conv bn-backward fusion: needs a statistics buffer and an NHWC output with Cout %% 4 == 0");
+        if (bn == 32) return launch<128, 32, 32, 32, false, 4, false, 256, true>(p, phases, st);
+        if (bn == 64 && bm == 64) return launch<64, 64, 32, 32, false, 4, false, 256, true>(p, phases, st);
+        if (bn == 64) return launch<128, 64, 64, 32, false, 4, false, 256, true>(p, phases, st);
+        if (bm == 64) return launch<64, 128, 32, 64, false, 4, false, 256, true>(p, phases, st);
+        return launch<128, 128, 64, 64, false, 4, false, 256, true>(p, phases, st);
     }
     if (bm == 64) {
         if (bn == 128) return launch<64, 128, 32, 64, false, 4>(p, phases, st);
@@ -1183,9 +1250,11 @@ extern "C" int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float
 // output scatter (oy*osy+ooy, ox*osx+oox) into an OH x OW image.  Transposed-conv style gradients are
 // phase-decomposed by the caller (alphapose/models/hip_train.py): e.g. the data gradient of a 3x3/2 conv is
 // four launches with 1x1 / 1x2 / 2x1 / 2x2 taps over the output-gradient grid, scattered with osy = osx = 2.
-extern "C" int vatl_conv2d_fwd_ex(const float* x, const float* w, const float* scale, const float* bias, const float* residual, float* y,
-                                  int N, int H, int W, int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad_y, int pad_x,
-                                  int Ho, int Wo, int OH, int OW, int osy, int osx, int ooy, int oox, int relu, void* stream) {
+static int conv2d_fwd_ex_impl(const float* x, const float* w, const float* scale, const float* bias, const float* residual, float* y,
+                              int N, int H, int W, int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad_y, int pad_x,
+                              int Ho, int Wo, int OH, int OW, int osy, int osx, int ooy, int oox, int relu, const float* bn_z, const float* bn_mask_y,
+                              const float* bn_scale, const float* bn_bias, const float* bn_mean, const float* bn_invstd, double* stats,
+                              int64_t* row_blocks_used, void* stream) {
     if (!x || !w || !y || N <= 0) return fail(VATL_EINVAL, "conv2d_fwd_ex: null pointer or empty batch");
     if (Cin % 32 != 0) return fail(VATL_EINVAL, "conv2d_fwd_ex: Cin %d must be a multiple of 32", Cin);
     ConvParams p{};
@@ -1200,5 +1269,31 @@ extern "C" int vatl_conv2d_fwd_ex(const float* x, const float* w, const float* s
     if (xe >= (1LL << 30) || ye >= (1LL << 30) || we >= (1LL << 30))
         return fail(VATL_EINVAL, "conv2d_fwd_ex: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
     p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.w_bytes = (unsigned)(we * 4);
-    return dispatch(p, 1, false, (hipStream_t)stream);
+    if (bn_z) {
+        if (!stats || !row_blocks_used || !bn_mean || !bn_invstd || relu || scale || bias || (bn_scale && !bn_bias))
+            return fail(VATL_EINVAL, "conv2d_fwd_ex_bnbwd: needs z, mean, invstd, a statistics buffer; no scale / bias / ReLU of its own");
+        p.bz = bn_z; p.bmy = bn_mask_y; p.bsc = bn_scale; p.bbi = bn_bias; p.bmu = bn_mean; p.bis = bn_invstd; p.stats = stats;
+    }
+    return dispatch(p, 1, false, (hipStream_t)stream, row_blocks_used);
+}
+
+extern "C" int vatl_conv2d_fwd_ex(const float* x, const float* w, const float* scale, const float* bias, const float* residual, float* y,
+                                  int N, int H, int W, int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad_y, int pad_x,
+                                  int Ho, int Wo, int OH, int OW, int osy, int osx, int ooy, int oox, int relu, void* stream) {
+    return conv2d_fwd_ex_impl(x, w, scale, bias, residual, y, N, H, W, Cin, Cout, CoutPad, R, S, stride, pad_y, pad_x, Ho, Wo, OH, OW, osy, osx, ooy, oox,
+                              relu, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// Data-gradient launch fused with the reduction pass of a BatchNorm backward (ActiveLearning.py:672, loss.backward()): y receives
+// g = (W^T dz + residual) * [consumer layer's ReLU mask] and `stats` the per-(row block, channel) double partials of
+// (sum g, sum g * xhat) in the layout vatl_bn_bwd_from_stats reduces.  bn_z = that layer's conv output (layout of y);
+// mask = bn_mask_y > 0 when given (layers whose ReLU follows a residual sum), else bn_z*bn_scale+bn_bias > 0 when bn_scale is
+// given, else none.  row_blocks_used returns how many row blocks were written (<= vatl_conv_stats_row_blocks(N*Ho*Wo, 1)).
+extern "C" int vatl_conv2d_fwd_ex_bnbwd(const float* x, const float* w, const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
+                                        int CoutPad, int R, int S, int stride, int pad_y, int pad_x, int Ho, int Wo, int OH, int OW, int osy, int osx,
+                                        int ooy, int oox, const float* bn_z, const float* bn_mask_y, const float* bn_scale, const float* bn_bias,
+                                        const float* bn_mean, const float* bn_invstd, double* stats, int64_t* row_blocks_used, void* stream) {
+    if (!bn_z) return fail(VATL_EINVAL, "conv2d_fwd_ex_bnbwd: null bn_z");
+    return conv2d_fwd_ex_impl(x, w, nullptr, nullptr, residual, y, N, H, W, Cin, Cout, CoutPad, R, S, stride, pad_y, pad_x, Ho, Wo, OH, OW, osy, osx, ooy,
+                              oox, 0, bn_z, bn_mask_y, bn_scale, bn_bias, bn_mean, bn_invstd, stats, row_blocks_used, stream);
 }

@@ -58,6 +58,8 @@ SIGNATURES = {
     "vatl_peaks5": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vatl_plane_entropy": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vatl_conv2d_fwd_ex": (_i, [_p] * 6 + [_i] * 20 + [_p]),
+    "vatl_conv2d_fwd_ex_bnbwd": (_i, [_p] * 4 + [_i] * 19 + [_p] * 9),
+    "vatl_bn_bwd_from_stats": (_i, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p]),
     "vatl_pack_dgrad_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "vatl_conv2d_wgrad_workspace_floats": (_i64, [_i, _i, _i, _i, _i64]),
     "vatl_conv2d_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -501,6 +503,53 @@ def conv2d_fwd_ex(x, w_packed, cout, r, s, stride, pad_y, pad_x, ho, wo, oh, ow,
                                     w_packed.shape[0], r, s, stride, pad_y, pad_x, ho, wo, oh, ow, osy, osx, ooy, oox, int(relu), _stream()),
            "vatl_conv2d_fwd_ex")
     return y
+
+
+class BnBwdSpec:
+    """What a data-gradient launch needs to run the reduction pass of the consumer layer's BatchNorm backward in its
+    epilogue: z (the consumer's conv output), its ReLU mask source (mask_y, or (scale, bias) to recompute it from z, or
+    neither) and the saved batch statistics.  ``stats`` / ``blocks`` collect the partial sums of one or more launches."""
+
+    def __init__(self, z, mean, invstd, mask_y=None, scale=None, bias=None):
+        self.z, self.mean, self.invstd, self.mask_y, self.scale, self.bias = z, mean, invstd, mask_y, scale, bias
+        c = z.shape[-1]
+        cap = int(lib().vatl_conv_stats_row_blocks(z.numel() // c, 1)) + 8     # + a partial tile per parity launch
+        self.stats = torch.empty(cap * c * 2, device=z.device, dtype=torch.float64)
+        self.blocks = 0
+
+
+def conv2d_fwd_ex_bnbwd(x, w_packed, cout, r, s, stride, pad_y, pad_x, ho, wo, oh, ow, osy, osx, ooy, oox, spec: BnBwdSpec, out=None, residual=None):
+    """conv2d_fwd_ex whose epilogue masks the result with the consumer layer's ReLU and appends the (sum g, sum g*xhat) row-block
+    partials to ``spec`` (several launches — the parity launches of a strided conv's data gradient — append one after another)."""
+    n, h, w, cin = x.shape
+    y = out if out is not None else torch.empty((n, oh, ow, cout), device=x.device, dtype=torch.float32)
+    if y.shape != spec.z.shape:
+        raise VatlError("conv2d_fwd_ex_bnbwd: the BatchNorm tensors must have the layout of the output")
+    used = C.c_int64(0)
+    c = spec.z.shape[-1]
+    stats_ptr = spec.stats.data_ptr() + spec.blocks * c * 2 * 8
+    need = int(lib().vatl_conv_stats_row_blocks(n * ho * wo, 1))
+    if (spec.blocks + need) * c * 2 > spec.stats.numel():
+        raise VatlError("conv2d_fwd_ex_bnbwd: statistics buffer too small")
+    _check(lib().vatl_conv2d_fwd_ex_bnbwd(_ptr(x), _ptr(w_packed), _ptr(residual), _ptr(y), n, h, w, cin, cout, w_packed.shape[0], r, s, stride, pad_y,
+                                          pad_x, ho, wo, oh, ow, osy, osx, ooy, oox, _ptr(spec.z), _ptr(spec.mask_y), _ptr(spec.scale), _ptr(spec.bias),
+                                          _ptr(spec.mean), _ptr(spec.invstd), stats_ptr, C.addressof(used), _stream()), "vatl_conv2d_fwd_ex_bnbwd")
+    spec.blocks += used.value
+    return y
+
+
+def bn_bwd_from_stats(spec: BnBwdSpec, g, gamma, dgamma=None, dbeta=None):
+    """Finish the BatchNorm backward whose reduction ran in the data-gradient epilogue: -> dz, dgamma, dbeta."""
+    z = spec.z
+    c = z.shape[-1]
+    m = z.numel() // c
+    dz = torch.empty_like(z)
+    dgamma = dgamma if dgamma is not None else torch.empty(c, device=z.device, dtype=torch.float32)
+    dbeta = dbeta if dbeta is not None else torch.empty(c, device=z.device, dtype=torch.float32)
+    coef = torch.empty(3 * c, device=z.device, dtype=torch.float32)
+    _check(lib().vatl_bn_bwd_from_stats(_ptr(spec.stats, torch.float64), spec.blocks, _ptr(g), _ptr(z), _ptr(gamma), _ptr(spec.mean), _ptr(spec.invstd),
+                                        _ptr(dz), _ptr(dgamma), _ptr(dbeta), m, c, _ptr(coef), _stream()), "vatl_bn_bwd_from_stats")
+    return dz, dgamma, dbeta
 
 
 def pack_dgrad_weight(w: torch.Tensor, taps, cout_k: int | None = None) -> torch.Tensor:
