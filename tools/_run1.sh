@@ -1,6 +1,4 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-run() { VATL_FUSE_BN_MINC=$1 timeout 300 python tools/train_bench.py --steps 40 --warmup 8 --model $2 --batch $3 2>&1 | tail -1 | sed 's/.*ms_per_step": \([0-9.]*\).*/\1/'; }
-for rep in 1 2; do
-for mc in 9999 256 128 64; do
-echo "rep $rep MINC $mc: simplepose $(run $mc simplepose 120)  fastpose $(run $mc fastpose 120)  hrnet $(run $mc hrnet 64)"
-done; done
+rm -f gpurun_out/parity_report.jsonl
+VATL_WGRAD_STREAM=${WS:-1} timeout 900 python -m pytest tests/test_gpu_train.py -q -k "every_block" 2>&1 | grep -E "^E  .*AssertionError|passed|failed" | cut -c1-3000
+grep "block_check\|block_grad" gpurun_out/parity_report.jsonl | cut -c1-220 | grep -v "e-0[6789]" | head -40

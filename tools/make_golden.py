@@ -542,6 +542,76 @@ def gen_crop(out: str):
     np.savez_compressed(os.path.join(out, "crop.npz"), **res)
 
 
+WELLCOND_SEED = 1234
+WELLCOND_MODELS = {
+    "simplepose": {"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50},
+    "fastpose": {"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50},
+}
+
+
+def gen_wellcond(EasyDict, out: str):
+    """A DISCRIMINATING whole-network gradient fixture: one fine-tune step (ActiveLearning.py:662-673) of the reference's
+    SimplePose-R50 and FastPose-R50 at B = 16 with default-initialised weights and untouched BatchNorm statistics (running
+    mean 0 / variance 1, gamma 1 / beta 0) — well conditioned, unlike the B = 2 steps with randomised statistics above, so a
+    1 % defect in any layer's gradient shows.  The weights are torch's default initialisation of the BUILD's modules under
+    a fixed seed (dumped by a child process that imports the build's package, loaded here into the reference's modules with
+    strict=True: same keys, same shapes), so the GPU box regenerates them without a 136 MB file.  Stored: loss, the gradient
+    norm and 512 sampled gradient values of every 10th parameter tensor, two weight checksums."""
+    import subprocess
+    import tempfile
+    from alphapose.models import builder                         # the reference's
+    preset = EasyDict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    B = 16
+    x = torch.from_numpy(synth.crops(B, seed=91))
+    labels, masks = synth.gaussian_targets(B, seed=92)
+    labels, masks = torch.from_numpy(labels), torch.from_numpy(masks)
+    res = {"batch": np.int64(B), "seed": np.int64(WELLCOND_SEED)}
+    for name, c in WELLCOND_MODELS.items():
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "sd.pt")
+            child = (f"import sys, torch; sys.path[:0] = [{ROOT!r}, {os.path.join(ROOT, 'vatl4pose-wacv2024_amd')!r}]\n"
+                     "from alphapose.models import builder; from alphapose.utils.config import edict\n"
+                     f"torch.manual_seed({WELLCOND_SEED}); m = builder.build_sppe(edict({c!r}), preset_cfg=edict({dict(preset)!r}))\n"
+                     f"torch.save(m.state_dict(), {path!r})\n")
+            subprocess.run([sys.executable, "-c", child], check=True)
+            sd = torch.load(path)
+        m = builder.build_sppe(EasyDict(c), preset_cfg=preset)
+        m.load_state_dict(sd, strict=True)
+        m.train()
+        outp = m(x.clone().requires_grad_())
+        loss = 0.5 * torch.nn.MSELoss()(outp.mul(masks), labels.mul(masks))
+        loss.backward()
+        res[f"{name}_loss"] = np.float64(loss.item())
+        res[f"{name}_out_absmean"] = np.float64(outp.detach().abs().mean().item())
+        params = list(m.named_parameters())
+        res[f"{name}_wsum"] = np.float64(sum(float(p.detach().double().abs().sum()) for _, p in params))
+        res[f"{name}_w0"] = params[0][1].detach().reshape(-1)[:8].numpy().copy()
+        picked = [k for i, (k, _) in enumerate(params) if i % 10 == 0] + [params[-1][0], params[-2][0]]
+        for k in dict.fromkeys(picked):
+            gr = dict(params)[k].grad
+            ii = _sample_idx(gr.numel(), "wc" + k, 512)
+            res[f"{name}_grad_idx::{k}"] = ii
+            res[f"{name}_grad_val::{k}"] = gr.reshape(-1)[ii].numpy()
+            res[f"{name}_grad_norm::{k}"] = np.float64(gr.double().norm().item())
+        res[f"{name}_bn1_running_mean"] = m.preact.bn1.running_mean.numpy().copy()
+        # the same step in float64 (oracle graph, bit-identical to the reference in fp32): how far the REFERENCE's own fp32 step
+        # is from exact arithmetic — the tolerance the parity test grants, tensor by tensor
+        from oracle import nets
+        ref64 = (nets.SimplePoseRef(50) if name == "simplepose" else nets.FastPoseRef(50))
+        ref64.load_state_dict(sd, strict=True)
+        ref64 = ref64.double().train()
+        o64 = ref64(x.double())
+        l64 = 0.5 * torch.nn.MSELoss()(o64 * masks.double(), labels.double() * masks.double())
+        l64.backward()
+        g64 = {k: p.grad for k, p in ref64.named_parameters()}
+        for k in dict.fromkeys(picked):
+            ii = res[f"{name}_grad_idx::{k}"]
+            res[f"{name}_grad_f64::{k}"] = g64[k].reshape(-1)[ii].numpy()
+        res[f"{name}_loss_f64"] = np.float64(l64.item())
+        print("wellcond", name, float(loss), float(l64), len(dict.fromkeys(picked)), "tensors")
+    np.savez_compressed(os.path.join(out, "wellcond_step.npz"), **res)
+
+
 def gen_hostaug(out: str):
     """Host-side augmentation arithmetic of the reference's SimpleTransform, called unbound on seeded joints:
     half_body_transform (simple_transform.py:253-304, one np.random.randn() draw each) and _integral_target_generator
@@ -592,6 +662,8 @@ def main():
         gen_l1_loss(a.out)
     if a.only in ("", "crop"):
         gen_crop(a.out)
+    if a.only in ("", "wellcond"):
+        gen_wellcond(EasyDict, a.out)
     if a.only in ("", "hostaug"):
         gen_hostaug(a.out)
     if a.only in ("", "r152"):
