@@ -457,3 +457,29 @@ def test_optin_splitk_matches_unsplit_kernel(vh):
     with torch.no_grad():
         again = cases[0]()
     assert torch.equal(again, base[0])
+
+
+@pytest.mark.parametrize("n,h,w", [(3, 64, 48), (2, 16, 24), (5, 8, 16), (1, 32, 8)])
+def test_halo_tile_kernel_is_bit_identical_to_the_implicit_gemm(vh, n, h, w):
+    """csrc/conv3x3_halo.hip serves the 32-channel 3x3 layers (HRNet's high-resolution branch) from a persistent block with the
+    filter and a halo tile in LDS; its reduction order is the implicit GEMM's, so the two kernels must agree bit for bit — with
+    and without BatchNorm affine, residual and ReLU, on both patch shapes (8x16 and 16x8) and on image borders."""
+    rng = np.random.RandomState(n * 1000 + h)
+    x = to_dev(rng.randn(n, h, w, 32).astype(np.float32))
+    wt = to_dev((rng.randn(32, 32, 3, 3) * 0.1).astype(np.float32))
+    wp = vh.pack_conv_weight(wt)
+    sc, bi = to_dev(rng.rand(32).astype(np.float32) + 0.5), to_dev(rng.randn(32).astype(np.float32))
+    res = to_dev(rng.randn(n, h, w, 32).astype(np.float32))
+    for scale, bias, residual, relu in ((sc, bi, res, True), (None, None, None, False), (sc, bi, None, True), (None, bi, res, False)):
+        vh.tune_set(8, 1)
+        a = vh.conv2d_fwd(x, wp, scale, bias, 32, 3, 3, 1, 1, relu, residual=residual)
+        vh.tune_set(8, 0)
+        try:
+            b = vh.conv2d_fwd(x, wp, scale, bias, 32, 3, 3, 1, 1, relu, residual=residual)
+        finally:
+            vh.tune_set(8, 1)
+        assert torch.equal(a, b)
+    # and against float64 (the generic kernel's own bound)
+    want = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), padding=1).permute(0, 2, 3, 1).numpy()
+    got = vh.conv2d_fwd(x, wp, None, None, 32, 3, 3, 1, 1, False).cpu().numpy()
+    assert rel_err(got, want) < 2e-6

@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--bm", default="", help="comma list of block-tile row counts to A/B (vatl_tune_set knob 5: 0 auto, 64, 128)")
     ap.add_argument("--persist", default="", help="comma list of persistent-1x1 settings to A/B (vatl_tune_set knob 7: 0 off, 1 = K <= 256 [default])")
     a = ap.parse_args()
+    if os.environ.get("VATL_HALO") == "0":
+        vh.tune_set(8, 0)                                  # 32-channel 3x3 layers on the generic kernel (A/B against csrc/conv3x3_halo.hip)
     # clock / cache warm-up: the first configuration measured in a fresh process otherwise reads 4-10 % slow, which biases every A/B
     warm_a = torch.randn((4096, 4096), device="cuda:0")
     t_end = torch.cuda.Event(enable_timing=True); t_beg = torch.cuda.Event(enable_timing=True)

@@ -1031,11 +1031,13 @@ static int tile_n_for(int Cout) { return Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 12
 //  * 128-wide tiles: 128 rows unless the launch has fewer than ~1.5 rounds of the 512 resident blocks (small batches:
 //    the B = 120 fine-tune step, single-frame inference), where 64-row tiles fill the chip better (+15..30 %).
 static int tile_m_for(const ConvParams& p, int phases, int bn, bool stem) {
-    if (stem || bn < 64) return 128;
+    if (stem || bn < 64) return 128;                      // (a 256x32 tile measured 8 % slower than 128x32 on the HRNet 32-channel branch)
     const int forced = g_bm.load(std::memory_order_relaxed);
     if (forced == 64 || forced == 128) return forced;
-    if (bn == 64) return 64;
     const long long blocks128 = (long long)cdiv(p.M, 128) * (p.CoutPad / bn) * phases;
+    // 64-channel outputs: with the swizzled LDS rows the 128x64 tile has three resident blocks per CU and beats the 64x64 tile
+    // (four blocks) by 2.5-3 % once the launch has a few rounds of them (l1.c2 1873 -> 1827 us, hr.b64 487 -> 474 us at 1024 crops)
+    if (bn == 64) return blocks128 >= 1536 ? 128 : 64;
     return blocks128 < 768 ? 64 : 128;
 }
 
@@ -1098,6 +1100,12 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, 
 
 }  // namespace vatl
 
+namespace vatl {
+int conv3x3_halo_try(const float* x, const float* w, const float* scale, const float* bias, const float* residual, float* y, int N, int H, int W,
+                     int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad, int relu, hipStream_t st);   // conv3x3_halo.hip
+int conv3x3_halo_enable(int on);
+}
+
 using namespace vatl;
 
 extern "C" int vatl_tune_wgrad_blocks(int blocks);
@@ -1119,6 +1127,7 @@ extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 5 && (value == 0 || value == 64 || value == 128)) { g_bm.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 6 && value >= 0 && value <= 3) { g_ablate.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 7 && value >= 0 && value <= 64) { g_persist.store(value, std::memory_order_relaxed); return 0; }
+    if (knob == 8 && (value == 0 || value == 1)) return conv3x3_halo_enable(value);
     if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
     if (knob == 0 && value >= 0 && value <= 13) { g_var.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }
@@ -1150,6 +1159,10 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* scale, c
     if (stats && ((Cout & 3) || out_nchw)) return fail(VATL_EINVAL, "conv2d_fwd_stats: Cout %d must be a multiple of 4 (NHWC output)", Cout);
     const bool stem = (Cin == 4);
     if (!stem && Cin % 32 != 0) return fail(VATL_EINVAL, "conv2d_fwd: Cin %d must be a multiple of 32 (or 4 for the stem)", Cin);
+    if (!stats && !out_nchw) {                            // narrow 3x3 layers: the persistent halo-tile kernel (bit-identical results)
+        const int rc = conv3x3_halo_try(x, w, scale, bias, residual, y, N, H, W, Cin, Cout, CoutPad, R, S, stride, pad, relu, (hipStream_t)stream);
+        if (rc <= 0) return rc;                           // 1 = not one of its shapes: fall through to the implicit GEMM
+    }
     if (stem && S > 8) return fail(VATL_EINVAL, "conv2d_fwd: stem filter width %d > 8", S);
     ConvParams p{};
     p.x = x; p.w = w; p.scale = scale; p.bias = bias; p.res = residual; p.y = y;
