@@ -459,7 +459,7 @@ def test_optin_splitk_matches_unsplit_kernel(vh):
     assert torch.equal(again, base[0])
 
 
-@pytest.mark.parametrize("n,h,w", [(3, 64, 48), (2, 16, 24), (5, 8, 16), (1, 32, 8)])
+@pytest.mark.parametrize("n,h,w", [(3, 64, 48), (2, 16, 24), (5, 8, 16), (1, 32, 8), (7, 32, 24)])
 def test_halo_tile_kernel_is_bit_identical_to_the_implicit_gemm(vh, n, h, w):
     """csrc/conv3x3_halo.hip serves the 32-channel 3x3 layers (HRNet's high-resolution branch) from a persistent block with the
     filter and a halo tile in LDS; its reduction order is the implicit GEMM's, so the two kernels must agree bit for bit — with

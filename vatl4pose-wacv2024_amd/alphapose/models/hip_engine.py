@@ -325,10 +325,15 @@ def _chunks(n: int, hw=(256, 192)):
 
 
 def _version_key(m: nn.Module, device):
-    v = 0
-    for t in list(m.parameters()) + list(m.buffers()):
-        v = v * 1000003 + t._version + (t.data_ptr() & 0xFFFF)
-    return (str(device), v & 0xFFFFFFFFFFFF)
+    """Exact signature of everything a plan bakes in (packed weights, folded BatchNorm): storage address and version counter of
+    every parameter and buffer — compared as a tuple, so two different states can never share a key.  Writers that go through
+    the C ABI bump the counters themselves (optimizers: active_learning/optim.py; BatchNorm running statistics: hip_train.py)."""
+    sig = [str(device)]
+    for t in m.parameters():
+        sig.append(t.data_ptr()); sig.append(t._version)
+    for t in m.buffers():
+        sig.append(t.data_ptr()); sig.append(t._version)
+    return tuple(sig)
 
 
 def _plan_for(m: nn.Module, device):

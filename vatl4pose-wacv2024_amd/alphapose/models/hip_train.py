@@ -128,12 +128,22 @@ def _count_batch(bn):
     """``num_batches_tracked += 1`` of a BatchNorm layer, deferred: the trainers bump all counters of a forward pass with
     one multi-tensor add (a 53- to 292-layer network otherwise spends a launch per layer on a one-element add)."""
     _pending_counters.append(bn.num_batches_tracked)
+    _pending_stats.append(bn.running_mean)
+    _pending_stats.append(bn.running_var)
+
+
+_pending_stats = []
 
 
 def _flush_batch_counters():
     if _pending_counters:
         torch._foreach_add_(_pending_counters, 1)
         _pending_counters.clear()
+    # the running statistics were updated through raw pointers (vatl_bn_train_finalize): bump their version counters so that the
+    # inference plans (which fold them into conv epilogues, hip_engine._version_key) see the change
+    for t in _pending_stats:
+        torch.autograd.graph.increment_version(t)
+    _pending_stats.clear()
 
 
 class _ConvBN:

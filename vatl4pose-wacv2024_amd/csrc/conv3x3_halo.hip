@@ -14,6 +14,11 @@
 //     them: no prologue, two barriers per patch, no per-k-tile barrier,
 //   * writes the output from the accumulators directly (a 32x32 MFMA tile has one lane per channel: a store instruction writes
 //     two full 128-byte NHWC pixel rows), scale / bias / residual / ReLU fused.
+// Measured and dropped (MI355X, hr.b32 at 1024 crops: this kernel 471 us, implicit GEMM 579-600 us):
+//   * two or three 4-wave groups per block sharing one filter copy (8 / 12 waves per CU behind one barrier): 505 / 495 us;
+//   * a 64-channel variant — halo tile resident, the 147 KB filter streamed one tap at a time through two LDS buffers in a ring
+//     that runs across patches: bit-identical, hr.b64 577 us against 480 us on the implicit GEMM, l1.c2 equal (ten barriers per
+//     patch and the first fragment reads of every tap exposed: the generic kernel's structure and its 79 %).
 // Reduction order per output = (tap, 8-channel group, pair) exactly as conv_igemm_kernel's k-tiles: results are BIT-IDENTICAL to
 // the generic kernel (tests/test_gpu_conv.py), so the evaluation path keeps its batch-position-independent bits.
 #include "common.h"
