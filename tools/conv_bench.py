@@ -27,6 +27,9 @@ SHAPES = {  # name: (H, W, Cin, Cout, k, stride, residual)
     "l2.c3nr": (32, 24, 128, 512, 1, 1, False), "l3.c3nr": (16, 12, 256, 1024, 1, 1, False), "l1.c3nr": (64, 48, 64, 256, 1, 1, False),
     "deconv1": (8, 6, 2048, 256, 0, 0, False), "deconv3": (32, 24, 256, 256, 0, 0, False),
     "head": (64, 48, 256, 17, 1, 1, False),
+    # FastPose-R152 at 384x288 (BASELINE.json configs[4]; use --batch 32): stage-3 / stage-4 bottleneck convs
+    "r152.l3.c1": (24, 18, 1024, 256, 1, 1, False), "r152.l3.c2": (24, 18, 256, 256, 3, 1, False), "r152.l3.c3": (24, 18, 256, 1024, 1, 1, True),
+    "r152.l2.c2": (48, 36, 128, 128, 3, 1, False), "r152.l4.c2": (12, 9, 512, 512, 3, 1, False), "r152.l4.c1": (12, 9, 2048, 512, 1, 1, False),
     # HRNet-W32 branches (basic blocks: 3x3, residual on the second conv), the 1x1 up paths and the 32->17 head
     "hr.b32": (64, 48, 32, 32, 3, 1, True), "hr.b64": (32, 24, 64, 64, 3, 1, True), "hr.b128": (16, 12, 128, 128, 3, 1, True),
     "hr.b256": (8, 6, 256, 256, 3, 1, True), "hr.up64_32": (32, 24, 64, 32, 1, 1, False), "hr.down32_64": (64, 48, 32, 64, 3, 2, False),
@@ -42,8 +45,11 @@ def main():
     ap.add_argument("--vars", default="", help="comma list of k-loop schedule variants to A/B (vatl_tune_set knob 0)")
     ap.add_argument("--ablate", default="", help="comma list of conv ablation bit sets (vatl_tune_set knob 6; needs VATL_ALLOW_ABLATION=1)")
     ap.add_argument("--bm", default="", help="comma list of block-tile row counts to A/B (vatl_tune_set knob 5: 0 auto, 64, 128)")
+    ap.add_argument("--splitk", type=int, default=0, help="register an N MB split-K workspace (vatl_set_splitk_workspace) before timing")
     ap.add_argument("--persist", default="", help="comma list of persistent-1x1 settings to A/B (vatl_tune_set knob 7: 0 off, 1 = K <= 256 [default])")
     a = ap.parse_args()
+    if a.splitk:
+        vh.enable_splitk(a.splitk)
     if os.environ.get("VATL_HALO") == "0":
         vh.tune_set(8, 0)                                  # 32-channel 3x3 layers on the generic kernel (A/B against csrc/conv3x3_halo.hip)
     # clock / cache warm-up: the first configuration measured in a fresh process otherwise reads 4-10 % slow, which biases every A/B
@@ -89,7 +95,7 @@ def main():
 
 def run(a):
     dev = torch.device("cuda:0")
-    names = a.layers.split(",") if a.layers else [n for n in SHAPES if not n.startswith("hr.") and not n.endswith("nr")]
+    names = a.layers.split(",") if a.layers else [n for n in SHAPES if not n.startswith("hr.") and not n.startswith("r152.") and not n.endswith("nr")]
     if a.layers == "hrnet":
         names = [n for n in SHAPES if n.startswith("hr.")]
     tot_f = tot_t = 0.0
