@@ -153,6 +153,17 @@ def test_mpe_margin_entropy_criteria():
     record("mpe_margin", mpe_rel=rel_err(got_mpe, want_mpe), margin_rel=rel_err(got_mar, want_mar))
     np.testing.assert_allclose(got_mpe, want_mpe, rtol=1e-5)
     np.testing.assert_allclose(got_mar, want_mar, rtol=1e-6)
+    # the wave-per-plane kernel (64 x 48, min_distance 5, 16-byte aligned) against the block kernel (any size; reached here through a
+    # 4-byte-offset view) on a larger random set: same peaks, same order, same criteria, bit for bit
+    big = synth.blob_heatmaps(48, seed=33)
+    big[5] = np.round(big[5] * 4) / 4                          # coarse values: many exact ties
+    flat = torch.empty(big.size + 1, device=d.device, dtype=torch.float32)
+    flat[1:] = to_dev(big).reshape(-1)
+    unaligned = flat[1:].view(big.shape)
+    assert unaligned.data_ptr() % 16 != 0
+    fast, slow = vh.peaks5(to_dev(big), 5), vh.peaks5(unaligned, 5)
+    for a_, b_ in zip(fast, slow):
+        assert torch.equal(a_, b_)
     want_ent = np.array([scorers.entropy_item(h) for h in hm])
     got_ent = multi_peak_scores(d, "Entropy").cpu().numpy()
     fin = np.isfinite(want_ent)
