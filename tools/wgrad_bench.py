@@ -24,6 +24,12 @@ SHAPES = [  # name, H, W, Cin, Cout, k, stride, pad
     ("l3.c3 1x1 256->1024 @16x12", 16, 12, 256, 1024, 1, 1, 0),
     ("l4.c2 3x3 512->512 @8x6", 8, 6, 512, 512, 3, 1, 1),
     ("l4.c3 1x1 512->2048 @8x6", 8, 6, 512, 2048, 1, 1, 0),
+    # FastPose-R152 at 384x288 (use --batch 32 --only r152)
+    ("r152.l2.c2 3x3 128->128 @48x36", 48, 36, 128, 128, 3, 1, 1),
+    ("r152.l3.c1 1x1 1024->256 @24x18", 24, 18, 1024, 256, 1, 1, 0),
+    ("r152.l3.c2 3x3 256->256 @24x18", 24, 18, 256, 256, 3, 1, 1),
+    ("r152.l3.c3 1x1 256->1024 @24x18", 24, 18, 256, 1024, 1, 1, 0),
+    ("r152.l4.c2 3x3 512->512 @12x9", 12, 9, 512, 512, 3, 1, 1),
 ]
 
 
