@@ -293,8 +293,12 @@ def have_workers() -> bool:
 
 
 def command(*msg):
-    """Rank 0 -> workers: the next thing every rank does together."""
+    """Rank 0 -> workers: the next thing every rank does together.  A worker that died (an exception in its replica) would leave
+    rank 0 waiting in the next collective until the backend's timeout: fail here instead."""
     if _workers:
+        dead = [(i + 1, p.returncode) for i, p in enumerate(_workers) if p.poll() is not None]
+        if dead:
+            raise RuntimeError(f"active_learning worker rank(s) exited: {dead} (rank, exit code); see their stderr above")
         broadcast_object(msg, src=0)
 
 
