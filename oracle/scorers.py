@@ -424,12 +424,22 @@ def target_generator(joints_xy: np.ndarray, vis: np.ndarray, hm_hw=(64, 48), in_
 # --------------------------------------------------------------------------
 # a13: MPE / Margin / Entropy          ActiveLearning.py:387-396, 762-796
 # --------------------------------------------------------------------------
-# `peak_local_max` is scikit-image's (pinned scikit-image==0.24.0, requirements.txt:172); the package is ABSENT from
-# this image, so the function below restates its published algorithm (skimage/feature/peak.py: maximum filter over a
-# (2*min_distance+1)^2 footprint with mode='nearest', threshold = image.min(), border of width min_distance excluded,
-# candidates sorted by descending intensity with a stable sort, `ensure_spacing` = greedy rejection of candidates at
-# Chebyshev distance < min_distance from an accepted one, first `num_peaks` kept).  PARITY UNPINNED for this one
-# function: it is checked against hand-built cases only.  softmax / entropy are scipy's (present: pinned directly).
+# `peak_local_max` is scikit-image's (the reference pins scikit-image==0.24.0, requirements.txt:172).  The package
+# does not import in this image, but the SOURCE of scikit-image 0.18.3 sits at /opt/conda/lib/python3.9/site-packages/
+# skimage and `feature/peak.py` + `_shared/coord.py` are pure Python: `tools/make_golden.py --only peaks` executes them
+# from there and freezes their answers (and the reference's compute_mpe / compute_margin run on top of them) in
+# tests/golden/peaks.npz.  PINNED on that fixture: positions, order and counts are identical on every plane whose
+# candidate maxima have pairwise distinct values (392 of 408 network-like planes, all border / spacing / truncation /
+# degenerate cases, the inputs of scikit-image's own test_peak.py) — tests/test_oracle_golden.py.
+# VERSION-DEPENDENT, and therefore not part of the parity claim: the order among candidates of EXACTLY equal value.
+# 0.18.3 sorts them with `np.argsort(-intensities)` (introsort, unstable beyond 16 elements, peak.py:17); 0.24 uses
+# kind="stable", i.e. row-major order among equals, which is what the function below restates (maximum filter over a
+# (2*min_distance+1)^2 footprint, threshold = image.min(), border of width min_distance excluded, candidates by
+# descending intensity, `ensure_spacing` = greedy rejection of candidates at Chebyshev distance < min_distance from an
+# accepted one, first `num_peaks` kept).  On the 16 tied planes of the fixture 12 agree with 0.18.3 and 4 pick another
+# of the equal maxima; MPE / Margin are unchanged by that choice there (equal values).  The filter's border mode
+# ('constant' in 0.18.3, 'nearest' in 0.24) cannot matter: every pixel whose window leaves the image is in the excluded
+# border.  softmax / entropy are scipy's (present: pinned directly).
 
 def peak_local_max_5(img: np.ndarray, min_distance: int = 5, num_peaks: int = 5) -> np.ndarray:
     """(H,W) -> (k,2) int rows of (row, col), k <= num_peaks, highest peaks first."""

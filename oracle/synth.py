@@ -100,6 +100,17 @@ def blob_heatmaps(n: int, seed: int = SEED, J: int = 17, hw=(64, 48), noise: flo
     return out
 
 
+def peak_items(n: int = 24, seed: int = 77) -> np.ndarray:
+    """Inputs of tests/golden/peaks.npz (MPE / Margin against the real scikit-image): network-like maps, one
+    non-negative item, one with a flat zero background, one all-negative, one value-quantised (ties among candidates)."""
+    hm = blob_heatmaps(n, seed=seed)
+    hm[3] = np.abs(hm[3]) + 1e-3
+    hm[7] = blob_heatmaps(1, seed=seed + 1, noise=0.0)[0]
+    hm[11] = -np.abs(hm[11]) - 0.1
+    hm[13] = np.round(hm[13] * 4) / 4
+    return hm
+
+
 def gaussian_targets(n: int, seed: int = SEED, J: int = 17, hw=(64, 48), sigma: float = 2.0, p_zero: float = 0.2):
     """Labels like SimpleTransform._target_generator (simple_transform.py:
     122-158): a (6*sigma+3)^2 Gaussian patch at an integer joint position;

@@ -124,7 +124,8 @@ def test_score_batch_all_scores(golden_scorers):
 
 def test_mpe_margin_entropy_criteria():
     """MPE / Margin (<= 5 local peaks per plane: positions and counts exact) and Entropy
-    (scipy semantics incl. -inf on signed maps) against the oracle."""
+    (scipy semantics incl. -inf on signed maps) against the oracle; the hand-made tie cases follow the oracle's stable
+    order among equal maxima (scikit-image >= 0.19) — the pin on a real scikit-image is the next test."""
     import vatl_hip as vh
     from active_learning.scoring import multi_peak_scores
     from oracle import scorers, synth
@@ -170,6 +171,46 @@ def test_mpe_margin_entropy_criteria():
     assert fin[4] and not fin[0] and np.isnan(want_ent[5])
     assert np.array_equal(np.isnan(got_ent), np.isnan(want_ent)) and np.array_equal(np.isneginf(got_ent), np.isneginf(want_ent))
     np.testing.assert_allclose(got_ent[fin], want_ent[fin], rtol=1e-5)
+
+
+def test_mpe_margin_pinned_on_real_scikit_image():
+    """Row a13 against tests/golden/peaks.npz (scikit-image 0.18.3's `peak_local_max` + the reference's compute_mpe /
+    compute_margin): `vatl_peaks5` positions, order and counts exact on every plane without exactly equal candidate
+    maxima (their order is scikit-image-version dependent, oracle/scorers.py), MPE / Margin within 1e-5."""
+    import os
+    import vatl_hip as vh
+    from active_learning.scoring import multi_peak_scores
+    from oracle import synth
+    from tests.gpu_util import record, rel_err, to_dev
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "peaks.npz"))
+    hm = synth.peak_items(24, seed=int(g["items_seed"]))
+    d = to_dev(hm)
+    W = hm.shape[3]
+    val, idx, cnt, _, _ = vh.peaks5(d, 5)
+    val, idx, cnt = val.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy()
+    free = ~g["tied"]
+    assert free.sum() >= 390
+    assert np.array_equal(cnt[free], g["cnt"][free])
+    want_idx = np.where(g["loc"][..., 0] >= 0, g["loc"][..., 0] * W + g["loc"][..., 1], -1)
+    assert np.array_equal(idx[free], want_idx[free])
+    n_, j_, k_ = np.nonzero((want_idx >= 0) & free[..., None])
+    assert np.array_equal(val[n_, j_, k_], hm[n_, j_, g["loc"][n_, j_, k_, 0], g["loc"][n_, j_, k_, 1]])
+    ok = ~g["item_tied"]
+    got_mpe, got_mar = multi_peak_scores(d, "MPE").cpu().numpy(), multi_peak_scores(d, "Margin").cpu().numpy()
+    record("mpe_margin_skimage", mpe_rel=rel_err(got_mpe[ok], g["mpe"][ok]), margin_rel=rel_err(got_mar[ok], g["margin"][ok]),
+           planes_exact=int(free.sum()), planes_tied=int((~free).sum()))
+    np.testing.assert_allclose(got_mpe[ok], g["mpe"][ok], rtol=1e-5)
+    np.testing.assert_allclose(got_mar[ok], g["margin"][ok], rtol=1e-5, atol=1e-6)
+    for name in g["case_names"]:                                # border / spacing / truncation / degenerate planes, other sizes
+        name = str(name)
+        if bool(g["tied_" + name]):
+            continue
+        plane = g["case_" + name]
+        _, ci, cc, _, _ = vh.peaks5(to_dev(plane[None, None]), 5)
+        want = g["loc_" + name]
+        assert int(cc[0, 0]) == len(want), name
+        assert ci[0, 0, :len(want)].cpu().tolist() == (want[:, 0] * plane.shape[1] + want[:, 1]).tolist(), name
+        assert (ci[0, 0, len(want):] == -1).all(), name
 
 
 def test_oks_kernel_matches_al_metric():

@@ -201,9 +201,46 @@ def test_fastpose_r152_384_restatement_matches_reference():
     np.testing.assert_allclose(emb, g["embedding"], rtol=1e-4, atol=1e-4)
 
 
+def test_peak_local_max_pinned_on_real_scikit_image():
+    """Row a13: `peak_local_max_5`, `mpe_item`, `margin_item` against tests/golden/peaks.npz = scikit-image 0.18.3's own
+    `peak_local_max(min_distance=5, num_peaks=5)` and the reference's compute_mpe / compute_margin (ActiveLearning.py:
+    762-788) run on top of it.  Exact positions / order / counts wherever the candidates' values are pairwise distinct;
+    the order among exactly equal maxima depends on the scikit-image version (oracle/scorers.py) and is only counted."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "peaks.npz"))
+    assert str(g["skimage_version"]) == "0.18.3"
+    hm = synth.peak_items(24, seed=int(g["items_seed"]))
+    tied_differ = 0
+    for n in range(hm.shape[0]):
+        for j in range(17):
+            loc = scorers.peak_local_max_5(hm[n, j])
+            k = int(g["cnt"][n, j])
+            same = len(loc) == k and np.array_equal(loc, g["loc"][n, j, :k])
+            if g["tied"][n, j]:
+                tied_differ += not same
+            else:
+                assert same, (n, j, loc.tolist(), g["loc"][n, j, :k].tolist())
+    assert int((~g["tied"]).sum()) >= 390 and tied_differ <= int(g["tied"].sum())
+    free = ~g["item_tied"]
+    assert free.sum() >= 20
+    mpe = np.array([scorers.mpe_item(h) for h in hm]); mar = np.array([scorers.margin_item(h) for h in hm])
+    np.testing.assert_allclose(mpe[free], g["mpe"][free], rtol=1e-6)
+    np.testing.assert_allclose(mar[free], g["margin"][free], rtol=1e-6)
+    for name in g["case_names"]:
+        name = str(name)
+        if not bool(g["tied_" + name]):
+            assert scorers.peak_local_max_5(g["case_" + name]).tolist() == g["loc_" + name].tolist(), name
+    # the cases that decide the border and spacing rules, spelled out
+    assert g["loc_border_rows_cols"].tolist() == [[5, 20], [58, 30]]
+    assert g["loc_border_shadow"].tolist() == [[40, 5]]
+    assert len(g["loc_distinct_5_apart"]) == 2 and len(g["loc_distinct_6_apart"]) == 4
+    assert len(g["loc_nine_distinct_peaks"]) == 5
+
+
 def test_multi_peak_criteria_restatement():
-    """MPE / Margin / Entropy (ActiveLearning.py:762-796).  scikit-image is absent here, so `peak_local_max_5` is
-    checked on cases whose answer follows from the documented algorithm; softmax / entropy are scipy's own."""
+    """MPE / Margin / Entropy (ActiveLearning.py:762-796) on cases whose answer follows from the documented algorithm
+    (the tie cases use the stable order of scikit-image >= 0.19; the pin on a real scikit-image is the test above);
+    softmax / entropy are scipy's own."""
     from scipy.special import softmax
     from scipy.stats import entropy
     h = np.zeros((64, 48), np.float32)

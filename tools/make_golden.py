@@ -640,6 +640,129 @@ def gen_hostaug(out: str):
     np.savez_compressed(os.path.join(out, "hostaug.npz"), **res)
 
 
+# ----------------------------------------------------------------------------
+# MPE / Margin pinned on the real scikit-image found in this image (row a13)
+# ----------------------------------------------------------------------------
+
+SKIMAGE_ROOT = "/opt/conda/lib/python3.9/site-packages/skimage"
+
+
+def load_real_skimage_peak(root: str = SKIMAGE_ROOT):
+    """``skimage.feature.peak.peak_local_max`` of the scikit-image source tree that sits in the build image
+    (0.18.3; its compiled parts do not load under this interpreter, but ``feature/peak.py`` and ``_shared/coord.py``
+    are pure Python over numpy / scipy).  Both files are executed FROM WHERE THEY LIE, by path; the three names they
+    import from the rest of the package and never reach on this call path are stubbed."""
+    ver = "unknown"
+    for line in open(os.path.join(root, "__init__.py"), encoding="utf-8"):
+        if line.startswith("__version__"):
+            ver = line.split("=")[1].strip().strip("'\"")
+    for name in ("skimage", "skimage._shared", "skimage.feature", "skimage.util", "skimage.measure", "skimage._shared.utils"):
+        m = types.ModuleType(name); m.__path__ = []
+        sys.modules[name] = m
+    sys.modules["skimage"].measure = sys.modules["skimage.measure"]
+
+    def remove_arg(*_a, **_k):                                 # decorator factory: warns about `indices=`; no-op here
+        return lambda f: f
+    sys.modules["skimage._shared.utils"].remove_arg = remove_arg
+    load_by_path("skimage._shared.coord", os.path.join(root, "_shared/coord.py"))
+    pk = load_by_path("skimage.feature.peak", os.path.join(root, "feature/peak.py"))
+    return pk.peak_local_max, ver
+
+
+def _peak_cases():
+    """name -> (H,W) float32 plane.  Besides seeded network-like maps: the excluded border, spacing boundaries,
+    truncation to five peaks, degenerate planes, and the input images of scikit-image's own
+    feature/tests/test_peak.py (their sizes and constructions) run with the reference's arguments."""
+    c = {}
+    z = lambda h=64, w=48: np.zeros((h, w), np.float32)
+    m = z(); m[4, 10] = 3; m[5, 20] = 2; m[58, 30] = 1.5; m[59, 40] = 4; m[30, 4] = 5; m[31, 5] = 1.2; m[40, 42] = 1.1; m[41, 43] = 6
+    c["border_rows_cols"] = m                                  # rows/cols 4, 59 / 4, 43 are border; 5, 58 / 5, 42 are not
+    m = z(); m[4, 10] = 2.0; m[5, 10] = 1.0; m[40, 5] = 0.5
+    c["border_shadow"] = m                                     # the border maximum is dropped but still shadows (5,10)
+    for d in (4, 5, 6, 7):
+        m = z(); m[20, 20] = 1.0; m[20, 20 + d] = 0.75; m[40, 10] = 0.5; m[40 + d, 10 + d] = 0.25
+        c[f"distinct_{d}_apart"] = m
+    m = z()
+    for k, (y, x) in enumerate([(8, 8), (8, 24), (8, 40), (24, 8), (24, 24), (24, 40), (44, 8), (44, 24), (56, 40)]):
+        m[y, x] = 1.0 + 0.125 * ((k * 5) % 9)
+    c["nine_distinct_peaks"] = m                               # num_peaks = 5 keeps the five highest
+    c["constant"] = np.full((64, 48), 0.25, np.float32)
+    c["zero"] = z()
+    m = np.full((64, 48), -1.0, np.float32); m[30, 30] = -0.5; m[12, 12] = -0.75
+    c["negative_with_bumps"] = m
+    m = z(); m[32, 24] = 1e-30
+    c["tiny_positive"] = m
+    m = z(); yy, xx = np.mgrid[0:64, 0:48]; m[:] = (yy * 48 + xx) * 1e-3
+    c["ramp"] = m                                              # strictly increasing: the only 11x11 maxima are at the border
+    m = z(); m[20, 20] = m[20, 24] = 1.0
+    c["tie_4_apart"] = m                                       # equal values: the order among them is version dependent
+    m = z(); m[20, 20] = m[20, 25] = 1.0
+    c["tie_5_apart"] = m
+    m = z(); m[30:33, 20:23] = 0.8
+    c["tie_plateau_3x3"] = m
+    # scikit-image feature/tests/test_peak.py inputs
+    r = np.random.RandomState(21)
+    m = 0.8 * r.rand(20, 20)
+    for y, x in [(7, 7), (7, 13), (13, 7), (13, 13)]:
+        m[y, x] = 1
+    c["sk_noisy_peaks_20x20"] = m.astype(np.float32)           # four equal peaks 6 apart
+    c["sk_constant_20x20"] = np.full((20, 20), 128, np.float32)
+    m = np.zeros((7, 7), np.float32); m[1, 1] = 10; m[1, 3] = 11; m[1, 5] = 12; m[3, 5] = 8; m[5, 3] = 7
+    c["sk_num_peaks_7x7"] = m                                  # smaller than the border: nothing survives
+    c["sk_uniform_20x30"] = np.random.RandomState(21).uniform(size=(20, 30)).astype(np.float32)
+    c["sk_uniform_40x60"] = np.random.RandomState(22).uniform(size=(40, 60)).astype(np.float32)
+    c["sk_uniform_10x20"] = np.random.RandomState(23).uniform(size=(10, 20)).astype(np.float32)
+    m = np.zeros((10, 20), np.float32); m[5, 5] = 1; m[5, 8] = .5
+    c["sk_not_adjacent_10x20"] = m
+    m = np.zeros((15, 15), np.float32); m[8, 12] = 10; m[2, 2] = 8; m[13, 5] = 10; m[7, 7] = 9; m[9, 5] = 7
+    c["sk_isolated_15x15"] = m
+    m = np.zeros((30, 30), np.float32); m[15, 15] = 1; m[5, 5] = 1
+    c["sk_two_points_30x30"] = m
+    return c
+
+
+def gen_peaks(ref: str, out: str):
+    from scipy.special import softmax
+    from scipy.stats import entropy
+    plm, ver = load_real_skimage_peak()
+    ns = _extract_methods(os.path.join(ref, "active_learning/ActiveLearning.py"), ("compute_mpe", "compute_margin"))
+    ns.update(peak_local_max=plm, softmax=softmax, entropy=entropy)
+
+    def run(plane):
+        loc = np.asarray(plm(plane, min_distance=5, num_peaks=5), np.int64).reshape(-1, 2)
+        # candidates of the selection = what _get_peak_mask + _exclude_border leave; a plane is "tied" when two of them are equal
+        from scipy import ndimage
+        mx = ndimage.maximum_filter(plane, size=11, mode="constant")
+        cand = (plane == mx) & (plane > plane.min())
+        cand[:5] = False; cand[-5:] = False; cand[:, :5] = False; cand[:, -5:] = False
+        v = plane[cand]
+        tied = v.size != np.unique(v).size
+        pad = np.full((5, 2), -1, np.int64); pad[:len(loc)] = loc
+        return pad, len(loc), tied
+
+    N = 24
+    hm = synth.peak_items(N, seed=77)
+    loc = np.zeros((N, 17, 5, 2), np.int64); cnt = np.zeros((N, 17), np.int64); tied = np.zeros((N, 17), bool)
+    for n in range(N):
+        for j in range(17):
+            loc[n, j], cnt[n, j], tied[n, j] = run(hm[n, j])
+    mpe = np.array([ns["compute_mpe"](None, h) for h in hm], np.float64)
+    margin = np.array([ns["compute_margin"](None, h) for h in hm], np.float64)
+    res = {"skimage_version": np.array(ver), "items_seed": np.int64(77), "loc": loc, "cnt": cnt, "tied": tied, "mpe": mpe, "margin": margin,
+           "item_tied": tied.any(1)}
+    names = []
+    for name, plane in _peak_cases().items():
+        l, k, t = run(plane)
+        names.append(name)
+        res["case_" + name] = plane
+        res["loc_" + name] = l[:k]
+        res["tied_" + name] = np.bool_(t)
+    res["case_names"] = np.array(names)
+    np.savez_compressed(os.path.join(out, "peaks.npz"), **res)
+    print(f"peaks.npz written (scikit-image {ver}; {int(tied.sum())} of {tied.size} item planes tied, "
+          f"cases tied: {[n for n in names if res['tied_' + n]]})")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -666,6 +789,8 @@ def main():
         gen_wellcond(EasyDict, a.out)
     if a.only in ("", "hostaug"):
         gen_hostaug(a.out)
+    if a.only in ("", "peaks"):
+        gen_peaks(a.ref, a.out)
     if a.only in ("", "r152"):
         gen_fastpose_r152(EasyDict, a.out)
 
