@@ -168,6 +168,132 @@ def test_grad_arena_single_process_is_a_plain_buffer():
     assert float(arena.flat[off:off + params[3].numel()].sum()) == 2.0 * params[3].numel() and float(arena.flat.sum()) == 2.0 * params[3].numel()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# round 3: rank-invariant collective sequences (ragged shards at world 4 / 8, ranks that reduce at different times)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _ragged_worker(rank, world, port, ns, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "vatl4pose-wacv2024_amd")]
+    import torch.distributed as dist
+    from active_learning import distributed as D
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    out = []
+    for n in ns:
+        # a row = (item id, id of the item before it inside the window, id of the item after it): what a halo must provide
+        def score(lo, hi):
+            r = torch.full((hi - lo, 3), -1.0)
+            for k, i in enumerate(range(lo, hi)):
+                r[k, 0] = i
+                r[k, 1] = i - 1 if i - 1 >= lo else -1
+                r[k, 2] = i + 1 if i + 1 < hi else -1
+            return r
+        out.append(D.sharded_rows(n, score, 3, torch.device("cpu")).numpy())
+        # DataParallel chunk walk of a mini-batch of n items over `world` replicas: every item belongs to exactly one rank
+        mine = D.chunk_bounds(n, world)[rank::world]
+        owned = torch.zeros(max(n, 1))
+        for lo, hi in mine:
+            owned[lo:hi] += 1
+        D.allreduce_sum_(owned)
+        assert n == 0 or bool((owned[:n] == 1).all()), (n, world, owned)
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_ragged_streams_shard_the_same_at_world_4_and_8(world):
+    """N % world != 0, N < world, N == 1: every rank issues the same all-gather, empty shards included."""
+    ns = (5, 13, 1, 3, 8, 33)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, ns, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for n, rows in zip(ns, got):
+        assert rows.shape == (n, 3)
+        ids = np.arange(n)
+        np.testing.assert_array_equal(rows[:, 0], ids)
+        np.testing.assert_array_equal(rows[:, 1], ids - 1)                              # -1 only at the stream's start
+        np.testing.assert_array_equal(rows[:, 2], np.where(ids + 1 < n, ids + 1, -1))   # and at its end
+
+
+def _mixed_arena_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "vatl4pose-wacv2024_amd")]
+    import torch.distributed as dist
+    from active_learning import distributed as D
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    params = _arena_params()
+    arena = D.GradArena(params, bucket_bytes=4 * 100)
+    for step in range(2):
+        arena.begin()
+        if rank == 2:                                          # no DataParallel chunk of a short last mini-batch: zeros, reduce at the end
+            arena.flat.zero_()
+        else:
+            filled = 0
+            for p in reversed(params):
+                arena.view(p).copy_(_rank_grad(p, rank, step))
+                filled += p.numel()
+                if rank == 0:                                  # one chunk: buckets start while the backward pass goes on
+                    arena.done_offset(arena.total - filled)
+                elif rank == 3 and p is params[3]:             # reports progress once, somewhere in the middle
+                    arena.done_offset(arena.total - filled)
+            # rank 1 walked several chunks and reduces only at the end
+        arena.finish()
+        q.put((rank, step, list(arena.fired), arena.flat.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_arena_collective_sequence_is_rank_invariant_world4():
+    """a rank that overlaps, a rank that reduces at the end, a rank with no chunk and a rank that reports
+    progress once must issue the SAME all-reduce sequence (count, order, sizes); mismatched sequences abort on gloo and hang on
+    RCCL.  The bucket cuts depend on (total, bucket_bytes) only."""
+    world = 4
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mixed_arena_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(2 * world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    params = _arena_params()
+    total = sum(p.numel() for p in params)
+    for step in range(2):
+        rows = sorted([g for g in got if g[1] == step], key=lambda t: t[0])
+        fired = rows[0][2]
+        assert len(fired) >= 3 and fired[0][1] == total and fired[-1][0] == 0
+        assert all(a[0] == b[1] for a, b in zip(fired, fired[1:]))                  # contiguous, from the top down
+        want = np.concatenate([sum(_rank_grad(p, r, step) for r in (0, 1, 3)).reshape(-1).numpy() for p in params])
+        for r in rows:
+            assert r[2] == fired, (r[0], r[2], fired)
+            np.testing.assert_allclose(r[3], want, rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(rows[0][3], rows[2][3])                       # every rank ends with the same bits
+
+
+def test_grad_arena_cuts_depend_on_sizes_only():
+    from active_learning import distributed as D
+    params = _arena_params()
+    a = D.GradArena(params, bucket_bytes=4 * 100)
+    assert a.cuts[0] == a.total and a.cuts[-1] == 0 and all(x - y == 100 for x, y in zip(a.cuts[:-2], a.cuts[1:-1]))
+    assert 0 < a.cuts[-2] <= 100
+    b = D.GradArena([torch.nn.Parameter(torch.zeros(200))], bucket_bytes=4 * 100)
+    assert b.cuts == [200, 100, 0]
+    assert D.GradArena([], bucket_bytes=400).cuts == [0]
+
+
 def _run_driver(tmp_path, script, extra_env=None, timeout=180):
     import subprocess
     import sys

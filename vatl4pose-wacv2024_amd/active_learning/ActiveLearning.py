@@ -65,6 +65,10 @@ def _collective(fn):
         self._depth += 1
         try:
             return fn(self, *a, **k)
+        except BaseException:
+            if self._depth == 1:
+                D.mark_failed()                # the workers are inside some other collective now: never broadcast to them again
+            raise
         finally:
             self._depth -= 1
     return wrapper
@@ -148,6 +152,9 @@ class ActiveLearning:
         self.norm_type = cfg.LOSS.get("NORM_TYPE", None)
         self.hm_size = cfg.DATA_PRESET.HEATMAP_SIZE
         self.heatmap_to_coord = get_func_heatmap_to_coord(cfg)
+        if D.mirrored():                           # every worker has built its replica: the pickled datasets can go
+            D.barrier()
+            D.release_payloads()
 
     # ------------------------------------------------------------------ estimator
     def initialize_estimator(self):

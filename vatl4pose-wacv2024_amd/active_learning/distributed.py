@@ -158,10 +158,16 @@ class GradArena:
     """One flat fp32 buffer holding every parameter gradient of a model, in ``parameters()`` order.
 
     ``view(p)`` is the slice the weight-gradient kernel of parameter ``p`` writes (and what becomes ``p.grad``).  The
-    backward pass produces gradients from the last layer to the first, i.e. from the high end of the arena downwards;
-    ``done_offset(o)`` tells the arena that every slice at or above element offset ``o`` is final, and whenever a bucket's worth has
-    accumulated the arena issues an asynchronous in-place SUM all-reduce of that range (on RCCL this runs on the
-    communicator's stream and overlaps the rest of the backward).  ``finish()`` reduces what is left and waits."""
+    backward pass produces gradients from the last layer to the first, i.e. from the high end of the arena downwards.
+
+    The arena is reduced as a FIXED sequence of buckets, cut from the top down every ``bucket_bytes`` — a function of
+    (total, bucket_bytes) only: ``cuts = [total, total - bucket, ..., 0]``.  Every rank therefore issues exactly the same
+    collectives (count, order, sizes) whatever it did locally — a rank that overlaps, a rank that walked several
+    DataParallel chunks and reduces only at the end, and a rank that had no chunk of a short last mini-batch all run the
+    same list; WHEN a bucket starts is the only thing that differs.  ``done_offset(o)`` tells the arena that every slice
+    at or above element offset ``o`` is final: each not-yet-started bucket that lies wholly at or above ``o`` starts as an
+    asynchronous in-place SUM all-reduce (on RCCL it runs on the communicator's stream and overlaps the rest of the
+    backward pass).  ``finish()`` starts whatever is left, in the same order, and waits."""
 
     def __init__(self, params, device=None, bucket_bytes: int = 32 << 20):
         self.params = [p for p in params]
@@ -174,43 +180,47 @@ class GradArena:
         self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
         self.views = {p: self.flat[o:o + p.numel()].view(p.shape) for p, o in self.offset.items()}
         self.bucket = max(1, bucket_bytes // 4)
-        self._lo = self.total
+        self.cuts = list(range(self.total, 0, -self.bucket)) + [0]       # descending bucket edges; the lowest bucket takes the remainder
+        self._next = 0                                                   # cuts[_next] = upper edge of the first bucket not started yet
         self._works = []
         self._group = None
         self._live = False
         self.launches = 0
+        self.fired = []                                                  # (lo, hi) of every collective of this step, in issue order
 
     def view(self, p):
         return self.views[p]
 
     def begin(self, group=None):
         """Start of a backward pass.  ``group`` None = the default process group (nothing to do at world size 1)."""
-        self._lo, self._works, self._group = self.total, [], group
+        self._next, self._works, self._group = 0, [], group
         self._live = dist.is_initialized() and dist.get_world_size(group) > 1
         self.launches = 0
+        self.fired = []
 
-    def _fire(self, lo, hi):
-        if hi > lo:
-            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self._group, async_op=True))
-            self.launches += 1
+    def _fire_next(self):
+        hi, lo = self.cuts[self._next], self.cuts[self._next + 1]
+        self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self._group, async_op=True))
+        self.fired.append((lo, hi))
+        self.launches += 1
+        self._next += 1
 
     def would_fire(self, off: int) -> bool:
         """Whether ``done_offset(off)`` would start an all-reduce (callers with work on other streams join them first)."""
-        return self._live and off < self._lo and self._lo - off >= self.bucket
+        return self._live and self._next + 1 < len(self.cuts) and self.cuts[self._next + 1] >= off
 
     def done_offset(self, off: int):
         """Every slice at or above element offset ``off`` holds its final value for this step."""
         if not self._live:
             return
-        if off < self._lo and self._lo - off >= self.bucket:
-            self._fire(off, self._lo)
-            self._lo = off
+        while self._next + 1 < len(self.cuts) and self.cuts[self._next + 1] >= off:
+            self._fire_next()
 
     def finish(self):
-        """Reduce the remaining low end of the arena and wait for every bucket (the optimizer step comes next)."""
+        """Start the buckets that have not started yet and wait for all of them (the optimizer step comes next)."""
         if self._live:
-            self._fire(0, self._lo)
-            self._lo = 0
+            while self._next + 1 < len(self.cuts):
+                self._fire_next()
             for w in self._works:
                 w.wait()
         self._works = []
@@ -302,31 +312,72 @@ def command(*msg):
         broadcast_object(msg, src=0)
 
 
+_failed = False                # a mirrored call raised on this rank: the workers are somewhere inside another collective
+_payload_files: list = []
+
+
+def mark_failed():
+    """The driver's outermost mirrored call ended with an exception: from here on no collective may be assumed to match
+    (the workers are blocked in whatever the call was doing), so ``shutdown_workers`` ends them directly."""
+    global _failed
+    _failed = True
+
+
 def shutdown_workers():
+    """At interpreter exit of the driver.  After a clean run: one ("exit",) broadcast, the workers leave by themselves.  After a
+    failed call the exit broadcast would itself be a mismatched collective (it can block until RCCL's watchdog fires), so the
+    children are terminated directly and the group is torn down without another collective."""
     global _workers
     if not _workers:
         return
-    try:
-        if dist.is_initialized():
-            broadcast_object(("exit",), src=0)
-    except Exception:                                      # a worker already died: fall through to the kill below
-        pass
-    for p in _workers:
+    clean = not _failed and all(p.poll() is None for p in _workers)
+    if clean:
         try:
-            p.wait(timeout=30)
+            if dist.is_initialized():
+                broadcast_object(("exit",), src=0)
+        except Exception:                                  # a worker died meanwhile: fall through to the kill below
+            clean = False
+    for p in _workers:
+        if not clean and p.poll() is None:
+            p.terminate()
+        try:
+            p.wait(timeout=30 if clean else 5)
         except subprocess.TimeoutExpired:
             p.kill()
     _workers = []
+    release_payloads()
     if dist.is_initialized():
         try:
-            dist.destroy_process_group()
+            if clean:
+                dist.destroy_process_group()
+            # else: peers are gone — no collective teardown; the process is exiting anyway
         except Exception:
             pass
 
 
 def dump_payload(obj) -> str:
-    """Objects too large for a broadcast (datasets handed to the constructor) go through a temp file."""
+    """Objects too large for a broadcast (datasets handed to the constructor) go through a temp file, removed by
+    ``release_payloads`` once every worker has built its replica (end of the constructor) or at shutdown."""
     fd, path = tempfile.mkstemp(prefix="vatl_payload_", suffix=".pkl")
     with os.fdopen(fd, "wb") as f:
         pickle.dump(obj, f)
+    _payload_files.append(path)
     return path
+
+
+def release_payloads():
+    while _payload_files:
+        try:
+            os.unlink(_payload_files.pop())
+        except OSError:
+            pass
+
+
+def mirrored() -> bool:
+    """This process is the driver of worker ranks, or one of those workers (every constructor is mirrored)."""
+    return bool(_workers) or bool(os.environ.get("VATL_WORKER_PARENT"))
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -55,6 +55,17 @@ class _Grads(dict):
                 self._low = min(self._low, self.arena.offset[p])
         super().__setitem__(p, t)
 
+    def close(self):
+        """End of a backward pass.  The arena's bucket sequence is fixed (rank-invariant), so a parameter the trainer never wrote
+        cannot desynchronise the ranks — but it silently turns the early buckets off (``flush`` needs a gap-free top) and leaves
+        a stale slice in the arena: a wiring error, reported where it happens."""
+        if self.arena is not None:
+            missing = self.arena.total - self._filled
+            if missing:
+                names = [tuple(p.shape) for p in self.arena.params if p not in self]
+                raise RuntimeError(f"backward pass left {missing} gradient elements of the arena unwritten: parameter shapes {names[:8]}")
+        return self
+
     def flush(self):
         # everything at or above the lowest offset written so far is final once that whole range has been written
         if self.overlap and self._filled == self.arena.total - self._low and self.arena.would_fire(self._low):
@@ -373,7 +384,7 @@ class SimplePoseTrainer:
         self.pool_idx = None
         self.stem.backward(dx, grads)
         _side.join()
-        return grads
+        return grads.close()
 
 
 class _LinearT:
@@ -482,7 +493,7 @@ class FastPoseTrainer:
         self.pool_idx = None
         self.stem.backward(dx, grads)
         _side.join()
-        return grads
+        return grads.close()
 
 
 class _BasicBlockT:
@@ -635,7 +646,7 @@ class HRNetTrainer:
         dx, _ = self.stem2.backward(dx, grads)
         self.stem1.backward(dx, grads)
         _side.join()
-        return grads
+        return grads.close()
 
 
 class _TrainFn(torch.autograd.Function):
