@@ -229,7 +229,7 @@ def _timed(fn, steps, warmup, dist_on):
     return dt / steps
 
 
-def finetune_step_fn(m, opt, x, labels, masks, world):
+def finetune_step_fn(m, opt, x, labels, masks, world, reduce=True):
     """One data-parallel fine-tune step as ActiveLearning.retrain_model runs it: train-mode forward, fused masked-MSE loss +
     gradient (scaled by this rank's share of the global mini-batch), backward into the flat gradient arena whose finished
     buckets are all-reduced over RCCL while the backward is still running, AdamW on the arena slices."""
@@ -244,6 +244,8 @@ def finetune_step_fn(m, opt, x, labels, masks, world):
             if world > 1:
                 dout.mul_(1.0 / world)
             arena.begin()
+            if not reduce:                                   # the same step with its collectives switched off (overlap accounting)
+                arena._live = False
             tr.backward(dout, arena=arena, overlap=True)
             arena.finish()
             arena.attach()
@@ -280,11 +282,22 @@ def extra_finetune(dev, name, cfg, hw, batch, gflop_fwd, groups, world, dist_on,
     masks = (torch.rand((batch, 17, 1, 1), device=dev, generator=g) > 0.2).float()
     step, arena = finetune_step_fn(m, opt, x, labels, masks, world)
     dt = _timed(step, steps, warmup, dist_on)
+    buckets = arena.launches if dist_on else 0
+    alone = _allreduce_alone_ms(arena, dist_on)
+    local_ms = hidden = None
+    if dist_on:
+        # the same step with no gradient exchange (what this rank would take alone) -> how much of the all-reduce the overlap hides:
+        # overlap_hidden_frac = 1 - (step_N - step_local) / allreduce_alone   (1 = fully hidden, 0 = fully exposed)
+        local_step, _ = finetune_step_fn(m, opt, x, labels, masks, world, reduce=False)
+        local_ms = round(_timed(local_step, steps, 1, dist_on) * 1e3, 3)
+        if alone:
+            hidden = round(max(0.0, min(1.0, 1.0 - (dt * 1e3 - local_ms) / alone)), 4)
     tf = 3 * gflop_fwd * 1e9 * batch / dt / 1e12              # fwd + dgrad + wgrad of every conv, per GPU
     out = {"workload": name, "batch_per_gpu": batch, "ms_per_step": round(dt * 1e3, 3), "crops_per_s": round(batch * world / dt, 1),
            "conv_tflops_per_gpu": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA, 4),
-           "grad_bytes": arena.total * 4, "allreduce_buckets": arena.launches if dist_on else 0,
-           "allreduce_alone_ms": _allreduce_alone_ms(arena, dist_on), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+           "grad_bytes": arena.total * 4, "allreduce_buckets": buckets, "allreduce_bucket_bytes": arena.bucket * 4,
+           "allreduce_alone_ms": alone, "step_without_allreduce_ms": local_ms, "overlap_hidden_frac": hidden,
+           "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
     del m, opt, step, arena, x, labels, masks
     torch.cuda.empty_cache()
     return out
@@ -458,6 +471,15 @@ def main():
         dt = float(t.item())
 
     roof = conv_roofline(model, x, bbox, is_prev, is_next, hm_buf) if rank == 0 else None
+    if roof is not None:
+        # the whole step (conv + pool + layout + scorers + launch gaps) against the same conv FLOPs: value per GPU x GFLOP / peak
+        per_gpu = a.steps * FRAMES / dt
+        roof["e2e_frac"] = round(per_gpu * GFLOP_PER_CROP * 1e9 / 1e12 / PEAK_FP32_MFMA, 4)
+    devices = [torch.cuda.get_device_name(dev)]
+    if dist:                                            # what actually ran: one entry per rank, gathered (not assumed from --gpus)
+        box = [None] * world
+        td.all_gather_object(box, {"rank": rank, "device": local, "name": torch.cuda.get_device_name(dev), "backend": td.get_backend()})
+        devices = box
     del model, x, hm_buf
     torch.cuda.empty_cache()
     extra = None
@@ -473,6 +495,7 @@ def main():
             "config": {"workload": "SimpleBaseline-R50 256x192 inference + decode + local-peak + THC-L1, 1024-frame synthetic video per GPU",
                        "frames_per_gpu": FRAMES, "batch": BATCH, "tracks": TRACKS, "parallelism": f"frame-sharded x{world}"},
             "roofline": roof,
+            "world_size_seen": td.get_world_size() if dist else 1, "rank_devices": devices,
         }
         if extra is not None:
             line["extra"] = extra

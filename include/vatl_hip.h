@@ -85,7 +85,8 @@ int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float* w, const 
  * knob 0 = k-loop schedule of the conv kernel, values 0, 2, 4, 5 (see csrc/conv_igemm.hip), 1 = tile order, 2 = block
  * stagger, 3 = target block count of the weight-gradient launches (number of pixel splits), 5 = rows of the conv block
  * tile (0 = chosen from the grid size, 64, 128), 7 = persistent 1x1 kernel for K <= 256 v (0 = off, default 1), 8 = halo-tile kernel for the
- * 32-channel 3x3 layers (csrc/conv3x3_halo.hip; 1 = on, default; 0 = generic implicit GEMM; bit-identical results).  Knob 0 values 10..13, knob 4 (wgrad ablation bits) and knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) are profiling
+ * 32-channel 3x3 layers (csrc/conv3x3_halo.hip; 1 = on, default; 0 = generic implicit GEMM; bit-identical results), 9 = split-K cut policy while a
+ * workspace is registered (0 = by the launch's own block count, 1 = by the layer's per-image geometry only: batch-invariant bits).  Knob 0 values 10..13, knob 4 (wgrad ablation bits) and knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) are profiling
  * ablations that compute WRONG results: they are not compiled into the product library at all (every such call returns
  * VATL_EINVAL); the profiling variant built with -DVATL_ABLATION (build.py --ablation -> libvatl_hip_ablation.so, loaded
  * through VATL_HIP_LIB) accepts them when the environment also has VATL_ALLOW_ABLATION=1. */

@@ -206,8 +206,13 @@ def test_mpe_margin_pinned_on_real_scikit_image():
         if bool(g["tied_" + name]):
             continue
         plane = g["case_" + name]
-        _, ci, cc, _, _ = vh.peaks5(to_dev(plane[None, None]), 5)
         want = g["loc_" + name]
+        if min(plane.shape) <= 10:                              # no pixel outside the excluded border: scikit-image returns nothing,
+            assert len(want) == 0                               # the C ABI refuses the plane loudly (VATL_EINVAL "plane too small")
+            with pytest.raises(vh.VatlError):
+                vh.peaks5(to_dev(plane[None, None]), 5)
+            continue
+        _, ci, cc, _, _ = vh.peaks5(to_dev(plane[None, None]), 5)
         assert int(cc[0, 0]) == len(want), name
         assert ci[0, 0, :len(want)].cpu().tolist() == (want[:, 0] * plane.shape[1] + want[:, 1]).tolist(), name
         assert (ci[0, 0, len(want):] == -1).all(), name

@@ -24,11 +24,14 @@ def test_bench_prints_one_contract_line():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert 0.5 < r["frac"] < 1.0 and d["value"] > 5000
+    assert 0.5 < r["e2e_frac"] <= r["frac"] + 0.02 and abs(r["e2e_frac"] - d["value"] * 10.853e-3 / 157.3) < 2e-3   # whole step vs conv launches only
+    assert d["world_size_seen"] == 1 and len(d["rank_devices"]) == 1
     ex = d["extra"]                                                     # configs[2..4] measured in the same run
     assert set(ex) == {"cfg3_simplepose_r50_finetune", "cfg4_hrnet_w32_thc_wpu", "cfg5_fastpose_r152_384_finetune"}
     for k in ("cfg3_simplepose_r50_finetune", "cfg5_fastpose_r152_384_finetune"):
         e = ex[k]
         assert e["ms_per_step"] > 0 and 0.2 < e["frac_of_fp32_mfma_peak"] < 1.0 and e["allreduce_alone_ms"] is None and e["allreduce_buckets"] == 0
+        assert e["overlap_hidden_frac"] is None and e["step_without_allreduce_ms"] is None
         assert abs(e["crops_per_s"] - e["batch_per_gpu"] * 1000.0 / e["ms_per_step"]) / e["crops_per_s"] < 0.01
     assert 130e6 < ex["cfg3_simplepose_r50_finetune"]["grad_bytes"] < 140e6 and 295e6 < ex["cfg5_fastpose_r152_384_finetune"]["grad_bytes"] < 305e6
     assert ex["cfg4_hrnet_w32_thc_wpu"]["frames_per_s"] > 3000 and ex["cfg4_hrnet_w32_thc_wpu"]["halo_frames"] == 0
@@ -73,8 +76,11 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "frame-sharded x2" and "cpu_baseline" not in d
+    assert d["world_size_seen"] == 2 and [r["rank"] for r in d["rank_devices"]] == [0, 1] and all(r["backend"] == "gloo" for r in d["rank_devices"])
     ex = d["extra"]
     for k in ("cfg3_simplepose_r50_finetune", "cfg5_fastpose_r152_384_finetune"):
         assert ex[k]["allreduce_buckets"] >= 2 and ex[k]["allreduce_alone_ms"] > 0      # bucketed, overlapped with the backward pass
+        assert ex[k]["allreduce_buckets"] == -(-ex[k]["grad_bytes"] // ex[k]["allreduce_bucket_bytes"])   # the fixed, rank-invariant cut list
+        assert 0.0 <= ex[k]["overlap_hidden_frac"] <= 1.0 and ex[k]["step_without_allreduce_ms"] > 0
         assert abs(ex[k]["crops_per_s"] - 2 * ex[k]["batch_per_gpu"] * 1000.0 / ex[k]["ms_per_step"]) / ex[k]["crops_per_s"] < 0.01
     assert ex["cfg4_hrnet_w32_thc_wpu"]["halo_frames"] == 1                              # rank 0 of 2: one interior edge

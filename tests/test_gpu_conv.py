@@ -483,3 +483,26 @@ def test_halo_tile_kernel_is_bit_identical_to_the_implicit_gemm(vh, n, h, w):
     want = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), padding=1).permute(0, 2, 3, 1).numpy()
     got = vh.conv2d_fwd(x, wp, None, None, 32, 3, 3, 1, 1, False).cpu().numpy()
     assert rel_err(got, want) < 2e-6
+
+
+def test_small_module_calls_use_splitk_and_the_stream_path_never_does(vh):
+    """`model(x)` with <= 16 crops (BASELINE.json configs[0] shape, scripts/poseestimator_eval.py) runs with split-K for the duration
+    of the call: same heat-maps to fp32 rounding (1e-5), arg-max identical.  The evaluation stream entry point keeps
+    batch-size-independent bits before and after such a call (the workspace is registered for the call only)."""
+    from alphapose.models import hip_engine
+    m = _build_simplepose()
+    x = to_dev(synth.crops(24, seed=8))
+    with torch.no_grad():
+        big = torch.empty((24, 17, 64, 48), device=x.device)
+        hip_engine.forward_into(m, x, big)
+        small = m(x[:4])                                           # split-K inside
+        solo, sixteen = m(x[1:2]), m(x[:16])                       # ... with a cut that depends on the layer geometry only:
+        after = torch.empty((4, 17, 64, 48), device=x.device)
+        hip_engine.forward_into(m, x[:4], after)
+        plain = m(x)                                               # 24 crops: unsplit
+    assert torch.equal(after, big[:4]) and torch.equal(plain, big)
+    assert not torch.equal(small, big[:4])                         # a different summation order really ran
+    assert torch.equal(solo[0], small[1]) and torch.equal(sixteen[:4], small)   # a crop's bits do not depend on its (small) batch
+    assert rel_err(small.cpu().numpy(), big[:4].cpu().numpy()) < 1e-5
+    assert torch.equal(small.flatten(2).argmax(2), big[:4].flatten(2).argmax(2))
+    record("auto_splitk", rel=rel_err(small.cpu().numpy(), big[:4].cpu().numpy()))

@@ -139,3 +139,65 @@ def test_single_process_driver_spawns_ranks_and_matches_the_replica_walk(tmp_pat
     for k in ("q0", "q1", "kp0", "kp1", "params", "bufs", "labeled"):
         assert np.array_equal(two[k], one[k]), k
     assert abs(float(two["loss"]) - float(one["loss"])) < 1e-6 * max(1.0, abs(float(one["loss"])))
+
+
+def test_arena_buckets_start_only_after_the_side_stream_joined(monkeypatch):
+    """Weight gradients are written on a second HIP stream; a bucket's all-reduce is issued from the main stream.  Every bucket
+    must start (a) only after `_side.join()` — no side-stream launch outstanding — and (b) in stream order after everything
+    that writes into it: a copy of the bucket taken AT the moment the collective is issued (same stream) must already hold the
+    bucket's final values.  The collective itself is replaced by that copy (one process; RCCL is not needed for the ordering)."""
+    import torch.distributed as dist
+    import vatl_hip as vh
+    from active_learning import distributed as D
+    from alphapose.models import builder, hip_train
+    from alphapose.utils.config import edict
+    cfg = edict({"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50})
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    torch.manual_seed(3)
+    dev = torch.device("cuda:0")
+    m = builder.build_sppe(cfg, preset_cfg=preset).to(dev).train()
+    tr = hip_train.trainer_for(m)
+    arena = D.GradArena([p for p in m.parameters() if p.requires_grad], device=dev, bucket_bytes=8 << 20)
+    assert hip_train._side.enabled
+    log, snaps = [], []
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        log.append(("fire", hip_train._side.used))
+        snaps.append((t.data_ptr(), t.numel(), t.clone()))          # on the issuing stream, like the collective's read of the bucket
+        return _Done()
+    real_join = hip_train._side.join
+
+    def join():
+        log.append(("join", hip_train._side.used))
+        real_join()
+    monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+    monkeypatch.setattr(hip_train._side, "join", join)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    x = torch.rand((24, 3, 256, 192), device=dev, generator=g) - 0.45
+    labels = torch.rand((24, 17, 64, 48), device=dev, generator=g) * 0.1
+    masks = torch.ones((24, 17, 1, 1), device=dev)
+    for _ in range(3):
+        log.clear(); snaps.clear()
+        with torch.no_grad():
+            out = tr.forward(x)
+            _, dout = vh.masked_mse_fwd_bwd(out, labels, masks)
+            arena.begin()
+            arena._live = True                                      # one process standing in for a rank of a larger group
+            tr.backward(dout, arena=arena, overlap=True)
+            early = len(snaps)
+            arena.finish()
+        torch.cuda.synchronize()
+        assert arena.fired == [(arena.cuts[i + 1], arena.cuts[i]) for i in range(len(arena.cuts) - 1)]
+        assert early >= 8, early                                    # most of the 17 buckets start during the backward pass
+        fires = [e for e in log if e[0] == "fire"]
+        assert len(fires) == len(arena.cuts) - 1 and not any(used for _, used in fires)      # (a) nothing outstanding on the side stream
+        first_fire = next(i for i, e in enumerate(log) if e[0] == "fire")
+        assert any(e == ("join", True) for e in log[:first_fire])   # the side stream really was in use and was joined first
+        base = arena.flat.data_ptr()
+        for ptr, n, snap in snaps:                                  # (b) the bucket was final when its collective was issued
+            lo = (ptr - base) // 4
+            assert torch.equal(snap, arena.flat[lo:lo + n]), (lo, n)

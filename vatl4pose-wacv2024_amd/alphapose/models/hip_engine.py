@@ -367,6 +367,12 @@ def _plan_for(m: nn.Module, device):
 
 _SPLITK_MB = int(os.environ.get("VATL_SPLITK_MB", "0"))   # opt-in small-batch latency mode (vatl_hip.enable_splitk); 0 = off
 _splitk_ready = set()                                      # device indices whose workspace is registered
+# Module calls `model(x)` with at most this many crops (scripts/poseestimator_eval.py style, BASELINE.json configs[0]: B = 4) run
+# with split-K for their duration: every conv launch of such a batch is a fraction of one round of blocks (SimplePose-R50
+# forward + decode at B = 4: 2.6 -> 1.2 ms).  Results agree with the unsplit kernels to fp32 rounding, not bit for bit, so the
+# evaluation stream of ActiveLearning (forward_into / forward_with_embedding: THC de-duplication needs a crop's bits to be
+# independent of its batch) never uses it.  VATL_SPLITK_AUTO=0 switches it off.
+_SPLITK_AUTO_MAX = int(os.environ.get("VATL_SPLITK_AUTO", "16"))
 
 
 def _prepare_input(m: nn.Module, x: torch.Tensor):
@@ -388,6 +394,9 @@ def run_module_nchw(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
         return hip_train.forward_train(m, x)
     x = _prepare_input(m, x)
     plan = _plan_for(m, x.device)
+    if 0 < x.shape[0] <= _SPLITK_AUTO_MAX:
+        with vh.splitk_scope(x.device):
+            return plan(x)
     if x.shape[0] <= _chunk_limit(x.shape[2:]):
         return plan(x)
     return torch.cat([plan(x[a:b]) for a, b in _chunks(x.shape[0], x.shape[2:])], 0)

@@ -903,6 +903,7 @@ static std::atomic<int> g_order{0};    // tile order (vatl_tune_set(1, v))
 static std::atomic<int> g_ablate{0};   // vatl_tune_set(6, bits): 1 = no epilogue, 2 = one k-tile only (profiling ablations, wrong results)
 static std::atomic<int> g_bm{0};       // tile rows (vatl_tune_set(5, v)): 0 = by grid size, 64 or 128 = forced
 static std::atomic<int> g_stagger{0};  // block stagger in percent of the k-loop time (vatl_tune_set(2, v)); 0 = off
+static std::atomic<int> g_splitk_policy{0};  // vatl_tune_set(9, v): 0 = cut by the launch's own block count, 1 = batch-invariant cut (per-image geometry)
 
 // Split-K (opt-in, vatl_set_splitk_workspace): y = act(sum_z part[z] * scale + bias (+ residual)), slices summed in order.
 // One thread per four channels of one output pixel (Cout % 4 == 0) or per element.
@@ -963,12 +964,27 @@ static int launch(const ConvParams& p, int phases, hipStream_t st) {
     long long ws_floats = 0;
     float* ws = splitk_workspace(&ws_floats);
     q.splits = 1;
-    if (ws && !STEM && !DUAL && !q.stats && !q.ablate && blocks < 256 && q.ktiles >= 16) {
-        // small launch with a long reduction (single-frame / small-batch inference): cut K so that ~512 blocks are in flight
+    if (ws && !STEM && !DUAL && !q.stats && !q.ablate && q.ktiles >= 16) {
         const long long out_elems = (long long)q.y_bytes / 4;
-        int splits = (int)std::min<long long>(q.ktiles / 8, (512 + blocks - 1) / blocks);
-        const long long fit = ws_floats / (out_elems > 0 ? out_elems : 1);
-        if (splits > fit) splits = (int)fit;
+        int splits = 0;
+        if (g_splitk_policy.load(std::memory_order_relaxed) == 1) {
+            // batch-invariant policy (module calls with <= 16 crops, vatl_tune_set(9, 1)): the cut depends on the layer's
+            // per-image geometry only — block count of a nominal 4-crop batch in 64-row tiles, workspace need of a 16-crop
+            // batch — so a crop's bits do not depend on how many crops share its call
+            const long long per_img_rows = p.M / (p.N > 0 ? p.N : 1), per_img_out = out_elems / (p.N > 0 ? p.N : 1);
+            const long long blocks4 = (long long)cdiv(4 * per_img_rows, 64) * q.n_tiles * phases;
+            if (blocks4 < 512) {
+                splits = (int)std::min<long long>(q.ktiles / 8, (1024 + blocks4 - 1) / blocks4);
+                const long long fit16 = ws_floats / (per_img_out > 0 ? 16 * per_img_out : 1);
+                if (splits > fit16) splits = (int)fit16;
+                if ((long long)splits * out_elems > ws_floats) splits = 0;          // more than 16 crops under this policy: unsplit
+            }
+        } else if (blocks < 256) {
+            // small launch with a long reduction (single-frame / small-batch inference): cut K so that ~512 blocks are in flight
+            splits = (int)std::min<long long>(q.ktiles / 8, (512 + blocks - 1) / blocks);
+            const long long fit = ws_floats / (out_elems > 0 ? out_elems : 1);
+            if (splits > fit) splits = (int)fit;
+        }
         if (splits >= 2) {
             q.kt_per_split = (q.ktiles + splits - 1) / splits;
             q.splits = (q.ktiles + q.kt_per_split - 1) / q.kt_per_split;
@@ -1128,6 +1144,7 @@ extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 6 && value >= 0 && value <= 3) { g_ablate.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 7 && value >= 0 && value <= 64) { g_persist.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 8 && (value == 0 || value == 1)) return conv3x3_halo_enable(value);
+    if (knob == 9 && (value == 0 || value == 1)) { g_splitk_policy.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
     if (knob == 0 && value >= 0 && value <= 13) { g_var.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }
