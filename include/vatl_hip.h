@@ -299,6 +299,17 @@ int vatl_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int N, int
  * and the backward that consumes it.  idx (N,Ho,Wo,C) uint8. */
 int vatl_maxpool3x3s2_fwd_idx(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream);
 int vatl_maxpool3x3s2_bwd_idx(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream);
+/* The stem tail bn1 -> relu -> maxpool of the ResNet trunks under model.train() (Resnet.py:171-172 via ActiveLearning.py:658-672)
+ * without the full-resolution activation or its gradient in HBM.  Forward: y (N,Ho,Wo,C) = maxpool(relu(z*scale + bias)) with
+ * the affine + ReLU applied to the conv output z on load (the fmaf of vatl_scale_bias_act: identical values and winners), idx
+ * as above.  Backward: dpool = gradient of y; the gradient of every stem pixel is gathered from the <= 4 windows covering it
+ * inside the BatchNorm backward's reduction and apply passes: dz (N,H,W,C), dgamma, dbeta as vatl_bn_train_bwd_relu.
+ * C % 4 == 0; workspace: vatl_col_reduce_workspace_doubles(N*H*W, C) doubles; coef3C: 3*C floats. */
+int vatl_maxpool3x3s2_fwd_idx_affine(const float* z, const float* scale, const float* bias, float* y, uint8_t* idx, int N, int H, int W, int C,
+                                     void* stream);
+int vatl_bn_train_bwd_relu_pool(const float* dpool, const uint8_t* idx, const float* scale, const float* bias, const float* z,
+                                const float* gamma, const float* save_mean, const float* save_invstd, float* dz, float* dgamma,
+                                float* dbeta, int N, int H, int W, int C, float* coef3C, double* workspace, void* stream);
 /* Backward of nn.PixelShuffle(2) on NHWC: x (N,2H,2W,C/4) -> y (N,H,W,C). */
 int vatl_pixelunshuffle2(const float* x, float* y, int N, int H, int W, int C, void* stream);
 /* Backward of the SE-gated residual y = relu(u*sigmoid(gate) + shortcut) (SE_Resnet.py:125-135), two stages:

@@ -269,12 +269,12 @@ def test_chunked_batches_are_bit_identical(vh):
     sequence, through forward(), forward_into() and get_embedding(), including a ragged last chunk."""
     from alphapose.models import hip_engine
     m = _build_simplepose()
-    x = to_dev(synth.crops(7))
+    x = to_dev(synth.crops(20))                               # > 16 crops: module calls this large never use the small-batch split-K
     with torch.no_grad():
         whole, emb = m(x), m.get_embedding(x)
     old = hip_engine.MAX_CHUNK
     try:
-        hip_engine.MAX_CHUNK = 3
+        hip_engine.MAX_CHUNK = 6                               # 6 + 6 + 6 + 2
         with torch.no_grad():
             parts, emb_parts = m(x), m.get_embedding(x)
             buf = torch.empty_like(whole)

@@ -154,6 +154,37 @@ def test_maxpool_backward(vh):
         np.testing.assert_allclose(_nchw(dx2.cpu().numpy()), xt.grad.numpy(), rtol=1e-6, atol=1e-6)
 
 
+def test_stem_tail_fused_pool_matches_the_separate_passes_and_float64(vh):
+    """bn1 -> relu -> maxpool (Resnet.py:171-172) in training mode without the full-resolution activation / gradient:
+    `maxpool3x3s2_fwd_idx_affine` == scale_bias_act + maxpool3x3s2_fwd_idx (values and winners, bit for bit, ties and odd sizes
+    included), `bn_train_bwd_relu_pool` == maxpool3x3s2_bwd_idx + bn_train_bwd_relu, and both against float64 autograd."""
+    r = np.random.RandomState(17)
+    for (n, c, h, w) in ((3, 64, 32, 24), (2, 8, 7, 5), (1, 128, 9, 12)):
+        z = (np.round(r.standard_normal((n, h, w, c)) * 4) / 4).astype(np.float32)          # quantised: ties inside windows
+        gamma, beta = r.uniform(-1.5, 1.5, c).astype(np.float32), r.standard_normal(c).astype(np.float32)   # negative scales too
+        zd, gd, bd = to_dev(z), to_dev(gamma), to_dev(beta)
+        rm, rv = torch.zeros(c, device=zd.device), torch.ones(c, device=zd.device)
+        mean, invstd, scale, bias = vh.bn_train_fwd_stats(zd, gd, bd, rm, rv, 0.1, 1e-5)
+        y_full = vh.scale_bias_act(zd, scale, bias, None, True)
+        yp0, idx0 = vh.maxpool3x3s2_fwd_idx(y_full)
+        yp1, idx1 = vh.maxpool3x3s2_fwd_idx_affine(zd, scale, bias)
+        assert torch.equal(yp0, yp1) and torch.equal(idx0, idx1)
+        dpool = to_dev(r.standard_normal(tuple(yp0.shape)).astype(np.float32))
+        dy_full = vh.maxpool3x3s2_bwd_idx(dpool, idx0, (h, w))
+        dz0, dg0, db0 = vh.bn_train_bwd_relu(dy_full, scale, bias, zd, gd, mean, invstd)
+        dz1, dg1, db1 = vh.bn_train_bwd_relu_pool(dpool, idx1, scale, bias, zd, gd, mean, invstd)
+        assert torch.equal(dz0, dz1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+        # float64 autograd of the same graph
+        zt = torch.from_numpy(_nchw(z).astype(np.float64)).requires_grad_()
+        gt, bt = torch.from_numpy(gamma.astype(np.float64)).requires_grad_(), torch.from_numpy(beta.astype(np.float64)).requires_grad_()
+        out = F.max_pool2d(F.relu(F.batch_norm(zt, None, None, gt, bt, True, 0.1, 1e-5)), 3, 2, 1)
+        np.testing.assert_allclose(_nchw(yp1.cpu().numpy()), out.detach().numpy(), rtol=1e-5, atol=1e-5)
+        out.backward(torch.from_numpy(_nchw(dpool.cpu().numpy()).astype(np.float64)))
+        e = rel_err(_nchw(dz1.cpu().numpy()), zt.grad.numpy())
+        record("stem_pool_fused", shape=[n, c, h, w], dz=e, dgamma=rel_err(dg1.cpu().numpy(), gt.grad.numpy()), dbeta=rel_err(db1.cpu().numpy(), bt.grad.numpy()))
+        assert e < 5e-5 and rel_err(dg1.cpu().numpy(), gt.grad.numpy()) < 5e-5 and rel_err(db1.cpu().numpy(), bt.grad.numpy()) < 5e-5
+
+
 def test_simplepose_finetune_step_vs_reference_golden(vh, golden_simplepose):
     """retrain_model's step (ActiveLearning.py:662-673): forward in train mode, 0.5*masked MSE, backward, AdamW with
     the three reference param groups — against the step the reference itself took (tools/make_golden.py)."""

@@ -394,7 +394,7 @@ def run_module_nchw(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
         return hip_train.forward_train(m, x)
     x = _prepare_input(m, x)
     plan = _plan_for(m, x.device)
-    if 0 < x.shape[0] <= _SPLITK_AUTO_MAX:
+    if 0 < x.shape[0] <= min(_SPLITK_AUTO_MAX, _chunk_limit(x.shape[2:])):
         with vh.splitk_scope(x.device):
             return plan(x)
     if x.shape[0] <= _chunk_limit(x.shape[2:]):

@@ -180,6 +180,34 @@ class _ConvBN:
         self.saved = (x, z, y if (relu and skip is not None) else None, mean, invstd, skip is not None, mask)
         return y
 
+    def forward_pool(self, x):
+        """Conv + BN(train) + ReLU + MaxPool2d(3,2,1) (the trunk's stem tail, Resnet.py:171-172): the affine + ReLU are applied to z
+        inside the pooling pass, relu(bn(z)) itself is never written.  -> pooled output; the winners stay on the tape."""
+        w = vh.pack_conv_weight(self.conv.weight.detach())
+        bn = self.bn
+        z, mean, invstd, scale, bias = vh.conv2d_fwd_bnstats(x, w, self.cout, self.r, self.s, self.stride, self.pad, bn.weight.detach(),
+                                                             bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        _count_batch(bn)
+        y, idx = vh.maxpool3x3s2_fwd_idx_affine(z, scale, bias)
+        self.saved = (x, z, None, mean, invstd, False, (scale, bias))
+        self.pool_idx = idx
+        return y
+
+    def backward_pool(self, dpool, grads):
+        """Backward of forward_pool from the pooled output's gradient (no full-resolution gradient tensor).  The stem's own input
+        gradient is never needed (need_dx False)."""
+        x, z, _, mean, invstd, _, mask = self.saved
+        self.saved = None
+        idx, self.pool_idx = self.pool_idx, None
+        dz, dgamma, dbeta = vh.bn_train_bwd_relu_pool(dpool, idx, mask[0], mask[1], z, self.bn.weight.detach(), mean, invstd,
+                                                      dgamma=_gout(grads, self.bn.weight), dbeta=_gout(grads, self.bn.bias))
+        grads[self.bn.weight] = dgamma
+        grads[self.bn.bias] = dbeta
+        cin_w = 3 if self.cin == 3 else self.cin
+        ow = _gout(grads, self.conv.weight)
+        grads[self.conv.weight] = _side.run(lambda: vh.conv2d_wgrad(x, dz, self.cout, cin_w, self.r, self.s, self.stride, self.pad, out=ow), x, dz)
+        assert not self.need_dx
+
     # ---- backward ------------------------------------------------------------
     def bn_spec(self):
         """What the launch that PRODUCES this layer's output gradient needs in order to run the reduction pass of this layer's
@@ -346,9 +374,7 @@ class SimplePoseTrainer:
 
     def forward(self, x_nchw):
         x = vh.nchw_to_nhwc(x_nchw, 4)
-        s = self.stem.forward(x)
-        x, self.pool_idx = vh.maxpool3x3s2_fwd_idx(s)
-        self.pool_hw = (s.shape[1], s.shape[2])
+        x = self.stem.forward_pool(x)                                           # conv + bn + relu + maxpool: the activation is never stored
         for b in self.blocks:
             x = b.forward(x)
         for d in self.deconvs:
@@ -380,9 +406,7 @@ class SimplePoseTrainer:
             pre = consumer
             grads.flush()
         dx = _chain_blocks_backward(self.blocks, dx, grads, pre, grads.flush)
-        dx = vh.maxpool3x3s2_bwd_idx(dx, self.pool_idx, self.pool_hw)
-        self.pool_idx = None
-        self.stem.backward(dx, grads)
+        self.stem.backward_pool(dx, grads)
         _side.join()
         return grads.close()
 
@@ -460,9 +484,7 @@ class FastPoseTrainer:
         self.head = m.conv_out
 
     def forward(self, x_nchw):
-        s = self.stem.forward(vh.nchw_to_nhwc(x_nchw, 4))
-        x, self.pool_idx = vh.maxpool3x3s2_fwd_idx(s)
-        self.pool_hw = (s.shape[1], s.shape[2])
+        x = self.stem.forward_pool(vh.nchw_to_nhwc(x_nchw, 4))                  # conv + bn + relu + maxpool: the activation is never stored
         for b in self.blocks:
             x = b.forward(x)
         x = vh.pixelshuffle2_fwd(x)
@@ -489,9 +511,7 @@ class FastPoseTrainer:
         grads.flush()
         dx = vh.pixelunshuffle2(dx)
         dx = _chain_blocks_backward(self.blocks, dx, grads, None, grads.flush)
-        dx = vh.maxpool3x3s2_bwd_idx(dx, self.pool_idx, self.pool_hw)
-        self.pool_idx = None
-        self.stem.backward(dx, grads)
+        self.stem.backward_pool(dx, grads)
         _side.join()
         return grads.close()
 

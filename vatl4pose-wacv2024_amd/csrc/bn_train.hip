@@ -139,11 +139,33 @@ __global__ __launch_bounds__(256) void col_stats_scalar_kernel(const float* __re
     }
 }
 
-// one wave per channel: lanes stride over the row-block partials
+// A 256-thread block owns four consecutive channels (c0 = 4 * blockIdx.x; wave w reports channel c0 + w): every thread walks
+// the row-block partials rb = t, t + 256, ... and adds the four channels' (sum, sum^2) pairs — 64 contiguous bytes per row
+// block — then the 256 per-thread sums are combined in a fixed order (xor-shuffle tree inside a wave, waves 0..3 in order).
+// (The first version gave each channel ONE wave striding 16-byte pairs C*16 bytes apart: with C = 64 and 23 040 row blocks
+// — the stem at B = 120 — sixteen blocks of four such waves took 159 us; this layout reads the same 23.6 MB in ~15 us.)
 __device__ __forceinline__ void sum_partials(const double* __restrict__ partial, int nrb, int C, int c, int lane, double& s, double& q) {
-    s = 0.0; q = 0.0;
-    for (int rb = lane; rb < nrb; rb += 64) { s += partial[((long long)rb * C + c) * 2]; q += partial[((long long)rb * C + c) * 2 + 1]; }
-    s = wave_sum(s); q = wave_sum(q);
+    (void)c; (void)lane;
+    const int c0 = blockIdx.x * 4;
+    const int nc = C - c0 < 4 ? C - c0 : 4;
+    double as[4] = {0.0, 0.0, 0.0, 0.0}, aq[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int rb = threadIdx.x; rb < nrb; rb += 256) {
+        const double* __restrict__ src = partial + ((long long)rb * C + c0) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < nc) { as[e] += src[2 * e]; aq[e] += src[2 * e + 1]; }
+    }
+    __shared__ double sh[4][8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { as[e] = wave_sum(as[e]); aq[e] = wave_sum(aq[e]); }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sh[w][e] = as[e]; sh[w][4 + e] = aq[e]; }
+    }
+    __syncthreads();
+    s = ((sh[0][w] + sh[1][w]) + sh[2][w]) + sh[3][w];
+    q = ((sh[0][4 + w] + sh[1][4 + w]) + sh[2][4 + w]) + sh[3][4 + w];
 }
 
 __global__ __launch_bounds__(256) void bn_train_finalize_kernel(const double* __restrict__ partial, int nrb, long long M, int C,
@@ -152,10 +174,9 @@ __global__ __launch_bounds__(256) void bn_train_finalize_kernel(const double* __
                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                          float* __restrict__ scale, float* __restrict__ bias) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
     double s, q;
-    sum_partials(partial, nrb, C, c, threadIdx.x & 63, s, q);
-    if ((threadIdx.x & 63) != 0) return;
+    sum_partials(partial, nrb, C, c, threadIdx.x & 63, s, q);     // whole block takes part (barrier inside)
+    if (c >= C || (threadIdx.x & 63) != 0) return;
     const double mean = s / (double)M;
     double var = q / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -202,10 +223,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coefA,
                                        float* __restrict__ coefB, float* __restrict__ coefC) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
     double sg, sgx;
     sum_partials(partial, nrb, C, c, threadIdx.x & 63, sg, sgx);
-    if ((threadIdx.x & 63) != 0) return;
+    if (c >= C || (threadIdx.x & 63) != 0) return;
     if (dbeta) dbeta[c] = (float)sg;
     if (dgamma) dgamma[c] = (float)sgx;
     const double s = (double)(gamma ? gamma[c] : 1.f) * (double)invstd[c];
@@ -327,13 +347,165 @@ __global__ void maxpool3x3s2_bwd_idx_kernel(const float* __restrict__ dy, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stem tail of the ResNet trunks in training mode (Resnet.py:171-172: bn1 -> relu -> maxpool) without the full-resolution
+// activation or its gradient ever being stored:
+//   forward   pooled[o] = max over the 3x3/2 window of relu(z*scale + bias), idx[o] = winning tap (first maximum in scan
+//             order): BatchNorm-affine and ReLU applied to z on load — the same fmaf as scale_bias_act_kernel, so values and
+//             winners are those of the unfused pair of passes, bit for bit
+//   backward  the gradient of a stem pixel is GATHERED from the <= 4 windows covering it (their idx byte says whether this
+//             pixel won) wherever it is needed: once in the (sum g, sum g*xhat) reduction, once in dz = A*g + B*z + C.
+// Four channels per thread (float4 / uchar4).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool AFFINE>
+__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_idx4_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                   float* __restrict__ y, uint8_t* __restrict__ idx, int N, int H, int W, int C4, int Ho, int Wo) {
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const long long n = t / Ho;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (AFFINE) { sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4); bi = *reinterpret_cast<const f32x4*>(bias + c4 * 4); }
+        f32x4 v[9];
+        bool ok[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {                      // all nine loads in flight together
+            const int yy = 2 * oy - 1 + k / 3, xx = 2 * ox - 1 + k % 3;
+            ok[k] = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            v[k] = ok[k] ? *reinterpret_cast<const f32x4*>(x + (((n * H + yy) * W + xx) * C4 + c4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bk[4] = {255, 255, 255, 255};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (!ok[k]) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = AFFINE ? fmaxf(fmaf(v[k][e], sc[e], bi[e]), 0.f) : v[k][e];
+                if (a > best[e] || bk[e] == 255) { best[e] = a; bk[e] = k; }
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = best;
+        *reinterpret_cast<unsigned*>(idx + i * 4) = (unsigned)bk[0] | ((unsigned)bk[1] << 8) | ((unsigned)bk[2] << 16) | ((unsigned)bk[3] << 24);
+    }
+}
+
+// gradient of stem pixel (n, iy, ix), channels 4*c4..: sum over the covering windows whose winner is this pixel
+__device__ __forceinline__ f32x4 pool_gather4(const float* __restrict__ dy, const uint8_t* __restrict__ idx, long long n, int iy, int ix, int c4,
+                                              int C4, int Ho, int Wo) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1, ox0 = ix >> 1, ox1 = (ix + 1) >> 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int oy = a ? oy1 : oy0;
+        if ((a && oy1 == oy0) || oy >= Ho) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ox = b ? ox1 : ox0;
+            if ((b && ox1 == ox0) || ox >= Wo) continue;
+            const long long o = ((n * Ho + oy) * Wo + ox) * C4 + c4;
+            const unsigned kk = *reinterpret_cast<const unsigned*>(idx + o * 4);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dy + o * 4);
+            const unsigned k = (unsigned)((iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1)));      // this pixel's tap inside that window
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += ((kk >> (8 * e)) & 255u) == k ? d[e] : 0.f;
+        }
+    }
+    return acc;
+}
+
+// max-pool backward alone (float4 version of maxpool3x3s2_bwd_idx_kernel; same sums, same order)
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_idx4_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                                                                   int N, int H, int W, int C4, int Ho, int Wo) {
+    const long long total = (long long)N * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        *reinterpret_cast<f32x4*>(dx + i * 4) = pool_gather4(dy, idx, t / H, iy, ix, c4, C4, Ho, Wo);
+    }
+}
+
+// reduction pass: block = row range, thread = fixed float4 column (C4 <= 256 columns: the stem has 16), rows in order;
+// partial[(rb*C + c)*2 + {0,1}] = (sum g, sum g*xhat), g = gathered gradient * [relu(z*msc + mbi) > 0]
+__global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, const float* __restrict__ z,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ mscale, const float* __restrict__ mbias,
+                                                                double* __restrict__ partial, long long M, int C, long long rows_per_block,
+                                                                int H, int W, int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const int cols = C4 < 256 ? C4 : 256;
+    const int col = threadIdx.x % cols, rlane = threadIdx.x / cols, rstep = 256 / cols;
+    const int c4 = blockIdx.y * 256 + col;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    if (c4 < C4 && rlane < rstep) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4), is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
+        const f32x4 msc = *reinterpret_cast<const f32x4*>(mscale + c4 * 4), mbi = *reinterpret_cast<const f32x4*>(mbias + c4 * 4);
+        for (long long r = r0 + rlane; r < r1; r += rstep) {
+            const int ix = (int)(r % W);
+            const long long t = r / W;
+            const int iy = (int)(t % H);
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(z + (r * C4 + c4) * 4);
+            const f32x4 g = pool_gather4(dy, idx, t / H, iy, ix, c4, C4, Ho, Wo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = relu_on(zz[e], msc[e], mbi[e]) ? g[e] : 0.f;
+                s[e] += v; q[e] += v * ((zz[e] - mu[e]) * is[e]);
+            }
+        }
+    }
+    __shared__ float sh[2][256][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sh[0][threadIdx.x][e] = s[e]; sh[1][threadIdx.x][e] = q[e]; }
+    __syncthreads();
+    if (rlane == 0 && c4 < C4) {
+        double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+        for (int k = 0; k < rstep; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ds[e] += sh[0][k * cols + col][e]; dq[e] += sh[1][k * cols + col][e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            partial[((long long)blockIdx.x * C + c4 * 4 + e) * 2 + 0] = ds[e];
+            partial[((long long)blockIdx.x * C + c4 * 4 + e) * 2 + 1] = dq[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx, const float* __restrict__ z,
+                                                               const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ Cc,
+                                                               const float* __restrict__ mscale, const float* __restrict__ mbias, float* __restrict__ dz,
+                                                               long long n4, int C4, int H, int W, int Ho, int Wo) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + i * 4);
+        const f32x4 g = pool_gather4(dy, idx, t / H, iy, ix, c4, C4, Ho, Wo);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(A + c4 * 4), b = *reinterpret_cast<const f32x4*>(B + c4 * 4), cc = *reinterpret_cast<const f32x4*>(Cc + c4 * 4);
+        const f32x4 msc = *reinterpret_cast<const f32x4*>(mscale + c4 * 4), mbi = *reinterpret_cast<const f32x4*>(mbias + c4 * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = relu_on(zz[e], msc[e], mbi[e]) ? g[e] : 0.f;
+            o[e] = a[e] * v + b[e] * zz[e] + cc[e];
+        }
+        *reinterpret_cast<f32x4*>(dz + i * 4) = o;
+    }
+}
+
 // out[c] = sum over rows of x[r][c]  (conv bias gradient); same two-stage scheme
 __global__ __launch_bounds__(256) void col_sum_finalize_kernel(const double* __restrict__ partial, int nrb, int C, float* __restrict__ out) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
     double s, q;
     sum_partials(partial, nrb, C, c, threadIdx.x & 63, s, q);
-    if ((threadIdx.x & 63) == 0) out[c] = (float)s;
+    if (c < C && (threadIdx.x & 63) == 0) out[c] = (float)s;
 }
 
 static inline int ew_grid(long long n) { long long g = (n + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1; return (int)g; }
@@ -447,16 +619,58 @@ extern "C" int vatl_col_sum(const float* x, int64_t M, int C, float* out, double
     return check_launch("col_sum");
 }
 
-extern "C" int vatl_maxpool3x3s2_fwd_idx(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+static int maxpool_fwd_idx_impl(const float* x, const float* scale, const float* bias, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {
     if (!x || !y || !idx) return fail(VATL_EINVAL, "maxpool3x3s2_fwd_idx: null pointer");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    if ((C & 3) == 0) {
+        const dim3 grid(ew_grid((long long)N * Ho * Wo * (C / 4)));
+        if (scale) hipLaunchKernelGGL(maxpool3x3s2_fwd_idx4_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, scale, bias, y, idx, N, H, W, C / 4, Ho, Wo);
+        else       hipLaunchKernelGGL(maxpool3x3s2_fwd_idx4_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, scale, bias, y, idx, N, H, W, C / 4, Ho, Wo);
+        return check_launch("maxpool3x3s2_fwd_idx");
+    }
+    if (scale) return fail(VATL_EINVAL, "maxpool3x3s2_fwd_idx_affine: C %d must be a multiple of 4", C);
     hipLaunchKernelGGL(maxpool3x3s2_fwd_idx_kernel, dim3(ew_grid((long long)N * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, H, W, C, Ho, Wo);
     return check_launch("maxpool3x3s2_fwd_idx");
+}
+
+extern "C" int vatl_maxpool3x3s2_fwd_idx(const float* x, float* y, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+    return maxpool_fwd_idx_impl(x, nullptr, nullptr, y, idx, N, H, W, C, stream);
+}
+
+// BatchNorm-affine + ReLU + MaxPool2d(3,2,1) in one pass over the conv output z (Resnet.py:171-172 in training mode):
+// y = pool(relu(z*scale + bias)), idx = winning taps; relu(z*scale + bias) itself is never stored.
+extern "C" int vatl_maxpool3x3s2_fwd_idx_affine(const float* z, const float* scale, const float* bias, float* y, uint8_t* idx, int N, int H, int W, int C,
+                                                void* stream) {
+    if (!scale || !bias) return fail(VATL_EINVAL, "maxpool3x3s2_fwd_idx_affine: null scale / bias");
+    return maxpool_fwd_idx_impl(z, scale, bias, y, idx, N, H, W, C, stream);
+}
+
+// Backward of the same tail + the BatchNorm backward of the layer in front of it: dpool (N,Ho,Wo,C) = gradient of the pooled
+// output, idx = the forward's winners; dz (N,H,W,C), dgamma, dbeta.  The full-resolution gradient is gathered on the fly in
+// the reduction and in the apply pass (never stored).  workspace: vatl_col_reduce_workspace_doubles(N*H*W, C) doubles.
+extern "C" int vatl_bn_train_bwd_relu_pool(const float* dpool, const uint8_t* idx, const float* scale, const float* bias, const float* z,
+                                           const float* gamma, const float* save_mean, const float* save_invstd, float* dz, float* dgamma,
+                                           float* dbeta, int N, int H, int W, int C, float* coef3C, double* workspace, void* stream) {
+    if (!dpool || !idx || !scale || !bias || !z || !save_mean || !save_invstd || !dz || !coef3C || !workspace || (C & 3) || C > 1024 || N <= 0)
+        return fail(VATL_EINVAL, "bn_train_bwd_relu_pool: bad arguments (C %% 4 == 0, C <= 1024)");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long M = (long long)N * H * W;
+    const RowSplit rs = row_split(M, C);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pool_bn_bwd_reduce_kernel, dim3(rs.nrb, cdiv(C / 4, 256)), dim3(256), 0, st, dpool, idx, z, save_mean, save_invstd, scale, bias,
+                       workspace, M, C, rs.rows_per_block, H, W, Ho, Wo);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, workspace, rs.nrb, M, C, gamma, save_mean, save_invstd, dgamma, dbeta,
+                       coef3C, coef3C + C, coef3C + 2 * C);
+    const long long n4 = M * C / 4;
+    hipLaunchKernelGGL(pool_bn_bwd_apply_kernel, dim3(ew_grid(n4)), dim3(256), 0, st, dpool, idx, z, coef3C, coef3C + C, coef3C + 2 * C, scale, bias, dz, n4,
+                       C / 4, H, W, Ho, Wo);
+    return check_launch("bn_train_bwd_relu_pool");
 }
 
 extern "C" int vatl_maxpool3x3s2_bwd_idx(const float* dy, const uint8_t* idx, float* dx, int N, int H, int W, int C, void* stream) {
     if (!dy || !idx || !dx) return fail(VATL_EINVAL, "maxpool3x3s2_bwd_idx: null pointer");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool3x3s2_bwd_idx_kernel, dim3(ew_grid((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W, C, Ho, Wo);
+    if ((C & 3) == 0) hipLaunchKernelGGL(maxpool3x3s2_bwd_idx4_kernel, dim3(ew_grid((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W, C / 4, Ho, Wo);
+    else hipLaunchKernelGGL(maxpool3x3s2_bwd_idx_kernel, dim3(ew_grid((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W, C, Ho, Wo);
     return check_launch("maxpool3x3s2_bwd_idx");
 }

@@ -76,6 +76,8 @@ SIGNATURES = {
     "vatl_bn_train_finalize": (_i, [_p, _i64, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
     "vatl_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_maxpool3x3s2_fwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "vatl_maxpool3x3s2_fwd_idx_affine": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vatl_bn_train_bwd_relu_pool": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "vatl_maxpool3x3s2_bwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_pixelunshuffle2": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vatl_se_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
@@ -722,6 +724,30 @@ def maxpool3x3s2_fwd_idx(x):
     idx = torch.empty(y.shape, device=x.device, dtype=torch.uint8)
     _check(lib().vatl_maxpool3x3s2_fwd_idx(_ptr(x), _ptr(y), _ptr(idx, torch.uint8), n, h, w, c, _stream()), "vatl_maxpool3x3s2_fwd_idx")
     return y, idx
+
+
+def maxpool3x3s2_fwd_idx_affine(z, scale, bias):
+    """pool(relu(z*scale + bias)) and the winning taps in one pass over the conv output z (the activation is never stored)."""
+    n, h, w, c = z.shape
+    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), device=z.device, dtype=torch.float32)
+    idx = torch.empty(y.shape, device=z.device, dtype=torch.uint8)
+    _check(lib().vatl_maxpool3x3s2_fwd_idx_affine(_ptr(z), _ptr(scale), _ptr(bias), _ptr(y), _ptr(idx, torch.uint8), n, h, w, c, _stream()),
+           "vatl_maxpool3x3s2_fwd_idx_affine")
+    return y, idx
+
+
+def bn_train_bwd_relu_pool(dpool, idx, scale, bias, z, gamma, save_mean, save_invstd, dgamma=None, dbeta=None):
+    """Backward of Conv+BN+ReLU+MaxPool(3,2,1) from the POOLED output's gradient (the full-resolution gradient is gathered on
+    the fly, never stored). -> dz, dgamma, dbeta."""
+    n, h, w, c = z.shape
+    dz = torch.empty_like(z)
+    dgamma = dgamma if dgamma is not None else torch.empty(c, device=z.device, dtype=torch.float32)
+    dbeta = dbeta if dbeta is not None else torch.empty(c, device=z.device, dtype=torch.float32)
+    coef = torch.empty(3 * c, device=z.device, dtype=torch.float32)
+    _check(lib().vatl_bn_train_bwd_relu_pool(_ptr(dpool), _ptr(idx, torch.uint8), _ptr(scale), _ptr(bias), _ptr(z), _ptr(gamma), _ptr(save_mean),
+                                             _ptr(save_invstd), _ptr(dz), _ptr(dgamma), _ptr(dbeta), n, h, w, c, _ptr(coef),
+                                             _ptr(_col_ws(n * h * w, c, z.device), torch.float64), _stream()), "vatl_bn_train_bwd_relu_pool")
+    return dz, dgamma, dbeta
 
 
 def maxpool3x3s2_bwd_idx(dy, idx, in_hw):
