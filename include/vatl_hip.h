@@ -86,7 +86,8 @@ int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float* w, const 
  * stagger, 3 = target block count of the weight-gradient launches (number of pixel splits), 5 = rows of the conv block
  * tile (0 = chosen from the grid size, 64, 128), 7 = persistent 1x1 kernel for K <= 256 v (0 = off, default 1), 8 = halo-tile kernel for the
  * 32-channel 3x3 layers (csrc/conv3x3_halo.hip; 1 = on, default; 0 = generic implicit GEMM; bit-identical results), 9 = split-K cut policy while a
- * workspace is registered (0 = by the launch's own block count, 1 = by the layer's per-image geometry only: batch-invariant bits).  Knob 0 values 10..13, knob 4 (wgrad ablation bits) and knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) are profiling
+ * workspace is registered (0 = by the launch's own block count, 1 = by the layer's per-image geometry only: batch-invariant bits), 10 = operand
+ * look-ahead of the persistent 1x1 kernel in k-tiles (1, or 2 = default; bit-identical results).  Knob 0 values 10..13, knob 4 (wgrad ablation bits) and knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) are profiling
  * ablations that compute WRONG results: they are not compiled into the product library at all (every such call returns
  * VATL_EINVAL); the profiling variant built with -DVATL_ABLATION (build.py --ablation -> libvatl_hip_ablation.so, loaded
  * through VATL_HIP_LIB) accepts them when the environment also has VATL_ALLOW_ABLATION=1. */
@@ -310,6 +311,22 @@ int vatl_maxpool3x3s2_fwd_idx_affine(const float* z, const float* scale, const f
 int vatl_bn_train_bwd_relu_pool(const float* dpool, const uint8_t* idx, const float* scale, const float* bias, const float* z,
                                 const float* gamma, const float* save_mean, const float* save_invstd, float* dz, float* dgamma,
                                 float* dbeta, int N, int H, int W, int C, float* coef3C, double* workspace, void* stream);
+/* Every weight re-pack of one fine-tune step in ONE launch (the per-tensor entry points vatl_pack_conv_weight,
+ * vatl_pack_dgrad_weight, vatl_pack_deconv4x4s2_weight produce the same bytes one launch each).  jobs_device: device
+ * array of njobs descriptors sorted by first_block = the running sum of ceil(elements / 1024) over the preceding jobs;
+ * total_blocks = that sum over all jobs.  kind 0: conv forward layout, (a, b, c) = (CoutPad, Spad, CinPad);
+ * kind 1: data-gradient layout, (a, b, c) = (CinPad, CoutK, ntaps) with the taps in tap_r / tap_s;
+ * kind 2: ConvTranspose2d(4,2,1) layout, src (Cin,Cout,4,4), a = CoutPad. */
+typedef struct VatlPackJob {
+    const float* src;
+    float* dst;
+    int64_t first_block;
+    int32_t kind;
+    int32_t Cout, Cin, R, S;
+    int32_t a, b, c;
+    int32_t tap_r[16], tap_s[16];
+} VatlPackJob;
+int vatl_pack_weights_multi(const VatlPackJob* jobs_device, int njobs, int64_t total_blocks, void* stream);
 /* Backward of nn.PixelShuffle(2) on NHWC: x (N,2H,2W,C/4) -> y (N,H,W,C). */
 int vatl_pixelunshuffle2(const float* x, float* y, int N, int H, int W, int C, void* stream);
 /* Backward of the SE-gated residual y = relu(u*sigmoid(gate) + shortcut) (SE_Resnet.py:125-135), two stages:

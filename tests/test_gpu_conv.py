@@ -289,14 +289,14 @@ def test_forward_with_embedding_is_bit_identical(vh):
     from alphapose.models import hip_engine
     m = _build_simplepose()
     x = to_dev(synth.crops(3))
-    with torch.no_grad():
-        hm, emb = m(x), m.get_embedding(x)
+    with torch.no_grad():                                      # (the stream entry points: `m(x)` with <= 16 crops runs with split-K)
+        hm, emb = hip_engine.forward_into(m, x, torch.empty((3, 17, 64, 48), device=x.device)), m.get_embedding(x)
     out, e = torch.empty_like(hm), torch.empty_like(emb)
     hip_engine.forward_with_embedding(m, x, out, e)
     assert torch.equal(out, hm) and torch.equal(e, emb)
     mf = _build({"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50})
     with torch.no_grad():
-        hm, emb = mf(x), mf.get_embedding(x)
+        hm, emb = hip_engine.forward_into(mf, x, torch.empty((3, 17, 64, 48), device=x.device)), mf.get_embedding(x)
     out, e = torch.empty_like(hm), torch.empty_like(emb)
     hip_engine.forward_with_embedding(mf, x, out, e)
     assert torch.equal(out, hm) and torch.equal(e, emb)

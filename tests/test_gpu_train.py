@@ -506,6 +506,56 @@ def test_simplepose_step_well_conditioned_batch(vh):
     assert np.median(ours) < 1.5 * np.median(ref32) + 1e-4 and max(ours) < 2 * max(ref32) + 1e-3
 
 
+@pytest.mark.parametrize("name", ["simplepose", "fastpose"])
+def test_one_launch_weight_repack_plan_equals_per_tensor_packs(vh, name, monkeypatch):
+    """vatl_pack_weights_multi behind vatl_hip.PackPlan: three fine-tune steps with AdamW (weights change every step, so every
+    step re-packs) end with the same bits whether the packed copies come from the plan's single launch (recorded in step 1,
+    replayed in steps 2-3) or from one launch per tensor; a weight written behind the plan's back is noticed, not used stale."""
+    from active_learning.optim import AdamW
+    from alphapose.models import builder, hip_train
+    from alphapose.utils.config import edict
+    cfgs = {"simplepose": {"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50},
+            "fastpose": {"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50}}
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    x = to_dev(synth.crops(4, seed=3))
+    labels, masks = synth.gaussian_targets(4, seed=4)
+    labels, masks = to_dev(labels), to_dev(masks)
+
+    def run(planned):
+        monkeypatch.setattr(hip_train, "_USE_PACK_PLAN", planned)
+        torch.manual_seed(21)
+        m = builder.build_sppe(edict(cfgs[name]), preset_cfg=preset).to(dev()).train()
+        opt = AdamW(params=[{"params": m.parameters(), "lr": 1e-3}], weight_decay=0.1)
+        tr = hip_train.trainer_for(m)
+        losses = []
+        for step in range(3):
+            with torch.no_grad():
+                out = tr.forward(x)
+                loss, dout = vh.masked_mse_fwd_bwd(out, labels, masks)
+                for p_, g_ in tr.backward(dout).items():
+                    p_.grad = g_
+            opt.step()
+            losses.append(float(loss))
+        return m, tr, losses
+
+    m1, tr1, l1 = run(True)
+    plan = tr1.__dict__["_pack_plan"]
+    assert plan.ready and not plan.stale and len(plan.jobs) >= 50 and plan.total_blocks > 0
+    m0, _, l0 = run(False)
+    assert l0 == l1 and l0[2] != l0[0]
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m0.state_dict().items()):
+        assert torch.equal(a, b), k
+    # a write the plan did not see (version counter bumped after begin()): the lookup refuses the kept copy
+    monkeypatch.setattr(hip_train, "_USE_PACK_PLAN", True)
+    with torch.no_grad():
+        out = tr1.forward(x)
+        w = next(p_ for n_, p_ in m1.named_parameters() if p_.dim() == 4 and p_.shape[2] == 3)
+        w.mul_(1.0)                                              # in-place: same values, new version
+        _, dout = vh.masked_mse_fwd_bwd(out, labels, masks)
+        tr1.backward(dout)
+    assert plan.stale
+
+
 def test_fine_tune_step_is_bitwise_reproducible(vh):
     """No atomics anywhere in the step (weight gradients are reduced over pixel splits in a fixed order, BN statistics
     and the loss through ordered partials): two runs of forward + backward give identical bits for every gradient."""

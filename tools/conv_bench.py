@@ -19,6 +19,7 @@ import vatl_hip as vh  # noqa: E402
 
 SHAPES = {  # name: (H, W, Cin, Cout, k, stride, residual)
     "stem": (256, 192, 3, 64, 7, 2, False),
+    "l1.c1s": (64, 48, 64, 64, 1, 1, False), "l2.c1w": (64, 48, 256, 128, 1, 1, False),
     "l1.c1": (64, 48, 256, 64, 1, 1, False), "l1.c2": (64, 48, 64, 64, 3, 1, False), "l1.c3": (64, 48, 64, 256, 1, 1, True),
     "l2.c1": (32, 24, 512, 128, 1, 1, False), "l2.c2": (32, 24, 128, 128, 3, 1, False), "l2.c3": (32, 24, 128, 512, 1, 1, True),
     "l3.c1": (16, 12, 1024, 256, 1, 1, False), "l3.c2": (16, 12, 256, 256, 3, 1, False), "l3.c3": (16, 12, 256, 1024, 1, 1, True),
@@ -46,6 +47,7 @@ def main():
     ap.add_argument("--ablate", default="", help="comma list of conv ablation bit sets (vatl_tune_set knob 6; needs VATL_ALLOW_ABLATION=1)")
     ap.add_argument("--bm", default="", help="comma list of block-tile row counts to A/B (vatl_tune_set knob 5: 0 auto, 64, 128)")
     ap.add_argument("--splitk", type=int, default=0, help="register an N MB split-K workspace (vatl_set_splitk_workspace) before timing")
+    ap.add_argument("--pdist", default="", help="comma list of operand look-ahead distances of the persistent 1x1 kernel to A/B (vatl_tune_set knob 10: 1, 2)")
     ap.add_argument("--persist", default="", help="comma list of persistent-1x1 settings to A/B (vatl_tune_set knob 7: 0 off, 1 = K <= 256 [default])")
     a = ap.parse_args()
     if a.splitk:
@@ -60,6 +62,13 @@ def main():
         warm_a @ warm_a
     t_end.record(); torch.cuda.synchronize()
     del warm_a
+    if a.pdist:
+        for v in a.pdist.split(","):
+            print(f"--- persistent 1x1 kernel look-ahead {v} k-tile(s)")
+            vh.tune_set(10, int(v))
+            run(a)
+        vh.tune_set(10, 2)
+        return
     if a.persist:
         for v in a.persist.split(","):
             print(f"--- persistent 1x1 kernel for K <= 256 * {v}")

@@ -157,6 +157,35 @@ def _flush_batch_counters():
     _pending_stats.clear()
 
 
+_USE_PACK_PLAN = __import__("os").environ.get("VATL_PACK_PLAN", "1") != "0"      # VATL_PACK_PLAN=0: every re-pack its own launch
+
+
+def _planned(kind):
+    """Trainer.forward / Trainer.backward under the trainer's PackPlan (vatl_hip.PackPlan): the forward pass starts with ONE
+    launch that refreshes every packed weight copy the step will use (forward layouts and data-gradient layouts), the pack calls
+    inside both passes then return the kept buffers; the first step records what is needed, the backward pass seals the record."""
+    def deco(fn):
+        def inner(self, *a, **k):
+            if not _USE_PACK_PLAN:
+                return fn(self, *a, **k)
+            plan = self.__dict__.get("_pack_plan")
+            if plan is None:
+                plan = self.__dict__["_pack_plan"] = vh.PackPlan()
+            prev = vh.set_pack_plan(plan)
+            try:
+                if kind == "forward":
+                    plan.begin()
+                out = fn(self, *a, **k)
+                if kind == "backward":
+                    plan.seal()
+                return out
+            finally:
+                vh.set_pack_plan(prev)
+        inner.__name__, inner.__doc__ = fn.__name__, fn.__doc__
+        return inner
+    return deco
+
+
 class _ConvBN:
     """Conv2d (bias-free) + BatchNorm2d(train) (+ residual) (+ ReLU)."""
 
@@ -372,6 +401,7 @@ class SimplePoseTrainer:
         self.deconvs = [_DeconvBN(d[0], d[1]), _DeconvBN(d[3], d[4]), _DeconvBN(d[6], d[7])]
         self.head = m.final_layer
 
+    @_planned("forward")
     def forward(self, x_nchw):
         x = vh.nchw_to_nhwc(x_nchw, 4)
         x = self.stem.forward_pool(x)                                           # conv + bn + relu + maxpool: the activation is never stored
@@ -385,6 +415,7 @@ class SimplePoseTrainer:
         _flush_batch_counters()
         return vh.conv2d_fwd(x, hw, None, hb, self.head.weight.shape[0], 1, 1, 1, 0, False, out_nchw=True)
 
+    @_planned("backward")
     def backward(self, dout_nchw, arena=None, overlap=False):
         """dout (B,J,H,W) NCHW -> {parameter: gradient} for every parameter of the model.  With ``arena`` the gradients are
         its slices; ``overlap`` lets the arena all-reduce finished buckets while the earlier layers are still in flight."""
@@ -483,6 +514,7 @@ class FastPoseTrainer:
         self.duc2 = _ConvBN(m.duc2.conv, m.duc2.bn, True)
         self.head = m.conv_out
 
+    @_planned("forward")
     def forward(self, x_nchw):
         x = self.stem.forward_pool(vh.nchw_to_nhwc(x_nchw, 4))                  # conv + bn + relu + maxpool: the activation is never stored
         for b in self.blocks:
@@ -496,6 +528,7 @@ class FastPoseTrainer:
         _flush_batch_counters()
         return vh.conv2d_fwd(x, vh.pack_conv_weight(self.head.weight.detach()), None, hb, j, 3, 3, 1, 1, False, out_nchw=True)
 
+    @_planned("backward")
     def backward(self, dout_nchw, arena=None, overlap=False):
         grads = _Grads(arena, overlap)
         j, cin = self.head.weight.shape[:2]
@@ -623,6 +656,7 @@ class HRNetTrainer:
             self.stages.append((trans, [_HRModuleT(mod) for mod in getattr(m, f"stage{s}")]))
         self.head = m.final_layer
 
+    @_planned("forward")
     def forward(self, x_nchw):
         x = self.stem2.forward(self.stem1.forward(vh.nchw_to_nhwc(x_nchw, 4)))
         for b in self.layer1:
@@ -641,6 +675,7 @@ class HRNetTrainer:
         _flush_batch_counters()
         return vh.conv2d_fwd(ys[0], vh.pack_conv_weight(self.head.weight.detach()), None, hb, j, k, k, 1, k // 2, False, out_nchw=True)
 
+    @_planned("backward")
     def backward(self, dout_nchw, arena=None, overlap=False):
         grads = _Grads(arena, False)                  # the branches' gradients do not complete in arena order: one reduce at the end
         j, cin, k, _ = self.head.weight.shape

@@ -743,6 +743,140 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_persistent_kernel(ConvParams p
     }
 }
 
+// The same persistent GEMM with a DISTANCE-2 operand stream that runs across tile boundaries.  With K = 64 .. 256 a tile has only
+// 2 .. 8 k-tiles; with one k-tile of look-ahead every one of them waits for an HBM round trip that 4096 matrix-pipe cycles do
+// not cover, and the pipe idles (l2.n.c3, K = 128: 61 % of peak at 3.4 TB/s — neither roof).  Here two staging register sets
+// alternate: while k-tile kt is multiplied, k-tile kt+1 sits in registers waiting to be written to LDS and k-tile kt+2 is being
+// requested — and "kt+2" simply continues into the NEXT tile's first two k-tiles, which therefore are in flight during the
+// whole epilogue of the current tile.  Requires an even number of k-tiles (statically indexed register sets).  Same LDS
+// layout, fragment mapping, MFMA order and epilogue: bit-identical to the other two kernels.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void gemm1x1_persistent2_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                          // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;           // [2][BN][LDK]
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int LA = BM / 32, LB = BN / 32;
+    constexpr int NG = BK / 8, MPG = 4 * TM * TN;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lrow = tid >> 3, kq = tid & 7;
+    const int wpos = (kq ^ ((lrow >> 1) & 7)) * 4;
+    const int frow = lane & 31;
+    int koff[BK / 8];
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) koff[g] = ((2 * g + (lane >> 5)) ^ ((frow >> 1) & 7)) * 4;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+
+    const int total = p.m_tiles * p.n_tiles;
+    const int per = (total + 7) >> 3, bpx = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int run_end = min((xcd + 1) * per, total);
+    int t = xcd * per + loc;
+    if (t >= run_end) return;
+
+    unsigned aoff[LA], boff[LB];               // byte offsets of this thread's float4s at k-tile 0
+    int m0, n0;
+    auto setup = [&](int tile, unsigned (&ao)[LA], unsigned (&bo)[LB], int& mm0, int& nn0) {
+        const int m_tile = tile / p.n_tiles, n_tile = tile - m_tile * p.n_tiles;
+        mm0 = m_tile * BM; nn0 = n_tile * BN;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) ao[i] = (unsigned)(((mm0 + lrow + 32 * i) * p.K + kq * 4) * 4);   // rows >= M: past the descriptor -> zeros
+#pragma unroll
+        for (int j = 0; j < LB; ++j) bo[j] = (unsigned)(((nn0 + lrow + 32 * j) * p.K + kq * 4) * 4);
+    };
+    f32x4 sa[2][LA], sb[2][LB];
+    auto issue = [&](f32x4 (&da)[LA], f32x4 (&db)[LB], const unsigned (&ao)[LA], const unsigned (&bo)[LB], int kt, bool live) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) da[i] = buf_load4(xr, live ? ao[i] + (unsigned)kt * (BK * 4) : OOB);
+#pragma unroll
+        for (int j = 0; j < LB; ++j) db[j] = buf_load4(wr, live ? bo[j] + (unsigned)kt * (BK * 4) : OOB);
+    };
+    auto stash = [&](const f32x4 (&da)[LA], const f32x4 (&db)[LB], int buf) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + 32 * i) * LDK + wpos]) = da[i];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + 32 * j) * LDK + wpos]) = db[j];
+    };
+    auto frag_read = [&](f32x4 (&af)[TM], f32x4 (&bf)[TN], int buf, int g) {
+        const float* Ab = As + (buf * BM + wm * WM + frow) * LDK + koff[g];
+        const float* Bb = Bs + (buf * BN + wn * WN + frow) * LDK + koff[g];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);
+    };
+
+    setup(t, aoff, boff, m0, n0);
+    issue(sa[0], sb[0], aoff, boff, 0, true);
+    stash(sa[0], sb[0], 0);
+    issue(sa[0], sb[0], aoff, boff, 1, true);          // ktiles >= 2
+    __syncthreads();
+    const int HoWo = p.Ho * p.Wo;
+    const int KT = p.ktiles;
+    for (;;) {
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const int tn = t + bpx;
+        const bool more = tn < run_end;
+        unsigned aoffn[LA], boffn[LB];
+        int m0n = 0, n0n = 0;
+        setup(more ? tn : t, aoffn, boffn, m0n, n0n);
+        f32x4 af[2][TM], bf[2][TN];
+        // one k-tile: fragment reads + 64 MFMAs on LDS buffer `buf`, the request of a later k-tile in the first group's shadow,
+        // the write of the waiting register set to the other buffer in the last group's
+        auto ktile = [&](int buf, auto&& request, auto&& write_back) {
+            frag_read(af[0], bf[0], buf, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) frag_read(af[(g + 1) & 1], bf[(g + 1) & 1], buf, g + 1);
+                if (g == 0) request();
+                if (g == NG - 1) write_back();
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][tt], bf[g & 1][j][tt], acc[i][j], 0, 0, 0);
+                if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+                for (int q = 0; q < MPG; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x216, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        };
+        for (int kt = 0; kt < KT; kt += 2) {
+            const bool in_tile = kt + 2 < KT;              // k-tiles kt+2, kt+3 belong to this tile; else: the next tile's first two
+            ktile(0, [&] { if (in_tile) issue(sa[1], sb[1], aoff, boff, kt + 2, true); else issue(sa[1], sb[1], aoffn, boffn, 0, more); },
+                  [&] { stash(sa[0], sb[0], 1); });
+            ktile(1, [&] { if (in_tile) issue(sa[0], sb[0], aoff, boff, kt + 3, true); else issue(sa[0], sb[0], aoffn, boffn, 1, more); },
+                  [&] { if (in_tile) stash(sa[1], sb[1], 0); });
+        }
+        conv_epilogue<BM, BN, WM, WN>(p, acc, smem, m0, n0, 0, 0, wm, wn, tid, lane, HoWo);
+        if (!more) break;
+        __syncthreads();                       // every thread is done with the epilogue's LDS tile
+        stash(sa[1], sb[1], 0);                // the next tile's k-tile 0 (requested two k-tiles ago); its k-tile 1 waits in set 0
+        __syncthreads();
+        t = tn; m0 = m0n; n0 = n0n;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) aoff[i] = aoffn[i];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) boff[j] = boffn[j];
+    }
+}
+
 // LDS-DMA variant (VAR 5): operand tiles go HBM/L2 -> LDS directly (buffer_load ... lds, 1 KiB per wave
 // instruction, no staging VGPRs, no ds_write pass).  The DMA destination is lane-linear (base + lane*16 B), so
 // the LDS rows are unpadded 32-float rows and bank conflicts are avoided by an XOR swizzle applied on the
@@ -1020,20 +1154,30 @@ static int launch_dma(const ConvParams& p, int phases, hipStream_t st) {
     return check_launch("conv_igemm_dma");
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_persistent(const ConvParams& p, hipStream_t st) {
+static std::atomic<int> g_persist_dist{2};   // vatl_tune_set(10, v): operand look-ahead of the persistent 1x1 kernel (1 or 2 k-tiles)
+
+template <int BM, int BN, int WM, int WN, bool D2>
+static int launch_persistent_impl(const ConvParams& p, hipStream_t st) {
     auto kern = gemm1x1_persistent_kernel<BM, BN, WM, WN>;
+    auto kern2 = gemm1x1_persistent2_kernel<BM, BN, WM, WN>;
     constexpr int smem = conv_smem_floats(BM, BN) * (int)sizeof(float);
     static std::atomic<unsigned> configured{0};
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, configured, "gemm1x1_persistent")) return rc;
+    if (int rc = ensure_dynamic_lds(D2 ? reinterpret_cast<const void*>(kern2) : reinterpret_cast<const void*>(kern), smem, configured, "gemm1x1_persistent")) return rc;
     ConvParams q = p;
     q.n_tiles = p.CoutPad / BN;
     q.m_tiles = cdiv(p.M, BM);
     const int total = q.m_tiles * q.n_tiles;
     int grid = 512;                            // two resident blocks per CU
     if (grid > total) grid = (total + 7) / 8 * 8;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, st, q);
+    if (D2) hipLaunchKernelGGL(kern2, dim3((unsigned)grid), dim3(256), smem, st, q);
+    else    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, st, q);
     return check_launch("gemm1x1_persistent");
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_persistent(const ConvParams& p, hipStream_t st) {
+    const bool d2 = g_persist_dist.load(std::memory_order_relaxed) == 2 && p.ktiles >= 2 && (p.ktiles & 1) == 0;
+    return d2 ? launch_persistent_impl<BM, BN, WM, WN, true>(p, st) : launch_persistent_impl<BM, BN, WM, WN, false>(p, st);
 }
 
 static std::atomic<int> g_persist{1};  // vatl_tune_set(7, v): persistent kernel for 1x1 layers with K <= 256 v (0 = off)
@@ -1145,6 +1289,7 @@ extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 7 && value >= 0 && value <= 64) { g_persist.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 8 && (value == 0 || value == 1)) return conv3x3_halo_enable(value);
     if (knob == 9 && (value == 0 || value == 1)) { g_splitk_policy.store(value, std::memory_order_relaxed); return 0; }
+    if (knob == 10 && (value == 1 || value == 2)) { g_persist_dist.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
     if (knob == 0 && value >= 0 && value <= 13) { g_var.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }

@@ -331,6 +331,63 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __r
 }
 
 
+// Every weight re-pack of a fine-tune step in ONE launch (the trainers need ~60 .. 180 packed copies per step — forward
+// layouts of the 3x3 / 7x7 / transposed convs, data-gradient layouts of every conv — and each used to be its own 5 us
+// launch).  jobs: device array sorted by first_block; a block of 256 threads makes 1024 consecutive elements of one job.
+// Element arithmetic = pack_conv_weight_kernel / pack_dgrad_weight_kernel / pack_deconv_weight_kernel.
+__global__ __launch_bounds__(256) void pack_multi_kernel(const VatlPackJob* __restrict__ jobs, int njobs) {
+    __shared__ int sj;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;
+        const long long b = blockIdx.x;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+        }
+        sj = lo;
+    }
+    __syncthreads();
+    const VatlPackJob* J = jobs + sj;
+    const float* __restrict__ w = J->src;
+    float* __restrict__ out = J->dst;
+    const int kind = J->kind, Cout = J->Cout, Cin = J->Cin, R = J->R, S = J->S, pa = J->a, pb = J->b, pc = J->c;
+    const long long base = ((long long)blockIdx.x - J->first_block) * 1024;
+    long long total;
+    if (kind == 0) total = (long long)pa * R * pb * pc;            // [CoutPad][R][Spad][CinPad]
+    else if (kind == 1) total = (long long)pa * pc * pb;           // [CinPad][ntaps][CoutK]
+    else total = 16LL * pa * Cin;                                  // [phase][CoutPad][ty][tx][Cin]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long long i = base + e * 256 + threadIdx.x;
+        if (i >= total) continue;
+        float v = 0.f;
+        if (kind == 0) {
+            const int c = (int)(i % pc);
+            long long t = i / pc;
+            const int s_ = (int)(t % pb); t /= pb;
+            const int r = (int)(t % R);
+            const int o = (int)(t / R);
+            if (o < Cout && s_ < S && c < Cin) v = w[(((long long)o * Cin + c) * R + r) * S + s_];
+        } else if (kind == 1) {
+            const int n = (int)(i % pb);
+            long long t = i / pb;
+            const int tp = (int)(t % pc);
+            const int c = (int)(t / pc);
+            if (c < Cin && n < Cout) v = w[(((long long)n * Cin + c) * R + J->tap_r[tp]) * S + J->tap_s[tp]];
+        } else {
+            const int c = (int)(i % Cin);
+            long long t = i / Cin;
+            const int tx = (int)(t & 1); t >>= 1;
+            const int ty = (int)(t & 1); t >>= 1;
+            const int o = (int)(t % pa);
+            const int ph = (int)(t / pa);
+            const int ky = 3 - (ph >> 1) - 2 * ty, kx = 3 - (ph & 1) - 2 * tx;
+            if (o < Cout) v = w[(((long long)c * Cout + o) * 4 + ky) * 4 + kx];
+        }
+        out[i] = v;
+    }
+}
+
 // inverse of PixelShuffle(2) on NHWC (its backward): in (N,2H,2W,C/4) -> out (N,H,W,C), out[y][x][4c+2i+j] = in[2y+i][2x+j][c]
 __global__ void pixelunshuffle2_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
     const int C4 = C >> 2;
@@ -523,6 +580,13 @@ extern "C" int vatl_pack_dgrad_weight(const float* w_oihw, float* out, int Cout,
     }
     hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3(grid_for((long long)CinPad * ntaps * CoutK)), dim3(256), 0, (hipStream_t)stream, w_oihw, out, Cout, Cin, R, S, CinPad, CoutK, t);
     return check_launch("pack_dgrad_weight");
+}
+
+extern "C" int vatl_pack_weights_multi(const VatlPackJob* jobs_device, int njobs, int64_t total_blocks, void* stream) {
+    if (njobs == 0) return 0;
+    if (!jobs_device || njobs < 0 || total_blocks <= 0 || total_blocks > 0x7FFFFFFF) return fail(VATL_EINVAL, "pack_weights_multi: bad arguments");
+    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_device, njobs);
+    return check_launch("pack_weights_multi");
 }
 
 extern "C" int vatl_pixelunshuffle2(const float* x, float* y, int N, int H, int W, int C, void* stream) {

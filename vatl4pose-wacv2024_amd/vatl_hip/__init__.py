@@ -76,6 +76,7 @@ SIGNATURES = {
     "vatl_bn_train_finalize": (_i, [_p, _i64, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
     "vatl_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_maxpool3x3s2_fwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "vatl_pack_weights_multi": (_i, [_p, _i, _i64, _p]),
     "vatl_maxpool3x3s2_fwd_idx_affine": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_bn_train_bwd_relu_pool": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "vatl_maxpool3x3s2_bwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
@@ -224,6 +225,78 @@ def conv_cout_pad(cout: int) -> int:
     return lib().vatl_conv_cout_pad(cout)
 
 
+class _PackJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("first_block", C.c_int64), ("kind", C.c_int32), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("R", C.c_int32), ("S", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32), ("tap_r", C.c_int32 * 16), ("tap_s", C.c_int32 * 16)]
+
+
+class PackPlan:
+    """The weight re-packs of one fine-tune step as ONE launch (vatl_pack_weights_multi).
+
+    The trainers (alphapose/models/hip_train.py) ask for packed copies through ``pack_conv_weight`` / ``pack_deconv_weight`` /
+    ``pack_dgrad_weight`` where they need them.  The first step under a plan runs those calls as usual and RECORDS them (source
+    tensor, layout, destination buffer, which is then kept); ``seal()`` uploads the descriptor table.  From the next step on,
+    ``begin()`` refreshes every recorded destination with one launch and the pack calls return the kept buffers.  A lookup is
+    honoured only if the source tensor is the recorded storage at the version it had at ``begin()`` (optimizers that write
+    through the C ABI bump the version counters): anything else is packed on the spot, and makes the plan re-record."""
+
+    def __init__(self):
+        self.jobs = {}            # key -> [src tensor, dst tensor, descriptor fields, version at begin()]
+        self.table = None
+        self.total_blocks = 0
+        self.ready = False
+        self.stale = False
+
+    def begin(self):
+        if self.ready and not self.stale:
+            for j in self.jobs.values():
+                j[3] = j[0]._version
+            _check(lib().vatl_pack_weights_multi(_ptr(self.table, torch.uint8), len(self.jobs), self.total_blocks, _stream()), "vatl_pack_weights_multi")
+        else:
+            self.jobs, self.table, self.ready, self.stale = {}, None, False, False
+
+    def lookup(self, key, w):
+        if not self.ready:
+            return None
+        j = self.jobs.get(key)
+        if j is None or j[0].data_ptr() != w.data_ptr() or j[3] != w._version:
+            self.stale = True                      # a layout the recording did not see, or weights that changed since begin()
+            return None
+        return j[1]
+
+    def record(self, key, w, dst, fields):
+        if not self.ready and key not in self.jobs:
+            self.jobs[key] = [w, dst, fields, w._version]
+
+    def seal(self):
+        if self.ready or not self.jobs:
+            return
+        arr = (_PackJob * len(self.jobs))()
+        blocks = 0
+        for k, (src, dst, f, _) in enumerate(self.jobs.values()):
+            jb = arr[k]
+            jb.src, jb.dst, jb.first_block = src.data_ptr(), dst.data_ptr(), blocks
+            jb.kind, jb.Cout, jb.Cin, jb.R, jb.S, jb.a, jb.b, jb.c = f[:8]
+            for t, (tr, ts) in enumerate(f[8]):
+                jb.tap_r[t], jb.tap_s[t] = tr, ts
+            blocks += (dst.numel() + 1023) // 1024
+        dev = next(iter(self.jobs.values()))[1].device
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = host.to(dev)
+        self.total_blocks = blocks
+        self.ready = True
+
+
+_pack_plan = None
+
+
+def set_pack_plan(plan):
+    """The plan the pack_* calls consult (None: every call packs on the spot).  Returns the previous one."""
+    global _pack_plan
+    prev, _pack_plan = _pack_plan, plan
+    return prev
+
+
 def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     """(Cout,Cin,R,S) -> [CoutPad][R][Spad][CinPad]; the 3-channel stem is padded to 4 channels x 8 taps."""
     cout, cin, r, s = w.shape
@@ -231,8 +304,15 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     if r == 1 and s == 1 and cpad == cout and cin != 3 and w.is_contiguous() and w.dtype == torch.float32:
         return w.detach().view(cout, 1, 1, cin)              # (Cout,Cin,1,1) already is the packed [Cout][1][1][Cin]: no copy
     spad, cinpad = (8, 4) if cin == 3 else (s, cin)
+    plan, key = _pack_plan, ("conv", w.data_ptr(), tuple(w.shape))
+    if plan is not None and w.is_contiguous():
+        kept = plan.lookup(key, w)
+        if kept is not None:
+            return kept
     out = torch.empty((cpad, r, spad, cinpad), device=w.device, dtype=torch.float32)
     _check(lib().vatl_pack_conv_weight(_ptr(w.contiguous()), _ptr(out), cout, cin, r, s, cpad, spad, cinpad, _stream()), "vatl_pack_conv_weight")
+    if plan is not None and w.is_contiguous():
+        plan.record(key, w, out, (0, cout, cin, r, s, cpad, spad, cinpad, ()))
     return out
 
 
@@ -263,8 +343,15 @@ def pack_deconv_weight(w: torch.Tensor) -> torch.Tensor:
     if (kh, kw) != (4, 4):
         raise VatlError("only ConvTranspose2d(4, 2, 1) is supported")
     cpad = conv_cout_pad(cout)
+    plan, key = _pack_plan, ("deconv", w.data_ptr(), tuple(w.shape))
+    if plan is not None and w.is_contiguous():
+        kept = plan.lookup(key, w)
+        if kept is not None:
+            return kept
     out = torch.empty((4, cpad, 2, 2, cin), device=w.device, dtype=torch.float32)
     _check(lib().vatl_pack_deconv4x4s2_weight(_ptr(w.contiguous()), _ptr(out), cin, cout, cpad, _stream()), "vatl_pack_deconv4x4s2_weight")
+    if plan is not None and w.is_contiguous():
+        plan.record(key, w, out, (2, cout, cin, 4, 4, cpad, 0, 0, ()))
     return out
 
 
@@ -593,7 +680,15 @@ def pack_dgrad_weight(w: torch.Tensor, taps, cout_k: int | None = None) -> torch
     cout, cin, r, s = w.shape
     cinpad = conv_cout_pad(cin)
     cout_k = cout_k or cout
+    taps = [(int(a), int(b)) for a, b in taps]
+    plan, key = _pack_plan, ("dgrad", w.data_ptr(), tuple(w.shape), tuple(taps), cout_k)
+    if plan is not None and w.is_contiguous() and len(taps) <= 16:
+        kept = plan.lookup(key, w)
+        if kept is not None:
+            return kept
     out = torch.empty((cinpad, len(taps), cout_k), device=w.device, dtype=torch.float32)
+    if plan is not None and w.is_contiguous() and len(taps) <= 16:
+        plan.record(key, w, out, (1, cout, cin, r, s, cinpad, cout_k, len(taps), tuple(taps)))
     tr = (C.c_int * len(taps))(*[t[0] for t in taps])
     ts = (C.c_int * len(taps))(*[t[1] for t in taps])
     _check(lib().vatl_pack_dgrad_weight(_ptr(w.contiguous()), _ptr(out), cout, cin, r, s, cinpad, cout_k, len(taps),
