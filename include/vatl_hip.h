@@ -100,6 +100,12 @@ int vatl_tune_set(int knob, int value);
  * batch-size-independent bits).  The workspace is registered for the CURRENT device (launches on other devices never touch
  * it) and is shared by that device's streams: use from one stream at a time.  NULL disables it for the current device. */
 int vatl_set_splitk_workspace(float* workspace, int64_t floats);
+/* The same for the launches of the CALLING HOST THREAD only (thread-local; takes precedence over the device-wide workspace
+ * while set; NULL clears it), always with the batch-invariant cut (vatl_tune_set knob 9 = 1 semantics: the cut depends on the
+ * layer's per-image geometry, so a crop's bits do not depend on how many crops share its call).  This is what module calls
+ * with <= 16 crops use for their duration (scripts/poseestimator_eval.py shape): no global switch, no buffer shared between
+ * host threads.  The workspace must be on the device the thread launches on; one stream per thread at a time. */
+int vatl_set_splitk_workspace_thread(float* workspace, int64_t floats);
 /* CoutPad the packer must use for a given Cout (multiple of the kernel's N tile). */
 int vatl_conv_cout_pad(int Cout);
 int vatl_conv2d_fwd(const float* x, const float* w, const float* scale, const float* bias, const float* residual,

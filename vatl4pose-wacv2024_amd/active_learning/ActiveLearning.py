@@ -204,16 +204,22 @@ class ActiveLearning:
     def _heatmaps(self, inps, emb_out=None):
         m = self.model
         x = inps[:, 0].to(self.device, non_blocking=True)
+        from alphapose.models import hip_engine
+
+        def heatmaps(t):
+            # the stream entry point, not `m(t)`: a crop's bits must not depend on the size of the loader batch or of the shard
+            # it arrives in (a short last batch would otherwise take the small-batch split-K route of the module call)
+            t = t.to(self.device)
+            return hip_engine.forward_into(m, t, torch.empty((t.shape[0], self.cfg.DATA_PRESET.NUM_JOINTS, *self.hm_size), device=self.device))
         with torch.no_grad():
             if emb_out is not None:                   # heat-maps and get_embedding from one trunk pass
-                from alphapose.models import hip_engine
                 cur = torch.empty((x.shape[0], self.cfg.DATA_PRESET.NUM_JOINTS, *self.hm_size), device=self.device)
                 hip_engine.forward_with_embedding(m, x, cur, emb_out)
             else:
-                cur = m(x)
+                cur = heatmaps(x)
             if not self.get_prenext or self.dedup:
                 return cur, None, None
-            return cur, m(inps[:, 1].to(self.device)), m(inps[:, 2].to(self.device))
+            return cur, heatmaps(inps[:, 1]), heatmaps(inps[:, 2])
 
     def _score_range(self, lo, hi):
         """Forward + score the id-sorted items lo..hi-1 (one shard plus its halo); returns (hi-lo, 55 [+ 2048]) float32

@@ -1067,7 +1067,15 @@ static std::atomic<float*> g_splitk_ws[kMaxDevices];
 static std::atomic<long long> g_splitk_floats[kMaxDevices];
 static std::atomic<int> g_splitk_any{0};
 
-static float* splitk_workspace(long long* floats) {
+// ... and the calling host thread's own workspace (vatl_set_splitk_workspace_thread): what the launches of THIS thread use while it
+// is set, with the batch-invariant cut policy — several host threads (DataParallel replica threads, one stream each) can run
+// small-batch calls side by side without sharing partial-sum buffers or any global switch.
+static thread_local float* tl_splitk_ws = nullptr;
+static thread_local long long tl_splitk_floats = 0;
+
+static float* splitk_workspace(long long* floats, int* policy) {
+    if (tl_splitk_ws) { *floats = tl_splitk_floats; *policy = 1; return tl_splitk_ws; }
+    *policy = g_splitk_policy.load(std::memory_order_relaxed);
     if (!g_splitk_any.load(std::memory_order_acquire)) return nullptr;
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return nullptr;
@@ -1096,12 +1104,13 @@ static int launch(const ConvParams& p, int phases, hipStream_t st) {
     const int m_tiles = cdiv(p.M, BM);
     const long long blocks = (long long)m_tiles * q.n_tiles * phases;
     long long ws_floats = 0;
-    float* ws = splitk_workspace(&ws_floats);
+    int sk_policy = 0;
+    float* ws = splitk_workspace(&ws_floats, &sk_policy);
     q.splits = 1;
     if (ws && !STEM && !DUAL && !q.stats && !q.ablate && q.ktiles >= 16) {
         const long long out_elems = (long long)q.y_bytes / 4;
         int splits = 0;
-        if (g_splitk_policy.load(std::memory_order_relaxed) == 1) {
+        if (sk_policy == 1) {
             // batch-invariant policy (module calls with <= 16 crops, vatl_tune_set(9, 1)): the cut depends on the layer's
             // per-image geometry only — block count of a nominal 4-crop batch in 64-row tiles, workspace need of a 16-crop
             // batch — so a crop's bits do not depend on how many crops share its call
@@ -1295,6 +1304,13 @@ extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 2 && value >= 0 && value <= 200) { g_stagger.store(value, std::memory_order_relaxed); return 0; }
     return fail(VATL_EINVAL, "tune_set: unknown knob %d / value %d", knob, value);
+}
+
+extern "C" int vatl_set_splitk_workspace_thread(float* workspace, int64_t floats) {
+    if (workspace && floats <= 0) return fail(VATL_EINVAL, "set_splitk_workspace_thread: empty workspace");
+    tl_splitk_ws = workspace;
+    tl_splitk_floats = workspace ? (long long)floats : 0;
+    return 0;
 }
 
 extern "C" int vatl_set_splitk_workspace(float* workspace, int64_t floats) {

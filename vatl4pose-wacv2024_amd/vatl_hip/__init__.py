@@ -35,6 +35,7 @@ SIGNATURES = {
     "vatl_bn_fold": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _i, _p]),
     "vatl_tune_set": (_i, [_i, _i]),
     "vatl_set_splitk_workspace": (_i, [_p, _i64]),
+    "vatl_set_splitk_workspace_thread": (_i, [_p, _i64]),
     "vatl_conv_cout_pad": (_i, [_i]),
     "vatl_conv2d_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_deconv4x4s2_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -187,14 +188,15 @@ def enable_splitk(megabytes: int = 64, device=None):
         _splitk_buf[idx] = buf
 
 
-_splitk_scratch = {}                                 # device index -> workspace kept for the automatic small-batch mode
+_splitk_scratch = {}                                 # (host thread, device index) -> workspace of the automatic small-batch mode
 
 
 class splitk_scope:
-    """Split-K registered for the duration of one call on ``device`` (the module-call path of small batches,
-    alphapose/models/hip_engine.py: run_module_nchw) and removed afterwards, so that the evaluation stream — whose crops must
-    have batch-size-independent bits — never sees it.  A device on which split-K was switched on explicitly
-    (``enable_splitk``) is left alone."""
+    """Split-K for the launches of THIS host thread for the duration of one call (the module-call path of small batches,
+    alphapose/models/hip_engine.py: run_module_nchw), with the batch-invariant cut, and removed afterwards: the evaluation stream
+    — whose crops must have batch-size-independent bits — never sees it, other host threads (DataParallel replicas) are not
+    affected and share no buffer with this one.  A device on which split-K was switched on explicitly (``enable_splitk``) is
+    left alone."""
 
     def __init__(self, device, megabytes: int = 256):
         self.idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -204,22 +206,19 @@ class splitk_scope:
     def __enter__(self):
         if self.idx in _splitk_buf:
             return self
-        buf = _splitk_scratch.get(self.idx)
+        import threading
+        key = (threading.get_ident(), self.idx)
+        buf = _splitk_scratch.get(key)
         if buf is None:
-            buf = _splitk_scratch[self.idx] = torch.empty(self.mb * (1 << 18), device=torch.device("cuda", self.idx), dtype=torch.float32)
-        with torch.cuda.device(self.idx):
-            _check(lib().vatl_set_splitk_workspace(_ptr(buf), buf.numel()), "vatl_set_splitk_workspace")
-        tune_set(9, 1)                                # batch-invariant cuts: a crop's bits do not depend on the size of its (small) batch
+            buf = _splitk_scratch[key] = torch.empty(self.mb * (1 << 18), device=torch.device("cuda", self.idx), dtype=torch.float32)
+        _check(lib().vatl_set_splitk_workspace_thread(_ptr(buf), buf.numel()), "vatl_set_splitk_workspace_thread")
         self.active = True
         return self
 
     def __exit__(self, *exc):
         if self.active:
-            tune_set(9, 0)
-            with torch.cuda.device(self.idx):
-                _check(lib().vatl_set_splitk_workspace(None, 0), "vatl_set_splitk_workspace")
+            _check(lib().vatl_set_splitk_workspace_thread(None, 0), "vatl_set_splitk_workspace_thread")
         return False
-
 
 def conv_cout_pad(cout: int) -> int:
     return lib().vatl_conv_cout_pad(cout)
