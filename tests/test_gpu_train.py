@@ -845,3 +845,175 @@ def test_every_block_gradient_vs_float64_on_real_activations(vh):
         assert fused >= 8
     record("block_check_summary", **worst)
     assert not failures, failures
+
+
+def _unit_vs_float64(tag, prefix, unit, ref64, xs64, dys64, named, hip_train, failures, worst, bound_y=2e-6, bound_g=2e-5):
+    """One trainer unit (an SE bottleneck, an HRNet fusion module ...) run ALONE on the float64 oracle's real inputs and upstream
+    gradients, against the same oracle module in float64 evaluated with the ReLU decisions the fp32 forward took (the trainers
+    report every ReLU mask in execution order through hip_train._relu_tap; the oracle replays them in ITS execution order — the
+    shapes must agree at every step, which also checks that both sides run the same graph).  xs64 / dys64: lists of NCHW tensors."""
+    import copy
+    from unittest import mock
+
+    def nhwc(t):
+        return to_dev(t.detach().permute(0, 2, 3, 1).contiguous().float().numpy())
+
+    def nchw64(t):
+        return t.detach().permute(0, 3, 1, 2).double().cpu() if t.dim() == 4 else t.detach().double().cpu()
+
+    def l2(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+    multi = isinstance(xs64, (list, tuple))
+    xin = [nhwc(t) for t in xs64] if multi else nhwc(xs64)
+    hip_train._relu_tap = []
+    try:
+        ys = unit.forward(xin)
+    finally:
+        masks, hip_train._relu_tap = hip_train._relu_tap, None
+    masks = [nchw64(mk) for mk in masks]
+    grads = hip_train._Grads()
+    dxs = unit.backward([nhwc(t) for t in dys64] if multi else nhwc(dys64), grads)
+    hip_train._side.join()
+    hip_train._flush_batch_counters()
+    blk = copy.deepcopy(ref64)
+    blk.zero_grad()
+    xi = [t.detach().clone().requires_grad_() for t in xs64] if multi else xs64.detach().clone().requires_grad_()
+    replay = list(masks)
+
+    def pinned_relu(t, inplace=False):
+        mk = replay.pop(0)
+        assert tuple(mk.shape) == tuple(t.shape), (tag, tuple(mk.shape), tuple(t.shape))
+        return t * mk
+    with torch.enable_grad(), mock.patch.object(torch.nn.functional, "relu", pinned_relu):
+        out = blk(xi)
+        if multi:
+            torch.autograd.backward(list(out), [d.detach() for d in dys64])
+        else:
+            out.backward(dys64.detach())
+    assert not replay, (tag, len(replay))
+    outs, ys_l, dx_l, xi_l = (list(out), list(ys), list(dxs), xi) if multi else ([out], [ys], [dxs], [xi])
+    for k, (y, y64, dx, x64) in enumerate(zip(ys_l, outs, dx_l, xi_l)):
+        ey, ed = l2(nchw64(y), y64.detach()), l2(nchw64(dx), x64.grad)
+        worst["y"], worst["dx"] = max(worst["y"], ey), max(worst["dx"], ed)
+        record("unit_check", unit=tag, branch=k, y=ey, dx=ed)
+        if not (ey < bound_y and ed < bound_g):
+            failures.append((tag, k, "y / dx", ey, ed))
+    g64 = {k: p.grad for k, p in blk.named_parameters()}
+    assert len(grads) == len(g64), (tag, len(grads), len(g64))
+    for p, gr in grads.items():
+        k = named[p]
+        e = l2(gr.cpu().numpy(), g64[k[len(prefix):]].numpy())
+        worst["dw"] = max(worst["dw"], e)
+        record("unit_grad", unit=tag, key=k, l2=e)
+        if not e < bound_g:
+            failures.append((tag, k, e))
+
+
+def _randomise_bn(m):
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5); mod.bias.normal_(0, 0.2)
+
+
+def test_fastpose_se_blocks_vs_float64_on_real_activations(vh):
+    """SE_Resnet.py:110-137 / SE_module.py:20-24 backward (gate, squeeze, fc pair, projection) — the path the whole-network
+    5e-2 band alone covered: each of the four SE bottlenecks of FastPose-R50 run alone on the float64 oracle's real activations and
+    gradients, block output 2e-6, input gradient and every parameter gradient (conv, BatchNorm, both fc layers) 2e-5."""
+    from alphapose.models import builder, hip_train
+    from alphapose.utils.config import edict
+    from oracle import nets
+    cfg = edict({"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50})
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    torch.manual_seed(78)
+    m = builder.build_sppe(cfg, preset_cfg=preset)
+    _randomise_bn(m)
+    B = 2
+    x = torch.from_numpy(synth.crops(B, seed=95))
+    labels, masks = synth.gaussian_targets(B, seed=96)
+    ref = nets.FastPoseRef(50)
+    ref.load_state_dict({k: v.clone() for k, v in m.state_dict().items()}, strict=True)
+    ref = ref.double().train()
+    taps, hooks = {}, []
+    se64 = [(f"layer{s}.0", getattr(ref.preact, f"layer{s}")[0]) for s in (1, 2, 3, 4)]
+    def se_hook(name):
+        def fn(_m, inp, out):
+            out.retain_grad()
+            taps[name] = (inp[0], out)
+        return fn
+    for name, b in se64:
+        hooks.append(b.register_forward_hook(se_hook(name)))
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    o64 = ref(x.double())
+    mk = torch.from_numpy(masks).double()
+    (0.5 * torch.nn.MSELoss()(o64 * mk, torch.from_numpy(labels).double() * mk)).backward()
+    for h in hooks:
+        h.remove()
+    m = m.to(dev()).train()
+    tr = hip_train.trainer_for(m)
+    named = {p: k for k, p in m.named_parameters()}
+    se_units = [b for b in tr.blocks if isinstance(b, hip_train._SEBottleneckT)]
+    assert len(se_units) == 4
+    failures, worst = [], {"y": 0.0, "dx": 0.0, "dw": 0.0}
+
+    class _One:                                             # single-tensor units behind the list-free calling convention
+        def __init__(self, u): self.u = u
+        def forward(self, x_): return self.u.forward(x_)
+        def backward(self, dy, grads): return self.u.backward(dy, grads)
+    with torch.no_grad():
+        for (name, b64), unit in zip(se64, se_units):
+            xin, out = taps[name]
+            _unit_vs_float64(name, f"preact.{name}.", _One(unit), b64, xin.detach(), out.grad, named, hip_train, failures, worst)
+    record("se_block_check_summary", **worst)
+    assert not failures, failures
+
+
+def test_hrnet_fusion_modules_vs_float64_on_real_activations(vh):
+    """hrnet.py:242-260 (multi-resolution fusion: strided 3x3 chains down, 1x1 + nearest up-sampling, sum, ReLU) and the basic
+    blocks of every branch, backward included: the first HighResolutionModule of stages 2, 3 and 4 of HRNet-W32 (2, 3 and 4
+    branches) run alone on the float64 oracle's real activations and gradients; every output, every input gradient and every
+    parameter gradient of the module within 2e-6 / 2e-5 of float64."""
+    from alphapose.models import builder, hip_train
+    from alphapose.utils.config import edict
+    from oracle import nets
+    from tests.test_gpu_conv import HRNET_CFG
+    preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+    torch.manual_seed(79)
+    m = builder.build_sppe(edict(HRNET_CFG), preset_cfg=preset)
+    _randomise_bn(m)
+    B = 2
+    x = torch.from_numpy(synth.crops(B, seed=97))
+    labels, masks = synth.gaussian_targets(B, seed=98)
+    ref = nets.HRNetRef()
+    ref.load_state_dict({k: v.clone() for k, v in m.state_dict().items()}, strict=True)
+    ref = ref.double().train()
+    taps, hooks = {}, []
+    mods64 = [(f"stage{s}.0", getattr(ref, f"stage{s}")[0]) for s in (2, 3, 4)]
+
+    def hook(name):
+        def fn(_m, inp, out):
+            for o in out:
+                o.retain_grad()
+            taps[name] = (list(inp[0]), list(out))
+        return fn
+    for name, b in mods64:
+        hooks.append(b.register_forward_hook(hook(name)))
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    o64 = ref(x.double())
+    mk = torch.from_numpy(masks).double()
+    (0.5 * torch.nn.MSELoss()(o64 * mk, torch.from_numpy(labels).double() * mk)).backward()
+    for h in hooks:
+        h.remove()
+    m = m.to(dev()).train()
+    tr = hip_train.trainer_for(m)
+    named = {p: k for k, p in m.named_parameters()}
+    failures, worst = [], {"y": 0.0, "dx": 0.0, "dw": 0.0}
+    with torch.no_grad():
+        for (name, b64), (_, mods) in zip(mods64, tr.stages):
+            xs, outs = taps[name]
+            assert len(outs) == len(xs)                      # multi-scale output: every branch is fused
+            _unit_vs_float64(name, name + ".", mods[0], b64, [t.detach() for t in xs], [o.grad for o in outs], named, hip_train, failures, worst)
+    record("hrnet_module_check_summary", **worst)
+    assert not failures, failures

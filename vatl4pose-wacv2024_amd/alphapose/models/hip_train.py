@@ -132,6 +132,17 @@ _FUSE_BN_BWD = _os.environ.get("VATL_FUSE_BN_BWD", "1") != "0"
 # more than the stand-alone reduction pass it replaces (HRNet-W32 step 63.9 -> 69.4 ms with every layer fused)
 _FUSE_BN_MIN_C = int(_os.environ.get("VATL_FUSE_BN_MINC", "128"))
 
+# tests only: when a list, every ReLU the trainers apply appends its output's mask (y > 0), in execution order — what lets a float64
+# reference of a block be evaluated with exactly the ReLU decisions the fp32 forward took (tests/test_gpu_train.py)
+_relu_tap = None
+
+
+def _tap(y):
+    if _relu_tap is not None:
+        _relu_tap.append(y > 0)
+    return y
+
+
 _pending_counters = []
 
 
@@ -204,6 +215,8 @@ class _ConvBN:
                                                              bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps)
         _count_batch(bn)
         y = vh.scale_bias_act(z, scale, bias, skip, relu)
+        if relu:
+            _tap(y)
         # ReLU without a skip: the backward recomputes the mask from (z, scale, bias) and never reads y
         mask = (scale, bias) if (relu and skip is None) else None
         self.saved = (x, z, y if (relu and skip is not None) else None, mean, invstd, skip is not None, mask)
@@ -317,7 +330,7 @@ class _DeconvBN:
         z, mean, invstd, scale, bias = vh.deconv4x4s2_fwd_bnstats(x, vh.pack_deconv_weight(self.dc.weight.detach()), self.cout, bn.weight.detach(),
                                                                   bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps)
         _count_batch(bn)
-        y = vh.scale_bias_act(z, scale, bias, None, True)
+        y = _tap(vh.scale_bias_act(z, scale, bias, None, True))
         self.saved = (x, z, scale, bias, mean, invstd)
         return y
 
@@ -454,6 +467,8 @@ class _LinearT:
         w4 = self.lin.weight.detach().reshape(self.co, self.ci, 1, 1)
         _, bias = vh.bn_fold(None, None, None, None, 0.0, self.lin.bias.detach(), channels=self.co)
         y = vh.conv2d_fwd(x2d.reshape(b, 1, 1, self.ci), vh.pack_conv_weight(w4), None, bias, self.co, 1, 1, 1, 0, self.relu).reshape(b, self.co)
+        if self.relu:
+            _tap(y)
         self.saved = (x2d, y)
         return y
 
@@ -485,7 +500,7 @@ class _SEBottleneckT:
     def forward(self, x):
         u = self.c3.forward(self.c2.forward(self.c1.forward(x)))
         gate = self.fc2.forward(self.fc1.forward(vh.gap_fwd(u)))              # pre-sigmoid
-        y = vh.se_scale_add_relu(u, gate, self.proj.forward(x))
+        y = _tap(vh.se_scale_add_relu(u, gate, self.proj.forward(x)))
         self.saved = (u, gate, y)
         return y
 
@@ -619,7 +634,7 @@ class _HRModuleT:
             acc = xs[i]
             for j, chain in downs:
                 acc = chain.forward(xs[j], skip=acc)
-            out.append(vh.fuse_upsample_add(acc, [(cb.forward(xs[j]), j - i) for j, cb in ups], relu=True))
+            out.append(_tap(vh.fuse_upsample_add(acc, [(cb.forward(xs[j]), j - i) for j, cb in ups], relu=True)))
         self.saved = out
         return out
 
