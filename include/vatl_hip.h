@@ -87,7 +87,8 @@ int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float* w, const 
  * tile (0 = chosen from the grid size, 64, 128), 7 = persistent 1x1 kernel for K <= 256 v (0 = off, default 1), 8 = halo-tile kernel for the
  * 32-channel 3x3 layers (csrc/conv3x3_halo.hip; 1 = on, default; 0 = generic implicit GEMM; bit-identical results), 9 = split-K cut policy while a
  * workspace is registered (0 = by the launch's own block count, 1 = by the layer's per-image geometry only: batch-invariant bits), 10 = operand
- * look-ahead of the persistent 1x1 kernel in k-tiles (1, or 2 = default; bit-identical results).  Knob 0 values 10..13, knob 4 (wgrad ablation bits) and knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) are profiling
+ * look-ahead of the persistent 1x1 kernel in k-tiles (1, or 2 = default; bit-identical results), 12 = stream-K route (see
+ * vatl_set_streamk_workspace_thread; 1 = default, 0 = off).  Knob 0 values 10..13, knob 4 (wgrad ablation bits) and knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) are profiling
  * ablations that compute WRONG results: they are not compiled into the product library at all (every such call returns
  * VATL_EINVAL); the profiling variant built with -DVATL_ABLATION (build.py --ablation -> libvatl_hip_ablation.so, loaded
  * through VATL_HIP_LIB) accepts them when the environment also has VATL_ALLOW_ABLATION=1. */
@@ -106,6 +107,16 @@ int vatl_set_splitk_workspace(float* workspace, int64_t floats);
  * with <= 16 crops use for their duration (scripts/poseestimator_eval.py shape): no global switch, no buffer shared between
  * host threads.  The workspace must be on the device the thread launches on; one stream per thread at a time. */
 int vatl_set_splitk_workspace_thread(float* workspace, int64_t floats);
+/* Stream-K for the fine-tune step's conv launches (forward and data gradient) of the CALLING HOST THREAD: while a workspace is
+ * registered, a 64x128-tile launch that would keep fewer than 85 % of the chip's block slots busy is run as exactly 768
+ * persistent blocks that share the flat (tile, k-tile) sequence evenly; a tile split between blocks is completed by the block
+ * that holds its last k-tile, which adds the other blocks' raw accumulators from the workspace in a fixed order (bitwise
+ * reproducible; agrees with the unsplit kernel to fp32 rounding, not bit for bit — which is why only the training paths use
+ * it).  workspace: vatl_streamk_workspace_bytes() bytes of device memory, ZEROED once by the caller before it is registered
+ * (flags carry a per-launch epoch and are never reset), owned by the caller, used by this thread's launches on one stream at
+ * a time; NULL clears the registration.  vatl_tune_set(12, 0) switches the route off. */
+int64_t vatl_streamk_workspace_bytes(void);
+int vatl_set_streamk_workspace_thread(void* workspace, int64_t bytes);
 /* CoutPad the packer must use for a given Cout (multiple of the kernel's N tile). */
 int vatl_conv_cout_pad(int Cout);
 int vatl_conv2d_fwd(const float* x, const float* w, const float* scale, const float* bias, const float* residual,

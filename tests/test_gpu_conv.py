@@ -506,3 +506,42 @@ def test_small_module_calls_use_splitk_and_the_stream_path_never_does(vh):
     assert rel_err(small.cpu().numpy(), big[:4].cpu().numpy()) < 1e-5
     assert torch.equal(small.flatten(2).argmax(2), big[:4].flatten(2).argmax(2))
     record("auto_splitk", rel=rel_err(small.cpu().numpy(), big[:4].cpu().numpy()))
+
+
+def test_streamk_route_matches_the_whole_tile_kernels(vh):
+    """vatl_set_streamk_workspace_thread: launches that would leave most block slots idle run as 768 persistent blocks sharing the
+    (tile, k-tile) units; tiles split between blocks are completed through workspace slabs in a fixed order.  Same results as
+    the whole-tile kernels to fp32 rounding (different summation order over K), bitwise reproducible run to run, ragged M,
+    residual / ReLU / BatchNorm-statistics epilogues included; nothing changes once the scope is closed."""
+    r = np.random.RandomState(77)
+    dev_ = dev()
+    cases = []
+    for (n, h, w, cin, cout, k, res) in ((120, 8, 6, 512, 512, 3, True), (24, 16, 12, 256, 256, 3, False), (120, 8, 6, 2048, 512, 1, False),
+                                         (31, 12, 9, 512, 512, 3, True), (32, 24, 18, 256, 1024, 1, True)):
+        x = to_dev(r.standard_normal((n, h, w, cin)).astype(np.float32))
+        wp = vh.pack_conv_weight(to_dev((r.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)))
+        sc, bi = to_dev(r.uniform(0.5, 1.5, cout).astype(np.float32)), to_dev(r.standard_normal(cout).astype(np.float32))
+        rs = to_dev(r.standard_normal((n, h, w, cout)).astype(np.float32)) if res else None
+        cases.append((x, wp, sc, bi, cout, k, rs))
+    with torch.no_grad():
+        base = [vh.conv2d_fwd(x, wp, sc, bi, cout, k, k, 1, k // 2, True, residual=rs) for (x, wp, sc, bi, cout, k, rs) in cases]
+        with vh.streamk_scope(dev_, force=True):
+            sk1 = [vh.conv2d_fwd(x, wp, sc, bi, cout, k, k, 1, k // 2, True, residual=rs) for (x, wp, sc, bi, cout, k, rs) in cases]
+            sk2 = [vh.conv2d_fwd(x, wp, sc, bi, cout, k, k, 1, k // 2, True, residual=rs) for (x, wp, sc, bi, cout, k, rs) in cases]
+            # training forward: z + BatchNorm batch statistics from the epilogue of the completing blocks
+            x, wp, _, _, cout, k, _ = cases[0]
+            g1, b1 = torch.ones(cout, device=dev_), torch.zeros(cout, device=dev_)
+            zs = vh.conv2d_fwd_bnstats(x, wp, cout, k, k, 1, k // 2, g1, b1, torch.zeros(cout, device=dev_), torch.ones(cout, device=dev_), 0.1, 1e-5)
+        zb = vh.conv2d_fwd_bnstats(x, wp, cout, k, k, 1, k // 2, g1, b1, torch.zeros(cout, device=dev_), torch.ones(cout, device=dev_), 0.1, 1e-5)
+        after = vh.conv2d_fwd(*cases[0][:4], cases[0][4], cases[0][5], cases[0][5], 1, cases[0][5] // 2, True, residual=cases[0][6])
+    took = 0
+    for a, b, c in zip(base, sk1, sk2):
+        assert torch.equal(b, c)                                  # reproducible
+        e = rel_err(b.cpu().numpy(), a.cpu().numpy())
+        assert e < 1e-5, e
+        took += not torch.equal(a, b)
+    assert took >= 4                                              # the route really ran (another summation order)
+    assert torch.equal(after, base[0])
+    for a, b in zip(zs, zb):                                      # z, mean, invstd, scale, bias
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    record("streamk", worst=max(rel_err(b.cpu().numpy(), a.cpu().numpy()) for a, b in zip(base, sk1)))

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--ablate", default="", help="comma list of conv ablation bit sets (vatl_tune_set knob 6; needs VATL_ALLOW_ABLATION=1)")
     ap.add_argument("--bm", default="", help="comma list of block-tile row counts to A/B (vatl_tune_set knob 5: 0 auto, 64, 128)")
     ap.add_argument("--splitk", type=int, default=0, help="register an N MB split-K workspace (vatl_set_splitk_workspace) before timing")
+    ap.add_argument("--streamk", default="", help="comma list of 0/1: run the layers without / with the stream-K route (vatl_hip.streamk_scope)")
     ap.add_argument("--pdist", default="", help="comma list of operand look-ahead distances of the persistent 1x1 kernel to A/B (vatl_tune_set knob 10: 1, 2)")
     ap.add_argument("--persist", default="", help="comma list of persistent-1x1 settings to A/B (vatl_tune_set knob 7: 0 off, 1 = K <= 256 [default])")
     a = ap.parse_args()
@@ -62,6 +63,15 @@ def main():
         warm_a @ warm_a
     t_end.record(); torch.cuda.synchronize()
     del warm_a
+    if a.streamk:
+        for v in a.streamk.split(","):
+            print(f"--- stream-K route {'on' if int(v) else 'off'}")
+            if int(v):
+                with vh.streamk_scope(torch.device("cuda:0"), force=True):
+                    run(a)
+            else:
+                run(a)
+        return
     if a.pdist:
         for v in a.pdist.split(","):
             print(f"--- persistent 1x1 kernel look-ahead {v} k-tile(s)")

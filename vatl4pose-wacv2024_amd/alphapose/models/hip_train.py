@@ -178,7 +178,8 @@ def _planned(kind):
     def deco(fn):
         def inner(self, *a, **k):
             if not _USE_PACK_PLAN:
-                return fn(self, *a, **k)
+                with vh.streamk_scope(a[0].device):
+                    return fn(self, *a, **k)
             plan = self.__dict__.get("_pack_plan")
             if plan is None:
                 plan = self.__dict__["_pack_plan"] = vh.PackPlan()
@@ -186,7 +187,8 @@ def _planned(kind):
             try:
                 if kind == "forward":
                     plan.begin()
-                out = fn(self, *a, **k)
+                with vh.streamk_scope(a[0].device):            # small launches share their (tile, k-tile) units over the whole chip
+                    out = fn(self, *a, **k)
                 if kind == "backward":
                     plan.seal()
                 return out

@@ -877,6 +877,228 @@ __global__ __launch_bounds__(256, 2) void gemm1x1_persistent2_kernel(ConvParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Stream-K scheduling for launches that cannot fill the chip with whole tiles (fine-tune batches: R50 stage 4 at B = 120 is 360
+// tiles of 64x128 on 768 resident block slots, FastPose-R152 stage 3 at 384x288 / B = 32 is 432 — 47 % / 56 % of the chip for
+// the whole launch).  The launch is exactly as many blocks as there are resident slots; the work is the flat sequence of
+// (tile, k-tile) units, cut into equal contiguous shares, so a block computes the tail of one tile, whole tiles, and the head of
+// another.  A share that STARTS inside a tile leaves that piece's raw fp32 accumulators in the block's slab of a caller-owned
+// workspace and publishes a flag at once (it is the block's first piece); the block that started the tile reaches it as the LAST
+// piece of its own share, adds the slabs of the blocks after it — in block order, a fixed order: bitwise reproducible — and runs
+// the ordinary epilogue (BatchNorm statistics / BatchNorm-backward fusion included).  (The first version had the roles the other
+// way round — the block holding a tile's last k-tile waited, at the START of its share, for a slab its predecessor wrote at the
+// END of its own: a chain of waits through all blocks, 1.7x slower than no stream-K at all.)  Every XCD owns a run of whole tiles and splits it among its own blocks, so a tile's pieces share one L2 and
+// a block only ever waits, with all of its own work done, for pieces that blocks publish before doing anything else: as long as
+// a handful of the launch's blocks are resident the wait ends (blocks without a successor to wait for retire and free their slots).  Visibility does not depend on that placement: slab stores -> s_waitcnt vmcnt(0) ->
+// barrier -> one lane's agent-scope release -> flag (relaxed agent store); the reader polls relaxed with s_sleep, then ONE
+// agent-scope acquire + barrier, then plain loads (cdna_hip_programming.md section 6, guideline 16).  The flags are never reset:
+// every launch carries a new epoch (the workspace is zeroed once, when it is registered).
+// The summation order over K differs from the unsplit kernel's (pieces are added per share), so results agree with it to
+// fp32 rounding, not bit for bit: only the training paths register a workspace (vatl_set_streamk_workspace_thread).
+// ---------------------------------------------------------------------------------------------------------
+struct StreamKArgs {
+    float* slabs;          // [grid][BM*BN] raw accumulators in register order
+    unsigned* flags;       // [grid] last epoch whose slab is complete
+    unsigned epoch;
+    int tiles;             // m_tiles * n_tiles
+};
+
+template <int BM, int BN, int WM, int WN, bool BNB>
+__global__ __launch_bounds__(256, 3) void conv_streamk_kernel(ConvParams p, StreamKArgs sk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                          // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;           // [2][BN][LDK]
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int RP = 32;
+    constexpr int LA = BM / RP, LB = BN / RP;
+    constexpr int NG = BK / 8, MPG = 4 * TM * TN;
+    static_assert((BM / WM) * (BN / WN) == 4, "one wave per wave tile");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lrow = tid >> 3, kq = tid & 7;
+    const int wpos = (kq ^ ((lrow >> 1) & 7)) * 4;
+    const int frow = lane & 31;
+    int koff[BK / 8];
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) koff[g] = ((2 * g + (lane >> 5)) ^ ((frow >> 1) & 7)) * 4;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+    const int HoWo = p.Ho * p.Wo;
+    const int KT = p.ktiles;
+
+    // this block's share: XCD x (= block id mod 8) owns tiles [T x / 8, T (x+1) / 8), its blocks cut that run's units evenly
+    const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3, bpx = gridDim.x >> 3;
+    const int t_lo = (int)((long long)sk.tiles * xcd / 8), t_hi = (int)((long long)sk.tiles * (xcd + 1) / 8);
+    const long long U = (long long)(t_hi - t_lo) * KT;
+    long long u = U * loc / bpx;
+    const long long u_end = U * (loc + 1) / bpx, u_begin = u;
+
+    int abase[LA], iy0[LA], ix0[LA];
+    unsigned boff[LB];
+    f32x4 ra[LA], rb[LB];
+    int g_r = 0, g_s = 0, g_off = 0;
+    auto gtap = [&](int kt) {
+        const int rs = kt / p.kpr;
+        const int c0 = (kt - rs * p.kpr) * BK;
+        g_r = rs / p.S; g_s = rs - g_r * p.S;
+        g_off = (g_r * p.W + g_s) * p.Cin + c0;
+    };
+    auto gloadA = [&](int i, bool live) {
+        const bool ok = live && (unsigned)(iy0[i] + g_r) < (unsigned)p.H && (unsigned)(ix0[i] + g_s) < (unsigned)p.W;
+        ra[i] = buf_load4(xr, ok ? (unsigned)(abase[i] + g_off) << 2 : OOB);
+    };
+    auto gloadB = [&](int j, int kt, bool live) { rb[j] = buf_load4(wr, live ? boff[j] + (unsigned)kt * (BK * 4) : OOB); };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4*>(&As[(buf * BM + lrow + RP * i) * LDK + wpos]) = ra[i];
+#pragma unroll
+        for (int j = 0; j < LB; ++j) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + lrow + RP * j) * LDK + wpos]) = rb[j];
+    };
+    auto frag_read = [&](f32x4 (&af)[TM], f32x4 (&bf)[TN], int buf, int g) {
+        const float* Ab = As + (buf * BM + wm * WM + frow) * LDK + koff[g];
+        const float* Bb = Bs + (buf * BN + wn * WN + frow) * LDK + koff[g];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);
+    };
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    f32x4* const slab_mine = reinterpret_cast<f32x4*>(sk.slabs) + (long long)bid * (BM * BN / 4);
+
+    while (u < u_end) {
+        const int tl = (int)(u / KT);
+        const int kb = (int)(u - (long long)tl * KT);
+        const int ke = (int)((long long)kb + (u_end - u) < (long long)KT ? (long long)kb + (u_end - u) : (long long)KT);
+        const int t = t_lo + tl;
+        const int m_tile = t / p.n_tiles, n_tile = t - m_tile * p.n_tiles;
+        const int m0 = m_tile * BM, n0 = n_tile * BN;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int m = m0 + lrow + RP * i;
+            if (m < p.M) {
+                const int b = m / HoWo;
+                const int rem = m - b * HoWo;
+                const int oy = rem / p.Wo;
+                const int ox = rem - oy * p.Wo;
+                iy0[i] = oy * p.stride - p.pad_y;
+                ix0[i] = ox * p.stride - p.pad_x;
+                abase[i] = ((b * p.H + iy0[i]) * p.W + ix0[i]) * p.Cin + kq * 4;
+            } else {
+                iy0[i] = -(1 << 20); ix0[i] = -(1 << 20); abase[i] = 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) boff[j] = (unsigned)(((n0 + lrow + RP * j) * p.K + kq * 4) * 4);
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        gtap(kb);
+#pragma unroll
+        for (int i = 0; i < LA; ++i) gloadA(i, true);
+#pragma unroll
+        for (int j = 0; j < LB; ++j) gloadB(j, kb, true);
+        lstore(0);
+        __syncthreads();
+        f32x4 af[2][TM], bf[2][TN];
+        for (int kt = kb; kt < ke; ++kt) {
+            const int buf = (kt - kb) & 1;
+            const bool live = kt + 1 < ke;
+            frag_read(af[0], bf[0], buf, 0);
+            gtap(kt + 1);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) frag_read(af[(g + 1) & 1], bf[(g + 1) & 1], buf, g + 1);
+                if (g == 0) {
+#pragma unroll
+                    for (int i = 0; i < LA; ++i) gloadA(i, live);
+                }
+                if (g == 1) {
+#pragma unroll
+                    for (int j = 0; j < LB; ++j) gloadB(j, kt + 1, live);
+                }
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][tt], bf[g & 1][j][tt], acc[i][j], 0, 0, 0);
+                if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+                for (int q = 0; q < MPG; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x016, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (live) lstore(buf ^ 1);
+            __syncthreads();
+        }
+
+        if (kb > 0) {
+            // the share starts inside this tile (always the block's FIRST piece): hand the accumulators to the block that started
+            // the tile — published right away, so that block finds them waiting when it gets to the tile at the END of its share
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4)
+                        slab_mine[((i * TN + j) * 4 + e4) * 256 + tid] =
+                            f32x4{acc[i][j][4 * e4], acc[i][j][4 * e4 + 1], acc[i][j][4 * e4 + 2], acc[i][j][4 * e4 + 3]};
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store((gu32*)(sk.flags + bid), sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (ke < KT) {
+                // this block started the tile and its share ends inside it (always the block's LAST piece): add the pieces of the
+                // blocks after it (same XCD: ids bid + 8, bid + 16, ...) in order, up to the one that holds the tile's last k-tile
+                const long long tile_end = (long long)(tl + 1) * KT;
+                long long s1 = u_end;
+                int q = loc + 1;
+                while (s1 < tile_end) {
+                    const long long qe = U * (q + 1) / bpx;
+                    if (qe == s1) { ++q; continue; }               // (a block without units publishes nothing)
+                    const int pb = q * 8 + xcd;
+                    if (tid == 0) {
+                        while (__hip_atomic_load((gu32*)(sk.flags + pb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch)
+                            __builtin_amdgcn_s_sleep(8);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    __syncthreads();
+                    const f32x4* slab = reinterpret_cast<const f32x4*>(sk.slabs) + (long long)pb * (BM * BN / 4);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int e4 = 0; e4 < 4; ++e4) {
+                                const f32x4 v = slab[((i * TN + j) * 4 + e4) * 256 + tid];
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) acc[i][j][4 * e4 + c] += v[c];
+                            }
+                    s1 = qe;
+                    ++q;
+                }
+            }
+            conv_epilogue<BM, BN, WM, WN, 256, BNB>(p, acc, smem, m0, n0, p.ooy, p.oox, wm, wn, tid, lane, HoWo);
+            __syncthreads();                       // the epilogue's LDS tile is free again
+        }
+        u += ke - kb;
+    }
+}
+
 // LDS-DMA variant (VAR 5): operand tiles go HBM/L2 -> LDS directly (buffer_load ... lds, 1 KiB per wave
 // instruction, no staging VGPRs, no ds_write pass).  The DMA destination is lane-linear (base + lane*16 B), so
 // the LDS rows are unpadded 32-float rows and bank conflicts are avoided by an XOR swizzle applied on the
@@ -1191,6 +1413,48 @@ static int launch_persistent(const ConvParams& p, hipStream_t st) {
 
 static std::atomic<int> g_persist{1};  // vatl_tune_set(7, v): persistent kernel for 1x1 layers with K <= 256 v (0 = off)
 
+// Stream-K workspace of the calling host thread (vatl_set_streamk_workspace_thread): [1024 flag words][kStreamKGrid slabs of 64 x 128
+// floats].  Thread-local like the split-K one: replica threads never share slabs, and a thread that registered nothing (every
+// inference path) never takes this route.
+constexpr int kStreamKGrid = 768;                 // three resident 64x128 blocks on each of the 256 CUs
+constexpr long long kStreamKBytes = 4096 + (long long)kStreamKGrid * 64 * 128 * 4;
+static thread_local char* tl_streamk_ws = nullptr;
+static thread_local unsigned tl_streamk_epoch = 0;
+static std::atomic<int> g_streamk{1};             // vatl_tune_set(12, v): 0 = never take the stream-K route
+
+template <bool BNB>
+static int launch_streamk(const ConvParams& p, hipStream_t st) {
+    auto kern = conv_streamk_kernel<64, 128, 32, 64, BNB>;
+    constexpr int smem = conv_smem_floats(64, 128) * (int)sizeof(float);
+    static std::atomic<unsigned> configured{0};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, configured, "conv_streamk")) return rc;
+    ConvParams q = p;
+    q.n_tiles = p.CoutPad / 128;
+    q.m_tiles = cdiv(p.M, 64);
+    q.splits = 1;
+    StreamKArgs sk{};
+    sk.flags = reinterpret_cast<unsigned*>(tl_streamk_ws);
+    sk.slabs = reinterpret_cast<float*>(tl_streamk_ws + 4096);
+    sk.epoch = ++tl_streamk_epoch;
+    if (sk.epoch == 0) sk.epoch = ++tl_streamk_epoch;          // 0 is the "never written" value of a fresh workspace
+    sk.tiles = q.m_tiles * q.n_tiles;
+    hipLaunchKernelGGL(kern, dim3(kStreamKGrid), dim3(256), smem, st, q, sk);
+    return check_launch("conv_streamk");
+}
+
+// Whole-tile launches that leave a large part of the chip idle take the stream-K route (64x128 tiles only: the tile the
+// dispatcher picks for small launches): fewer than 85 % of the block slots busy over the launch's rounds, a reduction long
+// enough to cut (>= 8 k-tiles) and at least 6 k-tiles of work per block.
+static bool streamk_wanted(const ConvParams& p, int phases, int bn, int bm, bool stem) {
+    if (!tl_streamk_ws || !g_streamk.load(std::memory_order_relaxed) || stem || phases != 1 || bn != 128 || bm != 64 || p.x2 || p.out_nchw || p.deconv ||
+        (p.Cout & 3) || p.ktiles < 8)
+        return false;
+    const long long tiles = (long long)cdiv(p.M, 64) * (p.CoutPad / 128);
+    const long long rounds = (tiles + kStreamKGrid - 1) / kStreamKGrid;
+    if (tiles * 100 >= rounds * kStreamKGrid * 85) return false;
+    return tiles * p.ktiles >= 6LL * kStreamKGrid && tiles >= 64;
+}
+
 // CoutPad granularity the packer must honour for a given Cout.
 static int tile_n_for(int Cout) { return Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128); }
 
@@ -1223,6 +1487,13 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, 
         if (bn == 64) return launch<128, 64, 64, 32, true, 0>(p, phases, st);
         if (bn == 128) return launch<128, 128, 64, 64, true, 0>(p, phases, st);
         return launch<128, 32, 32, 32, true, 0>(p, phases, st);
+    }
+    if (streamk_wanted(p, phases, bn, bm, stem)) {
+        if (p.bz) {
+            if (!p.stats || p.out_nchw) return fail(VATL_EINVAL, "conv bn-backward fusion: needs a statistics buffer and an NHWC output with Cout %% 4 == 0");
+            return launch_streamk<true>(p, st);
+        }
+        return launch_streamk<false>(p, st);
     }
     if (p.bz) {
         // data-gradient launch that also runs the reduction pass of the consumer layer's BatchNorm backward (fine-tune step)
@@ -1298,6 +1569,7 @@ extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 7 && value >= 0 && value <= 64) { g_persist.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 8 && (value == 0 || value == 1)) return conv3x3_halo_enable(value);
     if (knob == 9 && (value == 0 || value == 1)) { g_splitk_policy.store(value, std::memory_order_relaxed); return 0; }
+    if (knob == 12 && (value == 0 || value == 1)) { g_streamk.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 10 && (value == 1 || value == 2)) { g_persist_dist.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
     if (knob == 0 && value >= 0 && value <= 13) { g_var.store(value, std::memory_order_relaxed); return 0; }
@@ -1310,6 +1582,14 @@ extern "C" int vatl_set_splitk_workspace_thread(float* workspace, int64_t floats
     if (workspace && floats <= 0) return fail(VATL_EINVAL, "set_splitk_workspace_thread: empty workspace");
     tl_splitk_ws = workspace;
     tl_splitk_floats = workspace ? (long long)floats : 0;
+    return 0;
+}
+
+extern "C" int64_t vatl_streamk_workspace_bytes(void) { return kStreamKBytes; }
+
+extern "C" int vatl_set_streamk_workspace_thread(void* workspace, int64_t bytes) {
+    if (workspace && bytes < kStreamKBytes) return fail(VATL_EINVAL, "set_streamk_workspace_thread: %lld bytes, need %lld", (long long)bytes, kStreamKBytes);
+    tl_streamk_ws = static_cast<char*>(workspace);
     return 0;
 }
 

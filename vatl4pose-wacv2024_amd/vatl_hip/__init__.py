@@ -36,6 +36,8 @@ SIGNATURES = {
     "vatl_tune_set": (_i, [_i, _i]),
     "vatl_set_splitk_workspace": (_i, [_p, _i64]),
     "vatl_set_splitk_workspace_thread": (_i, [_p, _i64]),
+    "vatl_streamk_workspace_bytes": (_i64, []),
+    "vatl_set_streamk_workspace_thread": (_i, [_p, _i64]),
     "vatl_conv_cout_pad": (_i, [_i]),
     "vatl_conv2d_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_deconv4x4s2_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -284,6 +286,42 @@ class PackPlan:
         self.table = host.to(dev)
         self.total_blocks = blocks
         self.ready = True
+
+
+_streamk_ws = {}                                     # (host thread, device index) -> zero-initialised stream-K workspace
+
+
+class streamk_scope:
+    """Stream-K for this host thread's conv launches while the scope is open (the trainers' forward / backward passes): launches
+    that would leave much of the chip idle share their (tile, k-tile) units evenly over 768 persistent blocks
+    (vatl_set_streamk_workspace_thread).  Results are deterministic but not the unsplit kernels' bits, so nothing outside
+    training opens it — and the trainers open it only under VATL_STREAMK=1: measured on MI355X (profiles/r03_notes.md) the route
+    gains 8-23 % on the launches it takes when they run ALONE (R50 stage 4 at B = 120, FastPose-R152 stages 3-4 at B = 32), but
+    in the real step the block slots those launches leave idle are where the side stream's weight-gradient kernels run, and 768
+    persistent blocks take that overlap away: fine-tune step 44.8 -> 44.7 ms (R50), 67.5 -> 70.4 ms (R152).  ``force`` opens it
+    regardless (benchmarks, tests)."""
+
+    def __init__(self, device, force: bool = False):
+        self.idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.active = False
+        self.force = force
+
+    def __enter__(self):
+        if not self.force and os.environ.get("VATL_STREAMK", "0") != "1":
+            return self
+        import threading
+        key = (threading.get_ident(), self.idx)
+        buf = _streamk_ws.get(key)
+        if buf is None:
+            buf = _streamk_ws[key] = torch.zeros(int(lib().vatl_streamk_workspace_bytes()), device=torch.device("cuda", self.idx), dtype=torch.uint8)
+        _check(lib().vatl_set_streamk_workspace_thread(_ptr(buf, torch.uint8), buf.numel()), "vatl_set_streamk_workspace_thread")
+        self.active = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            _check(lib().vatl_set_streamk_workspace_thread(None, 0), "vatl_set_streamk_workspace_thread")
+        return False
 
 
 _pack_plan = None
