@@ -1529,6 +1529,8 @@ static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, 
         return launch<128, 128, 64, 64, false, 4>(p, phases, st);
     }
     if (bn == 64) {
+        // (a 256x64 tile — two 128-row tiles on one filter tile, 64x64 wave tiles, 238 VGPRs, two blocks per CU — measured 4 % SLOWER than
+        // 128x64 with three: hr.b64 480 -> 502 us, l1.c2 1838 -> 1904 us at 1024 crops; not kept)
         if (var == 2) return launch<128, 64, 64, 32, false, 2>(p, phases, st);
         if (var == 0) return launch<128, 64, 64, 32, false, 0>(p, phases, st);
         return launch<128, 64, 64, 32, false, 4>(p, phases, st);
