@@ -408,11 +408,13 @@ int vatl_ae_train_step(float* ae, float* m, float* v, const float* feat, int B, 
 int vatl_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                     double eps, double weight_decay, int step, void* stream);
 
-/* The same update for a whole parameter group in one launch: table_dev = n_tensors rows of {p, g, m, v, numel} (device
- * pointers and the element count as int64, resident on the device); every tensor shares the hyper-parameters and the
- * step count.  Arithmetic per element identical to vatl_adamw_step. */
-int vatl_adamw_step_multi(const int64_t* table_dev, int n_tensors, int64_t max_numel, double lr, double beta1, double beta2, double eps,
+/* The same update for a whole parameter group in one launch: table_dev = n_tensors rows of {p, g, m, v, numel, first_block}
+ * (device pointers, the element count, and the running sum of ceil(numel / vatl_adamw_multi_block_elems()) over the preceding
+ * rows — all int64, resident on the device); total_blocks = that sum over all rows.  Every tensor shares the hyper-parameters
+ * and the step count; tensors get blocks in proportion to their size.  Arithmetic per element identical to vatl_adamw_step. */
+int vatl_adamw_step_multi(const int64_t* table_dev, int n_tensors, int64_t total_blocks, double lr, double beta1, double beta2, double eps,
                           double weight_decay, int step, void* stream);
+int64_t vatl_adamw_multi_block_elems(void);
 
 /* torch.optim.Adam step (ActiveLearning.py:222-223): like AdamW but `weight_decay`
  * is an L2 term added to the gradient (the reference passes none: 0). */

@@ -35,10 +35,15 @@ def main():
     opt = [i for i, r in enumerate(rows) if "adamw_multi_kernel" in r["Kernel_Name"] or "adam_step" in r["Kernel_Name"]]
     if len(opt) < 2:
         sys.exit("need at least two optimizer steps in the trace")
-    # optimizer launches come in groups (one per parameter group): a step ends with the last launch of its group
-    ends = [i for k, i in enumerate(opt) if k + 1 == len(opt) or opt[k + 1] - i > 5]
-    lo, hi = ends[0] + 1, ends[-1] + 1
-    steps = len(ends) - 1
+    # optimizer launches come in groups (one per parameter group, a pointer-table copy between them): a step ends with the last
+    # launch of its group — the next optimizer launch is hundreds of dispatches away
+    ends = [i for k, i in enumerate(opt) if k + 1 == len(opt) or opt[k + 1] - i > 50]
+    # the first step of a process also initialises the optimizer state between its optimizer launches (it can look like two
+    # steps): start counting after the SECOND step boundary
+    if len(ends) < 3:
+        sys.exit("need at least three optimizer steps in the trace")
+    lo, hi = ends[1] + 1, ends[-1] + 1
+    steps = len(ends) - 2
     win = rows[lo:hi]
     t0, t1 = int(win[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in win)
     iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in win)

@@ -80,6 +80,7 @@ SIGNATURES = {
     "vatl_maxpool3x3s2_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_maxpool3x3s2_fwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_pack_weights_multi": (_i, [_p, _i, _i64, _p]),
+    "vatl_adamw_multi_block_elems": (_i64, []),
     "vatl_maxpool3x3s2_fwd_idx_affine": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_bn_train_bwd_relu_pool": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "vatl_maxpool3x3s2_bwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
@@ -1005,19 +1006,34 @@ def unpack_ae(flat: torch.Tensor, module) -> None:
                     off += t.numel()
 
 
+_adamw_tables = {}                                   # (device, pointers...) -> (device table, total blocks): the pointers of a group do not change
+
+
 def adamw_step_multi(params, grads, ms, vs, step: int, lr: float, weight_decay: float, betas=(0.9, 0.999), eps: float = 1e-8):
     """One launch for a list of tensors sharing hyper-parameters and step count."""
     if not params:
         return
-    rows = []
+    key = [params[0].device.index]
     for p_, g_, m_, v_ in zip(params, grads, ms, vs):
         for t in (p_, g_, m_, v_):
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
                 raise VatlError("adamw_step_multi needs contiguous fp32 device tensors")
-        rows.append((p_.data_ptr(), g_.data_ptr(), m_.data_ptr(), v_.data_ptr(), p_.numel()))
-    table = torch.tensor(rows, dtype=torch.int64).to(params[0].device, non_blocking=False)
-    _check(lib().vatl_adamw_step_multi(_ptr(table, torch.int64), len(rows), max(r[4] for r in rows), lr, betas[0], betas[1], eps, weight_decay, step,
-                                       _stream()), "vatl_adamw_step_multi")
+        key += [p_.data_ptr(), g_.data_ptr(), m_.data_ptr(), v_.data_ptr(), p_.numel()]
+    key = tuple(key)
+    hit = _adamw_tables.get(key)
+    if hit is None:                                  # built and uploaded once per (group, storage): no per-step host-to-device copy
+        be = int(lib().vatl_adamw_multi_block_elems())
+        rows, blocks = [], 0
+        for k in range(len(params)):
+            p_, g_, m_, v_, n = key[1 + 5 * k:6 + 5 * k]
+            rows.append((p_, g_, m_, v_, n, blocks))
+            blocks += (n + be - 1) // be
+        if len(_adamw_tables) > 64:
+            _adamw_tables.clear()
+        hit = _adamw_tables[key] = (torch.tensor(rows, dtype=torch.int64).to(params[0].device), blocks)
+    table, blocks = hit
+    _check(lib().vatl_adamw_step_multi(_ptr(table, torch.int64), len(params), blocks, lr, betas[0], betas[1], eps, weight_decay, step, _stream()),
+           "vatl_adamw_step_multi")
 
 
 def adam_step(p, g, m, v, step: int, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-8):
