@@ -107,11 +107,12 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
     ms = sum(a.elapsed_time(b) for a, b in events)
     flops = GFLOP_PER_CROP * 1e9 * FRAMES
     achieved = flops / (ms * 1e-3) / 1e12
-    traffic = None                                     # HBM bytes of the same launches, from the committed PMC passes
+    traffic, traffic_source = None, None               # HBM bytes of the same launches, from the committed PMC passes
     try:
         pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
         with open(os.path.join(ROOT, "profiles", pmcs[-1])) as f:
             traffic = json.load(f)["conv_igemm"]["hbm_bytes_per_step"]
+        traffic_source = "profiles/" + pmcs[-1]
     except (OSError, IndexError, KeyError, ValueError):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
@@ -119,8 +120,8 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
             "kernel": "conv_igemm_kernel + gemm1x1_persistent_kernel (all conv/deconv launches of one step; 4 of them fuse a projection shortcut with the block's last conv)", "launches": len(events),
             "avg_launch_us": round(ms * 1e3 / len(events), 2), "flops_per_step": flops,
             # the step's conv launches have different shapes: `achieved` is sum(flops) / sum(duration); per-launch averages for reference
-            "flops_per_launch": flops / len(events), "traffic_per_step": traffic,
-            "traffic_note": "`traffic` = HBM bytes per launch (average over the step's conv launches, like `achieved`); source: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE x2 on gfx950), summed over the conv launches of one step in the committed profiles/*_pmc_summary.json"}
+            "flops_per_launch": flops / len(events), "traffic_per_step": traffic, "traffic_source": traffic_source,
+            "traffic_note": "`traffic` = HBM bytes per launch (average over the step's conv launches, like `achieved`); source: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE x2 on gfx950) around this same command (tools/profile_round.sh), summed over the conv launches of one step — read from `traffic_source`, the newest committed summary: the counters cannot be sampled from inside the process, so this field does not move with the run"}
 
 
 def cpu_baseline():
