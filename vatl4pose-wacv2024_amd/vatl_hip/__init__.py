@@ -325,13 +325,15 @@ class streamk_scope:
         return False
 
 
-_pack_plan = None
+import threading as _threading
+
+_tls = _threading.local()                            # per host thread: the plan its pack_* calls consult
 
 
 def set_pack_plan(plan):
-    """The plan the pack_* calls consult (None: every call packs on the spot).  Returns the previous one."""
-    global _pack_plan
-    prev, _pack_plan = _pack_plan, plan
+    """The plan the pack_* calls of THIS host thread consult (None: every call packs on the spot).  Returns the previous one."""
+    prev = getattr(_tls, "pack_plan", None)
+    _tls.pack_plan = plan
     return prev
 
 
@@ -342,7 +344,7 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     if r == 1 and s == 1 and cpad == cout and cin != 3 and w.is_contiguous() and w.dtype == torch.float32:
         return w.detach().view(cout, 1, 1, cin)              # (Cout,Cin,1,1) already is the packed [Cout][1][1][Cin]: no copy
     spad, cinpad = (8, 4) if cin == 3 else (s, cin)
-    plan, key = _pack_plan, ("conv", w.data_ptr(), tuple(w.shape))
+    plan, key = getattr(_tls, "pack_plan", None), ("conv", w.data_ptr(), tuple(w.shape))
     if plan is not None and w.is_contiguous():
         kept = plan.lookup(key, w)
         if kept is not None:
@@ -381,7 +383,7 @@ def pack_deconv_weight(w: torch.Tensor) -> torch.Tensor:
     if (kh, kw) != (4, 4):
         raise VatlError("only ConvTranspose2d(4, 2, 1) is supported")
     cpad = conv_cout_pad(cout)
-    plan, key = _pack_plan, ("deconv", w.data_ptr(), tuple(w.shape))
+    plan, key = getattr(_tls, "pack_plan", None), ("deconv", w.data_ptr(), tuple(w.shape))
     if plan is not None and w.is_contiguous():
         kept = plan.lookup(key, w)
         if kept is not None:
@@ -719,7 +721,7 @@ def pack_dgrad_weight(w: torch.Tensor, taps, cout_k: int | None = None) -> torch
     cinpad = conv_cout_pad(cin)
     cout_k = cout_k or cout
     taps = [(int(a), int(b)) for a, b in taps]
-    plan, key = _pack_plan, ("dgrad", w.data_ptr(), tuple(w.shape), tuple(taps), cout_k)
+    plan, key = getattr(_tls, "pack_plan", None), ("dgrad", w.data_ptr(), tuple(w.shape), tuple(taps), cout_k)
     if plan is not None and w.is_contiguous() and len(taps) <= 16:
         kept = plan.lookup(key, w)
         if kept is not None:
