@@ -367,3 +367,66 @@ al.eval_and_query()
     import json
     for r in (0, 1):
         assert json.loads(open(tmp_path / "tr" / f"rank{r}.jsonl").readline())["value"] == 3.0
+
+
+def test_worker_shutdown_after_a_failed_call_skips_the_collective(monkeypatch):
+    """after an exception inside a mirrored call the workers are blocked in some other collective; the exit broadcast
+    would be a mismatched collective that can hang until the backend's watchdog.  `mark_failed()` (set by the `_collective`
+    wrapper) makes `shutdown_workers()` end the children directly; payload files are released either way."""
+    from active_learning import distributed as D
+
+    class FakeProc:
+        def __init__(self):
+            self.terminated = self.killed = False
+            self.returncode = None
+
+        def poll(self):
+            return self.returncode
+
+        def terminate(self):
+            self.terminated = True
+            self.returncode = -15
+
+        def wait(self, timeout=None):
+            return self.returncode
+
+        def kill(self):
+            self.killed = True
+    calls = []
+    monkeypatch.setattr(D, "broadcast_object", lambda *a, **k: calls.append(a))
+    monkeypatch.setattr(D.dist, "is_initialized", lambda: False)
+    path = D.dump_payload({"x": 1})
+    assert os.path.exists(path)
+    # clean run: one exit broadcast would be attempted (is_initialized False here -> skipped), nothing terminated
+    procs = [FakeProc(), FakeProc()]
+    monkeypatch.setattr(D, "_workers", procs)
+    monkeypatch.setattr(D, "_failed", False)
+    D.shutdown_workers()
+    assert not any(p.terminated for p in procs) and not os.path.exists(path) and D._workers == []
+    # failed run: children terminated, no collective
+    procs = [FakeProc(), FakeProc()]
+    monkeypatch.setattr(D, "_workers", procs)
+    D.mark_failed()
+    monkeypatch.setattr(D.dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(D.dist, "destroy_process_group", lambda: calls.append("destroy"))
+    D.shutdown_workers()
+    assert all(p.terminated for p in procs) and calls == [] and D._workers == []
+    monkeypatch.setattr(D, "_failed", False)
+
+
+def test_collective_wrapper_marks_the_failure():
+    import importlib
+    AL = importlib.import_module("active_learning.ActiveLearning")
+    from active_learning import distributed as D
+
+    class Obj:
+        _depth = 0
+
+        @AL._collective
+        def boom(self):
+            raise ValueError("inside a mirrored call")
+    D._failed = False
+    with pytest.raises(ValueError):
+        Obj().boom()
+    assert D._failed
+    D._failed = False
