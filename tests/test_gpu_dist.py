@@ -201,3 +201,64 @@ def test_arena_buckets_start_only_after_the_side_stream_joined(monkeypatch):
         for ptr, n, snap in snaps:                                  # (b) the bucket was final when its collective was issued
             lo = (ptr - base) // 4
             assert torch.equal(snap, arena.flat[lo:lo + n]), (lo, n)
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys
+import torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path[:0] = [root, os.path.join(root, "vatl4pose-wacv2024_amd")]
+import vatl_hip as vh
+from active_learning import distributed as D
+from alphapose.models import builder, hip_train
+from alphapose.utils.config import edict
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+cfg = edict({"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50})
+preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48]})
+torch.manual_seed(3)
+m = builder.build_sppe(cfg, preset_cfg=preset).to(dev).train()
+tr = hip_train.trainer_for(m)
+params = [p for p in m.parameters() if p.requires_grad]
+g = torch.Generator(device=dev); g.manual_seed(5)
+x = torch.rand((24, 3, 256, 192), device=dev, generator=g) - 0.45
+labels = torch.rand((24, 17, 64, 48), device=dev, generator=g) * 0.1
+masks = torch.ones((24, 17, 1, 1), device=dev)
+out = []
+for live in (False, True, True):
+    arena = D.GradArena(params, device=dev, bucket_bytes=8 << 20)
+    with torch.no_grad():
+        o = tr.forward(x)
+        _, dout = vh.masked_mse_fwd_bwd(o, labels, masks)
+        arena.begin()
+        arena._live = live                      # a one-rank RCCL group: the collectives are real launches on RCCL's stream, the sum is the identity
+        tr.backward(dout, arena=arena, overlap=True)
+        early = arena.launches
+        arena.finish()
+    torch.cuda.synchronize()
+    out.append((arena.flat.clone(), early, arena.launches))
+assert out[0][2] == 0 and out[1][2] == 17 and out[1][1] >= 8, [o[1:] for o in out]
+assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[1][0], out[2][0])
+dist.destroy_process_group()
+print("rccl one rank ok", out[1][1], out[1][2])
+"""
+
+
+def test_rccl_one_rank_group_runs_the_bucketed_allreduce_beside_the_backward_pass(tmp_path):
+    """The only RCCL the builder's one-GPU box can run: a world-size-1 "nccl" group.  The gradient arena's buckets are issued as
+    real asynchronous RCCL all-reduces (its own stream, work objects, in-place on arena slices) while the backward pass keeps
+    launching on the main stream and the weight gradients on the side stream; with one rank the sum is the identity, so the
+    arena must end with exactly the bits of a pass without collectives — which it only does if every bucket was final when its
+    collective read it and nothing overwrote a bucket afterwards."""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(_RCCL_ONE_RANK)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script), root, str(_free_port())], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl one rank ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
