@@ -1569,6 +1569,7 @@ int conv3x3_halo_enable(int on);
 using namespace vatl;
 
 extern "C" int vatl_tune_wgrad_blocks(int blocks);
+extern "C" int vatl_crop_tune_px(int px);
 
 extern "C" int vatl_tune_set(int knob, int value) {
     // Ablation settings (schedule variants 10..13, wgrad ablation bits) produce WRONG results by construction; they exist
@@ -1589,6 +1590,7 @@ extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 7 && value >= 0 && value <= 64) { g_persist.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 8 && (value == 0 || value == 1)) return conv3x3_halo_enable(value);
     if (knob == 9 && (value == 0 || value == 1)) { g_splitk_policy.store(value, std::memory_order_relaxed); return 0; }
+    if (knob == 16 && vatl_crop_tune_px(value) == 0) return 0;
     if (knob == 12 && (value == 0 || value == 1)) { g_streamk.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 10 && (value == 1 || value == 2)) { g_persist_dist.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
