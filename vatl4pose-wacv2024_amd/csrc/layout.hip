@@ -16,6 +16,26 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// Cpad % 4 == 0, Cpad > 4 (the 17 -> 32 channel gradient of the heat-map head): one thread per (pixel, four channels), the channel
+// group fastest, so a wave writes 1 KB of contiguous NHWC rows (the per-pixel version below wrote 4 bytes per lane 128 bytes apart:
+// 165 us for 120 x 17 x 64 x 48 at 0.44 TB/s)
+__global__ void nchw_to_nhwc_c4_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW, int Cpad) {
+    const int G = Cpad >> 2;
+    const long long total = (long long)N * HW * G;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        const long long pix = i / G;
+        const long long n = pix / HW;
+        const int px = (int)(pix - n * HW);
+        const float* s = src + (n * C + 4 * g) * HW + px;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * g + k < C) v[k] = s[(long long)k * HW];
+        *reinterpret_cast<f32x4*>(dst + i * 4) = v;
+    }
+}
+
 // one thread per destination pixel; Cpad floats written contiguously
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW, int Cpad) {
     const long long total = (long long)N * HW;
@@ -469,7 +489,10 @@ extern "C" const char* vatl_last_error(void) { return err_buf(); }
 
 extern "C" int vatl_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int Cpad, void* stream) {
     if (!src || !dst || Cpad < C) return fail(VATL_EINVAL, "nchw_to_nhwc: bad arguments");
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, H * W, Cpad);
+    if (Cpad > 4 && (Cpad & 3) == 0 && ((uintptr_t)dst & 15) == 0)
+        hipLaunchKernelGGL(nchw_to_nhwc_c4_kernel, dim3(grid_for((long long)N * H * W * (Cpad / 4))), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, H * W, Cpad);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)N * H * W)), dim3(256), 0, (hipStream_t)stream, src, dst, N, C, H * W, Cpad);
     return check_launch("nchw_to_nhwc");
 }
 
