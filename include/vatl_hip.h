@@ -449,6 +449,26 @@ int vatl_kcenter_update(const float* emb, int64_t n, int D, const int32_t* cente
 int vatl_kcenter_pick(const double* min_dist_or_null, double* unc_or_null, double a, double b, int32_t* selected_dev, int step,
                       int64_t n, void* stream);
 
+/* ---- Winograd F(2x2, 3x3) route of the 3x3 / stride 1 / pad 1 layers (csrc/conv_winograd.hip) ------------------------------------
+ * Replaces, for those layers, what the reference runs as torch.nn.Conv2d(k=3, s=1, p=1) inside Bottleneck / BasicBlock
+ * (alphapose/models/layers/Resnet.py:52-78 conv2, alphapose/models/hrnet.py:24-56) — the reference's cuDNN picks the same algorithm
+ * for them.  fp32 products and accumulation; 2.25x fewer multiplies than the direct sum, rounding differs in the last bits.
+ *
+ * vatl_pack_winograd_weight: w = the layer's (Cout, Cin, 3, 3) filter (OIHW, contiguous); u receives G g G^T in MFMA fragment order,
+ *   vatl_winograd_weight_floats(Cout, Cin) floats (Cout padded to vatl_winograd_cout_pad).  data_gradient != 0: w is still the FORWARD
+ *   filter (O, I, 3, 3) and (Cout, Cin) = (I, O): u is the filter of dX = conv(dY, rot180(w)^T).  Cin % 16 == 0.
+ * vatl_conv3x3_winograd_fwd: y = act((x * w) * scale + bias + residual), x / y / residual NHWC fp32, Cout % 4 == 0.
+ * vatl_conv3x3_winograd_fwd_stats: y = x * w and the per-(row block, channel) double (sum, sum of squares) partials of y in the layout
+ *   vatl_bn_train_finalize reduces; capacity vatl_winograd_stats_row_blocks(N, H, W) * Cout * 2 doubles. */
+int vatl_winograd_cout_pad(int Cout);
+int64_t vatl_winograd_weight_floats(int Cout, int Cin);
+int vatl_pack_winograd_weight(const float* w, float* u, int Cout, int Cin, int data_gradient, void* stream);
+int vatl_conv3x3_winograd_fwd(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y,
+                              int N, int H, int W, int Cin, int Cout, int relu, void* stream);
+int64_t vatl_winograd_stats_row_blocks(int64_t N, int H, int W);
+int vatl_conv3x3_winograd_fwd_stats(const float* x, const float* u, float* y, double* stats, int64_t* row_blocks_used, int N, int H, int W,
+                                    int Cin, int Cout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,12 @@ SIGNATURES = {
     "vatl_bn_train_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p]),
     "vatl_bn_train_bwd_relu": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _p, _p, _p]),
     "vatl_conv_stats_row_blocks": (_i64, [_i64, _i]),
+    "vatl_winograd_cout_pad": (_i, [_i]),
+    "vatl_winograd_weight_floats": (_i64, [_i, _i]),
+    "vatl_pack_winograd_weight": (_i, [_p, _p, _i, _i, _i, _p]),
+    "vatl_conv3x3_winograd_fwd": (_i, [_p] * 6 + [_i] * 6 + [_p]),
+    "vatl_winograd_stats_row_blocks": (_i64, [_i64, _i, _i]),
+    "vatl_conv3x3_winograd_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vatl_conv2d_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_deconv4x4s2_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_bn_train_finalize": (_i, [_p, _i64, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
@@ -417,6 +423,27 @@ def conv2d_fwd(x, w_packed, scale, bias, cout: int, r: int, s: int, stride: int,
     y = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
     _check(lib().vatl_conv2d_fwd(_ptr(x), _ptr(w_packed), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(y), n, h, w, cin, cout,
                                  w_packed.shape[0], r, s, stride, pad, int(relu), int(out_nchw), _stream()), "vatl_conv2d_fwd")
+    return y
+
+
+def pack_winograd_weight(w: torch.Tensor, data_gradient: bool = False) -> torch.Tensor:
+    """(Cout,Cin,3,3) -> the F(2x2,3x3) filter transform G g G^T in MFMA fragment order (csrc/conv_winograd.hip).  With
+    ``data_gradient`` the result is the filter of dX = conv(dY, rot180(w)^T): its output channels are the forward Cin."""
+    co, ci = w.shape[:2]
+    if tuple(w.shape[2:]) != (3, 3):
+        raise VatlError("pack_winograd_weight: 3x3 filters only")
+    cout, cin = (ci, co) if data_gradient else (co, ci)
+    out = torch.empty(int(lib().vatl_winograd_weight_floats(cout, cin)), device=w.device, dtype=torch.float32)
+    _check(lib().vatl_pack_winograd_weight(_ptr(w.contiguous()), _ptr(out), cout, cin, int(data_gradient), _stream()), "vatl_pack_winograd_weight")
+    return out
+
+
+def conv3x3_winograd_fwd(x, u_packed, scale, bias, cout: int, relu: bool, residual=None, out=None):
+    """3x3 / stride 1 / pad 1 convolution of an NHWC tensor through Winograd F(2x2, 3x3)."""
+    n, h, w, cin = x.shape
+    y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_conv3x3_winograd_fwd(_ptr(x), _ptr(u_packed), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(y), n, h, w, cin, cout,
+                                           int(relu), _stream()), "vatl_conv3x3_winograd_fwd")
     return y
 
 
