@@ -86,27 +86,34 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
     """Time every conv/deconv implicit-GEMM launch of one step with HIP events on the
     launch stream (torch's current stream) and relate the sum to the algorithmic FLOPs."""
     import vatl_hip as vh
-    events = []
-    orig_c, orig_d, orig_u = vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd
+    events, wino = [], []
+    orig_c, orig_d, orig_u, orig_w = vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd, vh.conv3x3_winograd_fwd
 
-    def wrap(fn):
+    def wrap(fn, is_wino=False):
         def inner(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = fn(*a, **k)
             e1.record()
             events.append((e0, e1))
+            if is_wino:                                    # direct-sum FLOPs of this launch: 2 * pixels * Cout * 9 Cin
+                wino.append((e0, e1, 2.0 * r.numel() * 9 * a[0].shape[-1]))
             return r
         return inner
-    vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd = wrap(orig_c), wrap(orig_d), wrap(orig_u)
+    vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd, vh.conv3x3_winograd_fwd = wrap(orig_c), wrap(orig_d), wrap(orig_u), wrap(orig_w, True)
     try:
         one_step(model, x, bbox, is_prev, is_next, hm_buf)
         torch.cuda.synchronize()
     finally:
-        vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd = orig_c, orig_d, orig_u
+        vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd, vh.conv3x3_winograd_fwd = orig_c, orig_d, orig_u, orig_w
     ms = sum(a.elapsed_time(b) for a, b in events)
     flops = GFLOP_PER_CROP * 1e9 * FRAMES
     achieved = flops / (ms * 1e-3) / 1e12
+    # the Winograd launches issue 16 multiplies per 2x2 output tile and channel pair where the direct sum has 36: what the matrix
+    # pipe actually executes is `flops` minus 5/9 of their direct-sum FLOPs
+    wino_flops = sum(f for _, _, f in wino)
+    wino_ms = sum(a.elapsed_time(b) for a, b, _ in wino)
+    executed = flops - wino_flops * 5.0 / 9.0
     traffic, traffic_source = None, None               # HBM bytes of the same launches, from the committed PMC passes
     try:
         pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
@@ -117,7 +124,13 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": (traffic / len(events)) if traffic else None,
-            "kernel": "conv_igemm_kernel + gemm1x1_persistent_kernel (all conv/deconv launches of one step; 4 of them fuse a projection shortcut with the block's last conv)", "launches": len(events),
+            "kernel": "conv_igemm_kernel + gemm1x1_persistent2_kernel + conv3x3_winograd_kernel (all conv/deconv launches of one step; 4 of them fuse a projection shortcut with the block's last conv; the 3x3 stride-1 layers run as Winograd F(2x2,3x3))", "launches": len(events),
+            # `achieved` / `frac` count ALGORITHMIC (direct-sum) FLOPs, as the contract asks; the Winograd launches reach them with 2.25x
+            # fewer multiplies, so their own algorithmic rate can exceed the pipe's peak.  `executed_frac` = MFMA FLOPs actually issued
+            # / time / peak: the occupancy of the matrix pipe.
+            "executed_flops_per_step": executed, "executed_frac": round(executed / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA, 4),
+            "winograd": {"launches": len(wino), "ms": round(wino_ms, 3), "algorithmic_tflops": round(wino_flops / (wino_ms * 1e-3) / 1e12, 2) if wino_ms else None,
+                         "executed_tflops": round(wino_flops * 4 / 9 / (wino_ms * 1e-3) / 1e12, 2) if wino_ms else None},
             "avg_launch_us": round(ms * 1e3 / len(events), 2), "flops_per_step": flops,
             # the step's conv launches have different shapes: `achieved` is sum(flops) / sum(duration); per-launch averages for reference
             "flops_per_launch": flops / len(events), "traffic_per_step": traffic, "traffic_source": traffic_source,

@@ -1,0 +1,168 @@
+"""Winograd F(2x2, 3x3) route of the 3x3 / stride-1 layers (csrc/conv_winograd.hip) against a float64 convolution, against the
+implicit GEMM, and for the properties the evaluation path relies on (bits independent of the batch position)."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import dev, record, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5      # max|err| / max|ref| per layer: the bar of the implicit GEMM (tests/test_gpu_conv.py)
+
+
+@pytest.fixture(scope="module")
+def vh():
+    import vatl_hip
+    vatl_hip.lib()
+    return vatl_hip
+
+
+def _nhwc(x):
+    return np.ascontiguousarray(np.transpose(x, (0, 2, 3, 1)))
+
+
+CASES = [
+    # name, N, H, W, Cin, Cout, relu, residual, fold (scale / bias)
+    ("r50_l1", 2, 64, 48, 64, 64, True, False, True),
+    ("r50_l4_tiny", 3, 8, 6, 512, 512, True, False, True),
+    ("hr_b32_res", 2, 64, 48, 32, 32, True, True, True),
+    ("hr_b128_res", 1, 16, 12, 128, 128, True, True, True),
+    ("odd_hw", 3, 13, 11, 32, 40, True, True, True),           # odd H and W, Cout not a multiple of the 64-channel tile
+    ("odd_w_r152_l4", 2, 12, 9, 64, 96, False, False, True),
+    ("one_pixel_rows", 2, 1, 7, 16, 8, False, False, False),      # a single tile row, Cin = 16 (one stage), no epilogue
+    ("h2_w2", 5, 2, 2, 48, 36, True, False, True),               # one tile per image: every column is a border
+    ("cout4", 1, 6, 10, 16, 4, False, True, False),
+    ("tail_tiles", 7, 10, 6, 32, 64, True, False, True),          # 7 * 15 = 105 tiles: the second block is partly empty
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_winograd_matches_float64_and_the_implicit_gemm(vh, case):
+    name, n, h, w, cin, cout, relu, use_res, fold = case
+    r = np.random.RandomState(zlib.crc32(name.encode()) % 2 ** 31)
+    x = r.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (r.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    ref = F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, 1, 1)
+    scale = bias = None
+    if fold:
+        gamma, beta = r.uniform(0.5, 1.5, cout).astype(np.float32), r.standard_normal(cout).astype(np.float32) * 0.1
+        mean, var = r.standard_normal(cout).astype(np.float32) * 0.1, r.uniform(0.5, 1.5, cout).astype(np.float32)
+        ref = F.batch_norm(ref, torch.from_numpy(mean).double(), torch.from_numpy(var).double(), torch.from_numpy(gamma).double(),
+                           torch.from_numpy(beta).double(), False, 0.0, 1e-5)
+        scale, bias = vh.bn_fold(to_dev(gamma), to_dev(beta), to_dev(mean), to_dev(var), 1e-5)
+    res = None
+    if use_res:
+        res = r.standard_normal(tuple(ref.shape)).astype(np.float32)
+        ref = ref + torch.from_numpy(res).double()
+    if relu:
+        ref = ref.relu()
+    ref = ref.numpy()
+    xd = to_dev(_nhwc(x))
+    resd = to_dev(_nhwc(res)) if use_res else None
+    u = vh.pack_winograd_weight(to_dev(wt))
+    y = vh.conv3x3_winograd_fwd(xd, u, scale, bias, cout, relu, residual=resd)
+    got = np.transpose(y.cpu().numpy(), (0, 3, 1, 2))
+    e = rel_err(got, ref)
+    record("winograd_" + name, rel=e)
+    assert e < TOL, (name, e)
+    if cin % 32 == 0:                                           # the implicit GEMM needs whole 32-channel k-tiles
+        yd = vh.conv2d_fwd(xd, vh.pack_conv_weight(to_dev(wt)), scale, bias, cout, 3, 3, 1, 1, relu, residual=resd)
+        assert rel_err(y.cpu().numpy(), yd.cpu().numpy()) < 2 * TOL
+
+
+def test_winograd_output_buffer_and_rejections(vh):
+    x = torch.randn((2, 8, 6, 32), device=dev())
+    wt = torch.randn((16, 32, 3, 3), device=dev()) * 0.1
+    u = vh.pack_winograd_weight(wt)
+    out = torch.full((2, 8, 6, 16), 7.0, device=dev())
+    y = vh.conv3x3_winograd_fwd(x, u, None, None, 16, False, out=out)
+    assert y.data_ptr() == out.data_ptr() and not (out == 7.0).any()
+    with pytest.raises(vh.VatlError):
+        vh.pack_winograd_weight(torch.randn((16, 24, 3, 3), device=dev()))          # Cin % 16
+    with pytest.raises(vh.VatlError):
+        vh.pack_winograd_weight(torch.randn((16, 32, 1, 1), device=dev()))
+    with pytest.raises(vh.VatlError):
+        vh.conv3x3_winograd_fwd(x, u, None, None, 18, False)                         # Cout % 4
+
+
+def test_winograd_bits_do_not_depend_on_the_batch_position(vh):
+    """A crop's output is the same bit pattern alone, in the middle of a large batch, and at a different offset inside a
+    64-tile block (the THC de-duplication compares heat-maps of the same crop computed in different batches)."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for h, w, cin, cout in ((16, 12, 64, 64), (13, 9, 32, 32), (8, 6, 128, 256)):
+        x = torch.randn((37, h, w, cin), generator=g).to(dev())
+        wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.05).to(dev())
+        sc, bi = (torch.rand(cout, generator=g) + 0.5).to(dev()), torch.randn(cout, generator=g).to(dev())
+        u = vh.pack_winograd_weight(wt)
+        full = vh.conv3x3_winograd_fwd(x, u, sc, bi, cout, True)
+        for i in (0, 5, 36):
+            alone = vh.conv3x3_winograd_fwd(x[i:i + 1].contiguous(), u, sc, bi, cout, True)
+            assert torch.equal(alone[0], full[i]), (h, w, i)
+        shifted = vh.conv3x3_winograd_fwd(x[3:].contiguous(), u, sc, bi, cout, True)
+        assert torch.equal(shifted, full[3:])
+        again = vh.conv3x3_winograd_fwd(x, u, sc, bi, cout, True)
+        assert torch.equal(again, full)
+
+
+def test_winograd_statistics_epilogue_matches_the_stored_tensor(vh):
+    """Training forward: y = x * w and the (sum, sum of squares) row-block partials that BatchNorm's finalize reduces."""
+    import ctypes as C
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for n, h, w, cin, cout in ((5, 16, 12, 64, 64), (3, 13, 9, 32, 40), (2, 8, 6, 128, 256)):
+        x = torch.randn((n, h, w, cin), generator=g).to(dev())
+        wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.05).to(dev())
+        u = vh.pack_winograd_weight(wt)
+        y, stats, blocks = vh.conv3x3_winograd_fwd_stats(x, u, cout)
+        plain = vh.conv3x3_winograd_fwd(x, u, None, None, cout, False)
+        assert torch.equal(y, plain)
+        s = stats[:blocks * cout * 2].view(blocks, cout, 2).sum(0)
+        y64 = y.double().reshape(-1, cout)
+        assert torch.allclose(s[:, 0], y64.sum(0), rtol=1e-6, atol=1e-4)
+        assert torch.allclose(s[:, 1], (y64 * y64).sum(0), rtol=1e-6, atol=1e-4)
+        record(f"winograd_stats_{cin}_{cout}", blocks=int(blocks))
+
+
+def test_winograd_data_gradient_filter(vh):
+    """dX = conv(dY, rot180(w)^T) through the same kernel with the data-gradient packing, against autograd in float64."""
+    g = torch.Generator(device="cpu").manual_seed(17)
+    for n, h, w, cin, cout in ((2, 16, 12, 64, 128), (3, 13, 9, 32, 48), (1, 8, 6, 256, 64)):
+        x = torch.randn((n, cin, h, w), generator=g, dtype=torch.float64, requires_grad=True)
+        wt = torch.randn((cout, cin, 3, 3), generator=g, dtype=torch.float64) * 0.05
+        dy = torch.randn((n, cout, h, w), generator=g, dtype=torch.float64)
+        F.conv2d(x, wt, None, 1, 1).backward(dy)
+        ud = vh.pack_winograd_weight(wt.float().to(dev()), data_gradient=True)
+        dx = vh.conv3x3_winograd_fwd(dy.float().permute(0, 2, 3, 1).contiguous().to(dev()), ud, None, None, cin, False)
+        e = rel_err(dx.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy())
+        record(f"winograd_dgrad_{cin}_{cout}", rel=e)
+        assert e < TOL, e
+
+
+def test_inference_plans_route_3x3_layers_through_winograd(vh, monkeypatch):
+    """SimplePose-R50: the 13 stride-1 3x3 layers of the trunk take the Winograd route; the heat-maps agree with the
+    all-implicit-GEMM plan to the layer tolerance."""
+    from alphapose.models import hip_engine
+    from oracle import synth
+    from tests.test_gpu_conv import _build_simplepose
+    m = _build_simplepose()
+    x = to_dev(synth.crops(3))
+    calls = []
+    orig = vh.conv3x3_winograd_fwd
+    monkeypatch.setattr(vh, "conv3x3_winograd_fwd", lambda *a, **k: (calls.append(a[0].shape), orig(*a, **k))[1])
+    out = torch.empty((3, 17, 64, 48), device=dev())
+    with torch.no_grad():
+        hip_engine.forward_into(m, x, out)
+    assert len(calls) == 13
+    monkeypatch.setattr(hip_engine, "WINOGRAD", False)
+    m.__dict__.pop("_vatl_plan", None)
+    direct = torch.empty_like(out)
+    with torch.no_grad():
+        hip_engine.forward_into(m, x, direct)
+    m.__dict__.pop("_vatl_plan", None)
+    assert len(calls) == 13
+    e = rel_err(out.cpu().numpy(), direct.cpu().numpy())
+    record("winograd_vs_direct_simplepose_r50", rel=e)
+    assert e < 1e-4

@@ -37,8 +37,14 @@ MAX_CHUNK = int(os.environ.get("VATL_MAX_CHUNK", "1024"))
 STAGE1_CHUNK = int(os.environ.get("VATL_STAGE1_CHUNK", "0"))   # measured neutral-to-negative on MI355X (profiles/r01_notes.md): off
 
 
+# 3x3 / stride 1 / pad 1 layers run as Winograd F(2x2, 3x3) (csrc/conv_winograd.hip: 2.25x fewer multiplies, fp32).  The choice depends
+# on the layer's geometry only — never on the batch — so a crop's heat-map bits do not depend on how it was batched.  VATL_WINOGRAD=0 = the
+# implicit GEMM everywhere.
+WINOGRAD = os.environ.get("VATL_WINOGRAD", "1") != "0"
+
+
 class _Conv:
-    __slots__ = ("w", "scale", "bias", "cout", "r", "s", "stride", "pad")
+    __slots__ = ("w", "u", "scale", "bias", "cout", "r", "s", "stride", "pad")
 
     def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d | None):
         assert conv.groups == 1 and conv.dilation == (1, 1)
@@ -46,6 +52,9 @@ class _Conv:
         self.w = vh.pack_conv_weight(conv.weight.detach())
         self.cout, _, self.r, self.s = conv.weight.shape
         self.stride, self.pad = conv.stride[0], conv.padding[0]
+        self.u = None
+        if WINOGRAD and (self.r, self.s, self.stride, self.pad) == (3, 3, 1, 1) and conv.in_channels % 16 == 0 and self.cout % 4 == 0:
+            self.u = vh.pack_winograd_weight(conv.weight.detach())
         cb = conv.bias.detach() if conv.bias is not None else None
         if bn is not None:
             self.scale, self.bias = vh.bn_fold(_d(bn.weight), _d(bn.bias), bn.running_mean, bn.running_var, bn.eps, cb)
@@ -55,6 +64,8 @@ class _Conv:
             self.scale = self.bias = None
 
     def __call__(self, x, relu, residual=None, out_nchw=False, out=None):
+        if self.u is not None and not out_nchw:
+            return vh.conv3x3_winograd_fwd(x, self.u, self.scale, self.bias, self.cout, relu, residual=residual, out=out)
         return vh.conv2d_fwd(x, self.w, self.scale, self.bias, self.cout, self.r, self.s, self.stride, self.pad, relu,
                              residual=residual, out_nchw=out_nchw, out=out)
 

@@ -1564,6 +1564,7 @@ namespace vatl {
 int conv3x3_halo_try(const float* x, const float* w, const float* scale, const float* bias, const float* residual, float* y, int N, int H, int W,
                      int Cin, int Cout, int CoutPad, int R, int S, int stride, int pad, int relu, hipStream_t st);   // conv3x3_halo.hip
 int conv3x3_halo_enable(int on);
+int wino_set_ablate(int bits);                                 // conv_winograd.hip
 }
 
 using namespace vatl;
@@ -1574,7 +1575,7 @@ extern "C" int vatl_crop_tune_px(int px);
 extern "C" int vatl_tune_set(int knob, int value) {
     // Ablation settings (schedule variants 10..13, wgrad ablation bits) produce WRONG results by construction; they exist
     // for the profiling notes only and are refused unless the process opted in.
-    const bool ablation = (knob == 0 && value >= 10) || ((knob == 4 || knob == 6) && value != 0);
+    const bool ablation = (knob == 0 && value >= 10) || ((knob == 4 || knob == 6 || knob == 17) && value != 0);
     if (ablation) {
 #ifdef VATL_ABLATION
         const char* ok = getenv("VATL_ALLOW_ABLATION");
@@ -1591,6 +1592,7 @@ extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 8 && (value == 0 || value == 1)) return conv3x3_halo_enable(value);
     if (knob == 9 && (value == 0 || value == 1)) { g_splitk_policy.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 16 && vatl_crop_tune_px(value) == 0) return 0;
+    if (knob == 17 && value >= 0 && value <= 31) return wino_set_ablate(value);
     if (knob == 12 && (value == 0 || value == 1)) { g_streamk.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 10 && (value == 1 || value == 2)) { g_persist_dist.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);

@@ -44,6 +44,8 @@ struct WinoParams {
     int m_tiles, n_tiles;
     int relu;
     int stages;                       // Cin / 16
+    int ablate;                       // profiling library only (vatl_tune_set(17, bits), wrong results): 1 no output transform, 2 no LDS
+                                      // reads / input transform, 4 no filter loads, 8 no staging DMA, 16 no barriers
     unsigned x_bytes, u_bytes, y_bytes;
 };
 
@@ -61,7 +63,9 @@ constexpr int W_TB = 64;                        // tiles per block
 constexpr int W_CK = 16;                        // channels per LDS stage
 constexpr int W_SLOTS = W_TB + 1;               // 64 tiles + one halo slot
 constexpr int W_PIX = 8 * W_SLOTS;              // (4 tile rows) x (even, odd) x slots
-constexpr int W_STAGE = W_PIX * W_CK;           // floats per stage
+constexpr int W_ITEMS = W_PIX * 4;              // 16-byte pieces of a stage
+constexpr int W_DMA = (W_ITEMS + 63) / 64;      // wave-wide LDS-DMA instructions per stage (1 KB each; the last one is half used)
+constexpr int W_STAGE = W_DMA * 256;            // floats per stage
 constexpr int W_ROW = 2 * W_SLOTS * W_CK;       // floats per tile row i
 constexpr int W_ZERO = 16;                      // floats of the zero pixel in front of the stages
 constexpr int wino_lds_floats(int NH) {
@@ -69,15 +73,16 @@ constexpr int wino_lds_floats(int NH) {
     return loop > epi ? loop : epi;
 }
 
+typedef __attribute__((address_space(3))) void wlds_void;
+
+// (body in a __device__ function: with the DMA builtin inside the __global__ template hipcc 7.2 drops the kernel's host stub)
 template <int NH>
-__global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void conv3x3_winograd_kernel(WinoParams p) {
-    constexpr int NT = 256 * NH, BN = 32 * NH;
-    constexpr int ITEMS = W_PIX * 4;                       // 16-byte pieces of a stage
-    constexpr int NLD = (ITEMS + NT - 1) / NT;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float* smem) {
+    constexpr int NT = 256 * NH, BN = 32 * NH, NW = 4 * NH;
+    constexpr int NLD = (W_DMA + NW - 1) / NW;             // DMA instructions per wave per stage
     float* Rs = smem + W_ZERO;                             // [2][4 rows][2 parities][65 slots][16 channels], chunk-swizzled
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xi = wave / NH, nh = wave % NH;
 
     // XCD-aware tile order: block b runs on XCD b % 8; each XCD gets a contiguous run of tiles with the m-tile fastest, so the
@@ -91,18 +96,20 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void conv3x3_winograd_ke
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
 
-    // ---- staging: item q = (pixel, 16-byte chunk); pixel = (row i, parity, slot) --------------------------------------------------
-    unsigned goff[NLD];                                    // byte offset of the item's first stage (WOOB: outside the image / launch)
-    int lw[NLD];                                           // its LDS position (floats, inside a stage); -1 = no item
+    // ---- staging by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write pass).  The destination of a wave instruction is
+    // lane-linear (base + lane * 16 bytes), so the chunk swizzle is applied on the SOURCE side: LDS position q = (pixel q >> 2, chunk
+    // position q & 3) receives the pixel's global chunk (q & 3) ^ ((slot >> 2) & 3).  pixel = (row i, parity, slot).  Outside the image
+    // / launch the offset is out of range and the DMA writes zeros.
+    unsigned goff[NLD];                                    // byte offset of the lane's piece in the first stage (WOOB: zeros)
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-        const int q = tid + NT * u;
-        goff[u] = WOOB; lw[u] = -1;
-        if (q < ITEMS) {
-            const int chunk = q & 3, pix = q >> 2;
+        const int q = (wave + NW * u) * 64 + lane;
+        goff[u] = WOOB;
+        if (q < W_ITEMS) {
+            const int cpos = q & 3, pix = q >> 2;
             const int ipar = pix / W_SLOTS, slot = pix - ipar * W_SLOTS;
             const int i = ipar >> 1, par = ipar & 1;
-            lw[u] = pix * W_CK + ((chunk ^ ((slot >> 2) & 3)) << 2);
+            const int chunk = cpos ^ ((slot >> 2) & 3);
             const int m = m0 + slot - par;                 // even array: slot s = tile m0 + s;  odd array: slot s = tile m0 + s - 1
             if (m >= 0 && m < p.Mtiles) {
                 const int b = m / p.tpi, r = m - b * p.tpi;
@@ -112,16 +119,13 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void conv3x3_winograd_ke
             }
         }
     }
-    f32x4 sg[NLD];
-    auto stage_load = [&](int st) {
+    auto stage_dma = [&](int buf, int st) {
         const bool live = st < p.stages;
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) sg[u] = wbuf_load4(xr, (live && goff[u] != WOOB) ? goff[u] + (unsigned)st * (W_CK * 4) : WOOB);
-    };
-    auto stage_store = [&](int buf) {
-#pragma unroll
         for (int u = 0; u < NLD; ++u)
-            if (lw[u] >= 0) *reinterpret_cast<f32x4*>(&Rs[buf * W_STAGE + lw[u]]) = sg[u];
+            if (wave + NW * u < W_DMA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (wlds_void*)(Rs + buf * W_STAGE + (wave + NW * u) * 256), 16,
+                                                         (live && goff[u] != WOOB) ? goff[u] + (unsigned)st * (W_CK * 4) : WOOB, 0, 0, 0);
     };
 
     // ---- fragment addressing: lane = (tile l & 31 of a half, channel quad l >> 5) ---------------------------------------------------
@@ -150,11 +154,16 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void conv3x3_winograd_ke
     const float sgn = xi == 1 ? 1.f : -1.f;
     const int roa = ia * W_ROW, rob = ib * W_ROW;
 
+#ifdef VATL_ABLATION
+    const int abl = p.ablate;
+#else
+    constexpr int abl = 0;
+#endif
     // ---- U fragments: [n_tile][step][position][nh][lane][4] ----------------------------------------------------------------------------
     const int steps = p.stages * 2;
     const unsigned ubase = (unsigned)((((n_tile * steps) * 16 + 4 * xi) * NH + nh) * 64 + lane) << 4;   // bytes; + step * 16*NH*1024 + nu * NH*1024
     auto u_load = [&](f32x4 (&dst)[4], int step) {
-        const bool live = step < steps;
+        const bool live = step < steps && !(abl & 4);
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? ubase + (unsigned)step * (16 * NH * 1024) + nu * (NH * 1024) : WOOB);
     };
@@ -169,15 +178,19 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void conv3x3_winograd_ke
 
     if (tid < W_ZERO / 4) *reinterpret_cast<f32x4*>(&smem[tid * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 ua[4], ub[4];
-    stage_load(0);
+    stage_dma(0, 0);
     u_load(ua, 0);
-    stage_store(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMA pieces have landed
     __syncthreads();
 
     auto step_mfma = [&](const float* Rb, int x8, const f32x4 (&uu)[4]) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x4 tc[4];
+            if (abl & 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tc[j] = f32x4{1.f + j, 2.f, 3.f, 4.f + x8};
+            } else
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool z = ra[half][j] < 0;            // the zero pixel has no rows / stages
@@ -200,15 +213,37 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void conv3x3_winograd_ke
     for (int st = 0; st < p.stages; ++st) {
         const int buf = st & 1;
         const float* Rb = Rs + buf * W_STAGE;
-        stage_load(st + 1);
+        // the scheduler barriers keep the requests where they are written: without them hipcc sinks the staging loads to just
+        // before their LDS writes and the filter loads to just before their first MFMA (latency fully exposed)
+        if (st + 1 < p.stages && !(abl & 8)) stage_dma(buf ^ 1, st + 1);
         u_load(ub, 2 * st + 1);
+        __builtin_amdgcn_sched_barrier(0);
         step_mfma(Rb, 0, ua);
+        __builtin_amdgcn_sched_barrier(0);
         u_load(ua, 2 * st + 2);
+        __builtin_amdgcn_sched_barrier(0);
         step_mfma(Rb, 8, ub);
-        if (st + 1 < p.stages) stage_store(buf ^ 1);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 16)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next stage have landed
+            __syncthreads();
+        }
     }
 
+#ifdef VATL_ABLATION
+    if (abl & 16) __syncthreads();
+    if (abl & 1) {                     // keep the accumulators alive, skip the write-out
+        float sacc = 0.f;
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc += acc[nu][half][e];
+        if (sacc == 12345.678f) p.y[0] = sacc;
+        return;
+    }
+#endif
     // ---- output transform -----------------------------------------------------------------------------------------------------------------
     // nu sum in registers: P[b = 0] = M0 + M1 + M2, P[b = 1] = M1 - M2 - M3;  Ps[xi][b][tile][n] in LDS
     constexpr int LDP = BN + 4;
@@ -301,6 +336,12 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void conv3x3_winograd_ke
     }
 }
 
+template <int NH>
+__global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void conv3x3_winograd_kernel(WinoParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv3x3_winograd_body<NH>(p, smem);
+}
+
 // U = G g G^T in double, rounded once; fragment order [n_tile][step = c / 8][position][nh][lane = (c % 8 / 4) * 32 + n % 32][c % 4].
 // mode 0: g = w[n][c] (forward);  mode 1: the data-gradient filter g = rot180(w[c][n]) (w is [Cin_eff = rows][Cout_eff]... see the C API)
 __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int CoutPad, int NH, int mode, int w_i) {
@@ -343,6 +384,8 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict_
 }
 
 static std::atomic<unsigned> g_wino_lds_done[2];
+static std::atomic<int> g_wino_ablate{0};
+int wino_set_ablate(int bits) { g_wino_ablate.store(bits, std::memory_order_relaxed); return 0; }
 
 template <int NH>
 static int launch_wino(const WinoParams& p, hipStream_t st) {
@@ -394,6 +437,7 @@ static int winograd_impl(const float* x, const float* u, const float* scale, con
     p.m_tiles = cdiv(mt, W_TB); p.n_tiles = cdiv(Cout, bn);
     p.stages = Cin / W_CK;
     p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.u_bytes = (unsigned)(ue * 4);
+    p.ablate = g_wino_ablate.load(std::memory_order_relaxed);
     if (row_blocks_used) *row_blocks_used = p.m_tiles;
     return nh == 1 ? launch_wino<1>(p, (hipStream_t)stream) : launch_wino<2>(p, (hipStream_t)stream);
 }

@@ -826,6 +826,24 @@ def conv2d_fwd_bnstats(x, w_packed, cout: int, r: int, s: int, stride: int, pad:
     return [z] + _bn_finalize(stats, used.value, m, cout, (gamma, beta, running_mean, running_var, momentum, eps), x.device)
 
 
+def conv3x3_winograd_fwd_stats(x, u_packed, cout: int):
+    """Training forward of a 3x3 / stride-1 layer through Winograd: z = conv(x) and the row-block (sum, sum^2) partials of z.
+    -> z, stats (float64), row blocks written."""
+    n, h, w, cin = x.shape
+    z = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    stats = torch.empty(int(lib().vatl_winograd_stats_row_blocks(n, h, w)) * cout * 2, device=x.device, dtype=torch.float64)
+    used = C.c_int64(0)
+    _check(lib().vatl_conv3x3_winograd_fwd_stats(_ptr(x), _ptr(u_packed), _ptr(z), _ptr(stats, torch.float64), C.addressof(used), n, h, w, cin,
+                                                 cout, _stream()), "vatl_conv3x3_winograd_fwd_stats")
+    return z, stats, used.value
+
+
+def conv3x3_winograd_fwd_bnstats(x, u_packed, cout: int, gamma, beta, running_mean, running_var, momentum: float, eps: float):
+    """conv2d_fwd_bnstats for the Winograd route: -> z, save_mean, save_invstd, scale, bias; running stats updated in place."""
+    z, stats, used = conv3x3_winograd_fwd_stats(x, u_packed, cout)
+    return [z] + _bn_finalize(stats, used, z.numel() // cout, cout, (gamma, beta, running_mean, running_var, momentum, eps), x.device)
+
+
 def deconv4x4s2_fwd_bnstats(x, w_packed, cout: int, gamma, beta, running_mean, running_var, momentum: float, eps: float):
     n, h, w, cin = x.shape
     z = torch.empty((n, 2 * h, 2 * w, cout), device=x.device, dtype=torch.float32)
