@@ -330,10 +330,14 @@ int vatl_bn_train_bwd_relu_pool(const float* dpool, const uint8_t* idx, const fl
                                 float* dbeta, int N, int H, int W, int C, float* coef3C, double* workspace, void* stream);
 /* Every weight re-pack of one fine-tune step in ONE launch (the per-tensor entry points vatl_pack_conv_weight,
  * vatl_pack_dgrad_weight, vatl_pack_deconv4x4s2_weight produce the same bytes one launch each).  jobs_device: device
- * array of njobs descriptors sorted by first_block = the running sum of ceil(elements / 1024) over the preceding jobs;
+ * array of njobs descriptors sorted by first_block = the running sum of ceil(elements / 1024) (kinds 3 / 4: elements / 4096) over the
+ * preceding jobs;
  * total_blocks = that sum over all jobs.  kind 0: conv forward layout, (a, b, c) = (CoutPad, Spad, CinPad);
  * kind 1: data-gradient layout, (a, b, c) = (CinPad, CoutK, ntaps) with the taps in tap_r / tap_s;
- * kind 2: ConvTranspose2d(4,2,1) layout, src (Cin,Cout,4,4), a = CoutPad. */
+ * kind 2: ConvTranspose2d(4,2,1) layout, src (Cin,Cout,4,4), a = CoutPad;
+ * kind 3 / 4: Winograd F(2x2,3x3) filter transform, forward / data gradient (vatl_pack_winograd_weight): (Cout, Cin) of the PACKED
+ *   filter, a = its padded Cout, b = 32-channel groups per tile (a / 32 <= 1 ? 1 : 2), c = Cin (kind 3) or Cout (kind 4) = the inner
+ *   dimension of src. */
 typedef struct VatlPackJob {
     const float* src;
     float* dst;
@@ -468,6 +472,12 @@ int vatl_conv3x3_winograd_fwd(const float* x, const float* u, const float* scale
 int64_t vatl_winograd_stats_row_blocks(int64_t N, int H, int W);
 int vatl_conv3x3_winograd_fwd_stats(const float* x, const float* u, float* y, double* stats, int64_t* row_blocks_used, int N, int H, int W,
                                     int Cin, int Cout, void* stream);
+/* Winograd counterpart of vatl_conv2d_fwd_ex_bnbwd (3x3 / stride 1 / pad 1 data gradients; u packed with data_gradient = 1): y receives
+ * g = (conv(x) + residual) * [consumer layer's ReLU mask], `stats` the (sum g, sum g * xhat) row-block partials
+ * (capacity vatl_winograd_stats_row_blocks(N, H, W) * Cout * 2 doubles). */
+int vatl_conv3x3_winograd_fwd_bnbwd(const float* x, const float* u, const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
+                                    const float* bn_z, const float* bn_mask_y, const float* bn_scale, const float* bn_bias,
+                                    const float* bn_mean, const float* bn_invstd, double* stats, int64_t* row_blocks_used, void* stream);
 
 #ifdef __cplusplus
 }

@@ -654,7 +654,9 @@ def test_b16_default_init_step_vs_reference_and_float64(vh, name):
         nrm = float(named[key].grad.double().norm()) / max(float(g[f"{name}_grad_norm::{key}"]), 1e-30)
         record("b16_grad", model=name, key=key, ours_vs_f64=ours, reference_vs_f64=theirs, norm_ratio=nrm)
         tight += theirs < 1e-4
-        if not (ours <= 1.5 * theirs + 1e-4 and abs(nrm - 1) < 5e-3):
+        # the norm may differ from the reference's by 0.5 % plus half of the reference's own distance from float64 on that tensor (two
+        # fp32 evaluations of a tensor that is 2 % away from float64 do not share their norm to 0.5 %)
+        if not (ours <= 1.5 * theirs + 1e-4 and abs(nrm - 1) < 5e-3 + 0.5 * theirs):
             bad.append((key, ours, theirs, nrm))
     assert not bad, bad
     assert tight >= 2                                        # the head tensors are pinned at the 1e-4 level

@@ -108,6 +108,27 @@ def test_winograd_bits_do_not_depend_on_the_batch_position(vh):
         assert torch.equal(again, full)
 
 
+def test_winograd_tile_configurations_give_the_same_bits(vh):
+    """Large launches run 64-tile blocks, small ones 32 x 32 blocks (vatl_tune_set(18, .): 1 / 2 force one): a tile's arithmetic is the same."""
+    g = torch.Generator(device="cpu").manual_seed(29)
+    try:
+        for n, h, w, cin, cout in ((9, 16, 12, 64, 128), (4, 13, 9, 32, 32), (70, 8, 6, 48, 96)):
+            x = torch.randn((n, h, w, cin), generator=g).to(dev())
+            wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.05).to(dev())
+            r = torch.randn((n, h, w, cout), generator=g).to(dev())
+            u = vh.pack_winograd_weight(wt)
+            outs = []
+            for cfg in (1, 2, 0):
+                vh.tune_set(18, cfg)
+                y, stats, blocks = vh.conv3x3_winograd_fwd_stats(x, u, cout)
+                outs.append((vh.conv3x3_winograd_fwd(x, u, None, None, cout, True, residual=r), y,
+                             stats[:blocks * cout * 2].view(blocks, cout, 2).sum(0)))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[2][0], outs[0][0])
+            assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-3)   # (fp32 partial sums over different row groups)
+    finally:
+        vh.tune_set(18, 0)
+
+
 def test_winograd_statistics_epilogue_matches_the_stored_tensor(vh):
     """Training forward: y = x * w and the (sum, sum of squares) row-block partials that BatchNorm's finalize reduces."""
     import ctypes as C
@@ -166,3 +187,28 @@ def test_inference_plans_route_3x3_layers_through_winograd(vh, monkeypatch):
     e = rel_err(out.cpu().numpy(), direct.cpu().numpy())
     record("winograd_vs_direct_simplepose_r50", rel=e)
     assert e < 1e-4
+
+
+def test_pack_plan_refreshes_winograd_filters_with_the_same_bits(vh):
+    """The one-launch re-pack of a fine-tune step (vatl_pack_weights_multi, kinds 3 / 4) writes what vatl_pack_winograd_weight writes."""
+    g = torch.Generator(device="cpu").manual_seed(23)
+    ws = [(torch.randn(s, generator=g) * 0.1).to(dev()) for s in ((64, 64, 3, 3), (32, 32, 3, 3), (48, 80, 3, 3), (128, 256, 3, 3))]
+    want = [(vh.pack_winograd_weight(w), vh.pack_winograd_weight(w, data_gradient=True)) for w in ws]
+    plan = vh.PackPlan()
+    prev = vh.set_pack_plan(plan)
+    try:
+        plan.begin()
+        first = [(vh.pack_winograd_weight(w), vh.pack_winograd_weight(w, data_gradient=True)) for w in ws]
+        other = vh.pack_conv_weight(ws[0])                  # a job of another kind in the same table
+        plan.seal()
+        for a, b in first:
+            a.zero_(); b.zero_()
+        other_want = other.clone(); other.zero_()
+        plan.begin()                                        # one launch refreshes every recorded destination
+        again = [(vh.pack_winograd_weight(w), vh.pack_winograd_weight(w, data_gradient=True)) for w in ws]
+    finally:
+        vh.set_pack_plan(prev)
+    for (a, b), (fa, fb), (wa, wb) in zip(again, first, want):
+        assert a.data_ptr() == fa.data_ptr() and b.data_ptr() == fb.data_ptr()
+        assert torch.equal(a, wa) and torch.equal(b, wb)
+    assert torch.equal(other, other_want)

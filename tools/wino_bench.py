@@ -40,8 +40,10 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--layers", default="")
     ap.add_argument("--check", type=int, default=8)
+    ap.add_argument("--cfg", type=int, default=0, help="vatl_tune_set(18, v): 0 tile configuration by launch size, 1 large tiles, 2 small tiles")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    vh.tune_set(18, a.cfg)
     warm = torch.randn((4096, 4096), device=dev)
     for _ in range(100):
         warm @ warm

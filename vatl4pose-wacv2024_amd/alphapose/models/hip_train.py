@@ -128,6 +128,7 @@ import os as _os
 # BatchNorm-backward reduction inside the producing data-gradient launch (vatl_conv2d_fwd_ex_bnbwd); VATL_FUSE_BN_BWD=0 = the
 # stand-alone reduction pass (same values up to the summation order of the per-channel sums)
 _FUSE_BN_BWD = _os.environ.get("VATL_FUSE_BN_BWD", "1") != "0"
+_WINOGRAD = _os.environ.get("VATL_WINOGRAD", "1") != "0"    # 3x3 / stride-1 layers: forward + data gradient as Winograd F(2x2,3x3)
 # ... for layers with at least this many channels: on the narrow tiles (32 / 64 output channels) the statistics epilogue costs
 # more than the stand-alone reduction pass it replaces (HRNet-W32 step 63.9 -> 69.4 ms with every layer fused)
 _FUSE_BN_MIN_C = int(_os.environ.get("VATL_FUSE_BN_MINC", "128"))
@@ -206,15 +207,22 @@ class _ConvBN:
         self.conv, self.bn, self.relu, self.need_dx = conv, bn, relu, need_dx
         self.cout, self.cin, self.r, self.s = conv.weight.shape
         self.stride, self.pad = conv.stride[0], conv.padding[0]
+        # 3x3 / stride 1 / pad 1: forward and data gradient on the Winograd route (csrc/conv_winograd.hip; geometry-only choice)
+        self.wino = (_WINOGRAD and (self.r, self.s, self.stride, self.pad) == (3, 3, 1, 1) and self.cin % 16 == 0 and self.cout % 16 == 0)
 
     # ---- forward -------------------------------------------------------------
     def forward(self, x, skip=None, relu=None):
         relu = self.relu if relu is None else relu
-        w = vh.pack_conv_weight(self.conv.weight.detach())
         bn = self.bn
         # z = conv(x); the batch statistics come out of the conv epilogue (no extra pass over z)
-        z, mean, invstd, scale, bias = vh.conv2d_fwd_bnstats(x, w, self.cout, self.r, self.s, self.stride, self.pad, bn.weight.detach(),
-                                                             bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        if self.wino:
+            z, mean, invstd, scale, bias = vh.conv3x3_winograd_fwd_bnstats(x, vh.pack_winograd_weight(self.conv.weight.detach()), self.cout,
+                                                                           bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                                                           bn.momentum, bn.eps)
+        else:
+            w = vh.pack_conv_weight(self.conv.weight.detach())
+            z, mean, invstd, scale, bias = vh.conv2d_fwd_bnstats(x, w, self.cout, self.r, self.s, self.stride, self.pad, bn.weight.detach(),
+                                                                 bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps)
         _count_batch(bn)
         y = vh.scale_bias_act(z, scale, bias, skip, relu)
         if relu:
@@ -296,6 +304,11 @@ class _ConvBN:
 
         def conv(*a, **k):                                # with a consumer spec: mask + BatchNorm-backward reduction in the epilogue
             return vh.conv2d_fwd_ex_bnbwd(*a, spec, **k) if spec is not None else vh.conv2d_fwd_ex(*a, **k)
+        if self.wino:
+            ud = vh.pack_winograd_weight(wt, data_gradient=True)
+            if spec is not None:
+                return vh.conv3x3_winograd_fwd_bnbwd(dz, ud, cin, spec, residual=residual)
+            return vh.conv3x3_winograd_fwd(dz, ud, None, None, cin, False, residual=residual)
         if self.stride == 1:
             wd = vh.pack_dgrad_weight(wt, _flipped_taps(self.r, self.s))
             return conv(dz, wd, cin, self.r, self.s, 1, self.r - 1 - self.pad, self.s - 1 - self.pad, h, w, h, w, 1, 1, 0, 0, residual=residual)

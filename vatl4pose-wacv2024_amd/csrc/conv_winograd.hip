@@ -26,7 +26,9 @@
 //     stores full NHWC rows, with scale / bias / residual / ReLU (and the BatchNorm statistics of the training forward) fused.
 // The per-output arithmetic depends only on the tile's own pixels: results are independent of the batch position (SURVEY.md §7 hard part 3).
 #include "common.h"
+#include "winograd_pack.h"
 
+#include <algorithm>
 #include <atomic>
 
 namespace vatl {
@@ -39,11 +41,21 @@ struct WinoParams {
     const float* res;
     float* y;
     double* stats;
+    // BatchNorm-backward fusion (data-gradient launches of the fine-tune step; semantics of ConvParams::bz.. in conv_igemm.hip): the
+    // tile being stored is dL/dy of a Conv+BN(+ReLU) layer whose conv output is bz; the epilogue applies that layer's ReLU mask, stores
+    // the masked gradient g and accumulates (sum g, sum g*xhat) into `stats`
+    const float* bz;
+    const float* bmy;
+    const float* bsc;
+    const float* bbi;
+    const float* bmu;
+    const float* bis;
     int N, H, W, Cin, Cout;
     int TH, TW, tpi, Mtiles;          // tiles per image column / row / image, tiles in the launch
     int m_tiles, n_tiles;
     int relu;
     int stages;                       // Cin / 16
+    int nhp;                          // 32-channel groups per filter tile of the packing (vatl_pack_winograd_weight: 1 if Cout <= 32, else 2)
     int ablate;                       // profiling library only (vatl_tune_set(17, bits), wrong results): 1 no output transform, 2 no LDS
                                       // reads / input transform, 4 no filter loads, 8 no staging DMA, 16 no barriers
     unsigned x_bytes, u_bytes, y_bytes;
@@ -59,25 +71,31 @@ __device__ __forceinline__ void wbuf_store4(__amdgpu_buffer_rsrc_t r, unsigned b
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wu32x4, v), r, byte_off, 0, 0);
 }
 
-constexpr int W_TB = 64;                        // tiles per block
 constexpr int W_CK = 16;                        // channels per LDS stage
-constexpr int W_SLOTS = W_TB + 1;               // 64 tiles + one halo slot
-constexpr int W_PIX = 8 * W_SLOTS;              // (4 tile rows) x (even, odd) x slots
-constexpr int W_ITEMS = W_PIX * 4;              // 16-byte pieces of a stage
-constexpr int W_DMA = (W_ITEMS + 63) / 64;      // wave-wide LDS-DMA instructions per stage (1 KB each; the last one is half used)
-constexpr int W_STAGE = W_DMA * 256;            // floats per stage
-constexpr int W_ROW = 2 * W_SLOTS * W_CK;       // floats per tile row i
 constexpr int W_ZERO = 16;                      // floats of the zero pixel in front of the stages
-constexpr int wino_lds_floats(int NH) {
-    const int loop = W_ZERO + 2 * W_STAGE, epi = 4 * 2 * W_TB * (32 * NH + 4);
+template <int HALVES>
+struct WinoGeom {
+    static constexpr int TB = 32 * HALVES;      // tiles per block
+    static constexpr int SLOTS = TB + 1;        // + one halo slot
+    static constexpr int PIX = 8 * SLOTS;       // (4 tile rows) x (even, odd) x slots
+    static constexpr int ITEMS = PIX * 4;       // 16-byte pieces of a stage
+    static constexpr int DMA = (ITEMS + 63) / 64;   // wave-wide LDS-DMA instructions per stage (1 KB each; the last one is partly used)
+    static constexpr int STAGE = DMA * 256;     // floats per stage
+    static constexpr int ROW = 2 * SLOTS * W_CK;    // floats per tile row i
+};
+template <int NH, int HALVES>
+constexpr int wino_lds_floats() {
+    const int loop = W_ZERO + 2 * WinoGeom<HALVES>::STAGE, epi = 4 * 2 * WinoGeom<HALVES>::TB * (32 * NH + 4);
     return loop > epi ? loop : epi;
 }
 
 typedef __attribute__((address_space(3))) void wlds_void;
 
 // (body in a __device__ function: with the DMA builtin inside the __global__ template hipcc 7.2 drops the kernel's host stub)
-template <int NH>
+template <int NH, int HALVES, bool BNB>
 __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float* smem) {
+    using G = WinoGeom<HALVES>;
+    constexpr int W_TB = G::TB, W_SLOTS = G::SLOTS, W_ITEMS = G::ITEMS, W_DMA = G::DMA, W_STAGE = G::STAGE, W_ROW = G::ROW;
     constexpr int NT = 256 * NH, BN = 32 * NH, NW = 4 * NH;
     constexpr int NLD = (W_DMA + NW - 1) / NW;             // DMA instructions per wave per stage
     float* Rs = smem + W_ZERO;                             // [2][4 rows][2 parities][65 slots][16 channels], chunk-swizzled
@@ -132,9 +150,9 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
     // ra[half][j]: float index (relative to Rs, tile row 0, stage 0, first 8-channel step) of column j of the lane's tile; the second
     // step of a stage is the same index ^ 8.  A border column points at the zero pixel (index -16).
     const int h = lane >> 5;
-    int ra[2][4];
+    int ra[HALVES][4];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < HALVES; ++half) {
         const int tl = 32 * half + (lane & 31);
         const int m = m0 + tl;
         const int mm = m < p.Mtiles ? m : p.Mtiles - 1;
@@ -161,18 +179,21 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
 #endif
     // ---- U fragments: [n_tile][step][position][nh][lane][4] ----------------------------------------------------------------------------
     const int steps = p.stages * 2;
-    const unsigned ubase = (unsigned)((((n_tile * steps) * 16 + 4 * xi) * NH + nh) * 64 + lane) << 4;   // bytes; + step * 16*NH*1024 + nu * NH*1024
+    // (the packing groups 32 p.nhp channels per filter tile; this block's 32-channel group nh_g of it)
+    const int n32 = n_tile * NH + nh, ut = n32 / p.nhp, nh_g = n32 - ut * p.nhp;
+    const unsigned ubase = (unsigned)((((ut * steps) * 16 + 4 * xi) * p.nhp + nh_g) * 64 + lane) << 4;   // bytes; + step * 16*nhp*1024 + nu * nhp*1024
+    const unsigned ustep = 16u * p.nhp * 1024u, unu = p.nhp * 1024u;
     auto u_load = [&](f32x4 (&dst)[4], int step) {
         const bool live = step < steps && !(abl & 4);
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? ubase + (unsigned)step * (16 * NH * 1024) + nu * (NH * 1024) : WOOB);
+        for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? ubase + (unsigned)step * ustep + nu * unu : WOOB);
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][HALVES];
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
+        for (int half = 0; half < HALVES; ++half)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[nu][half][e] = 0.f;
 
@@ -185,7 +206,7 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
 
     auto step_mfma = [&](const float* Rb, int x8, const f32x4 (&uu)[4]) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < HALVES; ++half) {
             f32x4 tc[4];
             if (abl & 2) {
 #pragma unroll
@@ -237,7 +258,7 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-            for (int half = 0; half < 2; ++half)
+            for (int half = 0; half < HALVES; ++half)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) sacc += acc[nu][half][e];
         if (sacc == 12345.678f) p.y[0] = sacc;
@@ -249,7 +270,7 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
     constexpr int LDP = BN + 4;
     float* Ps = smem;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < HALVES; ++half) {
         const int cl = 32 * nh + (lane & 31);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -266,7 +287,7 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? p.y_bytes : 0u, 0x00020000);
     constexpr int C4 = BN / 4;                             // channel quads per tile row
     constexpr int TPP = NT / (2 * C4);                     // tiles per pass (16)
-    constexpr int NP = W_TB / TPP;                         // passes (4)
+    constexpr int NP = W_TB / TPP;                         // passes
     const int c4 = tid % C4, bq = (tid / C4) & 1, tl0 = tid / (2 * C4);
     const int n = n0 + c4 * 4;
     const bool nv = n < p.Cout;
@@ -275,6 +296,13 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
     const f32x4 bi = (nv && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + n) : nul;
     const float lo = p.relu ? 0.f : -INFINITY;
     f32x4 ssum = nul, ssq = nul;
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bz : p.x), 0, BNB ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bmy : p.x), 0, (BNB && p.bmy) ? p.y_bytes : 0u, 0x00020000);
+    f32x4 mu = nul, is = nul, msc = nul, mbi = one;       // no mask: 0 * z + 1 > 0
+    if (BNB && nv) {
+        mu = *reinterpret_cast<const f32x4*>(p.bmu + n); is = *reinterpret_cast<const f32x4*>(p.bis + n);
+        if (p.bsc) { msc = *reinterpret_cast<const f32x4*>(p.bsc + n); mbi = *reinterpret_cast<const f32x4*>(p.bbi + n); }
+    }
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
         const int tl = tl0 + u * TPP;
@@ -298,6 +326,24 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
         f32x4 yv[2];
         yv[0] = pq[0] + pq[1] + pq[2];
         yv[1] = pq[1] - pq[2] - pq[3];
+        if constexpr (BNB) {
+            f32x4 zt[2], yt[2] = {nul, nul};
+            zt[0] = wbuf_load4(zr, off[0]); zt[1] = wbuf_load4(zr, off[1]);
+            if (p.bmy) { yt[0] = wbuf_load4(mr, off[0]); yt[1] = wbuf_load4(mr, off[1]); }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                f32x4 gq;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float d = yv[a][c] + rs[a][c];
+                    const bool on = p.bmy ? yt[a][c] > 0.f : fmaf(zt[a][c], msc[c], mbi[c]) > 0.f;
+                    gq[c] = (on && off[a] != WOOB) ? d : 0.f;
+                    ssum[c] += gq[c];
+                    ssq[c] += gq[c] * ((zt[a][c] - mu[c]) * is[c]);
+                }
+                wbuf_store4(yr, off[a], gq);
+            }
+        } else {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             f32x4 o;
@@ -308,6 +354,7 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { ssum[c] += o[c]; ssq[c] += o[c] * o[c]; }
             }
+        }
         }
     }
     if (p.stats) {
@@ -336,62 +383,33 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
     }
 }
 
-template <int NH>
-__global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void conv3x3_winograd_kernel(WinoParams p) {
+// <NH = 2, HALVES = 2>: 64 tiles x 64 channels, 8 waves, one block per CU (large launches);  <1, 2>: 64 tiles x 32 channels (Cout <= 32),
+// two blocks per CU;  <1, 1>: 32 tiles x 32 channels, 64 accumulator registers, three blocks per CU — small launches (fine-tune batches),
+// where the large tile leaves CUs idle.  The arithmetic of a tile does not depend on the configuration: same bits.
+template <int NH, int HALVES, bool BNB>
+__global__ __launch_bounds__(256 * NH, NH == 1 ? (HALVES == 1 ? 3 : 2) : 1) void conv3x3_winograd_kernel(WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    conv3x3_winograd_body<NH>(p, smem);
+    conv3x3_winograd_body<NH, HALVES, BNB>(p, smem);
 }
 
-// U = G g G^T in double, rounded once; fragment order [n_tile][step = c / 8][position][nh][lane = (c % 8 / 4) * 32 + n % 32][c % 4].
-// mode 0: g = w[n][c] (forward);  mode 1: the data-gradient filter g = rot180(w[c][n]) (w is [Cin_eff = rows][Cout_eff]... see the C API)
-__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int CoutPad, int NH, int mode, int w_i) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= CoutPad * Cin) return;
-    const int n = idx / Cin, c = idx - n * Cin;
-    double g[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            double v = 0.0;
-            if (n < Cout) {
-                if (mode == 0) v = w[((long long)n * w_i + c) * 9 + r * 3 + s];                    // w[Cout][Cin][3][3]
-                else           v = w[((long long)c * w_i + n) * 9 + (2 - r) * 3 + (2 - s)];        // w[o = c][i = n] rotated
-            }
-            g[r][s] = v;
-        }
-    double tg[4][3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        tg[0][s] = g[0][s];
-        tg[1][s] = 0.5 * (g[0][s] + g[1][s] + g[2][s]);
-        tg[2][s] = 0.5 * (g[0][s] - g[1][s] + g[2][s]);
-        tg[3][s] = g[2][s];
-    }
-    const int BN = 32 * NH, steps = Cin / 8;
-    const int n_tile = n / BN, nn = n % BN, nh = nn / 32, nl = nn % 32;
-    const int step = c / 8, cc = c % 8, lane = (cc / 4) * 32 + nl, tt = cc % 4;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const double u0 = tg[a][0], u1 = 0.5 * (tg[a][0] + tg[a][1] + tg[a][2]), u2 = 0.5 * (tg[a][0] - tg[a][1] + tg[a][2]), u3 = tg[a][2];
-        const double uu[4] = {u0, u1, u2, u3};
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const long long o = ((((long long)(n_tile * steps + step) * 16 + (a * 4 + b)) * NH + nh) * 64 + lane) * 4 + tt;
-            out[o] = (float)uu[b];
-        }
-    }
+// U = G g G^T (winograd_pack.h): one block per (32 output channels, 8 input channels)
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int NH, int mode, int w_i) {
+    wino_pack_block(w, out, mode, w_i, Cout, Cin, NH, blockIdx.x, threadIdx.x);
 }
 
-static std::atomic<unsigned> g_wino_lds_done[2];
+static std::atomic<unsigned> g_wino_lds_done[8];
+static std::atomic<int> g_wino_cfg{0};            // vatl_tune_set(18, v): 0 / 2 = 32 x 32 blocks (default), 1 = 64-tile blocks
+int wino_set_cfg(int v) { g_wino_cfg.store(v, std::memory_order_relaxed); return 0; }
 static std::atomic<int> g_wino_ablate{0};
 int wino_set_ablate(int bits) { g_wino_ablate.store(bits, std::memory_order_relaxed); return 0; }
 
-template <int NH>
-static int launch_wino(const WinoParams& p, hipStream_t st) {
-    constexpr int smem = wino_lds_floats(NH) * (int)sizeof(float);
-    auto kern = conv3x3_winograd_kernel<NH>;
-    if (int rc = ensure_dynamic_lds((const void*)kern, smem, g_wino_lds_done[NH - 1], "conv3x3_winograd")) return rc;
+template <int NH, int HALVES, bool BNB>
+static int launch_wino(WinoParams& p, int64_t* row_blocks_used, hipStream_t st) {
+    constexpr int smem = wino_lds_floats<NH, HALVES>() * (int)sizeof(float);
+    auto kern = conv3x3_winograd_kernel<NH, HALVES, BNB>;
+    if (int rc = ensure_dynamic_lds((const void*)kern, smem, g_wino_lds_done[(NH - 1) * 2 + (HALVES - 1) + (BNB ? 4 : 0)], "conv3x3_winograd")) return rc;
+    p.m_tiles = cdiv(p.Mtiles, 32 * HALVES); p.n_tiles = cdiv(p.Cout, 32 * NH);
+    if (row_blocks_used) *row_blocks_used = p.m_tiles;
     hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles), dim3(256 * NH), smem, st, p);
     return check_launch("conv3x3_winograd");
 }
@@ -412,16 +430,18 @@ extern "C" int64_t vatl_winograd_weight_floats(int Cout, int Cin) { return (int6
 extern "C" int vatl_pack_winograd_weight(const float* w, float* u, int Cout, int Cin, int data_gradient, void* stream) {
     if (!w || !u || Cout <= 0 || Cin <= 0) return fail(VATL_EINVAL, "pack_winograd_weight: null pointer or empty filter");
     if (Cin % 16 != 0) return fail(VATL_EINVAL, "pack_winograd_weight: Cin %d must be a multiple of 16", Cin);
-    const int pad = vatl_winograd_cout_pad(Cout), total = pad * Cin;
+    const int pad = vatl_winograd_cout_pad(Cout);
     // data_gradient: the caller passes the FORWARD filter w[O][I][3][3] and asks for the filter of dX = conv(dY, rot180(w)^T):
     // Cout = I (channels of dX), Cin = O (channels of dY)
-    hipLaunchKernelGGL(wino_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, u, Cout, Cin, pad, wino_nh(Cout),
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)(pad / 32 * (Cin / 8))), dim3(256), 0, (hipStream_t)stream, w, u, Cout, Cin, wino_nh(Cout),
                        data_gradient ? 1 : 0, data_gradient ? Cout : Cin);
     return check_launch("wino_pack");
 }
 
+struct WinoBn { const float *z, *mask_y, *scale, *bias, *mean, *invstd; };
+
 static int winograd_impl(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, double* stats,
-                         int64_t* row_blocks_used, int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
+                         int64_t* row_blocks_used, int N, int H, int W, int Cin, int Cout, int relu, void* stream, const WinoBn* fuse = nullptr) {
     if (!x || !u || !y || N <= 0 || H <= 0 || W <= 0) return fail(VATL_EINVAL, "conv3x3_winograd: null pointer or empty batch");
     if (Cin % 16 != 0 || (Cout & 3)) return fail(VATL_EINVAL, "conv3x3_winograd: Cin %d must be a multiple of 16 and Cout %d of 4", Cin, Cout);
     WinoParams p{};
@@ -433,13 +453,20 @@ static int winograd_impl(const float* x, const float* u, const float* scale, con
     if (xe >= (1LL << 30) || ye >= (1LL << 30) || ue >= (1LL << 30) || mt >= (1LL << 30))
         return fail(VATL_EINVAL, "conv3x3_winograd: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
     p.Mtiles = (int)mt;
-    const int nh = wino_nh(Cout), bn = 32 * nh;
-    p.m_tiles = cdiv(mt, W_TB); p.n_tiles = cdiv(Cout, bn);
+    p.nhp = wino_nh(Cout);
     p.stages = Cin / W_CK;
     p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.u_bytes = (unsigned)(ue * 4);
     p.ablate = g_wino_ablate.load(std::memory_order_relaxed);
-    if (row_blocks_used) *row_blocks_used = p.m_tiles;
-    return nh == 1 ? launch_wino<1>(p, (hipStream_t)stream) : launch_wino<2>(p, (hipStream_t)stream);
+    if (fuse) { p.bz = fuse->z; p.bmy = fuse->mask_y; p.bsc = fuse->scale; p.bbi = fuse->bias; p.bmu = fuse->mean; p.bis = fuse->invstd; }
+    // The 32 x 32 configuration (three blocks per CU, 12 waves) beats the 64-tile ones at every size measured on MI355X — 1024 crops:
+    // l1.c2 1245 vs 1333 us, l4.c2 967 vs 1029, hr.b32 476 vs 537;  120 crops: l3.c2 150 vs 197, l4.c2 142 vs 191 (tools/wino_bench.py
+    // --cfg 2 / 1): the blocks of a CU overlap each other's prologue, barriers and output transform.  The large ones stay selectable.
+    const int cfg = g_wino_cfg.load(std::memory_order_relaxed);
+    const bool small = cfg != 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (small) return fuse ? launch_wino<1, 1, true>(p, row_blocks_used, st) : launch_wino<1, 1, false>(p, row_blocks_used, st);
+    if (p.nhp == 1) return fuse ? launch_wino<1, 2, true>(p, row_blocks_used, st) : launch_wino<1, 2, false>(p, row_blocks_used, st);
+    return fuse ? launch_wino<2, 2, true>(p, row_blocks_used, st) : launch_wino<2, 2, false>(p, row_blocks_used, st);
 }
 
 extern "C" int vatl_conv3x3_winograd_fwd(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y,
@@ -447,10 +474,21 @@ extern "C" int vatl_conv3x3_winograd_fwd(const float* x, const float* u, const f
     return winograd_impl(x, u, scale, bias, residual, y, nullptr, nullptr, N, H, W, Cin, Cout, relu, stream);
 }
 
-extern "C" int64_t vatl_winograd_stats_row_blocks(int64_t N, int H, int W) { return (N * ((H + 1) / 2) * ((W + 1) / 2) + W_TB - 1) / W_TB; }
+extern "C" int64_t vatl_winograd_stats_row_blocks(int64_t N, int H, int W) { return (N * ((H + 1) / 2) * ((W + 1) / 2) + 31) / 32; }   // capacity
 
 extern "C" int vatl_conv3x3_winograd_fwd_stats(const float* x, const float* u, float* y, double* stats, int64_t* row_blocks_used, int N, int H,
                                                int W, int Cin, int Cout, void* stream) {
     if (!stats || !row_blocks_used) return fail(VATL_EINVAL, "conv3x3_winograd_fwd_stats: null statistics buffer");
     return winograd_impl(x, u, nullptr, nullptr, nullptr, y, stats, row_blocks_used, N, H, W, Cin, Cout, 0, stream);
+}
+
+// Data-gradient launch fused with the reduction pass of the consumer layer's BatchNorm backward: the Winograd counterpart of
+// vatl_conv2d_fwd_ex_bnbwd (same masks, same statistics layout; u = the data-gradient packing of the filter).
+extern "C" int vatl_conv3x3_winograd_fwd_bnbwd(const float* x, const float* u, const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
+                                               const float* bn_z, const float* bn_mask_y, const float* bn_scale, const float* bn_bias,
+                                               const float* bn_mean, const float* bn_invstd, double* stats, int64_t* row_blocks_used, void* stream) {
+    if (!bn_z || !stats || !row_blocks_used || !bn_mean || !bn_invstd || (bn_scale && !bn_bias))
+        return fail(VATL_EINVAL, "conv3x3_winograd_fwd_bnbwd: needs z, mean, invstd and a statistics buffer");
+    const WinoBn bn{bn_z, bn_mask_y, bn_scale, bn_bias, bn_mean, bn_invstd};
+    return winograd_impl(x, u, nullptr, nullptr, residual, y, stats, row_blocks_used, N, H, W, Cin, Cout, 0, stream, &bn);
 }

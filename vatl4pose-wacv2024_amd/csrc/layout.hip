@@ -1,6 +1,7 @@
 // Layout changes, parameter packing, pooling: the HBM-bound glue around the
 // implicit-GEMM kernel.  All NHWC unless the name says otherwise.
 #include "common.h"
+#include "winograd_pack.h"
 
 #include <cstring>
 
@@ -353,7 +354,8 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __r
 
 // Every weight re-pack of a fine-tune step in ONE launch (the trainers need ~60 .. 180 packed copies per step — forward
 // layouts of the 3x3 / 7x7 / transposed convs, data-gradient layouts of every conv — and each used to be its own 5 us
-// launch).  jobs: device array sorted by first_block; a block of 256 threads makes 1024 consecutive elements of one job.
+// launch).  jobs: device array sorted by first_block; a block of 256 threads makes 1024 consecutive elements of one job (4096 of a
+// Winograd filter transform, kinds 3 / 4).
 // Element arithmetic = pack_conv_weight_kernel / pack_dgrad_weight_kernel / pack_deconv_weight_kernel.
 __global__ __launch_bounds__(256) void pack_multi_kernel(const VatlPackJob* __restrict__ jobs, int njobs) {
     __shared__ int sj;
@@ -371,6 +373,10 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const VatlPackJob* __re
     const float* __restrict__ w = J->src;
     float* __restrict__ out = J->dst;
     const int kind = J->kind, Cout = J->Cout, Cin = J->Cin, R = J->R, S = J->S, pa = J->a, pb = J->b, pc = J->c;
+    if (kind >= 3) {                                               // 3: Winograd forward filter, 4: Winograd data-gradient filter; b = NH, c = w_i
+        wino_pack_block(w, out, kind - 3, pc, Cout, Cin, pb, (long long)blockIdx.x - J->first_block, threadIdx.x);   // 4096 elements per block
+        return;
+    }
     const long long base = ((long long)blockIdx.x - J->first_block) * 1024;
     long long total;
     if (kind == 0) total = (long long)pa * R * pb * pc;            // [CoutPad][R][Spad][CinPad]

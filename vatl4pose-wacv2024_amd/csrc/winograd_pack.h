@@ -1,0 +1,47 @@
+// One element of the F(2x2, 3x3) filter transform U = G g G^T, shared by the dedicated pack kernel (conv_winograd.hip) and the
+// table-driven multi-pack launch (layout.hip) so that both produce the same bits.  Computed in double, rounded once.
+#pragma once
+
+namespace vatl {
+
+// Fragment order of the packed filter: [n_tile][step = c / 8][position][nh][lane = (c % 8 / 4) * 32 + n % 32][c % 4], n_tile = n / (32 NH).
+// One block of 256 threads makes the 16 x 256 elements of (32 output channels, one 8-channel step): thread = (channel n % 32, c % 8) reads
+// its nine filter taps once and writes one float per position — per position the block writes 1 KB contiguous.
+//   bl = block index inside the filter = (n / 32) * (Cin / 8) + c / 8;   blocks per filter = CoutPad / 32 * Cin / 8 = elements / 4096
+// mode 0: g = w[n][c] of a (Cout, Cin, 3, 3) filter (w_i = Cin);  mode 1: data gradient, g = rot180(w[o = c][i = n]) of the forward
+// filter (O, I, 3, 3) (w_i = I).  n >= Cout: zero (padding rows of the last channel tile).  Computed in double, rounded once.
+__device__ __forceinline__ void wino_pack_block(const float* __restrict__ w, float* __restrict__ out, int mode, int w_i, int Cout, int Cin, int NH,
+                                                long long bl, int tid) {
+    const int steps = Cin >> 3;
+    const int n32 = (int)(bl / steps), step = (int)(bl - (long long)n32 * steps);
+    const int nl = tid & 31, cc = tid >> 5;
+    const int n = n32 * 32 + nl, c = step * 8 + cc;
+    const int n_tile = n32 / NH, nh = n32 - n_tile * NH;
+    const int lane = (cc >> 2) * 32 + nl, tt = cc & 3;
+    double g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            double v = 0.0;
+            if (n < Cout) v = mode == 0 ? (double)w[((long long)n * w_i + c) * 9 + r * 3 + s] : (double)w[((long long)c * w_i + n) * 9 + (2 - r) * 3 + (2 - s)];
+            g[r][s] = v;
+        }
+    double tg[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        tg[0][s] = g[0][s];
+        tg[1][s] = 0.5 * (g[0][s] + g[1][s] + g[2][s]);
+        tg[2][s] = 0.5 * (g[0][s] - g[1][s] + g[2][s]);
+        tg[3][s] = g[2][s];
+    }
+    float* o = out + ((((long long)(n_tile * steps + step) * 16) * NH + nh) * 64 + lane) * 4 + tt;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const double uu[4] = {tg[a][0], 0.5 * (tg[a][0] + tg[a][1] + tg[a][2]), 0.5 * (tg[a][0] - tg[a][1] + tg[a][2]), tg[a][2]};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) o[(long long)(a * 4 + b) * NH * 256] = (float)uu[b];
+    }
+}
+
+}  // namespace vatl

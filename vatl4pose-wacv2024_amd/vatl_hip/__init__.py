@@ -80,6 +80,7 @@ SIGNATURES = {
     "vatl_conv3x3_winograd_fwd": (_i, [_p] * 6 + [_i] * 6 + [_p]),
     "vatl_winograd_stats_row_blocks": (_i64, [_i64, _i, _i]),
     "vatl_conv3x3_winograd_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vatl_conv3x3_winograd_fwd_bnbwd": (_i, [_p] * 4 + [_i] * 5 + [_p] * 9),
     "vatl_conv2d_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_deconv4x4s2_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_bn_train_finalize": (_i, [_p, _i64, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
@@ -287,7 +288,7 @@ class PackPlan:
             jb.kind, jb.Cout, jb.Cin, jb.R, jb.S, jb.a, jb.b, jb.c = f[:8]
             for t, (tr, ts) in enumerate(f[8]):
                 jb.tap_r[t], jb.tap_s[t] = tr, ts
-            blocks += (dst.numel() + 1023) // 1024
+            blocks += (dst.numel() + 1023) // 1024 if f[0] < 3 else dst.numel() // 4096     # Winograd filters: 4096 elements per block
         dev = next(iter(self.jobs.values()))[1].device
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.table = host.to(dev)
@@ -433,8 +434,16 @@ def pack_winograd_weight(w: torch.Tensor, data_gradient: bool = False) -> torch.
     if tuple(w.shape[2:]) != (3, 3):
         raise VatlError("pack_winograd_weight: 3x3 filters only")
     cout, cin = (ci, co) if data_gradient else (co, ci)
+    plan, key = getattr(_tls, "pack_plan", None), ("winograd", w.data_ptr(), tuple(w.shape), bool(data_gradient))
+    if plan is not None and w.is_contiguous():
+        kept = plan.lookup(key, w)
+        if kept is not None:
+            return kept
     out = torch.empty(int(lib().vatl_winograd_weight_floats(cout, cin)), device=w.device, dtype=torch.float32)
     _check(lib().vatl_pack_winograd_weight(_ptr(w.contiguous()), _ptr(out), cout, cin, int(data_gradient), _stream()), "vatl_pack_winograd_weight")
+    if plan is not None and w.is_contiguous():
+        pad = int(lib().vatl_winograd_cout_pad(cout))
+        plan.record(key, w, out, (4 if data_gradient else 3, cout, cin, 3, 3, pad, 1 if pad <= 32 else 2, ci, ()))
     return out
 
 
@@ -836,6 +845,25 @@ def conv3x3_winograd_fwd_stats(x, u_packed, cout: int):
     _check(lib().vatl_conv3x3_winograd_fwd_stats(_ptr(x), _ptr(u_packed), _ptr(z), _ptr(stats, torch.float64), C.addressof(used), n, h, w, cin,
                                                  cout, _stream()), "vatl_conv3x3_winograd_fwd_stats")
     return z, stats, used.value
+
+
+def conv3x3_winograd_fwd_bnbwd(x, u_packed, cout: int, spec: "BnBwdSpec", out=None, residual=None):
+    """conv2d_fwd_ex_bnbwd for the 3x3 / stride-1 data gradients on the Winograd route (u_packed: data-gradient packing)."""
+    n, h, w, cin = x.shape
+    y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    if y.shape != spec.z.shape:
+        raise VatlError("conv3x3_winograd_fwd_bnbwd: the BatchNorm tensors must have the layout of the output")
+    used = C.c_int64(0)
+    c = spec.z.shape[-1]
+    need = int(lib().vatl_winograd_stats_row_blocks(n, h, w))
+    if (spec.blocks + need) * c * 2 > spec.stats.numel():
+        raise VatlError("conv3x3_winograd_fwd_bnbwd: statistics buffer too small")
+    stats_ptr = spec.stats.data_ptr() + spec.blocks * c * 2 * 8
+    _check(lib().vatl_conv3x3_winograd_fwd_bnbwd(_ptr(x), _ptr(u_packed), _ptr(residual), _ptr(y), n, h, w, cin, cout, _ptr(spec.z), _ptr(spec.mask_y),
+                                                 _ptr(spec.scale), _ptr(spec.bias), _ptr(spec.mean), _ptr(spec.invstd), stats_ptr, C.addressof(used),
+                                                 _stream()), "vatl_conv3x3_winograd_fwd_bnbwd")
+    spec.blocks += used.value
+    return y
 
 
 def conv3x3_winograd_fwd_bnstats(x, u_packed, cout: int, gamma, beta, running_mean, running_var, momentum: float, eps: float):
