@@ -87,30 +87,31 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
     launch stream (torch's current stream) and relate the sum to the algorithmic FLOPs."""
     import vatl_hip as vh
     events, wino = [], []
-    orig_c, orig_d, orig_u, orig_w = vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd, vh.conv3x3_winograd_fwd
+    orig_c, orig_d, orig_u, orig_w, orig_dw = vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd, vh.conv3x3_winograd_fwd, vh.deconv4x4s2_winograd_fwd
 
-    def wrap(fn, is_wino=False):
+    def wrap(fn, is_wino=0):
         def inner(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = fn(*a, **k)
             e1.record()
             events.append((e0, e1))
-            if is_wino:                                    # direct-sum FLOPs of this launch: 2 * pixels * Cout * 9 Cin
-                wino.append((e0, e1, 2.0 * r.numel() * 9 * a[0].shape[-1]))
+            if is_wino:                                    # direct-sum FLOPs of this launch: 2 * output elements * taps * Cin (9 / 4 taps)
+                wino.append((e0, e1, 2.0 * r.numel() * is_wino * a[0].shape[-1]))
             return r
         return inner
-    vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd, vh.conv3x3_winograd_fwd = wrap(orig_c), wrap(orig_d), wrap(orig_u), wrap(orig_w, True)
+    vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd = wrap(orig_c), wrap(orig_d), wrap(orig_u)
+    vh.conv3x3_winograd_fwd, vh.deconv4x4s2_winograd_fwd = wrap(orig_w, 9), wrap(orig_dw, 4)
     try:
         one_step(model, x, bbox, is_prev, is_next, hm_buf)
         torch.cuda.synchronize()
     finally:
-        vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd, vh.conv3x3_winograd_fwd = orig_c, orig_d, orig_u, orig_w
+        vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd, vh.conv3x3_winograd_fwd, vh.deconv4x4s2_winograd_fwd = orig_c, orig_d, orig_u, orig_w, orig_dw
     ms = sum(a.elapsed_time(b) for a, b in events)
     flops = GFLOP_PER_CROP * 1e9 * FRAMES
     achieved = flops / (ms * 1e-3) / 1e12
-    # the Winograd launches issue 16 multiplies per 2x2 output tile and channel pair where the direct sum has 36: what the matrix
-    # pipe actually executes is `flops` minus 5/9 of their direct-sum FLOPs
+    # the Winograd launches issue 16 multiplies per output tile and channel pair where the direct sum has 36 (2x2 outputs x 9 taps /
+    # 3x3 outputs x 4 taps): what the matrix pipe actually executes is `flops` minus 5/9 of their direct-sum FLOPs (tile padding aside)
     wino_flops = sum(f for _, _, f in wino)
     wino_ms = sum(a.elapsed_time(b) for a, b, _ in wino)
     executed = flops - wino_flops * 5.0 / 9.0
@@ -124,7 +125,7 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": (traffic / len(events)) if traffic else None,
-            "kernel": "conv_igemm_kernel + gemm1x1_persistent2_kernel + conv3x3_winograd_kernel (all conv/deconv launches of one step; 4 of them fuse a projection shortcut with the block's last conv; the 3x3 stride-1 layers run as Winograd F(2x2,3x3))", "launches": len(events),
+            "kernel": "conv_igemm_kernel + gemm1x1_persistent2_kernel + winograd_kernel (all conv/deconv launches of one step; 4 of them fuse a projection shortcut with the block's last conv; the 13 3x3 stride-1 layers run as Winograd F(2x2,3x3), the 3 transposed convs as F(3x3,2x2) on their four phases)", "launches": len(events),
             # `achieved` / `frac` count ALGORITHMIC (direct-sum) FLOPs, as the contract asks; the Winograd launches reach them with 2.25x
             # fewer multiplies, so their own algorithmic rate can exceed the pipe's peak.  `executed_frac` = MFMA FLOPs actually issued
             # / time / peak: the occupancy of the matrix pipe.

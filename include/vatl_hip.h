@@ -335,6 +335,8 @@ int vatl_bn_train_bwd_relu_pool(const float* dpool, const uint8_t* idx, const fl
  * total_blocks = that sum over all jobs.  kind 0: conv forward layout, (a, b, c) = (CoutPad, Spad, CinPad);
  * kind 1: data-gradient layout, (a, b, c) = (CinPad, CoutK, ntaps) with the taps in tap_r / tap_s;
  * kind 2: ConvTranspose2d(4,2,1) layout, src (Cin,Cout,4,4), a = CoutPad;
+ * kind 5: Winograd F(3x3,2x2) phase filters of ConvTranspose2d(4,2,1) (vatl_pack_winograd_deconv_weight): src (Cin,Cout,4,4), a / b as
+ *   for kinds 3 / 4, c = Cout;
  * kind 3 / 4: Winograd F(2x2,3x3) filter transform, forward / data gradient (vatl_pack_winograd_weight): (Cout, Cin) of the PACKED
  *   filter, a = its padded Cout, b = 32-channel groups per tile (a / 32 <= 1 ? 1 : 2), c = Cin (kind 3) or Cout (kind 4) = the inner
  *   dimension of src. */
@@ -475,6 +477,18 @@ int vatl_conv3x3_winograd_fwd_stats(const float* x, const float* u, float* y, do
 /* Winograd counterpart of vatl_conv2d_fwd_ex_bnbwd (3x3 / stride 1 / pad 1 data gradients; u packed with data_gradient = 1): y receives
  * g = (conv(x) + residual) * [consumer layer's ReLU mask], `stats` the (sum g, sum g * xhat) row-block partials
  * (capacity vatl_winograd_stats_row_blocks(N, H, W) * Cout * 2 doubles). */
+/* ConvTranspose2d(4, 2, 1) on the Winograd route: each of the four sub-pixel phases is a 2x2 convolution of the input, run as
+ * F(3x3, 2x2) (16 multiplies per 3x3 tile of phase outputs instead of 36).  Replaces nn.ConvTranspose2d(k=4, s=2, p=1) of
+ * simplepose.py:46-66 (_make_deconv_layer) for Cin % 16 == 0, Cout % 4 == 0.  w = (Cin, Cout, 4, 4) as torch stores it; u receives
+ * vatl_winograd_deconv_weight_floats(Cout, Cin) floats.  y: N x 2H x 2W x Cout (NHWC).  _stats: training forward, capacity
+ * vatl_winograd_deconv_stats_row_blocks(N, H, W) * Cout * 2 doubles. */
+int64_t vatl_winograd_deconv_weight_floats(int Cout, int Cin);
+int vatl_pack_winograd_deconv_weight(const float* w, float* u, int Cout, int Cin, void* stream);
+int vatl_deconv4x4s2_winograd_fwd(const float* x, const float* u, const float* scale, const float* bias, float* y, int N, int H, int W,
+                                  int Cin, int Cout, int relu, void* stream);
+int64_t vatl_winograd_deconv_stats_row_blocks(int64_t N, int H, int W);
+int vatl_deconv4x4s2_winograd_fwd_stats(const float* x, const float* u, float* y, double* stats, int64_t* row_blocks_used, int N, int H, int W,
+                                        int Cin, int Cout, void* stream);
 int vatl_conv3x3_winograd_fwd_bnbwd(const float* x, const float* u, const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
                                     const float* bn_z, const float* bn_mask_y, const float* bn_scale, const float* bn_bias,
                                     const float* bn_mean, const float* bn_invstd, double* stats, int64_t* row_blocks_used, void* stream);

@@ -23,8 +23,8 @@ def test_bench_prints_one_contract_line():
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert 0.5 < r["frac"] < 1.2 and d["value"] > 5000             # algorithmic FLOPs: the Winograd launches run 2.25x fewer multiplies
-    assert 0.5 < r["executed_frac"] < 1.0 and r["executed_frac"] <= r["frac"] and r["winograd"]["launches"] >= 13
+    assert 0.5 < r["frac"] < 1.6 and d["value"] > 5000             # algorithmic FLOPs: the Winograd launches run 2.25x fewer multiplies
+    assert 0.4 < r["executed_frac"] < 1.0 and r["executed_frac"] <= r["frac"] and r["winograd"]["launches"] >= 16
     assert 0.5 < r["e2e_frac"] <= r["frac"] + 0.02 and abs(r["e2e_frac"] - d["value"] * 10.853e-3 / 157.3) < 2e-3   # whole step vs conv launches only
     assert d["world_size_seen"] == 1 and len(d["rank_devices"]) == 1
     ex = d["extra"]                                                     # configs[2..4] measured in the same run

@@ -108,27 +108,6 @@ def test_winograd_bits_do_not_depend_on_the_batch_position(vh):
         assert torch.equal(again, full)
 
 
-def test_winograd_tile_configurations_give_the_same_bits(vh):
-    """Large launches run 64-tile blocks, small ones 32 x 32 blocks (vatl_tune_set(18, .): 1 / 2 force one): a tile's arithmetic is the same."""
-    g = torch.Generator(device="cpu").manual_seed(29)
-    try:
-        for n, h, w, cin, cout in ((9, 16, 12, 64, 128), (4, 13, 9, 32, 32), (70, 8, 6, 48, 96)):
-            x = torch.randn((n, h, w, cin), generator=g).to(dev())
-            wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.05).to(dev())
-            r = torch.randn((n, h, w, cout), generator=g).to(dev())
-            u = vh.pack_winograd_weight(wt)
-            outs = []
-            for cfg in (1, 2, 0):
-                vh.tune_set(18, cfg)
-                y, stats, blocks = vh.conv3x3_winograd_fwd_stats(x, u, cout)
-                outs.append((vh.conv3x3_winograd_fwd(x, u, None, None, cout, True, residual=r), y,
-                             stats[:blocks * cout * 2].view(blocks, cout, 2).sum(0)))
-            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[2][0], outs[0][0])
-            assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-3)   # (fp32 partial sums over different row groups)
-    finally:
-        vh.tune_set(18, 0)
-
-
 def test_winograd_statistics_epilogue_matches_the_stored_tensor(vh):
     """Training forward: y = x * w and the (sum, sum of squares) row-block partials that BatchNorm's finalize reduces."""
     import ctypes as C
@@ -212,3 +191,50 @@ def test_pack_plan_refreshes_winograd_filters_with_the_same_bits(vh):
         assert a.data_ptr() == fa.data_ptr() and b.data_ptr() == fb.data_ptr()
         assert torch.equal(a, wa) and torch.equal(b, wb)
     assert torch.equal(other, other_want)
+
+
+DECONV_CASES = [("2048_256", 2, 8, 6, 2048, 256), ("256_256", 3, 16, 12, 256, 256), ("odd", 2, 5, 3, 64, 48), ("256_256_big", 1, 32, 24, 256, 256),
+                ("w_multiple_of_3", 5, 9, 6, 32, 36), ("one_row", 3, 1, 4, 16, 8), ("ragged", 7, 7, 10, 48, 100)]
+
+
+@pytest.mark.parametrize("case", DECONV_CASES, ids=[c[0] for c in DECONV_CASES])
+def test_deconv_winograd_matches_float64_and_the_implicit_gemm(vh, case):
+    """ConvTranspose2d(4,2,1) + folded BN + ReLU as F(3x3,2x2) on the four phases (the shapes of tests/test_gpu_conv.py + border cases:
+    widths that are multiples of the tile step, a single input row, tiles that straddle images)."""
+    name, n, h, w, cin, cout = case
+    r = np.random.RandomState(len(name) + cin)
+    x = r.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (r.standard_normal((cin, cout, 4, 4)) / np.sqrt(cin * 4)).astype(np.float32)
+    gamma, beta = r.uniform(0.5, 1.5, cout).astype(np.float32), r.standard_normal(cout).astype(np.float32) * 0.1
+    mean, var = r.standard_normal(cout).astype(np.float32) * 0.1, r.uniform(0.5, 1.5, cout).astype(np.float32)
+    ref = F.conv_transpose2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, 2, 1)
+    ref = F.batch_norm(ref, torch.from_numpy(mean).double(), torch.from_numpy(var).double(), torch.from_numpy(gamma).double(),
+                       torch.from_numpy(beta).double(), False, 0.0, 1e-5).relu().numpy()
+    scale, bias = vh.bn_fold(to_dev(gamma), to_dev(beta), to_dev(mean), to_dev(var), 1e-5)
+    xd = to_dev(_nhwc(x))
+    y = vh.deconv4x4s2_winograd_fwd(xd, vh.pack_winograd_deconv_weight(to_dev(wt)), scale, bias, cout, True)
+    e = rel_err(np.transpose(y.cpu().numpy(), (0, 3, 1, 2)), ref)
+    record("deconv_winograd_" + name, rel=e)
+    assert e < TOL, (name, e)
+    if cin % 32 == 0:
+        yd = vh.deconv4x4s2_fwd(xd, vh.pack_deconv_weight(to_dev(wt)), scale, bias, cout, True)
+        assert rel_err(y.cpu().numpy(), yd.cpu().numpy()) < 2 * TOL
+
+
+def test_deconv_winograd_statistics_and_batch_position(vh):
+    g = torch.Generator(device="cpu").manual_seed(31)
+    for n, h, w, cin, cout in ((5, 8, 6, 64, 64), (3, 5, 3, 32, 40)):
+        x = torch.randn((n, h, w, cin), generator=g).to(dev())
+        wt = (torch.randn((cin, cout, 4, 4), generator=g) * 0.05).to(dev())
+        u = vh.pack_winograd_deconv_weight(wt)
+        gamma, beta = torch.ones(cout, device=dev()), torch.zeros(cout, device=dev())
+        rm, rv = torch.zeros(cout, device=dev()), torch.ones(cout, device=dev())
+        z, mean, invstd, scale, bias = vh.deconv4x4s2_winograd_fwd_bnstats(x, u, cout, gamma, beta, rm, rv, 0.1, 1e-5)
+        plain = vh.deconv4x4s2_winograd_fwd(x, u, None, None, cout, False)
+        assert torch.equal(z, plain)
+        z64 = z.double().reshape(-1, cout)
+        assert torch.allclose(mean.double(), z64.mean(0), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(invstd.double(), 1.0 / torch.sqrt(z64.var(0, unbiased=False) + 1e-5), rtol=1e-5)
+        for i in (0, n - 1):
+            alone = vh.deconv4x4s2_winograd_fwd(x[i:i + 1].contiguous(), u, None, None, cout, False)
+            assert torch.equal(alone[0], plain[i])

@@ -22,6 +22,7 @@ SHAPES = {  # name: (H, W, Cin, Cout, residual)
     "hr.b32": (64, 48, 32, 32, True), "hr.b64": (32, 24, 64, 64, True), "hr.b128": (16, 12, 128, 128, True), "hr.b256": (8, 6, 256, 256, True),
     "r152.l2.c2": (48, 36, 128, 128, False), "r152.l3.c2": (24, 18, 256, 256, False), "r152.l4.c2": (12, 9, 512, 512, False),
 }
+DECONVS = {"deconv1": (8, 6, 2048, 256), "deconv2": (16, 12, 256, 256), "deconv3": (32, 24, 256, 256)}
 
 
 def timed(fn, iters):
@@ -40,17 +41,35 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--layers", default="")
     ap.add_argument("--check", type=int, default=8)
-    ap.add_argument("--cfg", type=int, default=0, help="vatl_tune_set(18, v): 0 tile configuration by launch size, 1 large tiles, 2 small tiles")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    vh.tune_set(18, a.cfg)
     warm = torch.randn((4096, 4096), device=dev)
     for _ in range(100):
         warm @ warm
     torch.cuda.synchronize()
     g = torch.Generator(device="cpu").manual_seed(5)
-    names = a.layers.split(",") if a.layers else list(SHAPES)
+    names = a.layers.split(",") if a.layers else list(SHAPES) + list(DECONVS)
     for name in names:
+        if name in DECONVS:
+            h, w, cin, cout = DECONVS[name]
+            b = a.batch
+            x = torch.randn((b, h, w, cin), generator=g).to(dev)
+            wt = (torch.randn((cin, cout, 4, 4), generator=g) * (2.0 / (4 * cin)) ** 0.5).to(dev)
+            sc = (torch.rand(cout, generator=g) + 0.5).to(dev)
+            bi = torch.randn(cout, generator=g).to(dev)
+            wp, up = vh.pack_deconv_weight(wt), vh.pack_winograd_deconv_weight(wt)
+            yd = vh.deconv4x4s2_fwd(x, wp, sc, bi, cout, True)
+            yw = vh.deconv4x4s2_winograd_fwd(x, up, sc, bi, cout, True)
+            k = min(a.check, b)
+            ref = torch.nn.functional.conv_transpose2d(x[:k].permute(0, 3, 1, 2).double(), wt.double(), None, 2, 1) * sc.double().view(1, -1, 1, 1) + bi.double().view(1, -1, 1, 1)
+            ref = ref.clamp_min(0).permute(0, 2, 3, 1)
+            ed, ew = (yd[:k].double() - ref).abs().max().item(), (yw[:k].double() - ref).abs().max().item()
+            td = timed(lambda: vh.deconv4x4s2_fwd(x, wp, sc, bi, cout, True), a.iters)
+            tw = timed(lambda: vh.deconv4x4s2_winograd_fwd(x, up, sc, bi, cout, True), a.iters)
+            fl = 2.0 * b * h * w * 4 * cout * cin * 4
+            print(f"{name:11s} B={b:5d} direct {td:8.1f} us {fl / td / 1e6:6.1f} TF/s err {ed:.2e} | winograd {tw:8.1f} us {fl / tw / 1e6:6.1f} TF/s err {ew:.2e} "
+                  f"| ref max {ref.abs().max().item():.2f}  speed-up {td / tw:.2f}x", flush=True)
+            continue
         h, w, cin, cout, res = SHAPES[name]
         b = a.batch
         x = torch.randn((b, h, w, cin), generator=g).to(dev)

@@ -71,15 +71,21 @@ class _Conv:
 
 
 class _Deconv:
-    __slots__ = ("w", "scale", "bias", "cout")
+    __slots__ = ("w", "u", "scale", "bias", "cout")
 
     def __init__(self, dc: nn.ConvTranspose2d, bn: nn.BatchNorm2d):
         assert dc.kernel_size == (4, 4) and dc.stride == (2, 2) and dc.padding == (1, 1) and dc.bias is None
-        self.w = vh.pack_deconv_weight(dc.weight.detach())
         self.cout = dc.weight.shape[1]
+        self.w = self.u = None
+        if WINOGRAD and dc.weight.shape[0] % 16 == 0 and self.cout % 4 == 0:     # four 2x2 phase convolutions as Winograd F(3x3, 2x2)
+            self.u = vh.pack_winograd_deconv_weight(dc.weight.detach())
+        else:
+            self.w = vh.pack_deconv_weight(dc.weight.detach())
         self.scale, self.bias = vh.bn_fold(_d(bn.weight), _d(bn.bias), bn.running_mean, bn.running_var, bn.eps)
 
     def __call__(self, x, relu=True):
+        if self.u is not None:
+            return vh.deconv4x4s2_winograd_fwd(x, self.u, self.scale, self.bias, self.cout, relu)
         return vh.deconv4x4s2_fwd(x, self.w, self.scale, self.bias, self.cout, relu)
 
 

@@ -1,29 +1,37 @@
-// 3x3 / stride 1 / pad 1 convolution as Winograd F(2x2, 3x3) on the gfx950 fp32 matrix cores.
+// Winograd convolutions on the gfx950 fp32 matrix cores:
+//   * F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 layers (MO = 2): a 2x2 output tile from its 4x4 input tile,
+//   * F(3x3, 2x2) for ConvTranspose2d(4, 2, 1) (MO = 3): each of its four sub-pixel phases is a 2x2 convolution of the input; a 3x3
+//     tile of phase outputs comes from a 4x4 input tile.
+// Both need 16 multiplies per (tile, input channel, output channel) where the direct sums need 36: 2.25x fewer MFMAs.
 //
-// Why.  The 3x3 stride-1 layers are a quarter of the R50 trunk's time and nearly all of HRNet's (profiles/r03_layer_report.txt), and the
-// implicit GEMM already runs them at 76 - 89 % of the fp32 MFMA peak: the only way to make them substantially faster is fewer multiplies.
-// F(2x2, 3x3) computes a 2x2 output tile from its 4x4 input tile with 16 multiplies per (input channel, output channel) instead of 36:
+// Why.  These layers are half of the R50 trunk's time and nearly all of HRNet's (profiles/r03_layer_report.txt), and the implicit GEMM
+// already runs them at 76 - 89 % of the fp32 MFMA peak: the only way to make them substantially faster is fewer multiplies.
 //
-//     Y = A^T [ (G g G^T) .* (B^T d B) ] A          U = G g G^T (16 values per filter, packed once: vatl_pack_winograd_weight)
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A          U = G g G^T (16 values per filter, packed once: vatl_pack_winograd_*_weight)
 //                                                   V = B^T d B (16 values per tile and input channel, computed on the fly)
 //
-// i.e. 16 independent GEMMs  M_p[tile][n] = sum_c V_p[tile][c] U_p[c][n]  (p = (xi, nu), the position in the 4x4 transform domain), 2.25x
-// fewer MFMAs than the implicit GEMM, still exact fp32 products with fp32 accumulation (cuDNN picks the same algorithm for these layers
-// of the reference: the rounding differs from the direct sum in the last bits, not in class; tests hold it to the same tolerance).
+// i.e. 16 independent GEMMs  M_p[tile][n] = sum_c V_p[tile][c] U_p[c][n]  (p = (xi, nu), the position in the 4x4 transform domain), still
+// exact fp32 products with fp32 accumulation (cuDNN picks the same algorithm for these layers of the reference: the rounding differs
+// from the direct sum in the last bits, not in class; tests hold it to the same tolerance).  With the interpolation points (0, 1, -1,
+// inf) the two variants share B^T (rows d0 - d2, d1 + d2, d2 - d1, d1 - d3) — the input path of the kernel is the same — and differ in
+// the tile step (MO), in G (4x3 / 4x2) and in A^T (2x4: [1 1 1 0; 0 1 -1 -1] / 3x4: [1 1 1 0; 0 1 -1 0; 0 1 1 1]).
 //
-// Block = 64 tiles (flat index over image, tile row, tile column) x BN = 32 NH output channels x all 16 positions; 4 NH waves.  Wave
-// (xi, nh) owns the four positions (xi, nu = 0..3) for both 32-tile halves and its 32 channels: 8 accumulator tiles = 128 registers.
-//   * B operand (U): packed in MFMA fragment order, a wave's ds-free 16-byte-per-lane load is 1 KB contiguous; straight from L2 into
-//     registers one 8-channel step ahead (no LDS: every wave needs a different slice).
-//   * A operand (V): the raw input pixels of the block's tiles are staged in LDS 16 channels at a time (double buffer, register staging one
-//     stage ahead), de-duplicated along the tile row: per input row i of the tiles, the even (x = 2 tx) and odd (x = 2 tx + 1) pixels of
-//     64 consecutive tiles + one halo slot each; tile column j of tile t is then slot t or t + 1 of the odd / even array, and the left /
-//     right image border is a lane's address pointing at a zero pixel.  A wave needs two of the four tile rows (row transform: d0 - d2,
-//     d1 + d2, d2 - d1, d1 - d3 for xi = 0..3) and forms its four V_p = column transform in registers: 8 ds_read_b128 and 8 vector adds
-//     per 16 MFMAs.  The 16-byte read of a lane is four consecutive channels = four MFMA k-steps (the same k permutation on both operands).
-//   * Output transform: the nu sum happens in registers (4 accumulator tiles -> 2), the xi sum through LDS (the staging buffers are free
-//     by then): every wave writes its two partial tiles, every thread then combines the four xi for whole 16-byte channel groups and
-//     stores full NHWC rows, with scale / bias / residual / ReLU (and the BatchNorm statistics of the training forward) fused.
+// Block = 32 tiles (flat index over image, tile row, tile column) x 32 output channels x all 16 positions; 4 waves, 64 accumulator
+// registers per lane, three blocks per CU (12 waves): the blocks of a CU overlap each other's prologue, barriers and output transform.
+// Wave xi owns the four positions (xi, nu = 0..3).  (64-tile blocks with 128 accumulator registers — 8 waves x 64 channels, one block
+// per CU, or 4 waves x 32 channels, two per CU — measured 4 - 11 % slower at 1024 crops and 25 - 35 % slower at 120: removed.)
+//   * B operand (U): packed in MFMA fragment order, a wave's 16-byte-per-lane load is 1 KB contiguous; straight from L2 into registers
+//     one 8-channel step ahead (no LDS: every wave needs a different slice).
+//   * A operand (V): the raw input pixels of the block's tiles are staged in LDS 16 channels at a time by LDS-DMA (double buffer, one
+//     stage ahead), de-duplicated along the tile row: per input row i of the tiles, one slot per distinct pixel column — column j of
+//     tile (row r, tx) is slot (r - r0) * (MO TW + 4 - MO) + MO tx + j - MO tx0, so neighbours share their 4 - MO common columns and
+//     pixels outside the image are slots that the DMA filled with zeros.  A wave needs two of the four tile rows (row transform) and
+//     forms its four V_p = column transform in registers: 8 ds_read_b128 and 8 vector adds per 16 MFMAs.  The 16-byte read of a lane
+//     is four consecutive channels = four MFMA k-steps (the same k permutation on both operands).
+//   * Output transform: the nu sum happens in registers (4 accumulator tiles -> MO), the xi sum through LDS (the staging buffers are
+//     free by then): every wave writes its partial tiles, every thread then combines the four xi for whole 16-byte channel groups and
+//     stores NHWC channel runs, with scale / bias / residual / ReLU, the BatchNorm statistics of the training forward, or the
+//     BatchNorm-backward reduction of the fine-tune step's data gradients fused.
 // The per-output arithmetic depends only on the tile's own pixels: results are independent of the batch position (SURVEY.md §7 hard part 3).
 #include "common.h"
 #include "winograd_pack.h"
@@ -50,12 +58,19 @@ struct WinoParams {
     const float* bbi;
     const float* bmu;
     const float* bis;
-    int N, H, W, Cin, Cout;
+    int N, H, W, Cin, Cout;           // H x W: the input image = the grid the tiles cover (conv output / one deconv phase)
     int TH, TW, tpi, Mtiles;          // tiles per image column / row / image, tiles in the launch
     int m_tiles, n_tiles;
     int relu;
     int stages;                       // Cin / 16
-    int nhp;                          // 32-channel groups per filter tile of the packing (vatl_pack_winograd_weight: 1 if Cout <= 32, else 2)
+    int nhp;                          // 32-channel groups per filter tile of the packing (1 if Cout <= 32, else 2)
+    int RW;                           // slots per tile row = MO TW + 4 - MO
+    int ns;                           // slots staged per input row i (upper bound over the launch's blocks)
+    int ndma, stage_floats;           // LDS-DMA instructions per stage (1 KB each), floats per stage
+    int pad_y, pad_x;                 // tile (ty, tx) reads input rows MO ty - pad_y + i (deconv: 1 - phase bit, set in the kernel)
+    int OH, OW, os, ooy, oox;         // output pixel of grid point (y, x) = (y os + ooy, x os + oox) in an OH x OW image
+    int deconv;                       // blockIdx.y = sub-pixel phase py * 2 + px
+    long long u_phase_floats;         // deconv: floats of one phase's packed filter
     int ablate;                       // profiling library only (vatl_tune_set(17, bits), wrong results): 1 no output transform, 2 no LDS
                                       // reads / input transform, 4 no filter loads, 8 no staging DMA, 16 no barriers
     unsigned x_bytes, u_bytes, y_bytes;
@@ -71,117 +86,97 @@ __device__ __forceinline__ void wbuf_store4(__amdgpu_buffer_rsrc_t r, unsigned b
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wu32x4, v), r, byte_off, 0, 0);
 }
 
+constexpr int W_TB = 32;                        // tiles per block
 constexpr int W_CK = 16;                        // channels per LDS stage
-constexpr int W_ZERO = 16;                      // floats of the zero pixel in front of the stages
-template <int HALVES>
-struct WinoGeom {
-    static constexpr int TB = 32 * HALVES;      // tiles per block
-    static constexpr int SLOTS = TB + 1;        // + one halo slot
-    static constexpr int PIX = 8 * SLOTS;       // (4 tile rows) x (even, odd) x slots
-    static constexpr int ITEMS = PIX * 4;       // 16-byte pieces of a stage
-    static constexpr int DMA = (ITEMS + 63) / 64;   // wave-wide LDS-DMA instructions per stage (1 KB each; the last one is partly used)
-    static constexpr int STAGE = DMA * 256;     // floats per stage
-    static constexpr int ROW = 2 * SLOTS * W_CK;    // floats per tile row i
-};
-template <int NH, int HALVES>
-constexpr int wino_lds_floats() {
-    const int loop = W_ZERO + 2 * WinoGeom<HALVES>::STAGE, epi = 4 * 2 * WinoGeom<HALVES>::TB * (32 * NH + 4);
-    return loop > epi ? loop : epi;
-}
+constexpr int W_NLD = 8;                        // LDS-DMA instructions per wave per stage, at most (ns <= 128)
+constexpr int W_LDP = 32;                       // row stride of the output-transform tiles in LDS
 
 typedef __attribute__((address_space(3))) void wlds_void;
 
 // (body in a __device__ function: with the DMA builtin inside the __global__ template hipcc 7.2 drops the kernel's host stub)
-template <int NH, int HALVES, bool BNB>
-__device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float* smem) {
-    using G = WinoGeom<HALVES>;
-    constexpr int W_TB = G::TB, W_SLOTS = G::SLOTS, W_ITEMS = G::ITEMS, W_DMA = G::DMA, W_STAGE = G::STAGE, W_ROW = G::ROW;
-    constexpr int NT = 256 * NH, BN = 32 * NH, NW = 4 * NH;
-    constexpr int NLD = (W_DMA + NW - 1) / NW;             // DMA instructions per wave per stage
-    float* Rs = smem + W_ZERO;                             // [2][4 rows][2 parities][65 slots][16 channels], chunk-swizzled
+template <int MO, bool BNB>
+__device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) {
+    constexpr int NT = 256, BN = 32, NW = 4;
+    float* Rs = smem;                                      // [2][4 rows][ns slots][16 channels], chunk-swizzled
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xi = wave / NH, nh = wave % NH;
+    const int tid = threadIdx.x, lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // XCD-aware tile order: block b runs on XCD b % 8; each XCD gets a contiguous run of tiles with the m-tile fastest, so the
-    // blocks of an XCD share one filter slice (16 * Cin * BN * 4 bytes <= 2 MB) in their L2
+    // blocks of an XCD share few filter slices (16 * Cin * 32 * 4 bytes each) in their L2
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3, q8 = nblk >> 3, r8 = nblk & 7;
     const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
     const int n_tile = t / p.m_tiles, m_tile = t - n_tile * p.m_tiles;
     const int m0 = m_tile * W_TB, n0 = n_tile * BN;
 
+    int pad_y = p.pad_y, pad_x = p.pad_x, ooy = p.ooy, oox = p.oox;
+    const float* ubase_ptr = p.u;
+    if (p.deconv) {
+        const int py = blockIdx.y >> 1, px = blockIdx.y & 1;
+        pad_y = 1 - py; pad_x = 1 - px; ooy = py; oox = px;
+        ubase_ptr += (long long)blockIdx.y * p.u_phase_floats;
+    }
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ubase_ptr), 0, p.u_bytes, 0x00020000);
 
     // ---- staging by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write pass).  The destination of a wave instruction is
     // lane-linear (base + lane * 16 bytes), so the chunk swizzle is applied on the SOURCE side: LDS position q = (pixel q >> 2, chunk
-    // position q & 3) receives the pixel's global chunk (q & 3) ^ ((slot >> 2) & 3).  pixel = (row i, parity, slot).  Outside the image
-    // / launch the offset is out of range and the DMA writes zeros.
-    unsigned goff[NLD];                                    // byte offset of the lane's piece in the first stage (WOOB: zeros)
+    // position q & 3) receives the pixel's global chunk (q & 3) ^ ((slot >> 2) & 3);  pixel = (input row i, slot).  Outside the image /
+    // launch the offset is out of range and the DMA writes zeros: image borders need no special case in the reader.
+    const int gr0 = m0 / p.TW;                             // global tile row (image, ty) of the block's first tile
+    const int pos0 = MO * (m0 - gr0 * p.TW);               // its first column slot inside that row
+    unsigned goff[W_NLD];                                  // byte offset of the lane's piece in the first stage (WOOB: zeros)
 #pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-        const int q = (wave + NW * u) * 64 + lane;
+    for (int u = 0; u < W_NLD; ++u) {
+        const int q = (xi + NW * u) * 64 + lane;
         goff[u] = WOOB;
-        if (q < W_ITEMS) {
-            const int cpos = q & 3, pix = q >> 2;
-            const int ipar = pix / W_SLOTS, slot = pix - ipar * W_SLOTS;
-            const int i = ipar >> 1, par = ipar & 1;
+        const int cpos = q & 3, pix = q >> 2;
+        const int i = pix / p.ns, slot = pix - i * p.ns;
+        if (i < 4) {
             const int chunk = cpos ^ ((slot >> 2) & 3);
-            const int m = m0 + slot - par;                 // even array: slot s = tile m0 + s;  odd array: slot s = tile m0 + s - 1
-            if (m >= 0 && m < p.Mtiles) {
-                const int b = m / p.tpi, r = m - b * p.tpi;
-                const int ty = r / p.TW, tx = r - ty * p.TW;
-                const int yy = 2 * ty - 1 + i, xx = 2 * tx + par;
-                if ((unsigned)yy < (unsigned)p.H && xx < p.W) goff[u] = (unsigned)(((b * p.H + yy) * p.W + xx) * p.Cin + chunk * 4) << 2;
-            }
+            const int P = slot + pos0;
+            const int rr = P / p.RW, pos = P - rr * p.RW;
+            const int gr = gr0 + rr;
+            const int b = gr / p.TH, ty = gr - b * p.TH;
+            const int yy = MO * ty - pad_y + i, xx = pos - pad_x;
+            if (b < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+                goff[u] = (unsigned)(((b * p.H + yy) * p.W + xx) * p.Cin + chunk * 4) << 2;
         }
     }
     auto stage_dma = [&](int buf, int st) {
-        const bool live = st < p.stages;
 #pragma unroll
-        for (int u = 0; u < NLD; ++u)
-            if (wave + NW * u < W_DMA)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (wlds_void*)(Rs + buf * W_STAGE + (wave + NW * u) * 256), 16,
-                                                         (live && goff[u] != WOOB) ? goff[u] + (unsigned)st * (W_CK * 4) : WOOB, 0, 0, 0);
+        for (int u = 0; u < W_NLD; ++u)
+            if (xi + NW * u < p.ndma)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (wlds_void*)(Rs + buf * p.stage_floats + (xi + NW * u) * 256), 16,
+                                                         goff[u] != WOOB ? goff[u] + (unsigned)st * (W_CK * 4) : WOOB, 0, 0, 0);
     };
 
-    // ---- fragment addressing: lane = (tile l & 31 of a half, channel quad l >> 5) ---------------------------------------------------
-    // ra[half][j]: float index (relative to Rs, tile row 0, stage 0, first 8-channel step) of column j of the lane's tile; the second
-    // step of a stage is the same index ^ 8.  A border column points at the zero pixel (index -16).
+    // ---- fragment addressing: lane = (tile l & 31, channel quad l >> 5).  ra[j]: float index (relative to the stage, input row 0,
+    // first 8-channel step) of column j of the lane's tile; the second step of a stage is the same index ^ 8.
     const int h = lane >> 5;
-    int ra[HALVES][4];
+    int ra[4];
+    {
+        const int m = min(m0 + (lane & 31), p.Mtiles - 1);
+        const int gr = m / p.TW, tx = m - gr * p.TW;
+        const int sbase = (gr - gr0) * p.RW + MO * tx - pos0;
 #pragma unroll
-    for (int half = 0; half < HALVES; ++half) {
-        const int tl = 32 * half + (lane & 31);
-        const int m = m0 + tl;
-        const int mm = m < p.Mtiles ? m : p.Mtiles - 1;
-        const int r = mm % p.tpi;
-        const int tx = r % p.TW;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int par = (j & 1) ^ 1;                   // j = 0, 2: odd pixels;  j = 1, 3: even pixels
-            const int slot = tl + (j >> 1);                // j = 0: odd[t], 1: even[t], 2: odd[t + 1], 3: even[t + 1]
-            const bool border = (j == 0 && tx == 0) || (j == 3 && tx == p.TW - 1);
-            ra[half][j] = border ? -W_ZERO : (par * W_SLOTS + slot) * W_CK + ((h ^ ((slot >> 2) & 3)) << 2);
-        }
+        for (int j = 0; j < 4; ++j) ra[j] = (sbase + j) * W_CK + ((h ^ (((sbase + j) >> 2) & 3)) << 2);
     }
-    // row transform of this wave: t = d[ia] + sg * d[ib]
+    // row transform of this wave: t = d[ia] + sgn * d[ib]   (B^T rows: d0 - d2, d1 + d2, d2 - d1, d1 - d3)
     const int ia = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
     const int ib = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
     const float sgn = xi == 1 ? 1.f : -1.f;
-    const int roa = ia * W_ROW, rob = ib * W_ROW;
+    const int roa = ia * p.ns * W_CK, rob = ib * p.ns * W_CK;
 
 #ifdef VATL_ABLATION
     const int abl = p.ablate;
 #else
     constexpr int abl = 0;
 #endif
-    // ---- U fragments: [n_tile][step][position][nh][lane][4] ----------------------------------------------------------------------------
+    // ---- U fragments: [n_tile][step][position][nh][lane][4]; the packing groups 32 p.nhp channels per filter tile ----------------------
     const int steps = p.stages * 2;
-    // (the packing groups 32 p.nhp channels per filter tile; this block's 32-channel group nh_g of it)
-    const int n32 = n_tile * NH + nh, ut = n32 / p.nhp, nh_g = n32 - ut * p.nhp;
-    const unsigned ubase = (unsigned)((((ut * steps) * 16 + 4 * xi) * p.nhp + nh_g) * 64 + lane) << 4;   // bytes; + step * 16*nhp*1024 + nu * nhp*1024
+    const int ut = n_tile / p.nhp, nh_g = n_tile - ut * p.nhp;
+    const unsigned ubase = (unsigned)((((ut * steps) * 16 + 4 * xi) * p.nhp + nh_g) * 64 + lane) << 4;   // bytes; + step * ustep + nu * unu
     const unsigned ustep = 16u * p.nhp * 1024u, unu = p.nhp * 1024u;
     auto u_load = [&](f32x4 (&dst)[4], int step) {
         const bool live = step < steps && !(abl & 4);
@@ -189,15 +184,12 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
         for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? ubase + (unsigned)step * ustep + nu * unu : WOOB);
     };
 
-    f32x16 acc[4][HALVES];
+    f32x16 acc[4];
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-        for (int half = 0; half < HALVES; ++half)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[nu][half][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
 
-    if (tid < W_ZERO / 4) *reinterpret_cast<f32x4*>(&smem[tid * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 ua[4], ub[4];
     stage_dma(0, 0);
     u_load(ua, 0);
@@ -205,37 +197,32 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
     __syncthreads();
 
     auto step_mfma = [&](const float* Rb, int x8, const f32x4 (&uu)[4]) {
+        f32x4 tc[4];
+        if (abl & 2) {
 #pragma unroll
-        for (int half = 0; half < HALVES; ++half) {
-            f32x4 tc[4];
-            if (abl & 2) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) tc[j] = f32x4{1.f + j, 2.f, 3.f, 4.f + x8};
-            } else
+            for (int j = 0; j < 4; ++j) tc[j] = f32x4{1.f + j, 2.f, 3.f, 4.f + x8};
+        } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool z = ra[half][j] < 0;            // the zero pixel has no rows / stages
-                const float* pa = z ? smem : Rb + roa + (ra[half][j] ^ x8);
-                const float* pb = z ? smem : Rb + rob + (ra[half][j] ^ x8);
-                const f32x4 da = *reinterpret_cast<const f32x4*>(pa);
-                const f32x4 db = *reinterpret_cast<const f32x4*>(pb);
+                const f32x4 da = *reinterpret_cast<const f32x4*>(Rb + roa + (ra[j] ^ x8));
+                const f32x4 db = *reinterpret_cast<const f32x4*>(Rb + rob + (ra[j] ^ x8));
                 tc[j] = da + sgn * db;
             }
-            f32x4 v[4];
-            v[0] = tc[0] - tc[2]; v[1] = tc[1] + tc[2]; v[2] = tc[2] - tc[1]; v[3] = tc[1] - tc[3];
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int nu = 0; nu < 4; ++nu)
-                    acc[nu][half] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][tt], uu[nu][tt], acc[nu][half], 0, 0, 0);
         }
+        f32x4 v[4];
+        v[0] = tc[0] - tc[2]; v[1] = tc[1] + tc[2]; v[2] = tc[2] - tc[1]; v[3] = tc[1] - tc[3];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu)
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][tt], uu[nu][tt], acc[nu], 0, 0, 0);
     };
 
     for (int st = 0; st < p.stages; ++st) {
         const int buf = st & 1;
-        const float* Rb = Rs + buf * W_STAGE;
-        // the scheduler barriers keep the requests where they are written: without them hipcc sinks the staging loads to just
-        // before their LDS writes and the filter loads to just before their first MFMA (latency fully exposed)
+        const float* Rb = Rs + buf * p.stage_floats;
+        // the scheduler barriers keep the requests where they are written: without them hipcc sinks the filter loads to just before
+        // their first MFMA (latency fully exposed)
         if (st + 1 < p.stages && !(abl & 8)) stage_dma(buf ^ 1, st + 1);
         u_load(ub, 2 * st + 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -258,37 +245,39 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-            for (int half = 0; half < HALVES; ++half)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sacc += acc[nu][half][e];
+            for (int e = 0; e < 16; ++e) sacc += acc[nu][e];
         if (sacc == 12345.678f) p.y[0] = sacc;
         return;
     }
 #endif
     // ---- output transform -----------------------------------------------------------------------------------------------------------------
-    // nu sum in registers: P[b = 0] = M0 + M1 + M2, P[b = 1] = M1 - M2 - M3;  Ps[xi][b][tile][n] in LDS
-    constexpr int LDP = BN + 4;
+    // nu sum in registers (rows of A^T):  MO = 2: P0 = M0 + M1 + M2, P1 = M1 - M2 - M3;   MO = 3: P0 = M0 + M1 + M2, P1 = M1 - M2,
+    // P2 = M1 + M2 + M3.   Ps[xi][b][tile][n] in LDS
     float* Ps = smem;
-#pragma unroll
-    for (int half = 0; half < HALVES; ++half) {
-        const int cl = 32 * nh + (lane & 31);
+    {
+        const int cl = lane & 31;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int row = 32 * half + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            const float m0v = acc[0][half][e], m1v = acc[1][half][e], m2v = acc[2][half][e], m3v = acc[3][half][e];
-            Ps[((xi * 2 + 0) * W_TB + row) * LDP + cl] = m0v + m1v + m2v;
-            Ps[((xi * 2 + 1) * W_TB + row) * LDP + cl] = m1v - m2v - m3v;
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            const float m0v = acc[0][e], m1v = acc[1][e], m2v = acc[2][e], m3v = acc[3][e];
+            Ps[((xi * MO + 0) * W_TB + row) * W_LDP + cl] = m0v + m1v + m2v;
+            if (MO == 2) {
+                Ps[((xi * MO + 1) * W_TB + row) * W_LDP + cl] = m1v - m2v - m3v;
+            } else {
+                Ps[((xi * MO + 1) * W_TB + row) * W_LDP + cl] = m1v - m2v;
+                Ps[((xi * MO + MO - 1) * W_TB + row) * W_LDP + cl] = m1v + m2v + m3v;
+            }
         }
     }
     __syncthreads();
 
-    // xi sum: Y[a = 0] = P0 + P1 + P2, Y[a = 1] = P1 - P2 - P3 per (tile, b, channel quad); full-row 16-byte stores
+    // xi sum (the same rows of A^T) per (tile, output column b, channel quad); 16-byte stores of NHWC channel runs
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bz : p.x), 0, BNB ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bmy : p.x), 0, (BNB && p.bmy) ? p.y_bytes : 0u, 0x00020000);
     constexpr int C4 = BN / 4;                             // channel quads per tile row
-    constexpr int TPP = NT / (2 * C4);                     // tiles per pass (16)
-    constexpr int NP = W_TB / TPP;                         // passes
-    const int c4 = tid % C4, bq = (tid / C4) & 1, tl0 = tid / (2 * C4);
+    const int c4 = tid % C4;
     const int n = n0 + c4 * 4;
     const bool nv = n < p.Cout;
     const f32x4 one = {1.f, 1.f, 1.f, 1.f}, nul = {0.f, 0.f, 0.f, 0.f};
@@ -296,42 +285,51 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
     const f32x4 bi = (nv && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + n) : nul;
     const float lo = p.relu ? 0.f : -INFINITY;
     f32x4 ssum = nul, ssq = nul;
-    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bz : p.x), 0, BNB ? p.y_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bmy : p.x), 0, (BNB && p.bmy) ? p.y_bytes : 0u, 0x00020000);
     f32x4 mu = nul, is = nul, msc = nul, mbi = one;       // no mask: 0 * z + 1 > 0
     if (BNB && nv) {
         mu = *reinterpret_cast<const f32x4*>(p.bmu + n); is = *reinterpret_cast<const f32x4*>(p.bis + n);
         if (p.bsc) { msc = *reinterpret_cast<const f32x4*>(p.bsc + n); mbi = *reinterpret_cast<const f32x4*>(p.bbi + n); }
     }
 #pragma unroll
-    for (int u = 0; u < NP; ++u) {
-        const int tl = tl0 + u * TPP;
+    for (int u = 0; u < MO; ++u) {
+        const int rest = (tid + NT * u) / C4;              // 0 .. 32 MO - 1
+        const int tl = rest / MO, bq = rest - tl * MO;
         const int m = m0 + tl;
-        unsigned off[2] = {WOOB, WOOB};
+        unsigned off[MO];
+#pragma unroll
+        for (int a = 0; a < MO; ++a) off[a] = WOOB;
         if (nv && m < p.Mtiles) {
             const int b = m / p.tpi, r = m - b * p.tpi;
             const int ty = r / p.TW, tx = r - ty * p.TW;
-            const int xx = 2 * tx + bq;
+            const int xx = MO * tx + bq;
             if (xx < p.W) {
-                const int pix = (b * p.H + 2 * ty) * p.W + xx;
-                off[0] = (unsigned)(pix * p.Cout + n) << 2;
-                if (2 * ty + 1 < p.H) off[1] = (unsigned)((pix + p.W) * p.Cout + n) << 2;
+#pragma unroll
+                for (int a = 0; a < MO; ++a) {
+                    const int yy = MO * ty + a;
+                    if (yy < p.H) off[a] = (unsigned)(((b * p.OH + yy * p.os + ooy) * p.OW + xx * p.os + oox) * p.Cout + n) << 2;
+                }
             }
         }
-        f32x4 rs[2] = {nul, nul};
-        if (p.res) { rs[0] = wbuf_load4(rr, off[0]); rs[1] = wbuf_load4(rr, off[1]); }
+        f32x4 rs[MO];
+#pragma unroll
+        for (int a = 0; a < MO; ++a) rs[a] = p.res ? wbuf_load4(rr, off[a]) : nul;
         f32x4 pq[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pq[k] = *reinterpret_cast<const f32x4*>(&Ps[((k * 2 + bq) * W_TB + tl) * LDP + c4 * 4]);
-        f32x4 yv[2];
+        for (int k = 0; k < 4; ++k) pq[k] = *reinterpret_cast<const f32x4*>(&Ps[((k * MO + bq) * W_TB + tl) * W_LDP + c4 * 4]);
+        f32x4 yv[MO];
         yv[0] = pq[0] + pq[1] + pq[2];
-        yv[1] = pq[1] - pq[2] - pq[3];
+        if (MO == 2) {
+            yv[1] = pq[1] - pq[2] - pq[3];
+        } else {
+            yv[1] = pq[1] - pq[2];
+            yv[MO - 1] = pq[1] + pq[2] + pq[3];
+        }
         if constexpr (BNB) {
-            f32x4 zt[2], yt[2] = {nul, nul};
-            zt[0] = wbuf_load4(zr, off[0]); zt[1] = wbuf_load4(zr, off[1]);
-            if (p.bmy) { yt[0] = wbuf_load4(mr, off[0]); yt[1] = wbuf_load4(mr, off[1]); }
+            f32x4 zt[MO], yt[MO];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
+            for (int a = 0; a < MO; ++a) { zt[a] = wbuf_load4(zr, off[a]); yt[a] = p.bmy ? wbuf_load4(mr, off[a]) : nul; }
+#pragma unroll
+            for (int a = 0; a < MO; ++a) {
                 f32x4 gq;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -345,20 +343,20 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
             }
         } else {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            f32x4 o;
+            for (int a = 0; a < MO; ++a) {
+                f32x4 o;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = fmaxf(yv[a][c] * sc[c] + bi[c] + rs[a][c], lo);
-            wbuf_store4(yr, off[a], o);
-            if (p.stats && off[a] != WOOB) {
+                for (int c = 0; c < 4; ++c) o[c] = fmaxf(yv[a][c] * sc[c] + bi[c] + rs[a][c], lo);
+                wbuf_store4(yr, off[a], o);
+                if (p.stats && off[a] != WOOB) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { ssum[c] += o[c]; ssq[c] += o[c] * o[c]; }
+                    for (int c = 0; c < 4; ++c) { ssum[c] += o[c]; ssq[c] += o[c] * o[c]; }
+                }
             }
-        }
         }
     }
     if (p.stats) {
-        // BatchNorm batch statistics of the pixels just stored: one (sum, sum^2) double pair per (m-tile, channel), fixed order
+        // BatchNorm batch statistics of the pixels just stored: one (sum, sum^2) double pair per (row block, channel), fixed order
         __syncthreads();
         f32x4* sh = reinterpret_cast<f32x4*>(smem);
         sh[tid] = ssum; sh[NT + tid] = ssq;
@@ -371,47 +369,45 @@ __device__ __forceinline__ void conv3x3_winograd_body(const WinoParams& p, float
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { ds[c] += a[c]; dq[c] += b[c]; }
             }
+            const long long rb = (long long)blockIdx.y * p.m_tiles + m_tile;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int nn = n0 + tid * 4 + c;
                 if (nn < p.Cout) {
-                    p.stats[((long long)m_tile * p.Cout + nn) * 2 + 0] = ds[c];
-                    p.stats[((long long)m_tile * p.Cout + nn) * 2 + 1] = dq[c];
+                    p.stats[(rb * p.Cout + nn) * 2 + 0] = ds[c];
+                    p.stats[(rb * p.Cout + nn) * 2 + 1] = dq[c];
                 }
             }
         }
     }
 }
 
-// <NH = 2, HALVES = 2>: 64 tiles x 64 channels, 8 waves, one block per CU (large launches);  <1, 2>: 64 tiles x 32 channels (Cout <= 32),
-// two blocks per CU;  <1, 1>: 32 tiles x 32 channels, 64 accumulator registers, three blocks per CU — small launches (fine-tune batches),
-// where the large tile leaves CUs idle.  The arithmetic of a tile does not depend on the configuration: same bits.
-template <int NH, int HALVES, bool BNB>
-__global__ __launch_bounds__(256 * NH, NH == 1 ? (HALVES == 1 ? 3 : 2) : 1) void conv3x3_winograd_kernel(WinoParams p) {
+template <int MO, bool BNB>
+__global__ __launch_bounds__(256, 3) void winograd_kernel(WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    conv3x3_winograd_body<NH, HALVES, BNB>(p, smem);
+    winograd_body<MO, BNB>(p, smem);
 }
 
-// U = G g G^T (winograd_pack.h): one block per (32 output channels, 8 input channels)
+// U = G g G^T (winograd_pack.h): one block per (32 output channels, 8 input channels) (x 4 phases for the transposed conv)
 __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int NH, int mode, int w_i) {
     wino_pack_block(w, out, mode, w_i, Cout, Cin, NH, blockIdx.x, threadIdx.x);
 }
 
-static std::atomic<unsigned> g_wino_lds_done[8];
-static std::atomic<int> g_wino_cfg{0};            // vatl_tune_set(18, v): 0 / 2 = 32 x 32 blocks (default), 1 = 64-tile blocks
-int wino_set_cfg(int v) { g_wino_cfg.store(v, std::memory_order_relaxed); return 0; }
+static std::atomic<unsigned> g_wino_lds_done[4];
 static std::atomic<int> g_wino_ablate{0};
 int wino_set_ablate(int bits) { g_wino_ablate.store(bits, std::memory_order_relaxed); return 0; }
 
-template <int NH, int HALVES, bool BNB>
-static int launch_wino(WinoParams& p, int64_t* row_blocks_used, hipStream_t st) {
-    constexpr int smem = wino_lds_floats<NH, HALVES>() * (int)sizeof(float);
-    auto kern = conv3x3_winograd_kernel<NH, HALVES, BNB>;
-    if (int rc = ensure_dynamic_lds((const void*)kern, smem, g_wino_lds_done[(NH - 1) * 2 + (HALVES - 1) + (BNB ? 4 : 0)], "conv3x3_winograd")) return rc;
-    p.m_tiles = cdiv(p.Mtiles, 32 * HALVES); p.n_tiles = cdiv(p.Cout, 32 * NH);
-    if (row_blocks_used) *row_blocks_used = p.m_tiles;
-    hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles), dim3(256 * NH), smem, st, p);
-    return check_launch("conv3x3_winograd");
+constexpr int kWinoMaxLds = 64 * 1024;            // upper bound of a block's dynamic LDS (ns <= 128: two 32 KB stages)
+
+template <int MO, bool BNB>
+static int launch_wino(const WinoParams& p, int phases, hipStream_t st) {
+    auto kern = winograd_kernel<MO, BNB>;
+    if (int rc = ensure_dynamic_lds((const void*)kern, kWinoMaxLds, g_wino_lds_done[(MO - 2) * 2 + (BNB ? 1 : 0)], "winograd")) return rc;
+    const int loop = 2 * p.stage_floats, epi = 4 * MO * W_TB * W_LDP, sta = 2 * 256 * 4;
+    const int smem = std::max(loop, std::max(epi, sta)) * (int)sizeof(float);
+    if (smem > kWinoMaxLds) return fail(VATL_EINVAL, "winograd: %d bytes of LDS per block", smem);
+    hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles, phases), dim3(256), smem, st, p);
+    return check_launch("winograd");
 }
 
 }  // namespace vatl
@@ -438,48 +434,68 @@ extern "C" int vatl_pack_winograd_weight(const float* w, float* u, int Cout, int
     return check_launch("wino_pack");
 }
 
+// ConvTranspose2d(4, 2, 1) filter (Cin, Cout, 4, 4) -> four phase filters G g_phase G^T, [phase][fragment order of vatl_pack_winograd_weight]
+extern "C" int64_t vatl_winograd_deconv_weight_floats(int Cout, int Cin) { return 4 * vatl_winograd_weight_floats(Cout, Cin); }
+
+extern "C" int vatl_pack_winograd_deconv_weight(const float* w, float* u, int Cout, int Cin, void* stream) {
+    if (!w || !u || Cout <= 0 || Cin <= 0) return fail(VATL_EINVAL, "pack_winograd_deconv_weight: null pointer or empty filter");
+    if (Cin % 16 != 0) return fail(VATL_EINVAL, "pack_winograd_deconv_weight: Cin %d must be a multiple of 16", Cin);
+    const int pad = vatl_winograd_cout_pad(Cout);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)(4 * (pad / 32) * (Cin / 8))), dim3(256), 0, (hipStream_t)stream, w, u, Cout, Cin, wino_nh(Cout),
+                       2, Cout);
+    return check_launch("wino_pack_deconv");
+}
+
 struct WinoBn { const float *z, *mask_y, *scale, *bias, *mean, *invstd; };
 
-static int winograd_impl(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, double* stats,
-                         int64_t* row_blocks_used, int N, int H, int W, int Cin, int Cout, int relu, void* stream, const WinoBn* fuse = nullptr) {
-    if (!x || !u || !y || N <= 0 || H <= 0 || W <= 0) return fail(VATL_EINVAL, "conv3x3_winograd: null pointer or empty batch");
-    if (Cin % 16 != 0 || (Cout & 3)) return fail(VATL_EINVAL, "conv3x3_winograd: Cin %d must be a multiple of 16 and Cout %d of 4", Cin, Cout);
+// MO = 2: 3x3 / stride 1 / pad 1 conv (y: N x H x W x Cout);  MO = 3: ConvTranspose2d(4, 2, 1) (y: N x 2H x 2W x Cout)
+static int winograd_impl(int MO, const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y,
+                         double* stats, int64_t* row_blocks_used, int N, int H, int W, int Cin, int Cout, int relu, void* stream,
+                         const WinoBn* fuse = nullptr) {
+    if (!x || !u || !y || N <= 0 || H <= 0 || W <= 0) return fail(VATL_EINVAL, "winograd: null pointer or empty batch");
+    if (Cin % 16 != 0 || (Cout & 3)) return fail(VATL_EINVAL, "winograd: Cin %d must be a multiple of 16 and Cout %d of 4", Cin, Cout);
     WinoParams p{};
     p.x = x; p.u = u; p.scale = scale; p.bias = bias; p.res = residual; p.y = y; p.stats = stats;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
-    p.TH = (H + 1) / 2; p.TW = (W + 1) / 2; p.tpi = p.TH * p.TW;
-    const long long mt = (long long)N * p.tpi, xe = (long long)N * H * W * Cin, ye = (long long)N * H * W * Cout;
+    p.TH = (H + MO - 1) / MO; p.TW = (W + MO - 1) / MO; p.tpi = p.TH * p.TW;
+    const int phases = MO == 3 ? 4 : 1, os = MO == 3 ? 2 : 1;
+    const long long mt = (long long)N * p.tpi, xe = (long long)N * H * W * Cin, ye = (long long)N * H * W * os * os * Cout;
     const long long ue = vatl_winograd_weight_floats(Cout, Cin);
     if (xe >= (1LL << 30) || ye >= (1LL << 30) || ue >= (1LL << 30) || mt >= (1LL << 30))
-        return fail(VATL_EINVAL, "conv3x3_winograd: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
+        return fail(VATL_EINVAL, "winograd: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
     p.Mtiles = (int)mt;
     p.nhp = wino_nh(Cout);
     p.stages = Cin / W_CK;
+    p.RW = MO * p.TW + 4 - MO;
+    p.ns = 31 * MO + 4 + (4 - MO) * ((p.TW + 30) / p.TW);  // slots a block of 32 consecutive tiles can touch (header comment)
+    p.ndma = (4 * p.ns * 4 + 63) / 64;
+    p.stage_floats = p.ndma * 256;
+    p.pad_y = 1; p.pad_x = 1; p.OH = H * os; p.OW = W * os; p.os = os; p.ooy = 0; p.oox = 0;
+    p.deconv = MO == 3; p.u_phase_floats = ue;
     p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.u_bytes = (unsigned)(ue * 4);
     p.ablate = g_wino_ablate.load(std::memory_order_relaxed);
-    if (fuse) { p.bz = fuse->z; p.bmy = fuse->mask_y; p.bsc = fuse->scale; p.bbi = fuse->bias; p.bmu = fuse->mean; p.bis = fuse->invstd; }
-    // The 32 x 32 configuration (three blocks per CU, 12 waves) beats the 64-tile ones at every size measured on MI355X — 1024 crops:
-    // l1.c2 1245 vs 1333 us, l4.c2 967 vs 1029, hr.b32 476 vs 537;  120 crops: l3.c2 150 vs 197, l4.c2 142 vs 191 (tools/wino_bench.py
-    // --cfg 2 / 1): the blocks of a CU overlap each other's prologue, barriers and output transform.  The large ones stay selectable.
-    const int cfg = g_wino_cfg.load(std::memory_order_relaxed);
-    const bool small = cfg != 1;
+    p.m_tiles = cdiv(mt, W_TB); p.n_tiles = cdiv(Cout, 32);
+    if (row_blocks_used) *row_blocks_used = (int64_t)p.m_tiles * phases;
     hipStream_t st = (hipStream_t)stream;
-    if (small) return fuse ? launch_wino<1, 1, true>(p, row_blocks_used, st) : launch_wino<1, 1, false>(p, row_blocks_used, st);
-    if (p.nhp == 1) return fuse ? launch_wino<1, 2, true>(p, row_blocks_used, st) : launch_wino<1, 2, false>(p, row_blocks_used, st);
-    return fuse ? launch_wino<2, 2, true>(p, row_blocks_used, st) : launch_wino<2, 2, false>(p, row_blocks_used, st);
+    if (fuse) {
+        if (MO != 2) return fail(VATL_EINVAL, "winograd: the BatchNorm-backward epilogue exists for the 3x3 route only");
+        p.bz = fuse->z; p.bmy = fuse->mask_y; p.bsc = fuse->scale; p.bbi = fuse->bias; p.bmu = fuse->mean; p.bis = fuse->invstd;
+        return launch_wino<2, true>(p, phases, st);
+    }
+    return MO == 2 ? launch_wino<2, false>(p, phases, st) : launch_wino<3, false>(p, phases, st);
 }
 
 extern "C" int vatl_conv3x3_winograd_fwd(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y,
                                          int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
-    return winograd_impl(x, u, scale, bias, residual, y, nullptr, nullptr, N, H, W, Cin, Cout, relu, stream);
+    return winograd_impl(2, x, u, scale, bias, residual, y, nullptr, nullptr, N, H, W, Cin, Cout, relu, stream);
 }
 
-extern "C" int64_t vatl_winograd_stats_row_blocks(int64_t N, int H, int W) { return (N * ((H + 1) / 2) * ((W + 1) / 2) + 31) / 32; }   // capacity
+extern "C" int64_t vatl_winograd_stats_row_blocks(int64_t N, int H, int W) { return (N * ((H + 1) / 2) * ((W + 1) / 2) + W_TB - 1) / W_TB; }
 
 extern "C" int vatl_conv3x3_winograd_fwd_stats(const float* x, const float* u, float* y, double* stats, int64_t* row_blocks_used, int N, int H,
                                                int W, int Cin, int Cout, void* stream) {
     if (!stats || !row_blocks_used) return fail(VATL_EINVAL, "conv3x3_winograd_fwd_stats: null statistics buffer");
-    return winograd_impl(x, u, nullptr, nullptr, nullptr, y, stats, row_blocks_used, N, H, W, Cin, Cout, 0, stream);
+    return winograd_impl(2, x, u, nullptr, nullptr, nullptr, y, stats, row_blocks_used, N, H, W, Cin, Cout, 0, stream);
 }
 
 // Data-gradient launch fused with the reduction pass of the consumer layer's BatchNorm backward: the Winograd counterpart of
@@ -490,5 +506,19 @@ extern "C" int vatl_conv3x3_winograd_fwd_bnbwd(const float* x, const float* u, c
     if (!bn_z || !stats || !row_blocks_used || !bn_mean || !bn_invstd || (bn_scale && !bn_bias))
         return fail(VATL_EINVAL, "conv3x3_winograd_fwd_bnbwd: needs z, mean, invstd and a statistics buffer");
     const WinoBn bn{bn_z, bn_mask_y, bn_scale, bn_bias, bn_mean, bn_invstd};
-    return winograd_impl(x, u, nullptr, nullptr, residual, y, stats, row_blocks_used, N, H, W, Cin, Cout, 0, stream, &bn);
+    return winograd_impl(2, x, u, nullptr, nullptr, residual, y, stats, row_blocks_used, N, H, W, Cin, Cout, 0, stream, &bn);
+}
+
+// ConvTranspose2d(4, 2, 1) + folded BatchNorm + ReLU (inference) / + batch statistics (training forward) on the F(3x3, 2x2) route
+extern "C" int vatl_deconv4x4s2_winograd_fwd(const float* x, const float* u, const float* scale, const float* bias, float* y, int N, int H, int W,
+                                             int Cin, int Cout, int relu, void* stream) {
+    return winograd_impl(3, x, u, scale, bias, nullptr, y, nullptr, nullptr, N, H, W, Cin, Cout, relu, stream);
+}
+
+extern "C" int64_t vatl_winograd_deconv_stats_row_blocks(int64_t N, int H, int W) { return 4 * ((N * ((H + 2) / 3) * ((W + 2) / 3) + W_TB - 1) / W_TB); }
+
+extern "C" int vatl_deconv4x4s2_winograd_fwd_stats(const float* x, const float* u, float* y, double* stats, int64_t* row_blocks_used, int N, int H,
+                                                   int W, int Cin, int Cout, void* stream) {
+    if (!stats || !row_blocks_used) return fail(VATL_EINVAL, "deconv4x4s2_winograd_fwd_stats: null statistics buffer");
+    return winograd_impl(3, x, u, nullptr, nullptr, nullptr, y, stats, row_blocks_used, N, H, W, Cin, Cout, 0, stream);
 }

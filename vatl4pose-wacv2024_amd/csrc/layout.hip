@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const VatlPackJob* __re
     const float* __restrict__ w = J->src;
     float* __restrict__ out = J->dst;
     const int kind = J->kind, Cout = J->Cout, Cin = J->Cin, R = J->R, S = J->S, pa = J->a, pb = J->b, pc = J->c;
-    if (kind >= 3) {                                               // 3: Winograd forward filter, 4: Winograd data-gradient filter; b = NH, c = w_i
+    if (kind >= 3) {                                               // 3 / 4 / 5: Winograd filter transforms (forward, data gradient, transposed conv); b = NH, c = w_i
         wino_pack_block(w, out, kind - 3, pc, Cout, Cin, pb, (long long)blockIdx.x - J->first_block, threadIdx.x);   // 4096 elements per block
         return;
     }

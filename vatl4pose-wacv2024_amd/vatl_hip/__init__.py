@@ -81,6 +81,11 @@ SIGNATURES = {
     "vatl_winograd_stats_row_blocks": (_i64, [_i64, _i, _i]),
     "vatl_conv3x3_winograd_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vatl_conv3x3_winograd_fwd_bnbwd": (_i, [_p] * 4 + [_i] * 5 + [_p] * 9),
+    "vatl_winograd_deconv_weight_floats": (_i64, [_i, _i]),
+    "vatl_pack_winograd_deconv_weight": (_i, [_p, _p, _i, _i, _p]),
+    "vatl_deconv4x4s2_winograd_fwd": (_i, [_p] * 5 + [_i] * 6 + [_p]),
+    "vatl_winograd_deconv_stats_row_blocks": (_i64, [_i64, _i, _i]),
+    "vatl_deconv4x4s2_winograd_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vatl_conv2d_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_deconv4x4s2_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_bn_train_finalize": (_i, [_p, _i64, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
@@ -445,6 +450,34 @@ def pack_winograd_weight(w: torch.Tensor, data_gradient: bool = False) -> torch.
         pad = int(lib().vatl_winograd_cout_pad(cout))
         plan.record(key, w, out, (4 if data_gradient else 3, cout, cin, 3, 3, pad, 1 if pad <= 32 else 2, ci, ()))
     return out
+
+
+def pack_winograd_deconv_weight(w: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d(4,2,1) weight (Cin,Cout,4,4) -> the four sub-pixel phase filters in the F(3x3,2x2) transform domain,
+    MFMA fragment order (csrc/conv_winograd.hip)."""
+    cin, cout = w.shape[:2]
+    if tuple(w.shape[2:]) != (4, 4):
+        raise VatlError("pack_winograd_deconv_weight: 4x4 filters only")
+    plan, key = getattr(_tls, "pack_plan", None), ("winograd_deconv", w.data_ptr(), tuple(w.shape))
+    if plan is not None and w.is_contiguous():
+        kept = plan.lookup(key, w)
+        if kept is not None:
+            return kept
+    out = torch.empty(int(lib().vatl_winograd_deconv_weight_floats(cout, cin)), device=w.device, dtype=torch.float32)
+    _check(lib().vatl_pack_winograd_deconv_weight(_ptr(w.contiguous()), _ptr(out), cout, cin, _stream()), "vatl_pack_winograd_deconv_weight")
+    if plan is not None and w.is_contiguous():
+        pad = int(lib().vatl_winograd_cout_pad(cout))
+        plan.record(key, w, out, (5, cout, cin, 4, 4, pad, 1 if pad <= 32 else 2, cout, ()))
+    return out
+
+
+def deconv4x4s2_winograd_fwd(x, u_packed, scale, bias, cout: int, relu: bool, out=None):
+    """ConvTranspose2d(4,2,1) of an NHWC tensor through Winograd F(3x3, 2x2) on its four sub-pixel phases."""
+    n, h, w, cin = x.shape
+    y = out if out is not None else torch.empty((n, 2 * h, 2 * w, cout), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_deconv4x4s2_winograd_fwd(_ptr(x), _ptr(u_packed), _ptr(scale), _ptr(bias), _ptr(y), n, h, w, cin, cout, int(relu), _stream()),
+           "vatl_deconv4x4s2_winograd_fwd")
+    return y
 
 
 def conv3x3_winograd_fwd(x, u_packed, scale, bias, cout: int, relu: bool, residual=None, out=None):
@@ -864,6 +897,17 @@ def conv3x3_winograd_fwd_bnbwd(x, u_packed, cout: int, spec: "BnBwdSpec", out=No
                                                  _stream()), "vatl_conv3x3_winograd_fwd_bnbwd")
     spec.blocks += used.value
     return y
+
+
+def deconv4x4s2_winograd_fwd_bnstats(x, u_packed, cout: int, gamma, beta, running_mean, running_var, momentum: float, eps: float):
+    """deconv4x4s2_fwd_bnstats on the Winograd route: -> z, save_mean, save_invstd, scale, bias; running stats updated in place."""
+    n, h, w, cin = x.shape
+    z = torch.empty((n, 2 * h, 2 * w, cout), device=x.device, dtype=torch.float32)
+    stats = torch.empty(int(lib().vatl_winograd_deconv_stats_row_blocks(n, h, w)) * cout * 2, device=x.device, dtype=torch.float64)
+    used = C.c_int64(0)
+    _check(lib().vatl_deconv4x4s2_winograd_fwd_stats(_ptr(x), _ptr(u_packed), _ptr(z), _ptr(stats, torch.float64), C.addressof(used), n, h, w, cin,
+                                                     cout, _stream()), "vatl_deconv4x4s2_winograd_fwd_stats")
+    return [z] + _bn_finalize(stats, used.value, z.numel() // cout, cout, (gamma, beta, running_mean, running_var, momentum, eps), x.device)
 
 
 def conv3x3_winograd_fwd_bnstats(x, u_packed, cout: int, gamma, beta, running_mean, running_var, momentum: float, eps: float):
