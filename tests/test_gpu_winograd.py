@@ -172,6 +172,8 @@ def test_pack_plan_refreshes_winograd_filters_with_the_same_bits(vh):
     """The one-launch re-pack of a fine-tune step (vatl_pack_weights_multi, kinds 3 / 4) writes what vatl_pack_winograd_weight writes."""
     g = torch.Generator(device="cpu").manual_seed(23)
     ws = [(torch.randn(s, generator=g) * 0.1).to(dev()) for s in ((64, 64, 3, 3), (32, 32, 3, 3), (48, 80, 3, 3), (128, 256, 3, 3))]
+    wdc = [(torch.randn(s, generator=g) * 0.1).to(dev()) for s in ((64, 48, 4, 4), (32, 256, 4, 4))]
+    want_dc = [vh.pack_winograd_deconv_weight(w) for w in wdc]
     want = [(vh.pack_winograd_weight(w), vh.pack_winograd_weight(w, data_gradient=True)) for w in ws]
     plan = vh.PackPlan()
     prev = vh.set_pack_plan(plan)
@@ -179,7 +181,10 @@ def test_pack_plan_refreshes_winograd_filters_with_the_same_bits(vh):
         plan.begin()
         first = [(vh.pack_winograd_weight(w), vh.pack_winograd_weight(w, data_gradient=True)) for w in ws]
         other = vh.pack_conv_weight(ws[0])                  # a job of another kind in the same table
+        first_dc = [vh.pack_winograd_deconv_weight(w) for w in wdc]
         plan.seal()
+        for t in first_dc:
+            t.zero_()
         for a, b in first:
             a.zero_(); b.zero_()
         other_want = other.clone(); other.zero_()
@@ -191,6 +196,8 @@ def test_pack_plan_refreshes_winograd_filters_with_the_same_bits(vh):
         assert a.data_ptr() == fa.data_ptr() and b.data_ptr() == fb.data_ptr()
         assert torch.equal(a, wa) and torch.equal(b, wb)
     assert torch.equal(other, other_want)
+    for t, w in zip(first_dc, want_dc):
+        assert torch.equal(t, w)
 
 
 DECONV_CASES = [("2048_256", 2, 8, 6, 2048, 256), ("256_256", 3, 16, 12, 256, 256), ("odd", 2, 5, 3, 64, 48), ("256_256_big", 1, 32, 24, 256, 256),

@@ -342,8 +342,13 @@ class _DeconvBN:
 
     def forward(self, x):
         bn = self.bn
-        z, mean, invstd, scale, bias = vh.deconv4x4s2_fwd_bnstats(x, vh.pack_deconv_weight(self.dc.weight.detach()), self.cout, bn.weight.detach(),
-                                                                  bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        if _WINOGRAD and self.cin % 16 == 0 and self.cout % 4 == 0:      # four 2x2 phase convolutions as Winograd F(3x3, 2x2)
+            z, mean, invstd, scale, bias = vh.deconv4x4s2_winograd_fwd_bnstats(x, vh.pack_winograd_deconv_weight(self.dc.weight.detach()), self.cout,
+                                                                               bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                                                               bn.momentum, bn.eps)
+        else:
+            z, mean, invstd, scale, bias = vh.deconv4x4s2_fwd_bnstats(x, vh.pack_deconv_weight(self.dc.weight.detach()), self.cout, bn.weight.detach(),
+                                                                      bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps)
         _count_batch(bn)
         y = _tap(vh.scale_bias_act(z, scale, bias, None, True))
         self.saved = (x, z, scale, bias, mean, invstd)
