@@ -69,7 +69,8 @@ struct WinoParams {
     int ndma, stage_floats;           // LDS-DMA instructions per stage (1 KB each), floats per stage
     int pad_y, pad_x;                 // tile (ty, tx) reads input rows MO ty - pad_y + i (deconv: 1 - phase bit, set in the kernel)
     int OH, OW, os, ooy, oox;         // output pixel of grid point (y, x) = (y os + ooy, x os + oox) in an OH x OW image
-    int deconv;                       // blockIdx.y = sub-pixel phase py * 2 + px
+    int deconv;                       // four sub-pixel phases py * 2 + px, each with its own filter
+    int rn;                           // filter slices per group of the tile order (see the kernel)
     long long u_phase_floats;         // deconv: floats of one phase's packed filter
     int ablate;                       // profiling library only (vatl_tune_set(17, bits), wrong results): 1 no output transform, 2 no LDS
                                       // reads / input transform, 4 no filter loads, 8 no staging DMA, 16 no barriers
@@ -101,20 +102,26 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
 
     const int tid = threadIdx.x, lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // XCD-aware tile order: block b runs on XCD b % 8; each XCD gets a contiguous run of tiles with the m-tile fastest, so the
-    // blocks of an XCD share few filter slices (16 * Cin * 32 * 4 bytes each) in their L2
+    // XCD-aware tile order: block b runs on XCD b % 8; each XCD gets a contiguous run of the sequence
+    //     for (group of rn filter slices) for (m-tile) for (slice in the group)        slice = (phase, 32 output channels)
+    // so the blocks that are resident together read the same input tiles (fetched from HBM once per group instead of once per slice)
+    // while the group's filter slices (rn * Cin * 2 KB <= 2 MB) stay in that XCD's L2 for the whole sweep over the m-tiles.
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3, q8 = nblk >> 3, r8 = nblk & 7;
     const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    const int n_tile = t / p.m_tiles, m_tile = t - n_tile * p.m_tiles;
+    const int units = p.n_tiles * (p.deconv ? 4 : 1);
+    const int grp = t / (p.m_tiles * p.rn), rem = t - grp * (p.m_tiles * p.rn);
+    const int rn_g = min(p.rn, units - grp * p.rn);        // the last group may be smaller
+    const int m_tile = rem / rn_g, unit = grp * p.rn + (rem - m_tile * rn_g);
+    const int phase = unit / p.n_tiles, n_tile = unit - phase * p.n_tiles;
     const int m0 = m_tile * W_TB, n0 = n_tile * BN;
 
     int pad_y = p.pad_y, pad_x = p.pad_x, ooy = p.ooy, oox = p.oox;
     const float* ubase_ptr = p.u;
     if (p.deconv) {
-        const int py = blockIdx.y >> 1, px = blockIdx.y & 1;
+        const int py = phase >> 1, px = phase & 1;
         pad_y = 1 - py; pad_x = 1 - px; ooy = py; oox = px;
-        ubase_ptr += (long long)blockIdx.y * p.u_phase_floats;
+        ubase_ptr += (long long)phase * p.u_phase_floats;
     }
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ubase_ptr), 0, p.u_bytes, 0x00020000);
@@ -369,7 +376,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { ds[c] += a[c]; dq[c] += b[c]; }
             }
-            const long long rb = (long long)blockIdx.y * p.m_tiles + m_tile;
+            const long long rb = (long long)phase * p.m_tiles + m_tile;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int nn = n0 + tid * 4 + c;
@@ -395,6 +402,8 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 
 static std::atomic<unsigned> g_wino_lds_done[4];
 static std::atomic<int> g_wino_ablate{0};
+static std::atomic<int> g_wino_group_kb{2048};     // vatl_tune_set(18, v): KB of filter slices per group of the tile order (0 = one slice)
+int wino_set_group_kb(int v) { g_wino_group_kb.store(v, std::memory_order_relaxed); return 0; }
 int wino_set_ablate(int bits) { g_wino_ablate.store(bits, std::memory_order_relaxed); return 0; }
 
 constexpr int kWinoMaxLds = 64 * 1024;            // upper bound of a block's dynamic LDS (ns <= 128: two 32 KB stages)
@@ -406,7 +415,7 @@ static int launch_wino(const WinoParams& p, int phases, hipStream_t st) {
     const int loop = 2 * p.stage_floats, epi = 4 * MO * W_TB * W_LDP, sta = 2 * 256 * 4;
     const int smem = std::max(loop, std::max(epi, sta)) * (int)sizeof(float);
     if (smem > kWinoMaxLds) return fail(VATL_EINVAL, "winograd: %d bytes of LDS per block", smem);
-    hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles, phases), dim3(256), smem, st, p);
+    hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles * phases), dim3(256), smem, st, p);
     return check_launch("winograd");
 }
 
@@ -476,6 +485,9 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
     p.ablate = g_wino_ablate.load(std::memory_order_relaxed);
     p.m_tiles = cdiv(mt, W_TB); p.n_tiles = cdiv(Cout, 32);
     if (row_blocks_used) *row_blocks_used = (int64_t)p.m_tiles * phases;
+    // a slice is Cin * 2 KB; at least two per group (deconv1, Cin = 2048: 4 MB slices, 4326 -> 4135 us with two), unless the knob says 0
+    const int gkb = g_wino_group_kb.load(std::memory_order_relaxed);
+    p.rn = std::max(1, std::min(p.n_tiles * phases, std::max(gkb > 0 ? 2 : 1, gkb / (2 * Cin))));
     hipStream_t st = (hipStream_t)stream;
     if (fuse) {
         if (MO != 2) return fail(VATL_EINVAL, "winograd: the BatchNorm-backward epilogue exists for the 3x3 route only");
