@@ -138,6 +138,8 @@ def lib() -> C.CDLL:
         _lib = l
         if os.environ.get("VATL_CONV_VAR"):          # A/B knob for benchmarks and tests (results are identical)
             l.vatl_tune_set(0, int(os.environ["VATL_CONV_VAR"]))
+        if os.environ.get("VATL_WINO_GROUP_KB"):     # tile-order knob of the Winograd kernel (results are identical)
+            l.vatl_tune_set(18, int(os.environ["VATL_WINO_GROUP_KB"]))
     return _lib
 
 
