@@ -489,6 +489,16 @@ int vatl_deconv4x4s2_winograd_fwd(const float* x, const float* u, const float* s
 int64_t vatl_winograd_deconv_stats_row_blocks(int64_t N, int H, int W);
 int vatl_deconv4x4s2_winograd_fwd_stats(const float* x, const float* u, float* y, double* stats, int64_t* row_blocks_used, int N, int H, int W,
                                         int Cin, int Cout, void* stream);
+/* Weight gradients on the Winograd route (csrc/winograd_wgrad.hip): dw (Cout, Cin, 3, 3) of a 3x3 / stride 1 / pad 1 conv from its input
+ * x (N,H,W,Cin) and output gradient dz (N,H,W,Cout); dw (Cin, Cout, 4, 4) of ConvTranspose2d(4,2,1) from its input x (N,H,W,Cin) and output
+ * gradient dy (N,2H,2W,Cout).  Replace loss.backward() through those layers (ActiveLearning.py:672) like vatl_conv2d_wgrad /
+ * vatl_deconv4x4s2_wgrad; channel counts % 4 == 0, N * tiles < 2^20.  workspace: the *_workspace_floats query; partial sums per tile
+ * range are added in a fixed order (bitwise reproducible). */
+int64_t vatl_conv3x3_winograd_wgrad_workspace_floats(int Cout, int Cin, int64_t N, int H, int W);
+int vatl_conv3x3_winograd_wgrad(const float* x, const float* dz, float* dw, float* workspace, int N, int H, int W, int Cin, int Cout, void* stream);
+int64_t vatl_deconv4x4s2_winograd_wgrad_workspace_floats(int Cin, int Cout, int64_t N, int H, int W);
+int vatl_deconv4x4s2_winograd_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int H, int W, int Cin, int Cout,
+                                    void* stream);
 int vatl_conv3x3_winograd_fwd_bnbwd(const float* x, const float* u, const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
                                     const float* bn_z, const float* bn_mask_y, const float* bn_scale, const float* bn_bias,
                                     const float* bn_mean, const float* bn_invstd, double* stats, int64_t* row_blocks_used, void* stream);

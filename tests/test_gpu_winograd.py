@@ -245,3 +245,46 @@ def test_deconv_winograd_statistics_and_batch_position(vh):
         for i in (0, n - 1):
             alone = vh.deconv4x4s2_winograd_fwd(x[i:i + 1].contiguous(), u, None, None, cout, False)
             assert torch.equal(alone[0], plain[i])
+
+
+WGRAD_CASES = [(2, 16, 12, 64, 128), (3, 13, 9, 32, 48), (1, 8, 6, 256, 64), (7, 8, 6, 64, 64), (5, 2, 2, 16, 8), (2, 64, 48, 32, 32), (40, 16, 12, 36, 20)]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=["x".join(map(str, c)) for c in WGRAD_CASES])
+def test_winograd_weight_gradient_of_the_3x3_layers(vh, case):
+    """dW of a 3x3 / stride 1 / pad 1 conv through the transform domain against autograd in float64 and against the implicit GEMM."""
+    n, h, w, cin, cout = case
+    g = torch.Generator(device="cpu").manual_seed(41 + n)
+    x = torch.randn((n, cin, h, w), generator=g, dtype=torch.float64)
+    wt = (torch.randn((cout, cin, 3, 3), generator=g, dtype=torch.float64) * 0.05).requires_grad_(True)
+    dy = torch.randn((n, cout, h, w), generator=g, dtype=torch.float64)
+    F.conv2d(x, wt, None, 1, 1).backward(dy)
+    xd = x.float().permute(0, 2, 3, 1).contiguous().to(dev())
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().to(dev())
+    dw = vh.conv3x3_winograd_wgrad(xd, dyd)
+    e = rel_err(dw.cpu().numpy(), wt.grad.numpy())
+    record(f"winograd_wgrad_{n}x{h}x{w}_{cin}_{cout}", rel=e)
+    assert e < TOL, e
+    again = vh.conv3x3_winograd_wgrad(xd, dyd)
+    assert torch.equal(again, dw)                               # fixed reduction order
+    if cin % 4 == 0 and cout % 4 == 0:
+        direct = vh.conv2d_wgrad(xd, dyd, cout, cin, 3, 3, 1, 1)
+        assert rel_err(dw.cpu().numpy(), direct.cpu().numpy()) < 2 * TOL
+
+
+@pytest.mark.parametrize("case", [(2, 8, 6, 64, 48), (3, 5, 3, 32, 40), (1, 16, 12, 128, 64), (9, 9, 6, 16, 16), (4, 1, 4, 16, 8)], ids=str)
+def test_winograd_weight_gradient_of_the_transposed_conv(vh, case):
+    n, h, w, cin, cout = case
+    g = torch.Generator(device="cpu").manual_seed(43 + n)
+    x = torch.randn((n, cin, h, w), generator=g, dtype=torch.float64)
+    wt = (torch.randn((cin, cout, 4, 4), generator=g, dtype=torch.float64) * 0.05).requires_grad_(True)
+    dy = torch.randn((n, cout, 2 * h, 2 * w), generator=g, dtype=torch.float64)
+    F.conv_transpose2d(x, wt, None, 2, 1).backward(dy)
+    xd = x.float().permute(0, 2, 3, 1).contiguous().to(dev())
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().to(dev())
+    dw = vh.deconv4x4s2_winograd_wgrad(xd, dyd)
+    e = rel_err(dw.cpu().numpy(), wt.grad.numpy())
+    record(f"winograd_deconv_wgrad_{n}x{h}x{w}_{cin}_{cout}", rel=e)
+    assert e < TOL, e
+    direct = vh.deconv4x4s2_wgrad(xd, dyd)
+    assert rel_err(dw.cpu().numpy(), direct.cpu().numpy()) < 2 * TOL

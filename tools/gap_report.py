@@ -16,14 +16,14 @@ import sys
 def category(name: str) -> str:
     if "conv_wgrad" in name:
         return "wgrad"
-    if "conv_igemm" in name or "gemm1x1" in name or "conv3x3_halo" in name or "streamk" in name:
+    if "conv_igemm" in name or "gemm1x1" in name or "conv3x3_halo" in name or "streamk" in name or "winograd_kernel" in name:
         return "conv_fwd_dgrad"
     if "adamw" in name or "adam_" in name or "sgd" in name:
         return "optimizer"
     for k in ("bn_", "scale_bias", "col_reduce", "maxpool", "relu", "nchw", "se_", "pixel", "fuse_up", "col_sum", "hw_reduce", "masked_mse", "mse_finish"):
         if k in name:
             return "bn_elementwise"
-    if "wgrad_reduce" in name or "pack_" in name or "splitk_reduce" in name:
+    if "wgrad_reduce" in name or "pack_" in name or "splitk_reduce" in name or "wino_pack" in name:
         return "reduce_pack"
     return "other"
 

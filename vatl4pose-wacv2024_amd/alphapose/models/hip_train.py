@@ -129,6 +129,9 @@ import os as _os
 # stand-alone reduction pass (same values up to the summation order of the per-channel sums)
 _FUSE_BN_BWD = _os.environ.get("VATL_FUSE_BN_BWD", "1") != "0"
 _WINOGRAD = _os.environ.get("VATL_WINOGRAD", "1") != "0"    # 3x3 / stride-1 layers: forward + data gradient as Winograd F(2x2,3x3)
+# ... and the weight gradient from this many channels on (measured at B = 120, tools/wino_wgrad_bench.py: 128 channels 1.30x, 256 1.35x, 512 1.44x
+# over the implicit GEMM; 64 channels 1.0x, 32 channels slower — both operands are transformed per tile pair, 2.5x the vector work of the forward)
+_WINOGRAD_WGRAD_MIN_C = int(_os.environ.get("VATL_WINOGRAD_WGRAD_MINC", "128"))
 # ... for layers with at least this many channels: on the narrow tiles (32 / 64 output channels) the statistics epilogue costs
 # more than the stand-alone reduction pass it replaces (HRNet-W32 step 63.9 -> 69.4 ms with every layer fused)
 _FUSE_BN_MIN_C = int(_os.environ.get("VATL_FUSE_BN_MINC", "128"))
@@ -293,7 +296,10 @@ class _ConvBN:
         grads[self.bn.bias] = dbeta
         cin_w = 3 if self.cin == 3 else self.cin
         ow = _gout(grads, self.conv.weight)
-        grads[self.conv.weight] = _side.run(lambda: vh.conv2d_wgrad(x, dz, self.cout, cin_w, self.r, self.s, self.stride, self.pad, out=ow), x, dz)
+        if self.wino and min(self.cin, self.cout) >= _WINOGRAD_WGRAD_MIN_C:      # transform-domain weight gradient (csrc/winograd_wgrad.hip)
+            grads[self.conv.weight] = _side.run(lambda: vh.conv3x3_winograd_wgrad(x, dz, out=ow), x, dz)
+        else:
+            grads[self.conv.weight] = _side.run(lambda: vh.conv2d_wgrad(x, dz, self.cout, cin_w, self.r, self.s, self.stride, self.pad, out=ow), x, dz)
         dx = self._dgrad(dz, x.shape, dx_residual, consumer) if self.need_dx else None
         return dx, g
 

@@ -1,0 +1,355 @@
+// Weight gradients on the Winograd route (the backward counterpart of conv_winograd.hip):
+//   * 3x3 / stride 1 / pad 1 conv (MO = 2):        dW = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G
+//   * ConvTranspose2d(4, 2, 1), per phase (MO = 3): the same with the 2x2 phase filter, dY = that phase's 3x3 output-gradient tile
+// i.e. per transform position p = (xi, nu) one GEMM  dU_p[n][c] = sum_t Z_p[t][n] V_p[t][c]  with the reduction over ALL tiles of the
+// batch: 16 multiplies per (tile, n, c) where the direct sum has 36 (conv_wgrad.hip).  Exact fp32 products, fp32 accumulation.
+//
+// Block = 32 output channels (n) x 32 input channels (c) x 16 positions x one contiguous range of tiles (split); 4 waves, wave xi owns
+// the positions (xi, 0..3) = 64 accumulator registers.  The MFMA reduces over tile pairs: A operand Z_p[tile][n], B operand V_p[tile][c].
+// Per stage of TK tiles the raw pixels are staged by LDS-DMA, channel-fastest: the input x as in the forward kernel (four tile rows,
+// one slot per distinct pixel column), the output gradient as MO rows x (TK MO) pixels; pixels outside the image / the split are
+// out-of-range DMA offsets = zeros.  A lane (channel l & 31, tile parity l >> 5) reads its channel of 8 input pixels and <= MO^2 gradient
+// pixels per tile pair (ds_read_b32: 32 consecutive channels = 128 contiguous bytes), forms V (row transform by xi, then the four nu)
+// and Z in registers, and issues four MFMAs.
+// The nu side of G^T . G is applied to the accumulators in registers (4 tiles -> 3, or 2 for the phase filters); each block writes its
+// partial sums into its slice of a workspace and winograd_wgrad_finish_kernel adds the slices in split order, applies the xi side and
+// writes the filter in the tensor's own layout — no atomics, bitwise reproducible.
+#include "common.h"
+
+#include <algorithm>
+#include <atomic>
+
+namespace vatl {
+
+struct WinoWgradParams {
+    const float* x;                   // (N, H, W, Cx): the conv input (transposed conv: its input)
+    const float* g;                   // (N, OH, OW, Cn): gradient of the conv output
+    float* part;                      // [split][phase][set][xi][CnPad][CxPad]
+    int N, H, W, Cx, Cn;
+    int CnPad, CxPad;
+    int TH, TW, tpi, Mtiles;
+    int n_tiles, c_tiles, splits, tps; // tiles per split (a multiple of TK)
+    int RW, ns;                       // slot geometry of the x stage (conv_winograd.hip)
+    int ndma_x, ndma_g, stage_floats, g_floats_off;   // LDS-DMA instructions per stage, floats per stage, offset of the gradient pixels
+    int OH, OW, os;                   // gradient pixel of grid point (y, x) = (y os + phase_y, x os + phase_x)
+    int deconv;
+    float inv_TW, inv_TH, inv_RW, inv_ns;
+    unsigned x_bytes, g_bytes;
+};
+
+constexpr unsigned WWOOB = 0xFFFFFFFFu;
+typedef __attribute__((address_space(3))) void wwlds_void;
+
+template <int MO, int TK>
+__device__ __forceinline__ void winograd_wgrad_body(const WinoWgradParams& p, float* smem) {
+    constexpr int NS = MO == 2 ? 3 : 2;                    // accumulator sets after the nu side of G
+    constexpr int GP = TK * MO;                            // gradient pixels per stage row
+    constexpr int NLX = 6, NLG = (MO * GP * 8 + 255) / 256;   // DMA instructions per wave per stage, at most (x: ns <= 48)
+    const int tid = threadIdx.x, lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // block -> (n tile, c tile, phase, split), the channel tiles fastest: the blocks of one split read the same pixels
+    int bid = blockIdx.x;
+    const int n_tile = bid % p.n_tiles; bid /= p.n_tiles;
+    const int c_tile = bid % p.c_tiles; bid /= p.c_tiles;
+    const int phases = p.deconv ? 4 : 1;
+    const int phase = bid % phases;
+    const int split = bid / phases;
+    const int n0 = n_tile * 32, c0 = c_tile * 32;
+    const int py = phase >> 1, px = phase & 1;
+    const int pad_y = p.deconv ? 1 - py : 1, pad_x = p.deconv ? 1 - px : 1;
+    const int ooy = p.deconv ? py : 0, oox = p.deconv ? px : 0;
+    const int t_begin = split * p.tps, t_end = min(t_begin + p.tps, p.Mtiles);
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, p.g_bytes, 0x00020000);
+
+    // ---- staging items of this lane (constant over the stages): x item = (row i, slot, 16-byte chunk), gradient item = (row a, tile, col b, chunk)
+    int xi_i[NLX], xi_slot[NLX], xi_c[NLX];
+#pragma unroll
+    for (int u = 0; u < NLX; ++u) {
+        const int q = (xi + 4 * u) * 64 + lane;
+        const int pix = q >> 3;
+        const int i = fast_div(pix, p.inv_ns);
+        xi_i[u] = i; xi_slot[u] = pix - i * p.ns; xi_c[u] = c0 + (q & 7) * 4;
+    }
+    int gi_a[NLG], gi_t[NLG], gi_b[NLG], gi_c[NLG];
+#pragma unroll
+    for (int u = 0; u < NLG; ++u) {
+        const int q = (xi + 4 * u) * 64 + lane;
+        const int pix = q >> 3;
+        const int a = pix / GP, sl = pix - a * GP;
+        gi_a[u] = a; gi_t[u] = sl / MO; gi_b[u] = sl - gi_t[u] * MO; gi_c[u] = n0 + (q & 7) * 4;
+    }
+    auto stage_dma = [&](int buf, int t0) {
+        float* Xs = smem + buf * p.stage_floats;
+        float* Gs = Xs + p.g_floats_off;
+        const int gr0 = fast_div(t0, p.inv_TW);            // global tile row (image, ty) of the stage's first tile
+        const int pos0 = MO * (t0 - gr0 * p.TW);
+#pragma unroll
+        for (int u = 0; u < NLX; ++u) {
+            if (xi + 4 * u < p.ndma_x) {
+                unsigned off = WWOOB;
+                if (xi_i[u] < 4 && xi_c[u] < p.Cx) {
+                    const int P = xi_slot[u] + pos0;
+                    const int rr = fast_div(P, p.inv_RW), pos = P - rr * p.RW;
+                    const int grow = gr0 + rr;
+                    const int b = fast_div(grow, p.inv_TH), ty = grow - b * p.TH;
+                    const int yy = MO * ty - pad_y + xi_i[u], xx = pos - pad_x;
+                    if (b < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+                        off = (unsigned)(((b * p.H + yy) * p.W + xx) * p.Cx + xi_c[u]) << 2;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (wwlds_void*)(Xs + (xi + 4 * u) * 256), 16, off, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NLG; ++u) {
+            if (xi + 4 * u < p.ndma_g) {
+                unsigned off = WWOOB;
+                const int t = t0 + gi_t[u];
+                if (gi_a[u] < MO && t < t_end && gi_c[u] < p.Cn) {
+                    const int grow = fast_div(t, p.inv_TW), tx = t - grow * p.TW;
+                    const int b = fast_div(grow, p.inv_TH), ty = grow - b * p.TH;
+                    const int yy = MO * ty + gi_a[u], xx = MO * tx + gi_b[u];
+                    if (yy < p.H && xx < p.W)
+                        off = (unsigned)(((b * p.OH + yy * p.os + ooy) * p.OW + xx * p.os + oox) * p.Cn + gi_c[u]) << 2;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (wwlds_void*)(Gs + (xi + 4 * u) * 256), 16, off, 0, 0, 0);
+            }
+        }
+    };
+
+    // row transforms of this wave.  V: t = d[ia] + vs * d[ib] (B^T rows d0 - d2, d1 + d2, d2 - d1, d1 - d3);
+    // Z: rows of A (MO = 2: [1 0], [1 1], [1 -1], [0 -1];  MO = 3: [1 0 0], [1 1 1], [1 -1 1], [0 0 1])
+    const int ia = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
+    const int ib = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+    const float vs = xi == 1 ? 1.f : -1.f;
+    float za[3];
+    if (MO == 2) { za[0] = xi == 3 ? 0.f : 1.f; za[1] = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f); za[2] = 0.f; }
+    else { za[0] = xi == 3 ? 0.f : 1.f; za[1] = xi == 1 ? 1.f : (xi == 2 ? -1.f : 0.f); za[2] = xi == 0 ? 0.f : 1.f; }
+    const int ch = lane & 31, kh = lane >> 5;
+    const int roa = ia * p.ns * 32, rob = ib * p.ns * 32;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
+
+    if (t_begin < t_end) {
+        stage_dma(0, t_begin);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int t0 = t_begin; t0 < t_end; t0 += TK, buf ^= 1) {
+        if (t0 + TK < t_end) stage_dma(buf ^ 1, t0 + TK);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Xs = smem + buf * p.stage_floats;
+        const float* Gs = Xs + p.g_floats_off;
+        const int gr0 = fast_div(t0, p.inv_TW);
+        const int pos0 = MO * (t0 - gr0 * p.TW);
+#pragma unroll
+        for (int s = 0; s < TK / 2; ++s) {
+            const int tk = 2 * s + kh;                     // this lane's tile of the pair
+            const int t = min(t0 + tk, p.Mtiles - 1);
+            const int grow = fast_div(t, p.inv_TW), tx = t - grow * p.TW;
+            const int sb = ((grow - gr0) * p.RW + MO * tx - pos0) * 32 + ch;
+            float tc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tc[j] = Xs[roa + sb + j * 32] + vs * Xs[rob + sb + j * 32];
+            const float v0 = tc[0] - tc[2], v1 = tc[1] + tc[2], v2 = tc[2] - tc[1], v3 = tc[1] - tc[3];
+            float zr[MO];
+#pragma unroll
+            for (int b = 0; b < MO; ++b) {
+                float z = za[0] * Gs[(0 * GP + tk * MO + b) * 32 + ch] + za[1] * Gs[(1 * GP + tk * MO + b) * 32 + ch];
+                if (MO == 3) z += za[2] * Gs[(2 * GP + tk * MO + b) * 32 + ch];
+                zr[b] = z;
+            }
+            float z0, z1, z2, z3;
+            if (MO == 2) { z0 = zr[0]; z1 = zr[0] + zr[1]; z2 = zr[0] - zr[1]; z3 = -zr[1]; }
+            else { z0 = zr[0]; z1 = zr[0] + zr[1] + zr[MO - 1]; z2 = zr[0] - zr[1] + zr[MO - 1]; z3 = zr[MO - 1]; }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, v0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, v1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(z2, v2, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(z3, v3, acc[3], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // nu side of G^T . G in registers:  MO = 2 (G 4x3): S0 = D0 + (D1 + D2)/2, S1 = (D1 - D2)/2, S2 = (D1 + D2)/2 + D3
+    //                                   MO = 3 (G 4x2): S0 = D0 + (D1 + D2)/2, S1 = (D1 - D2)/2 - D3
+    // D[row n = (e & 3) + 8 (e >> 2) + 4 (l >> 5)][col c = l & 31]
+    float* out = p.part + ((((long long)split * phases + phase) * NS) * 4 + xi) * ((long long)p.CnPad * p.CxPad);
+    const long long set_stride = 4LL * p.CnPad * p.CxPad;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = n0 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const float d0 = acc[0][e], d1 = acc[1][e], d2 = acc[2][e], d3 = acc[3][e];
+        float* o = out + (long long)row * p.CxPad + c0 + ch;
+        o[0] = d0 + 0.5f * (d1 + d2);
+        if (MO == 2) { o[set_stride] = 0.5f * (d1 - d2); o[2 * set_stride] = 0.5f * (d1 + d2) + d3; }
+        else { o[set_stride] = 0.5f * (d1 - d2) - d3; }
+    }
+}
+
+template <int MO, int TK>
+__global__ __launch_bounds__(256, 3) void winograd_wgrad_kernel(WinoWgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    winograd_wgrad_body<MO, TK>(p, smem);
+}
+
+// Sum of the split partials in split order + the xi side of G^T . G, written in the filter's own layout:
+//   MO = 2: dw (Cout, Cin, 3, 3):  dw[n][c][r][s] = sum_xi G[xi][r] S_s[xi]      G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+//   MO = 3: dw (Cin, Cout, 4, 4):  dw[c][n][3 - py - 2a][3 - px - 2b] = sum_xi G'[xi][a] S_b[xi]   G' = [1 0; .5 .5; .5 -.5; 0 -1]
+// Sum of the split partials + the xi side of G^T . G, written in the filter's own layout:
+//   MO = 2: dw (Cout, Cin, 3, 3):  dw[n][c][r][s] = sum_xi G[xi][r] S_s[xi]      G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+//   MO = 3: dw (Cin, Cout, 4, 4):  dw[c][n][3 - py - 2a][3 - px - 2b] = sum_xi G'[xi][a] S_b[xi]   G' = [1 0; .5 .5; .5 -.5; 0 -1]
+// One block per (phase, n, 64 consecutive c): thread = (c, split group g of 4); group g adds the splits sp = g, g + 4, .. in order, the four
+// group sums are combined in a fixed order through LDS (deterministic), thread group 0 applies the xi side and stores.
+template <int MO>
+__global__ __launch_bounds__(256) void winograd_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cn, int Cx, int CnPad,
+                                                                     int CxPad, int splits) {
+    constexpr int NS = MO == 2 ? 3 : 2, PH = MO == 2 ? 1 : 4;
+    __shared__ float red[3][NS * 4][64];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int cblocks = (Cx + 63) / 64;
+    int bid = blockIdx.x;
+    const int cb = bid % cblocks; bid /= cblocks;
+    const int n = bid % Cn;
+    const int phase = bid / Cn;
+    const int c = cb * 64 + cl;
+    const long long plane = (long long)CnPad * CxPad;
+    float s[NS][4];
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) s[k][x] = 0.f;
+    if (c < Cx) {
+        for (int sp = grp; sp < splits; sp += 4) {
+            const float* q = part + (((long long)sp * PH + phase) * NS * 4) * plane + (long long)n * CxPad + c;
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) s[k][x] += q[(k * 4 + x) * plane];
+        }
+    }
+    if (grp > 0) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) red[grp - 1][k * 4 + x][cl] = s[k][x];
+    }
+    __syncthreads();
+    if (grp == 0 && c < Cx) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) s[k][x] += red[g][k * 4 + x][cl];
+        if (MO == 2) {
+            float* o = dw + ((long long)n * Cx + c) * 9;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                o[0 * 3 + k] = s[k][0] + 0.5f * (s[k][1] + s[k][2]);
+                o[1 * 3 + k] = 0.5f * (s[k][1] - s[k][2]);
+                o[2 * 3 + k] = 0.5f * (s[k][1] + s[k][2]) + s[k][3];
+            }
+        } else {
+            const int py = phase >> 1, px = phase & 1;
+            float* o = dw + ((long long)c * Cn + n) * 16;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int kx = 3 - px - 2 * k;
+                o[(3 - py) * 4 + kx] = s[k][0] + 0.5f * (s[k][1] + s[k][2]);
+                o[(1 - py) * 4 + kx] = 0.5f * (s[k][1] - s[k][2]) - s[k][3];
+            }
+        }
+    }
+}
+
+static std::atomic<unsigned> g_ww_lds_done[2];
+static std::atomic<int> g_ww_blocks{1024};         // target block count of a launch (vatl_tune_set(19, v))
+int wino_wgrad_set_blocks(int v) { g_ww_blocks.store(v, std::memory_order_relaxed); return 0; }
+
+constexpr int kWWTK = 8;
+constexpr int kWWMaxLds = 64 * 1024;
+
+struct WWPlan { int n_tiles, c_tiles, splits, tps, phases, ns; long long floats; };
+
+static WWPlan ww_plan(int MO, int Cn, int Cx, long long Mtiles, int TW) {
+    WWPlan q{};
+    q.n_tiles = cdiv(Cn, 32); q.c_tiles = cdiv(Cx, 32); q.phases = MO == 3 ? 4 : 1;
+    const long long per_split = (long long)q.n_tiles * q.c_tiles * q.phases;
+    long long want = std::max<long long>(1, g_ww_blocks.load(std::memory_order_relaxed) / per_split);
+    const long long stages = (Mtiles + kWWTK - 1) / kWWTK;
+    want = std::min(want, stages);
+    const long long sps = (stages + want - 1) / want;      // stages per split
+    q.tps = (int)(sps * kWWTK);
+    q.splits = (int)((Mtiles + q.tps - 1) / q.tps);
+    q.ns = (kWWTK - 1) * MO + 4 + (4 - MO) * ((TW + kWWTK - 2) / TW);
+    const int NS = MO == 2 ? 3 : 2;
+    q.floats = (long long)q.splits * q.phases * NS * 4 * (q.n_tiles * 32LL) * (q.c_tiles * 32LL);
+    return q;
+}
+
+template <int MO>
+static int winograd_wgrad_impl(const float* x, const float* g, float* dw, float* workspace, int N, int H, int W, int Cx, int Cn, hipStream_t st) {
+    if (!x || !g || !dw || !workspace || N <= 0 || H <= 0 || W <= 0) return fail(VATL_EINVAL, "winograd_wgrad: null pointer or empty batch");
+    if ((Cx & 3) || (Cn & 3)) return fail(VATL_EINVAL, "winograd_wgrad: channel counts %d / %d must be multiples of 4", Cx, Cn);
+    WinoWgradParams p{};
+    p.x = x; p.g = g; p.part = workspace;
+    p.N = N; p.H = H; p.W = W; p.Cx = Cx; p.Cn = Cn;
+    p.TH = (H + MO - 1) / MO; p.TW = (W + MO - 1) / MO; p.tpi = p.TH * p.TW;
+    const long long mt = (long long)N * p.tpi;
+    const int os = MO == 3 ? 2 : 1;
+    const long long xe = (long long)N * H * W * Cx, ge = (long long)N * H * W * os * os * Cn;
+    if (xe >= (1LL << 30) || ge >= (1LL << 30) || mt >= (1LL << 20) || (long long)N * p.TH >= (1LL << 20))
+        return fail(VATL_EINVAL, "winograd_wgrad: tensor too large for this route (2^30 elements / 2^20 tiles); use the implicit GEMM");
+    p.Mtiles = (int)mt;
+    const WWPlan q = ww_plan(MO, Cn, Cx, mt, p.TW);
+    p.n_tiles = q.n_tiles; p.c_tiles = q.c_tiles; p.splits = q.splits; p.tps = q.tps;
+    p.CnPad = q.n_tiles * 32; p.CxPad = q.c_tiles * 32;
+    p.RW = MO * p.TW + 4 - MO; p.ns = q.ns;
+    p.ndma_x = (4 * p.ns * 8 + 63) / 64;
+    p.ndma_g = (MO * kWWTK * MO * 8 + 63) / 64;
+    p.g_floats_off = p.ndma_x * 256;
+    p.stage_floats = (p.ndma_x + p.ndma_g) * 256;
+    if (p.ndma_x > 24) return fail(VATL_EINVAL, "winograd_wgrad: stage too large");
+    p.OH = H * os; p.OW = W * os; p.os = os; p.deconv = MO == 3;
+    p.inv_TW = 1.0f / (float)p.TW; p.inv_TH = 1.0f / (float)p.TH; p.inv_RW = 1.0f / (float)p.RW; p.inv_ns = 1.0f / (float)p.ns;
+    p.x_bytes = (unsigned)(xe * 4); p.g_bytes = (unsigned)(ge * 4);
+    auto kern = winograd_wgrad_kernel<MO, kWWTK>;
+    if (int rc = ensure_dynamic_lds((const void*)kern, kWWMaxLds, g_ww_lds_done[MO - 2], "winograd_wgrad")) return rc;
+    const int smem = 2 * p.stage_floats * (int)sizeof(float);
+    if (smem > kWWMaxLds) return fail(VATL_EINVAL, "winograd_wgrad: %d bytes of LDS per block", smem);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long long)q.n_tiles * q.c_tiles * q.phases * q.splits)), dim3(256), smem, st, p);
+    if (int rc = check_launch("winograd_wgrad")) return rc;
+    hipLaunchKernelGGL(winograd_wgrad_finish_kernel<MO>, dim3((unsigned)((long long)q.phases * Cn * ((Cx + 63) / 64))), dim3(256), 0, st, workspace, dw, Cn, Cx,
+                       p.CnPad, p.CxPad, q.splits);
+    return check_launch("winograd_wgrad_finish");
+}
+
+}  // namespace vatl
+
+using namespace vatl;
+
+extern "C" int64_t vatl_conv3x3_winograd_wgrad_workspace_floats(int Cout, int Cin, int64_t N, int H, int W) {
+    return ww_plan(2, Cout, Cin, N * ((H + 1) / 2) * ((W + 1) / 2), (W + 1) / 2).floats;
+}
+
+extern "C" int vatl_conv3x3_winograd_wgrad(const float* x, const float* dz, float* dw, float* workspace, int N, int H, int W, int Cin, int Cout,
+                                           void* stream) {
+    return winograd_wgrad_impl<2>(x, dz, dw, workspace, N, H, W, Cin, Cout, (hipStream_t)stream);
+}
+
+extern "C" int64_t vatl_deconv4x4s2_winograd_wgrad_workspace_floats(int Cin, int Cout, int64_t N, int H, int W) {
+    return ww_plan(3, Cout, Cin, N * ((H + 2) / 3) * ((W + 2) / 3), (W + 2) / 3).floats;
+}
+
+extern "C" int vatl_deconv4x4s2_winograd_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int H, int W, int Cin, int Cout,
+                                               void* stream) {
+    return winograd_wgrad_impl<3>(x, dy, dw, workspace, N, H, W, Cin, Cout, (hipStream_t)stream);
+}

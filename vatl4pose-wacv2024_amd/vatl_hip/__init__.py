@@ -81,6 +81,10 @@ SIGNATURES = {
     "vatl_winograd_stats_row_blocks": (_i64, [_i64, _i, _i]),
     "vatl_conv3x3_winograd_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vatl_conv3x3_winograd_fwd_bnbwd": (_i, [_p] * 4 + [_i] * 5 + [_p] * 9),
+    "vatl_conv3x3_winograd_wgrad_workspace_floats": (_i64, [_i, _i, _i64, _i, _i]),
+    "vatl_conv3x3_winograd_wgrad": (_i, [_p] * 4 + [_i] * 5 + [_p]),
+    "vatl_deconv4x4s2_winograd_wgrad_workspace_floats": (_i64, [_i, _i, _i64, _i, _i]),
+    "vatl_deconv4x4s2_winograd_wgrad": (_i, [_p] * 4 + [_i] * 5 + [_p]),
     "vatl_winograd_deconv_weight_floats": (_i64, [_i, _i]),
     "vatl_pack_winograd_deconv_weight": (_i, [_p, _p, _i, _i, _p]),
     "vatl_deconv4x4s2_winograd_fwd": (_i, [_p] * 5 + [_i] * 6 + [_p]),
@@ -818,6 +822,30 @@ def conv2d_wgrad(x, dz, cout: int, cin: int, r: int, s: int, stride: int, pad: i
     ws = torch.empty(int(lib().vatl_conv2d_wgrad_workspace_floats(cout, cin, r, s, m)), device=x.device, dtype=torch.float32)
     _check(lib().vatl_conv2d_wgrad(_ptr(x), _ptr(dz), _ptr(dw), _ptr(ws), n, h, w, cin, cout, dz.shape[3], r, s, stride, pad, _stream()),
            "vatl_conv2d_wgrad")
+    return dw
+
+
+def conv3x3_winograd_wgrad(x, dz, out=None) -> torch.Tensor:
+    """Weight gradient of a 3x3 / stride 1 / pad 1 conv on the Winograd route: x (N,H,W,Cin), dz (N,H,W,Cout) -> dw (Cout,Cin,3,3)."""
+    n, h, w, cin = x.shape
+    cout = dz.shape[3]
+    dw = out if out is not None else torch.empty((cout, cin, 3, 3), device=x.device, dtype=torch.float32)
+    if dw.numel() != cout * cin * 9:
+        raise VatlError("conv3x3_winograd_wgrad: out has the wrong size")
+    ws = torch.empty(int(lib().vatl_conv3x3_winograd_wgrad_workspace_floats(cout, cin, n, h, w)), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_conv3x3_winograd_wgrad(_ptr(x), _ptr(dz), _ptr(dw), _ptr(ws), n, h, w, cin, cout, _stream()), "vatl_conv3x3_winograd_wgrad")
+    return dw
+
+
+def deconv4x4s2_winograd_wgrad(x, dy, out=None) -> torch.Tensor:
+    """Weight gradient of ConvTranspose2d(4,2,1) on the Winograd route: x (N,H,W,Cin), dy (N,2H,2W,Cout) -> dw (Cin,Cout,4,4)."""
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    dw = out if out is not None else torch.empty((cin, cout, 4, 4), device=x.device, dtype=torch.float32)
+    if dw.numel() != cin * cout * 16:
+        raise VatlError("deconv4x4s2_winograd_wgrad: out has the wrong size")
+    ws = torch.empty(int(lib().vatl_deconv4x4s2_winograd_wgrad_workspace_floats(cin, cout, n, h, w)), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_deconv4x4s2_winograd_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), n, h, w, cin, cout, _stream()), "vatl_deconv4x4s2_winograd_wgrad")
     return dw
 
 
