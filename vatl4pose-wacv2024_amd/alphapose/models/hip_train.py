@@ -377,7 +377,10 @@ class _DeconvBN:
         grads[self.bn.weight] = dgamma
         grads[self.bn.bias] = dbeta
         ow = _gout(grads, self.dc.weight)
-        grads[self.dc.weight] = _side.run(lambda: vh.deconv4x4s2_wgrad(x, dz, out=ow), x, dz)
+        if _WINOGRAD and min(self.cin, self.cout) >= _WINOGRAD_WGRAD_MIN_C:      # transform-domain weight gradient (1.04 - 1.16x at B = 120)
+            grads[self.dc.weight] = _side.run(lambda: vh.deconv4x4s2_winograd_wgrad(x, dz, out=ow), x, dz)
+        else:
+            grads[self.dc.weight] = _side.run(lambda: vh.deconv4x4s2_wgrad(x, dz, out=ow), x, dz)
         # dx[y][x][ci] = sum_{ky,kx,co} dz[2y-1+ky][2x-1+kx][co] * W[ci][co][ky][kx]: a 4x4/2 pad-1 conv whose
         # "OIHW" weight is the deconv weight itself (O = Cin, I = Cout)
         wd = vh.pack_conv_weight(self.dc.weight.detach())

@@ -283,7 +283,9 @@ static WWPlan ww_plan(int MO, int Cn, int Cx, long long Mtiles, int TW) {
     WWPlan q{};
     q.n_tiles = cdiv(Cn, 32); q.c_tiles = cdiv(Cx, 32); q.phases = MO == 3 ? 4 : 1;
     const long long per_split = (long long)q.n_tiles * q.c_tiles * q.phases;
-    long long want = std::max<long long>(1, g_ww_blocks.load(std::memory_order_relaxed) / per_split);
+    // target block count: the knob for the 3x3 layers, 4x that for the transposed convs (B = 120, tools/wino_wgrad_bench.py: deconv3 1.03x
+    // over the implicit GEMM at 1024 blocks, 1.13x at 2048, 1.16x at 4096; the 3x3 layers peak at 1024)
+    long long want = std::max<long long>(1, (long long)g_ww_blocks.load(std::memory_order_relaxed) * (MO == 3 ? 4 : 1) / per_split);
     const long long stages = (Mtiles + kWWTK - 1) / kWWTK;
     want = std::min(want, stages);
     const long long sps = (stages + want - 1) / want;      // stages per split
