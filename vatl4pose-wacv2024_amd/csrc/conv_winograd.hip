@@ -21,7 +21,8 @@
 // Wave xi owns the four positions (xi, nu = 0..3).  (64-tile blocks with 128 accumulator registers — 8 waves x 64 channels, one block
 // per CU, or 4 waves x 32 channels, two per CU — measured 4 - 11 % slower at 1024 crops and 25 - 35 % slower at 120: removed.  FOUR blocks
 // per CU — 128 VGPRs with a single filter-fragment set loaded just in time — 5 - 12 % slower (3x3) / 25 - 60 % slower (transposed convs): the
-// one-step look-ahead of the filter loads is worth more than the fourth block.  s_setprio around the MFMA bursts: no effect.)
+// one-step look-ahead of the filter loads is worth more than the fourth block.  A TWO-step look-ahead (three fragment sets) needs 171
+// VGPRs, i.e. 13 spills under the 168 of three waves per SIMD: 5 - 15 % slower.  s_setprio around the MFMA bursts: no effect.)
 //   * B operand (U): packed in MFMA fragment order, a wave's 16-byte-per-lane load is 1 KB contiguous; straight from L2 into registers
 //     one 8-channel step ahead (no LDS: every wave needs a different slice).
 //   * A operand (V): the raw input pixels of the block's tiles are staged in LDS 16 channels at a time by LDS-DMA (double buffer, one
