@@ -482,6 +482,7 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
     p.ns = 31 * MO + 4 + (4 - MO) * ((p.TW + 30) / p.TW);  // slots a block of 32 consecutive tiles can touch (header comment)
     p.ndma = (4 * p.ns * 4 + 63) / 64;
     p.stage_floats = p.ndma * 256;
+    if (p.ndma > 4 * W_NLD) return fail(VATL_EINVAL, "winograd: %d staging instructions per stage (image width %d)", p.ndma, W);
     p.pad_y = 1; p.pad_x = 1; p.OH = H * os; p.OW = W * os; p.os = os; p.ooy = 0; p.oox = 0;
     p.deconv = MO == 3; p.u_phase_floats = ue;
     p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.u_bytes = (unsigned)(ue * 4);

@@ -319,7 +319,7 @@ static int winograd_wgrad_impl(const float* x, const float* g, float* dw, float*
     p.ndma_g = (MO * kWWTK * MO * 8 + 63) / 64;
     p.g_floats_off = p.ndma_x * 256;
     p.stage_floats = (p.ndma_x + p.ndma_g) * 256;
-    if (p.ndma_x > 24) return fail(VATL_EINVAL, "winograd_wgrad: stage too large");
+    if (p.ndma_x > 24 || p.RW > 4096 || p.TH > 4096) return fail(VATL_EINVAL, "winograd_wgrad: image %dx%d outside the range of this route", H, W);
     p.OH = H * os; p.OW = W * os; p.os = os; p.deconv = MO == 3;
     p.inv_TW = 1.0f / (float)p.TW; p.inv_TH = 1.0f / (float)p.TH; p.inv_RW = 1.0f / (float)p.RW; p.inv_ns = 1.0f / (float)p.ns;
     p.x_bytes = (unsigned)(xe * 4); p.g_bytes = (unsigned)(ge * 4);
