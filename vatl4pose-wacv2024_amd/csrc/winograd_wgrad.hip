@@ -11,6 +11,10 @@
 // out-of-range DMA offsets = zeros.  A lane (channel l & 31, tile parity l >> 5) reads its channel of 8 input pixels and <= MO^2 gradient
 // pixels per tile pair (ds_read_b32: 32 consecutive channels = 128 contiguous bytes), forms V (row transform by xi, then the four nu)
 // and Z in registers, and issues four MFMAs.
+// Measured and dropped: a 32 x 64 block of 8 waves (same 16 waves per CU, half the staging-address work and workspace traffic per MFMA):
+// equal to 10 % slower on the 3x3 layers, 15 - 30 % slower on the transposed convs; division-free staging addresses for maps at least TK - 1
+// tiles wide (row bases in scalar registers, one compare per item): 2 - 5 % slower at 128 VGPRs.  (An ablation with constant staging
+// addresses runs 17 % faster — but that is the memory system seeing the same few lines, not the address arithmetic.)
 // The nu side of G^T . G is applied to the accumulators in registers (4 tiles -> 3, or 2 for the phase filters); each block writes its
 // partial sums into its slice of a workspace and winograd_wgrad_finish_kernel adds the slices in split order, applies the xi side and
 // writes the filter in the tensor's own layout — no atomics, bitwise reproducible.
@@ -148,12 +152,16 @@ __device__ __forceinline__ void winograd_wgrad_body(const WinoWgradParams& p, fl
         const float* Gs = Xs + p.g_floats_off;
         const int gr0 = fast_div(t0, p.inv_TW);
         const int pos0 = MO * (t0 - gr0 * p.TW);
+        // this lane's tiles of the stage: t0 + kh, + 2, ..: (tile row, column) advance with carries instead of a division per pair.  (Tiles past
+        // the split's end keep the pattern: their slots exist, their gradient pixels were staged as zeros.)
+        int grow = fast_div(t0 + kh, p.inv_TW), tx = t0 + kh - grow * p.TW;
 #pragma unroll
         for (int s = 0; s < TK / 2; ++s) {
             const int tk = 2 * s + kh;                     // this lane's tile of the pair
-            const int t = min(t0 + tk, p.Mtiles - 1);
-            const int grow = fast_div(t, p.inv_TW), tx = t - grow * p.TW;
             const int sb = ((grow - gr0) * p.RW + MO * tx - pos0) * 32 + ch;
+            tx += 2;
+            if (tx >= p.TW) { tx -= p.TW; ++grow; }
+            if (tx >= p.TW) { tx -= p.TW; ++grow; }
             float tc[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) tc[j] = Xs[roa + sb + j * 32] + vs * Xs[rob + sb + j * 32];
