@@ -288,3 +288,26 @@ def test_winograd_weight_gradient_of_the_transposed_conv(vh, case):
     assert e < TOL, e
     direct = vh.deconv4x4s2_wgrad(xd, dyd)
     assert rel_err(dw.cpu().numpy(), direct.cpu().numpy()) < 2 * TOL
+
+
+def test_small_batch_module_calls_stay_on_the_implicit_gemm(vh, monkeypatch):
+    """`model(x)` with <= 16 crops is the latency path (split-K for this thread, hip_engine.run_module_nchw): it keeps its own,
+    batch-size-independent bits on the implicit GEMM — no Winograd launch — while the stream entry point takes the Winograd route."""
+    from alphapose.models import hip_engine
+    from oracle import synth
+    from tests.test_gpu_conv import _build_simplepose
+    m = _build_simplepose()
+    x = to_dev(synth.crops(4))
+    calls = []
+    for name in ("conv3x3_winograd_fwd", "deconv4x4s2_winograd_fwd"):
+        orig = getattr(vh, name)
+        monkeypatch.setattr(vh, name, (lambda o: lambda *a, **k: (calls.append(1), o(*a, **k))[1])(orig))
+    with torch.no_grad():
+        small = m(x)
+    assert not calls and not vh.latency_mode()
+    with torch.no_grad():
+        one = m(x[1:2])
+        stream = hip_engine.forward_into(m, x, torch.empty_like(small))
+    assert torch.equal(one[0], small[1])                       # the module-call bits do not depend on the batch size
+    assert len(calls) == 16                                     # 13 3x3 layers + 3 transposed convs
+    assert rel_err(stream.cpu().numpy(), small.cpu().numpy()) < 1e-4

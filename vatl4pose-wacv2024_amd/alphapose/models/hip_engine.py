@@ -38,8 +38,9 @@ STAGE1_CHUNK = int(os.environ.get("VATL_STAGE1_CHUNK", "0"))   # measured neutra
 
 
 # 3x3 / stride 1 / pad 1 layers run as Winograd F(2x2, 3x3) (csrc/conv_winograd.hip: 2.25x fewer multiplies, fp32).  The choice depends
-# on the layer's geometry only — never on the batch — so a crop's heat-map bits do not depend on how it was batched.  VATL_WINOGRAD=0 = the
-# implicit GEMM everywhere.
+# on the layer's geometry only — never on the batch — so a crop's heat-map bits do not depend on how it was batched.  The one exception is the
+# small-batch module call (`model(x)` with <= 16 crops, run_module_nchw below), which has always had its own bits (split-K): it stays on
+# the implicit GEMM for every batch size it serves (vh.latency_mode()).  VATL_WINOGRAD=0 = the implicit GEMM everywhere.
 WINOGRAD = os.environ.get("VATL_WINOGRAD", "1") != "0"
 
 
@@ -64,7 +65,7 @@ class _Conv:
             self.scale = self.bias = None
 
     def __call__(self, x, relu, residual=None, out_nchw=False, out=None):
-        if self.u is not None and not out_nchw:
+        if self.u is not None and not out_nchw and not vh.latency_mode():
             return vh.conv3x3_winograd_fwd(x, self.u, self.scale, self.bias, self.cout, relu, residual=residual, out=out)
         return vh.conv2d_fwd(x, self.w, self.scale, self.bias, self.cout, self.r, self.s, self.stride, self.pad, relu,
                              residual=residual, out_nchw=out_nchw, out=out)
@@ -76,15 +77,14 @@ class _Deconv:
     def __init__(self, dc: nn.ConvTranspose2d, bn: nn.BatchNorm2d):
         assert dc.kernel_size == (4, 4) and dc.stride == (2, 2) and dc.padding == (1, 1) and dc.bias is None
         self.cout = dc.weight.shape[1]
-        self.w = self.u = None
+        self.u = None
         if WINOGRAD and dc.weight.shape[0] % 16 == 0 and self.cout % 4 == 0:     # four 2x2 phase convolutions as Winograd F(3x3, 2x2)
             self.u = vh.pack_winograd_deconv_weight(dc.weight.detach())
-        else:
-            self.w = vh.pack_deconv_weight(dc.weight.detach())
+        self.w = vh.pack_deconv_weight(dc.weight.detach())                      # the implicit GEMM serves the small-batch module calls
         self.scale, self.bias = vh.bn_fold(_d(bn.weight), _d(bn.bias), bn.running_mean, bn.running_var, bn.eps)
 
     def __call__(self, x, relu=True):
-        if self.u is not None:
+        if self.u is not None and not vh.latency_mode():
             return vh.deconv4x4s2_winograd_fwd(x, self.u, self.scale, self.bias, self.cout, relu)
         return vh.deconv4x4s2_fwd(x, self.w, self.scale, self.bias, self.cout, relu)
 

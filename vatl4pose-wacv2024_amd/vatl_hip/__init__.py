@@ -234,12 +234,21 @@ class splitk_scope:
             buf = _splitk_scratch[key] = torch.empty(self.mb * (1 << 18), device=torch.device("cuda", self.idx), dtype=torch.float32)
         _check(lib().vatl_set_splitk_workspace_thread(_ptr(buf), buf.numel()), "vatl_set_splitk_workspace_thread")
         self.active = True
+        _tls.latency_mode = getattr(_tls, "latency_mode", 0) + 1
         return self
 
     def __exit__(self, *exc):
         if self.active:
+            _tls.latency_mode -= 1
             _check(lib().vatl_set_splitk_workspace_thread(None, 0), "vatl_set_splitk_workspace_thread")
         return False
+
+
+def latency_mode() -> bool:
+    """True inside a ``splitk_scope`` of this host thread: the module-call path of small batches (<= 16 crops).  The inference plans
+    then keep every conv on the implicit GEMM, whose split-K fills the chip from a handful of tiles; the Winograd kernels have no
+    reduction split (one crop: deconv1 = 32 blocks x 128 serial stages) and are 27 - 40 % slower end to end below ~8 crops."""
+    return getattr(_tls, "latency_mode", 0) > 0
 
 def conv_cout_pad(cout: int) -> int:
     return lib().vatl_conv_cout_pad(cout)
