@@ -339,7 +339,8 @@ int vatl_bn_train_bwd_relu_pool(const float* dpool, const uint8_t* idx, const fl
  * kind 1: data-gradient layout, (a, b, c) = (CinPad, CoutK, ntaps) with the taps in tap_r / tap_s;
  * kind 2: ConvTranspose2d(4,2,1) layout, src (Cin,Cout,4,4), a = CoutPad;
  * kind 5: Winograd F(3x3,2x2) phase filters of ConvTranspose2d(4,2,1) (vatl_pack_winograd_deconv_weight): src (Cin,Cout,4,4), a / b as
- *   for kinds 3 / 4, c = Cout;
+ *   for kinds 3 / 4, c = Cout;  kind 6: the filters of its data gradient (vatl_pack_winograd_deconv_dgrad_weight): (Cout, Cin) fields =
+ *   (layer Cin, layer Cout), c = layer Cout;
  * kind 3 / 4: Winograd F(2x2,3x3) filter transform, forward / data gradient (vatl_pack_winograd_weight): (Cout, Cin) of the PACKED
  *   filter, a = its padded Cout, b = 32-channel groups per tile (a / 32 <= 1 ? 1 : 2), c = Cin (kind 3) or Cout (kind 4) = the inner
  *   dimension of src. */
@@ -502,6 +503,18 @@ int vatl_conv3x3_winograd_wgrad(const float* x, const float* dz, float* dw, floa
 int64_t vatl_deconv4x4s2_winograd_wgrad_workspace_floats(int Cin, int Cout, int64_t N, int H, int W);
 int vatl_deconv4x4s2_winograd_wgrad(const float* x, const float* dy, float* dw, float* workspace, int N, int H, int W, int Cin, int Cout,
                                     void* stream);
+/* Data gradient of ConvTranspose2d(4,2,1) on the Winograd route: dx[ci][y][x] = sum dz[co][2y-1+ky][2x-1+kx] W[ci][co][ky][kx] is a 4x4 /
+ * stride 2 conv = the sum over the four pixel phases of dz of 2x2 convolutions: F(3x3,2x2) with the reduction over (phase, channel).
+ * w = the layer's (Cin, Cout, 4, 4) weight, Cout % 16 == 0, Cin % 4 == 0; u: vatl_winograd_deconv_dgrad_weight_floats(Cin, Cout) floats.
+ * dz (N, 2H, 2W, Cout) -> dx (N, H, W, Cin) (+ residual); _bnbwd: vatl_conv2d_fwd_ex_bnbwd semantics for the consumer layer's BatchNorm,
+ * statistics capacity ceil(N * ceil(H/3) * ceil(W/3) / 32) * Cin * 2 doubles. */
+int64_t vatl_winograd_deconv_dgrad_weight_floats(int Cin, int Cout);
+int vatl_pack_winograd_deconv_dgrad_weight(const float* w, float* u, int Cin, int Cout, void* stream);
+int vatl_deconv4x4s2_winograd_dgrad(const float* dz, const float* u, const float* residual, float* dx, int N, int H, int W, int Cin, int Cout,
+                                    void* stream);
+int vatl_deconv4x4s2_winograd_dgrad_bnbwd(const float* dz, const float* u, const float* residual, float* dx, int N, int H, int W, int Cin,
+                                          int Cout, const float* bn_z, const float* bn_mask_y, const float* bn_scale, const float* bn_bias,
+                                          const float* bn_mean, const float* bn_invstd, double* stats, int64_t* row_blocks_used, void* stream);
 int vatl_conv3x3_winograd_fwd_bnbwd(const float* x, const float* u, const float* residual, float* y, int N, int H, int W, int Cin, int Cout,
                                     const float* bn_z, const float* bn_mask_y, const float* bn_scale, const float* bn_bias,
                                     const float* bn_mean, const float* bn_invstd, double* stats, int64_t* row_blocks_used, void* stream);

@@ -173,7 +173,7 @@ def test_pack_plan_refreshes_winograd_filters_with_the_same_bits(vh):
     g = torch.Generator(device="cpu").manual_seed(23)
     ws = [(torch.randn(s, generator=g) * 0.1).to(dev()) for s in ((64, 64, 3, 3), (32, 32, 3, 3), (48, 80, 3, 3), (128, 256, 3, 3))]
     wdc = [(torch.randn(s, generator=g) * 0.1).to(dev()) for s in ((64, 48, 4, 4), (32, 256, 4, 4))]
-    want_dc = [vh.pack_winograd_deconv_weight(w) for w in wdc]
+    want_dc = [vh.pack_winograd_deconv_weight(w) for w in wdc] + [vh.pack_winograd_deconv_dgrad_weight(w) for w in wdc]
     want = [(vh.pack_winograd_weight(w), vh.pack_winograd_weight(w, data_gradient=True)) for w in ws]
     plan = vh.PackPlan()
     prev = vh.set_pack_plan(plan)
@@ -181,7 +181,7 @@ def test_pack_plan_refreshes_winograd_filters_with_the_same_bits(vh):
         plan.begin()
         first = [(vh.pack_winograd_weight(w), vh.pack_winograd_weight(w, data_gradient=True)) for w in ws]
         other = vh.pack_conv_weight(ws[0])                  # a job of another kind in the same table
-        first_dc = [vh.pack_winograd_deconv_weight(w) for w in wdc]
+        first_dc = [vh.pack_winograd_deconv_weight(w) for w in wdc] + [vh.pack_winograd_deconv_dgrad_weight(w) for w in wdc]
         plan.seal()
         for t in first_dc:
             t.zero_()
@@ -311,3 +311,35 @@ def test_small_batch_module_calls_stay_on_the_implicit_gemm(vh, monkeypatch):
     assert torch.equal(one[0], small[1])                       # the module-call bits do not depend on the batch size
     assert len(calls) == 16                                     # 13 3x3 layers + 3 transposed convs
     assert rel_err(stream.cpu().numpy(), small.cpu().numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("case", [(2, 8, 6, 64, 48), (3, 5, 3, 32, 48), (1, 16, 12, 128, 64), (9, 9, 6, 16, 32), (4, 1, 4, 8, 16), (120, 8, 6, 32, 16)], ids=str)
+def test_winograd_data_gradient_of_the_transposed_conv(vh, case):
+    """dx of ConvTranspose2d(4,2,1) = a 4x4 / stride 2 conv over dz, as F(3x3,2x2) over the four pixel phases of dz; plain, with a
+    residual, and with the BatchNorm-backward epilogue against the implicit-GEMM launch it replaces."""
+    n, h, w, cin, cout = case
+    g = torch.Generator(device="cpu").manual_seed(47 + n)
+    x = torch.randn((n, cin, h, w), generator=g, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn((cin, cout, 4, 4), generator=g, dtype=torch.float64) * 0.05
+    dy = torch.randn((n, cout, 2 * h, 2 * w), generator=g, dtype=torch.float64)
+    F.conv_transpose2d(x, wt, None, 2, 1).backward(dy)
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().to(dev())
+    u = vh.pack_winograd_deconv_dgrad_weight(wt.float().to(dev()))
+    dx = vh.deconv4x4s2_winograd_dgrad(dyd, u, cin)
+    e = rel_err(dx.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy())
+    record(f"winograd_deconv_dgrad_{n}x{h}x{w}_{cin}_{cout}", rel=e)
+    assert e < TOL, e
+    r = torch.randn((n, h, w, cin), generator=g).to(dev())
+    assert torch.allclose(vh.deconv4x4s2_winograd_dgrad(dyd, u, cin, residual=r), dx + r, rtol=0, atol=1e-5)
+    if cin % 4 == 0 and cout % 32 == 0:
+        # the fused BatchNorm-backward epilogue: same masked gradient and the same statistics as the implicit-GEMM launch
+        z = torch.randn((n, h, w, cin), generator=g).to(dev())
+        mean, invstd = z.reshape(-1, cin).mean(0), 1.0 / (z.reshape(-1, cin).var(0, unbiased=False) + 1e-5).sqrt()
+        sc, bi = (torch.rand(cin, generator=g) + 0.5).to(dev()), (torch.randn(cin, generator=g) * 0.3).to(dev())
+        s1, s2 = vh.BnBwdSpec(z, mean, invstd, scale=sc, bias=bi), vh.BnBwdSpec(z, mean, invstd, scale=sc, bias=bi)
+        g1 = vh.deconv4x4s2_winograd_dgrad(dyd, u, cin, spec=s1)
+        g2 = vh.conv2d_fwd_ex_bnbwd(dyd, vh.pack_conv_weight(wt.float().to(dev())), cin, 4, 4, 2, 1, 1, h, w, h, w, 1, 1, 0, 0, s2)
+        assert rel_err(g1.cpu().numpy(), g2.cpu().numpy()) < 2 * TOL
+        t1 = s1.stats[:s1.blocks * cin * 2].view(s1.blocks, cin, 2).sum(0)
+        t2 = s2.stats[:s2.blocks * cin * 2].view(s2.blocks, cin, 2).sum(0)
+        assert torch.allclose(t1, t2, rtol=1e-4, atol=1e-3 * float(t2.abs().max()))

@@ -383,6 +383,9 @@ class _DeconvBN:
             grads[self.dc.weight] = _side.run(lambda: vh.deconv4x4s2_wgrad(x, dz, out=ow), x, dz)
         # dx[y][x][ci] = sum_{ky,kx,co} dz[2y-1+ky][2x-1+kx][co] * W[ci][co][ky][kx]: a 4x4/2 pad-1 conv whose
         # "OIHW" weight is the deconv weight itself (O = Cin, I = Cout)
+        if _WINOGRAD and self.cout % 16 == 0 and self.cin % 4 == 0:
+            # ... = the sum over the four pixel phases of dz of 2x2 convolutions: Winograd F(3x3,2x2) with the reduction over (phase, channel)
+            return vh.deconv4x4s2_winograd_dgrad(dz, vh.pack_winograd_deconv_dgrad_weight(self.dc.weight.detach()), self.cin, spec=consumer)
         wd = vh.pack_conv_weight(self.dc.weight.detach())
         if consumer is not None:
             n, h, w, _ = x.shape

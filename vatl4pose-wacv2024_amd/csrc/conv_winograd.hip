@@ -73,6 +73,9 @@ struct WinoParams {
     int pad_y, pad_x;                 // tile (ty, tx) reads input rows MO ty - pad_y + i (deconv: 1 - phase bit, set in the kernel)
     int OH, OW, os, ooy, oox;         // output pixel of grid point (y, x) = (y os + ooy, x os + oox) in an OH x OW image
     int deconv;                       // four sub-pixel phases py * 2 + px, each with its own filter
+    int gather;                       // data gradient of the transposed conv: the reduction runs over (input phase, channel); the pixels of
+                                      // phase (p, q) are x[2 y + p][2 x + q] of an (N, 2H, 2W, Cin) tensor, read with pad (p, q)
+    int spp;                          // gather: 16-channel stages per phase (Cin / 16); stages = 4 spp
     int rn;                           // filter slices per group of the tile order (see the kernel)
     long long u_phase_floats;         // deconv: floats of one phase's packed filter
     int ablate;                       // profiling library only (vatl_tune_set(17, bits), wrong results): 1 no output transform, 2 no LDS
@@ -112,7 +115,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3, q8 = nblk >> 3, r8 = nblk & 7;
     const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
-    const int units = p.n_tiles * (p.deconv ? 4 : 1);
+    const int units = p.n_tiles * (p.deconv ? 4 : 1);      // (gather mode: deconv = 0, the four input phases are part of the reduction)
     const int grp = t / (p.m_tiles * p.rn), rem = t - grp * (p.m_tiles * p.rn);
     const int rn_g = min(p.rn, units - grp * p.rn);        // the last group may be smaller
     const int m_tile = rem / rn_g, unit = grp * p.rn + (rem - m_tile * rn_g);
@@ -136,29 +139,42 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
     const int gr0 = m0 / p.TW;                             // global tile row (image, ty) of the block's first tile
     const int pos0 = MO * (m0 - gr0 * p.TW);               // its first column slot inside that row
     unsigned goff[W_NLD];                                  // byte offset of the lane's piece in the first stage (WOOB: zeros)
+    auto set_goff = [&](int ph) {                          // ph: input phase of the gather mode (0 otherwise)
+        const int gy = ph >> 1, gx = ph & 1;
+        const int py_ = p.gather ? gy : pad_y, px_ = p.gather ? gx : pad_x;
 #pragma unroll
-    for (int u = 0; u < W_NLD; ++u) {
-        const int q = (xi + NW * u) * 64 + lane;
-        goff[u] = WOOB;
-        const int cpos = q & 3, pix = q >> 2;
-        const int i = pix / p.ns, slot = pix - i * p.ns;
-        if (i < 4) {
-            const int chunk = cpos ^ ((slot >> 2) & 3);
-            const int P = slot + pos0;
-            const int rr = P / p.RW, pos = P - rr * p.RW;
-            const int gr = gr0 + rr;
-            const int b = gr / p.TH, ty = gr - b * p.TH;
-            const int yy = MO * ty - pad_y + i, xx = pos - pad_x;
-            if (b < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
-                goff[u] = (unsigned)(((b * p.H + yy) * p.W + xx) * p.Cin + chunk * 4) << 2;
+        for (int u = 0; u < W_NLD; ++u) {
+            const int q = (xi + NW * u) * 64 + lane;
+            goff[u] = WOOB;
+            const int cpos = q & 3, pix = q >> 2;
+            const int i = pix / p.ns, slot = pix - i * p.ns;
+            if (i < 4) {
+                const int chunk = cpos ^ ((slot >> 2) & 3);
+                const int P = slot + pos0;
+                const int rr = P / p.RW, pos = P - rr * p.RW;
+                const int gr = gr0 + rr;
+                const int b = gr / p.TH, ty = gr - b * p.TH;
+                const int yy = MO * ty - py_ + i, xx = pos - px_;
+                if (b < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+                    if (p.gather) goff[u] = (unsigned)(((b * 2 * p.H + 2 * yy + gy) * 2 * p.W + 2 * xx + gx) * p.Cin + chunk * 4) << 2;
+                    else goff[u] = (unsigned)(((b * p.H + yy) * p.W + xx) * p.Cin + chunk * 4) << 2;
+                }
+            }
         }
-    }
+    };
+    set_goff(0);
     auto stage_dma = [&](int buf, int st) {
+        int cst = st;                                      // 16-channel slice inside the (phase's) tensor
+        if (p.gather) {
+            const int ph = st / p.spp;
+            cst = st - ph * p.spp;
+            if (cst == 0 && ph > 0) set_goff(ph);          // a new input phase: other pixels, other padding
+        }
 #pragma unroll
         for (int u = 0; u < W_NLD; ++u)
             if (xi + NW * u < p.ndma)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (wlds_void*)(Rs + buf * p.stage_floats + (xi + NW * u) * 256), 16,
-                                                         goff[u] != WOOB ? goff[u] + (unsigned)st * (W_CK * 4) : WOOB, 0, 0, 0);
+                                                         goff[u] != WOOB ? goff[u] + (unsigned)cst * (W_CK * 4) : WOOB, 0, 0, 0);
     };
 
     // ---- fragment addressing: lane = (tile l & 31, channel quad l >> 5).  ra[j]: float index (relative to the stage, input row 0,
@@ -186,12 +202,19 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
     // ---- U fragments: [n_tile][step][position][nh][lane][4]; the packing groups 32 p.nhp channels per filter tile ----------------------
     const int steps = p.stages * 2;
     const int ut = n_tile / p.nhp, nh_g = n_tile - ut * p.nhp;
-    const unsigned ubase = (unsigned)((((ut * steps) * 16 + 4 * xi) * p.nhp + nh_g) * 64 + lane) << 4;   // bytes; + step * ustep + nu * unu
+    const int usteps = p.gather ? 2 * p.spp : steps;      // steps of one packed filter
+    const unsigned ubase = (unsigned)((((ut * usteps) * 16 + 4 * xi) * p.nhp + nh_g) * 64 + lane) << 4;   // bytes; + step * ustep + nu * unu
     const unsigned ustep = 16u * p.nhp * 1024u, unu = p.nhp * 1024u;
+    const unsigned uphase = (unsigned)(p.u_phase_floats * 4);   // gather: bytes between the filters of consecutive input phases
     auto u_load = [&](f32x4 (&dst)[4], int step) {
         const bool live = step < steps && !(abl & 4);
+        unsigned off = ubase + (unsigned)step * ustep;
+        if (p.gather) {
+            const int ph = step / (2 * p.spp);
+            off = ubase + (unsigned)ph * uphase + (unsigned)(step - ph * 2 * p.spp) * ustep;
+        }
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? ubase + (unsigned)step * ustep + nu * unu : WOOB);
+        for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? off + nu * unu : WOOB);
     };
 
     f32x16 acc[4];
@@ -403,7 +426,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     wino_pack_block(w, out, mode, w_i, Cout, Cin, NH, blockIdx.x, threadIdx.x);
 }
 
-static std::atomic<unsigned> g_wino_lds_done[4];
+static std::atomic<unsigned> g_wino_lds_done[4];   // (MO - 2) * 2 + BNB
 static std::atomic<int> g_wino_ablate{0};
 static std::atomic<int> g_wino_group_kb{2048};     // vatl_tune_set(18, v): KB of filter slices per group of the tile order (0 = one slice)
 int wino_set_group_kb(int v) { g_wino_group_kb.store(v, std::memory_order_relaxed); return 0; }
@@ -460,43 +483,47 @@ extern "C" int vatl_pack_winograd_deconv_weight(const float* w, float* u, int Co
 
 struct WinoBn { const float *z, *mask_y, *scale, *bias, *mean, *invstd; };
 
-// MO = 2: 3x3 / stride 1 / pad 1 conv (y: N x H x W x Cout);  MO = 3: ConvTranspose2d(4, 2, 1) (y: N x 2H x 2W x Cout)
+// MO = 2: 3x3 / stride 1 / pad 1 conv (y: N x H x W x Cout);  MO = 3: ConvTranspose2d(4, 2, 1) (y: N x 2H x 2W x Cout), or with
+// `gather` its data gradient: x = dz (N x 2H x 2W x Cin), y = dx (N x H x W x Cout), the four input phases part of the reduction
 static int winograd_impl(int MO, const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y,
                          double* stats, int64_t* row_blocks_used, int N, int H, int W, int Cin, int Cout, int relu, void* stream,
-                         const WinoBn* fuse = nullptr) {
+                         const WinoBn* fuse = nullptr, bool gather = false) {
     if (!x || !u || !y || N <= 0 || H <= 0 || W <= 0) return fail(VATL_EINVAL, "winograd: null pointer or empty batch");
     if (Cin % 16 != 0 || (Cout & 3)) return fail(VATL_EINVAL, "winograd: Cin %d must be a multiple of 16 and Cout %d of 4", Cin, Cout);
     WinoParams p{};
     p.x = x; p.u = u; p.scale = scale; p.bias = bias; p.res = residual; p.y = y; p.stats = stats;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
     p.TH = (H + MO - 1) / MO; p.TW = (W + MO - 1) / MO; p.tpi = p.TH * p.TW;
-    const int phases = MO == 3 ? 4 : 1, os = MO == 3 ? 2 : 1;
-    const long long mt = (long long)N * p.tpi, xe = (long long)N * H * W * Cin, ye = (long long)N * H * W * os * os * Cout;
+    const bool deconv = MO == 3 && !gather;
+    const int phases = deconv ? 4 : 1, os = deconv ? 2 : 1;
+    const long long mt = (long long)N * p.tpi, xe = (long long)N * H * W * Cin * (gather ? 4 : 1), ye = (long long)N * H * W * os * os * Cout;
     const long long ue = vatl_winograd_weight_floats(Cout, Cin);
-    if (xe >= (1LL << 30) || ye >= (1LL << 30) || ue >= (1LL << 30) || mt >= (1LL << 30))
+    if (xe >= (1LL << 30) || ye >= (1LL << 30) || ue >= (1LL << 28) || mt >= (1LL << 30))
         return fail(VATL_EINVAL, "winograd: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
     p.Mtiles = (int)mt;
     p.nhp = wino_nh(Cout);
-    p.stages = Cin / W_CK;
+    p.spp = Cin / W_CK;
+    p.stages = gather ? 4 * p.spp : p.spp;
     p.RW = MO * p.TW + 4 - MO;
     p.ns = 31 * MO + 4 + (4 - MO) * ((p.TW + 30) / p.TW);  // slots a block of 32 consecutive tiles can touch (header comment)
     p.ndma = (4 * p.ns * 4 + 63) / 64;
     p.stage_floats = p.ndma * 256;
     if (p.ndma > 4 * W_NLD) return fail(VATL_EINVAL, "winograd: %d staging instructions per stage (image width %d)", p.ndma, W);
     p.pad_y = 1; p.pad_x = 1; p.OH = H * os; p.OW = W * os; p.os = os; p.ooy = 0; p.oox = 0;
-    p.deconv = MO == 3; p.u_phase_floats = ue;
-    p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.u_bytes = (unsigned)(ue * 4);
+    p.deconv = deconv; p.gather = gather; p.u_phase_floats = ue;
+    p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.u_bytes = (unsigned)(ue * 4 * (gather ? 4 : 1));
     p.ablate = g_wino_ablate.load(std::memory_order_relaxed);
     p.m_tiles = cdiv(mt, W_TB); p.n_tiles = cdiv(Cout, 32);
     if (row_blocks_used) *row_blocks_used = (int64_t)p.m_tiles * phases;
-    // a slice is Cin * 2 KB; at least two per group (deconv1, Cin = 2048: 4 MB slices, 4326 -> 4135 us with two), unless the knob says 0
+    // a slice is Cin * 2 KB (x 4 input phases in the gather mode); at least two per group (deconv1, Cin = 2048: 4 MB slices, 4326 -> 4135 us
+    // with two), unless the knob says 0
     const int gkb = g_wino_group_kb.load(std::memory_order_relaxed);
-    p.rn = std::max(1, std::min(p.n_tiles * phases, std::max(gkb > 0 ? 2 : 1, gkb / (2 * Cin))));
+    p.rn = std::max(1, std::min(p.n_tiles * phases, std::max(gkb > 0 ? 2 : 1, gkb / (2 * Cin * (gather ? 4 : 1)))));
     hipStream_t st = (hipStream_t)stream;
     if (fuse) {
-        if (MO != 2) return fail(VATL_EINVAL, "winograd: the BatchNorm-backward epilogue exists for the 3x3 route only");
+        if (deconv) return fail(VATL_EINVAL, "winograd: the BatchNorm-backward epilogue exists for the data-gradient launches only");
         p.bz = fuse->z; p.bmy = fuse->mask_y; p.bsc = fuse->scale; p.bbi = fuse->bias; p.bmu = fuse->mean; p.bis = fuse->invstd;
-        return launch_wino<2, true>(p, phases, st);
+        return MO == 2 ? launch_wino<2, true>(p, phases, st) : launch_wino<3, true>(p, phases, st);
     }
     return MO == 2 ? launch_wino<2, false>(p, phases, st) : launch_wino<3, false>(p, phases, st);
 }
@@ -537,4 +564,33 @@ extern "C" int vatl_deconv4x4s2_winograd_fwd_stats(const float* x, const float* 
                                                    int W, int Cin, int Cout, void* stream) {
     if (!stats || !row_blocks_used) return fail(VATL_EINVAL, "deconv4x4s2_winograd_fwd_stats: null statistics buffer");
     return winograd_impl(3, x, u, nullptr, nullptr, nullptr, y, stats, row_blocks_used, N, H, W, Cin, Cout, 0, stream);
+}
+
+// Data gradient of ConvTranspose2d(4, 2, 1): dx[ci][y][x] = sum_{ky,kx,co} dz[co][2y - 1 + ky][2x - 1 + kx] W[ci][co][ky][kx] — a 4x4 / stride 2 conv,
+// i.e. the sum over the four pixel phases of dz of 2x2 convolutions: F(3x3, 2x2) with the reduction over (phase, channel).  w = the layer's
+// (Cin, Cout, 4, 4) weight; u receives 4 x vatl_winograd_weight_floats(Cin, Cout) floats.  dz (N, 2H, 2W, Cout) -> dx (N, H, W, Cin) (+ residual).
+extern "C" int64_t vatl_winograd_deconv_dgrad_weight_floats(int Cin, int Cout) { return 4 * vatl_winograd_weight_floats(Cin, Cout); }
+
+extern "C" int vatl_pack_winograd_deconv_dgrad_weight(const float* w, float* u, int Cin, int Cout, void* stream) {
+    if (!w || !u || Cout <= 0 || Cin <= 0) return fail(VATL_EINVAL, "pack_winograd_deconv_dgrad_weight: null pointer or empty filter");
+    if (Cout % 16 != 0) return fail(VATL_EINVAL, "pack_winograd_deconv_dgrad_weight: Cout %d must be a multiple of 16", Cout);
+    const int pad = vatl_winograd_cout_pad(Cin);          // the packed filter's output channels are the layer's Cin, its reduction channels the layer's Cout
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)(4 * (pad / 32) * (Cout / 8))), dim3(256), 0, (hipStream_t)stream, w, u, Cin, Cout, wino_nh(Cin),
+                       3, Cout);
+    return check_launch("wino_pack_deconv_dgrad");
+}
+
+extern "C" int vatl_deconv4x4s2_winograd_dgrad(const float* dz, const float* u, const float* residual, float* dx, int N, int H, int W, int Cin,
+                                               int Cout, void* stream) {
+    return winograd_impl(3, dz, u, nullptr, nullptr, residual, dx, nullptr, nullptr, N, H, W, Cout, Cin, 0, stream, nullptr, true);
+}
+
+extern "C" int vatl_deconv4x4s2_winograd_dgrad_bnbwd(const float* dz, const float* u, const float* residual, float* dx, int N, int H, int W, int Cin,
+                                                     int Cout, const float* bn_z, const float* bn_mask_y, const float* bn_scale,
+                                                     const float* bn_bias, const float* bn_mean, const float* bn_invstd, double* stats,
+                                                     int64_t* row_blocks_used, void* stream) {
+    if (!bn_z || !stats || !row_blocks_used || !bn_mean || !bn_invstd || (bn_scale && !bn_bias))
+        return fail(VATL_EINVAL, "deconv4x4s2_winograd_dgrad_bnbwd: needs z, mean, invstd and a statistics buffer");
+    const WinoBn bn{bn_z, bn_mask_y, bn_scale, bn_bias, bn_mean, bn_invstd};
+    return winograd_impl(3, dz, u, nullptr, nullptr, residual, dx, stats, row_blocks_used, N, H, W, Cout, Cin, 0, stream, &bn, true);
 }

@@ -12,12 +12,14 @@ namespace vatl {
 // mode 1: its data gradient, g = rot180(w[o = c][i = n]) of the forward filter (O, I, 3, 3) (w_i = I);
 // mode 2: F(3x3,2x2) of ConvTranspose2d(4,2,1), w = (Cin, Cout, 4, 4) (w_i = Cout): four phase filters one after another
 //         (bl = phase * blocks per filter + ...), phase (py, px): g[a][b] = w[c][n][3 - py - 2a][3 - px - 2b], G = [1 0; .5 .5; .5 -.5; 0 -1].
+// mode 3: data gradient of ConvTranspose2d(4,2,1) (a 4x4 / stride 2 conv over dz): w = (Cin_d, Cout_d, 4, 4) read as [n = Cin_d][c = Cout_d]
+//         (w_i = Cout_d); four INPUT-phase filters one after another, phase (p, q): g[a][b] = w[n][c][2a + 1 - p][2b + 1 - q], same G as mode 2.
 // n >= Cout: zero (padding rows of the last channel tile).  Computed in double, rounded once.
 __device__ __forceinline__ void wino_pack_block(const float* __restrict__ w, float* __restrict__ out, int mode, int w_i, int Cout, int Cin, int NH,
                                                 long long bl, int tid) {
     const int steps = Cin >> 3;
     int phase = 0;
-    if (mode == 2) {
+    if (mode >= 2) {
         const long long per = (long long)((Cout + 32 * NH - 1) / (32 * NH)) * NH * steps;
         phase = (int)(bl / per);
         bl -= phase * per;
@@ -29,14 +31,18 @@ __device__ __forceinline__ void wino_pack_block(const float* __restrict__ w, flo
     const int n_tile = n32 / NH, nh = n32 - n_tile * NH;
     const int lane = (cc >> 2) * 32 + nl, tt = cc & 3;
     double tg[4][3];
-    if (mode == 2) {
+    if (mode >= 2) {
         const int py = phase >> 1, px = phase & 1;
         double g[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-                g[a][b] = n < Cout ? (double)w[(((long long)c * w_i + n) * 4 + (3 - py - 2 * a)) * 4 + (3 - px - 2 * b)] : 0.0;
+            for (int b = 0; b < 2; ++b) {
+                double v = 0.0;
+                if (n < Cout) v = mode == 2 ? (double)w[(((long long)c * w_i + n) * 4 + (3 - py - 2 * a)) * 4 + (3 - px - 2 * b)]
+                                            : (double)w[(((long long)n * w_i + c) * 4 + (2 * a + 1 - py)) * 4 + (2 * b + 1 - px)];
+                g[a][b] = v;
+            }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             tg[0][s] = g[0][s];
@@ -66,7 +72,7 @@ __device__ __forceinline__ void wino_pack_block(const float* __restrict__ w, flo
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         double uu[4];
-        if (mode == 2) { uu[0] = tg[a][0]; uu[1] = 0.5 * (tg[a][0] + tg[a][1]); uu[2] = 0.5 * (tg[a][0] - tg[a][1]); uu[3] = -tg[a][1]; }
+        if (mode >= 2) { uu[0] = tg[a][0]; uu[1] = 0.5 * (tg[a][0] + tg[a][1]); uu[2] = 0.5 * (tg[a][0] - tg[a][1]); uu[3] = -tg[a][1]; }
         else { uu[0] = tg[a][0]; uu[1] = 0.5 * (tg[a][0] + tg[a][1] + tg[a][2]); uu[2] = 0.5 * (tg[a][0] - tg[a][1] + tg[a][2]); uu[3] = tg[a][2]; }
 #pragma unroll
         for (int b = 0; b < 4; ++b) o[(long long)(a * 4 + b) * NH * 256] = (float)uu[b];

@@ -85,6 +85,10 @@ SIGNATURES = {
     "vatl_conv3x3_winograd_wgrad": (_i, [_p] * 4 + [_i] * 5 + [_p]),
     "vatl_deconv4x4s2_winograd_wgrad_workspace_floats": (_i64, [_i, _i, _i64, _i, _i]),
     "vatl_deconv4x4s2_winograd_wgrad": (_i, [_p] * 4 + [_i] * 5 + [_p]),
+    "vatl_winograd_deconv_dgrad_weight_floats": (_i64, [_i, _i]),
+    "vatl_pack_winograd_deconv_dgrad_weight": (_i, [_p, _p, _i, _i, _p]),
+    "vatl_deconv4x4s2_winograd_dgrad": (_i, [_p] * 4 + [_i] * 5 + [_p]),
+    "vatl_deconv4x4s2_winograd_dgrad_bnbwd": (_i, [_p] * 4 + [_i] * 5 + [_p] * 9),
     "vatl_winograd_deconv_weight_floats": (_i64, [_i, _i]),
     "vatl_pack_winograd_deconv_weight": (_i, [_p, _p, _i, _i, _p]),
     "vatl_deconv4x4s2_winograd_fwd": (_i, [_p] * 5 + [_i] * 6 + [_p]),
@@ -484,6 +488,50 @@ def pack_winograd_deconv_weight(w: torch.Tensor) -> torch.Tensor:
         pad = int(lib().vatl_winograd_cout_pad(cout))
         plan.record(key, w, out, (5, cout, cin, 4, 4, pad, 1 if pad <= 32 else 2, cout, ()))
     return out
+
+
+def pack_winograd_deconv_dgrad_weight(w: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d(4,2,1) weight (Cin,Cout,4,4) -> the filters of its DATA gradient (a 4x4 / stride 2 conv over dz = four pixel
+    phases x 2x2 convolutions) in the F(3x3,2x2) transform domain."""
+    cin, cout = w.shape[:2]
+    if tuple(w.shape[2:]) != (4, 4):
+        raise VatlError("pack_winograd_deconv_dgrad_weight: 4x4 filters only")
+    plan, key = getattr(_tls, "pack_plan", None), ("winograd_deconv_dgrad", w.data_ptr(), tuple(w.shape))
+    if plan is not None and w.is_contiguous():
+        kept = plan.lookup(key, w)
+        if kept is not None:
+            return kept
+    out = torch.empty(int(lib().vatl_winograd_deconv_dgrad_weight_floats(cin, cout)), device=w.device, dtype=torch.float32)
+    _check(lib().vatl_pack_winograd_deconv_dgrad_weight(_ptr(w.contiguous()), _ptr(out), cin, cout, _stream()), "vatl_pack_winograd_deconv_dgrad_weight")
+    if plan is not None and w.is_contiguous():
+        pad = int(lib().vatl_winograd_cout_pad(cin))
+        plan.record(key, w, out, (6, cin, cout, 4, 4, pad, 1 if pad <= 32 else 2, cout, ()))
+    return out
+
+
+def deconv4x4s2_winograd_dgrad(dz, u_packed, cin: int, spec: "BnBwdSpec" = None, residual=None, out=None):
+    """dx (N,H,W,Cin) of ConvTranspose2d(4,2,1) from dz (N,2H,2W,Cout); with ``spec`` the epilogue masks the result with the consumer
+    layer's ReLU and appends the (sum g, sum g*xhat) row-block partials (conv2d_fwd_ex_bnbwd semantics)."""
+    n, h2, w2, cout = dz.shape
+    h, w = h2 // 2, w2 // 2
+    dx = out if out is not None else torch.empty((n, h, w, cin), device=dz.device, dtype=torch.float32)
+    if spec is None:
+        _check(lib().vatl_deconv4x4s2_winograd_dgrad(_ptr(dz), _ptr(u_packed), _ptr(residual), _ptr(dx), n, h, w, cin, cout, _stream()),
+               "vatl_deconv4x4s2_winograd_dgrad")
+        return dx
+    if dx.shape != spec.z.shape:
+        raise VatlError("deconv4x4s2_winograd_dgrad: the BatchNorm tensors must have the layout of the output")
+    used = C.c_int64(0)
+    c = spec.z.shape[-1]
+    need = (n * ((h + 2) // 3) * ((w + 2) // 3) + 31) // 32
+    if (spec.blocks + need) * c * 2 > spec.stats.numel():
+        raise VatlError("deconv4x4s2_winograd_dgrad: statistics buffer too small")
+    stats_ptr = spec.stats.data_ptr() + spec.blocks * c * 2 * 8
+    _check(lib().vatl_deconv4x4s2_winograd_dgrad_bnbwd(_ptr(dz), _ptr(u_packed), _ptr(residual), _ptr(dx), n, h, w, cin, cout, _ptr(spec.z),
+                                                       _ptr(spec.mask_y), _ptr(spec.scale), _ptr(spec.bias), _ptr(spec.mean), _ptr(spec.invstd),
+                                                       stats_ptr, C.addressof(used), _stream()), "vatl_deconv4x4s2_winograd_dgrad_bnbwd")
+    spec.blocks += used.value
+    return dx
 
 
 def deconv4x4s2_winograd_fwd(x, u_packed, scale, bias, cout: int, relu: bool, out=None):
