@@ -101,7 +101,7 @@ constexpr int W_LDP = 32;                       // row stride of the output-tran
 typedef __attribute__((address_space(3))) void wlds_void;
 
 // (body in a __device__ function: with the DMA builtin inside the __global__ template hipcc 7.2 drops the kernel's host stub)
-template <int MO, bool BNB>
+template <int MO, bool BNB, bool GATHER>
 __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) {
     constexpr int NT = 256, BN = 32, NW = 4;
     float* Rs = smem;                                      // [2][4 rows][ns slots][16 channels], chunk-swizzled
@@ -141,7 +141,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
     unsigned goff[W_NLD];                                  // byte offset of the lane's piece in the first stage (WOOB: zeros)
     auto set_goff = [&](int ph) {                          // ph: input phase of the gather mode (0 otherwise)
         const int gy = ph >> 1, gx = ph & 1;
-        const int py_ = p.gather ? gy : pad_y, px_ = p.gather ? gx : pad_x;
+        const int py_ = GATHER ? gy : pad_y, px_ = GATHER ? gx : pad_x;
 #pragma unroll
         for (int u = 0; u < W_NLD; ++u) {
             const int q = (xi + NW * u) * 64 + lane;
@@ -156,7 +156,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
                 const int b = gr / p.TH, ty = gr - b * p.TH;
                 const int yy = MO * ty - py_ + i, xx = pos - px_;
                 if (b < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
-                    if (p.gather) goff[u] = (unsigned)(((b * 2 * p.H + 2 * yy + gy) * 2 * p.W + 2 * xx + gx) * p.Cin + chunk * 4) << 2;
+                    if (GATHER) goff[u] = (unsigned)(((b * 2 * p.H + 2 * yy + gy) * 2 * p.W + 2 * xx + gx) * p.Cin + chunk * 4) << 2;
                     else goff[u] = (unsigned)(((b * p.H + yy) * p.W + xx) * p.Cin + chunk * 4) << 2;
                 }
             }
@@ -165,7 +165,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
     set_goff(0);
     auto stage_dma = [&](int buf, int st) {
         int cst = st;                                      // 16-channel slice inside the (phase's) tensor
-        if (p.gather) {
+        if constexpr (GATHER) {
             const int ph = st / p.spp;
             cst = st - ph * p.spp;
             if (cst == 0 && ph > 0) set_goff(ph);          // a new input phase: other pixels, other padding
@@ -202,14 +202,14 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
     // ---- U fragments: [n_tile][step][position][nh][lane][4]; the packing groups 32 p.nhp channels per filter tile ----------------------
     const int steps = p.stages * 2;
     const int ut = n_tile / p.nhp, nh_g = n_tile - ut * p.nhp;
-    const int usteps = p.gather ? 2 * p.spp : steps;      // steps of one packed filter
+    const int usteps = GATHER ? 2 * p.spp : steps;        // steps of one packed filter
     const unsigned ubase = (unsigned)((((ut * usteps) * 16 + 4 * xi) * p.nhp + nh_g) * 64 + lane) << 4;   // bytes; + step * ustep + nu * unu
     const unsigned ustep = 16u * p.nhp * 1024u, unu = p.nhp * 1024u;
     const unsigned uphase = (unsigned)(p.u_phase_floats * 4);   // gather: bytes between the filters of consecutive input phases
     auto u_load = [&](f32x4 (&dst)[4], int step) {
         const bool live = step < steps && !(abl & 4);
         unsigned off = ubase + (unsigned)step * ustep;
-        if (p.gather) {
+        if constexpr (GATHER) {
             const int ph = step / (2 * p.spp);
             off = ubase + (unsigned)ph * uphase + (unsigned)(step - ph * 2 * p.spp) * ustep;
         }
@@ -415,10 +415,12 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
     }
 }
 
-template <int MO, bool BNB>
+// GATHER: the data gradient of the transposed conv (reduction over the four pixel phases of dz x channels); a separate instantiation —
+// its phase changes keep the loader's geometry live across the stage loop, which costs the other variants 37 spilled registers
+template <int MO, bool BNB, bool GATHER>
 __global__ __launch_bounds__(256, 3) void winograd_kernel(WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    winograd_body<MO, BNB>(p, smem);
+    winograd_body<MO, BNB, GATHER>(p, smem);
 }
 
 // U = G g G^T (winograd_pack.h): one block per (32 output channels, 8 input channels) (x 4 phases for the transposed conv)
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     wino_pack_block(w, out, mode, w_i, Cout, Cin, NH, blockIdx.x, threadIdx.x);
 }
 
-static std::atomic<unsigned> g_wino_lds_done[4];   // (MO - 2) * 2 + BNB
+static std::atomic<unsigned> g_wino_lds_done[6];   // (MO - 2) * 2 + BNB, + 4 for the gather instantiations
 static std::atomic<int> g_wino_ablate{0};
 static std::atomic<int> g_wino_group_kb{2048};     // vatl_tune_set(18, v): KB of filter slices per group of the tile order (0 = one slice)
 int wino_set_group_kb(int v) { g_wino_group_kb.store(v, std::memory_order_relaxed); return 0; }
@@ -434,10 +436,10 @@ int wino_set_ablate(int bits) { g_wino_ablate.store(bits, std::memory_order_rela
 
 constexpr int kWinoMaxLds = 64 * 1024;            // upper bound of a block's dynamic LDS (ns <= 128: two 32 KB stages)
 
-template <int MO, bool BNB>
+template <int MO, bool BNB, bool GATHER = false>
 static int launch_wino(const WinoParams& p, int phases, hipStream_t st) {
-    auto kern = winograd_kernel<MO, BNB>;
-    if (int rc = ensure_dynamic_lds((const void*)kern, kWinoMaxLds, g_wino_lds_done[(MO - 2) * 2 + (BNB ? 1 : 0)], "winograd")) return rc;
+    auto kern = winograd_kernel<MO, BNB, GATHER>;
+    if (int rc = ensure_dynamic_lds((const void*)kern, kWinoMaxLds, g_wino_lds_done[GATHER ? 4 + (BNB ? 1 : 0) : (MO - 2) * 2 + (BNB ? 1 : 0)], "winograd")) return rc;
     const int loop = 2 * p.stage_floats, epi = 4 * MO * W_TB * W_LDP, sta = 2 * 256 * 4;
     const int smem = std::max(loop, std::max(epi, sta)) * (int)sizeof(float);
     if (smem > kWinoMaxLds) return fail(VATL_EINVAL, "winograd: %d bytes of LDS per block", smem);
@@ -523,8 +525,10 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
     if (fuse) {
         if (deconv) return fail(VATL_EINVAL, "winograd: the BatchNorm-backward epilogue exists for the data-gradient launches only");
         p.bz = fuse->z; p.bmy = fuse->mask_y; p.bsc = fuse->scale; p.bbi = fuse->bias; p.bmu = fuse->mean; p.bis = fuse->invstd;
+        if (gather) return launch_wino<3, true, true>(p, phases, st);
         return MO == 2 ? launch_wino<2, true>(p, phases, st) : launch_wino<3, true>(p, phases, st);
     }
+    if (gather) return launch_wino<3, false, true>(p, phases, st);
     return MO == 2 ? launch_wino<2, false>(p, phases, st) : launch_wino<3, false>(p, phases, st);
 }
 
