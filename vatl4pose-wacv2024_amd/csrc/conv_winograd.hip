@@ -1,7 +1,8 @@
 // Winograd convolutions on the gfx950 fp32 matrix cores:
 //   * F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 layers (MO = 2): a 2x2 output tile from its 4x4 input tile,
 //   * F(3x3, 2x2) for ConvTranspose2d(4, 2, 1) (MO = 3): each of its four sub-pixel phases is a 2x2 convolution of the input; a 3x3
-//     tile of phase outputs comes from a 4x4 input tile.
+//     tile of phase outputs comes from a 4x4 input tile.  Its data gradient (a 4x4 / stride 2 conv over dz) is the sum over the four
+//     PIXEL phases of dz of 2x2 convolutions: the same kernel with the reduction running over (phase, channel) (GATHER instantiation).
 // Both need 16 multiplies per (tile, input channel, output channel) where the direct sums need 36: 2.25x fewer MFMAs.
 //
 // Why.  These layers are half of the R50 trunk's time and nearly all of HRNet's (profiles/r03_layer_report.txt), and the implicit GEMM
