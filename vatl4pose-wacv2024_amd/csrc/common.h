@@ -64,4 +64,19 @@ __device__ __forceinline__ int wave_sum(int v) {
 // every integer, far more than the float32 rounding error of the product, so the truncation is exact.
 __device__ __forceinline__ int fast_div(int q, float inv_w) { return (int)(((float)q + 0.5f) * inv_w); }
 
+// Exact unsigned division by a launch constant without the ~40-instruction integer division: q / w = (mulhi(q, magic) + q) >> shift for
+// 0 <= q < 2^31, 1 <= w < 2^31 (Granlund & Montgomery; shift = ceil(log2 w), magic = floor(2^32 (2^shift - w) / w) + 1).
+struct FastDivU {
+    unsigned magic, shift;
+};
+static inline FastDivU make_fastdiv(unsigned w) {
+    FastDivU f{};
+    unsigned sh = 0;
+    while ((1ull << sh) < w) ++sh;
+    f.shift = sh;
+    f.magic = (unsigned)((((1ull << 32) * ((1ull << sh) - w)) / w) + 1);
+    return f;
+}
+__device__ __forceinline__ int fdiv(int q, FastDivU f) { return (int)((__umulhi((unsigned)q, f.magic) + (unsigned)q) >> f.shift); }
+
 }  // namespace vatl

@@ -82,6 +82,9 @@ struct WinoParams {
     int ablate;                       // profiling library only (vatl_tune_set(17, bits), wrong results): 1 no output transform, 2 no LDS
                                       // reads / input transform, 4 no filter loads, 8 no staging DMA, 16 no barriers
     unsigned x_bytes, u_bytes, y_bytes;
+    // divisions by launch constants (common.h: fdiv): a block's setup has ~30 of them per lane, which for the short layers (Cin = 32 / 64:
+    // 64 / 128 MFMAs per wave and block) cost as much as the MFMAs when done as integer divisions
+    FastDivU d_ns, d_RW, d_TH, d_TW, d_tpi, d_grp, d_rn, d_rn_last, d_ntiles;
 };
 
 constexpr unsigned WOOB = 0xFFFFFFFFu;
@@ -117,10 +120,11 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
     const int xcd = bid & 7, loc = bid >> 3, q8 = nblk >> 3, r8 = nblk & 7;
     const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
     const int units = p.n_tiles * (p.deconv ? 4 : 1);      // (gather mode: deconv = 0, the four input phases are part of the reduction)
-    const int grp = t / (p.m_tiles * p.rn), rem = t - grp * (p.m_tiles * p.rn);
-    const int rn_g = min(p.rn, units - grp * p.rn);        // the last group may be smaller
-    const int m_tile = rem / rn_g, unit = grp * p.rn + (rem - m_tile * rn_g);
-    const int phase = unit / p.n_tiles, n_tile = unit - phase * p.n_tiles;
+    const int grp = fdiv(t, p.d_grp), rem = t - grp * (p.m_tiles * p.rn);
+    const bool last_grp = units - grp * p.rn < p.rn;       // the last group may be smaller
+    const int rn_g = last_grp ? units - grp * p.rn : p.rn;
+    const int m_tile = fdiv(rem, last_grp ? p.d_rn_last : p.d_rn), unit = grp * p.rn + (rem - m_tile * rn_g);
+    const int phase = fdiv(unit, p.d_ntiles), n_tile = unit - phase * p.n_tiles;
     const int m0 = m_tile * W_TB, n0 = n_tile * BN;
 
     int pad_y = p.pad_y, pad_x = p.pad_x, ooy = p.ooy, oox = p.oox;
@@ -137,7 +141,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
     // lane-linear (base + lane * 16 bytes), so the chunk swizzle is applied on the SOURCE side: LDS position q = (pixel q >> 2, chunk
     // position q & 3) receives the pixel's global chunk (q & 3) ^ ((slot >> 2) & 3);  pixel = (input row i, slot).  Outside the image /
     // launch the offset is out of range and the DMA writes zeros: image borders need no special case in the reader.
-    const int gr0 = m0 / p.TW;                             // global tile row (image, ty) of the block's first tile
+    const int gr0 = fdiv(m0, p.d_TW);                      // global tile row (image, ty) of the block's first tile
     const int pos0 = MO * (m0 - gr0 * p.TW);               // its first column slot inside that row
     unsigned goff[W_NLD];                                  // byte offset of the lane's piece in the first stage (WOOB: zeros)
     auto set_goff = [&](int ph) {                          // ph: input phase of the gather mode (0 otherwise)
@@ -147,14 +151,15 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
         for (int u = 0; u < W_NLD; ++u) {
             const int q = (xi + NW * u) * 64 + lane;
             goff[u] = WOOB;
+            if (xi + NW * u >= p.ndma) continue;           // (wave-uniform) no such staging instruction
             const int cpos = q & 3, pix = q >> 2;
-            const int i = pix / p.ns, slot = pix - i * p.ns;
+            const int i = fdiv(pix, p.d_ns), slot = pix - i * p.ns;
             if (i < 4) {
                 const int chunk = cpos ^ ((slot >> 2) & 3);
                 const int P = slot + pos0;
-                const int rr = P / p.RW, pos = P - rr * p.RW;
+                const int rr = fdiv(P, p.d_RW), pos = P - rr * p.RW;
                 const int gr = gr0 + rr;
-                const int b = gr / p.TH, ty = gr - b * p.TH;
+                const int b = fdiv(gr, p.d_TH), ty = gr - b * p.TH;
                 const int yy = MO * ty - py_ + i, xx = pos - px_;
                 if (b < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
                     if (GATHER) goff[u] = (unsigned)(((b * 2 * p.H + 2 * yy + gy) * 2 * p.W + 2 * xx + gx) * p.Cin + chunk * 4) << 2;
@@ -184,7 +189,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
     int ra[4];
     {
         const int m = min(m0 + (lane & 31), p.Mtiles - 1);
-        const int gr = m / p.TW, tx = m - gr * p.TW;
+        const int gr = fdiv(m, p.d_TW), tx = m - gr * p.TW;
         const int sbase = (gr - gr0) * p.RW + MO * tx - pos0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) ra[j] = (sbase + j) * W_CK + ((h ^ (((sbase + j) >> 2) & 3)) << 2);
@@ -333,8 +338,8 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
 #pragma unroll
         for (int a = 0; a < MO; ++a) off[a] = WOOB;
         if (nv && m < p.Mtiles) {
-            const int b = m / p.tpi, r = m - b * p.tpi;
-            const int ty = r / p.TW, tx = r - ty * p.TW;
+            const int b = fdiv(m, p.d_tpi), r = m - b * p.tpi;
+            const int ty = fdiv(r, p.d_TW), tx = r - ty * p.TW;
             const int xx = MO * tx + bq;
             if (xx < p.W) {
 #pragma unroll
@@ -522,6 +527,11 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
     // with two), unless the knob says 0
     const int gkb = g_wino_group_kb.load(std::memory_order_relaxed);
     p.rn = std::max(1, std::min(p.n_tiles * phases, std::max(gkb > 0 ? 2 : 1, gkb / (2 * Cin * (gather ? 4 : 1)))));
+    const int units = p.n_tiles * phases;
+    p.d_ns = make_fastdiv(p.ns); p.d_RW = make_fastdiv(p.RW); p.d_TH = make_fastdiv(p.TH); p.d_TW = make_fastdiv(p.TW); p.d_tpi = make_fastdiv(p.tpi);
+    p.d_grp = make_fastdiv((unsigned)(p.m_tiles * p.rn)); p.d_rn = make_fastdiv(p.rn); p.d_ntiles = make_fastdiv(p.n_tiles);
+    p.d_rn_last = make_fastdiv(units % p.rn ? units % p.rn : p.rn);
+    if ((long long)p.m_tiles * units >= (1LL << 31)) return fail(VATL_EINVAL, "winograd: too many blocks");
     hipStream_t st = (hipStream_t)stream;
     if (fuse) {
         if (deconv) return fail(VATL_EINVAL, "winograd: the BatchNorm-backward epilogue exists for the data-gradient launches only");
