@@ -356,10 +356,16 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
     int abase[LA], iy0[LA], ix0[LA];  // element offset of (b, iy0, ix0, kq*4); may be negative
     int abase2[DUAL ? LA : 1];        // DUAL: element offset of the row's pixel in the second source
     const int HoWo = p.Ho * p.Wo;
+    // 1x1 / stride 1 / pad 0: the input pixel of GEMM row m is pixel m — no (image, row, column) split, i.e. none of the two integer
+    // divisions per staged row (8 per thread and block for a 128-row tile)
+    const bool flat = !STEM && !DUAL && p.R == 1 && p.S == 1 && p.stride == 1 && pad_y == 0 && pad_x == 0 && p.H == p.Ho && p.W == p.Wo;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         const int m = m0 + lrow + RP * i;
-        if (m < p.M) {
+        if (flat && m < p.M) {
+            iy0[i] = 0; ix0[i] = 0;
+            abase[i] = m * p.Cin + kq * 4;
+        } else if (m < p.M) {
             const int b = m / HoWo;
             const int rem = m - b * HoWo;
             const int oy = rem / p.Wo;
