@@ -88,6 +88,7 @@ struct ConvParams {
     float* part;
     long long part_slice;
     unsigned x_bytes, w_bytes, y_bytes;   // buffer extents (hardware bounds checks: OOB loads read 0, OOB stores drop)
+    FastDivU d_HoWo, d_Wo;                // m -> (image, row, column) without integer divisions (common.h: fdiv; filled in by dispatch())
 };
 
 constexpr int BK = 32;
@@ -143,9 +144,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             const int m = m0 + r0 + u * RPP;
             int orow = m;
             if (!plain) {
-                const int b = m / HoWo;
+                const int b = fdiv(m, p.d_HoWo);
                 const int rem = m - b * HoWo;
-                const int oy = rem / p.Wo;
+                const int oy = fdiv(rem, p.d_Wo);
                 const int ox = rem - oy * p.Wo;
                 orow = b * OHW + (oy * p.osy + ooy) * p.OW + (ox * p.osx + oox);
             }
@@ -261,9 +262,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
         const int row = tid % BM, cl0 = tid / BM;
         const int m = m0 + row;
         const bool mv = m < p.M;
-        const int b = m / HoWo;
+        const int b = fdiv(m, p.d_HoWo);
         const int rem = m - b * HoWo;
-        const int oy = rem / p.Wo;
+        const int oy = fdiv(rem, p.d_Wo);
         const int ox = rem - oy * p.Wo;
         const int opix = (oy * p.osy + ooy) * p.OW + (ox * p.osx + oox);
         const int nstride = p.out_nchw ? OHW : 1;
@@ -366,9 +367,9 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(ConvParams p) {
             iy0[i] = 0; ix0[i] = 0;
             abase[i] = m * p.Cin + kq * 4;
         } else if (m < p.M) {
-            const int b = m / HoWo;
+            const int b = fdiv(m, p.d_HoWo);
             const int rem = m - b * HoWo;
-            const int oy = rem / p.Wo;
+            const int oy = fdiv(rem, p.d_Wo);
             const int ox = rem - oy * p.Wo;
             iy0[i] = oy * p.stride - pad_y;
             ix0[i] = ox * p.stride - pad_x;
@@ -995,9 +996,9 @@ __global__ __launch_bounds__(256, 3) void conv_streamk_kernel(ConvParams p, Stre
         for (int i = 0; i < LA; ++i) {
             const int m = m0 + lrow + RP * i;
             if (m < p.M) {
-                const int b = m / HoWo;
+                const int b = fdiv(m, p.d_HoWo);
                 const int rem = m - b * HoWo;
-                const int oy = rem / p.Wo;
+                const int oy = fdiv(rem, p.d_Wo);
                 const int ox = rem - oy * p.Wo;
                 iy0[i] = oy * p.stride - p.pad_y;
                 ix0[i] = ox * p.stride - p.pad_x;
@@ -1170,9 +1171,9 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, float* 
     for (int i = 0; i < IA; ++i) {
         const int m = m0 + (4 * i + wave) * 8 + lrow;
         if (m < p.M) {
-            const int b = m / HoWo;
+            const int b = fdiv(m, p.d_HoWo);
             const int rem = m - b * HoWo;
-            const int oy = rem / p.Wo;
+            const int oy = fdiv(rem, p.d_Wo);
             const int ox = rem - oy * p.Wo;
             iy0[i] = oy * p.stride - pad_y;
             ix0[i] = ox * p.stride - pad_x;
@@ -1498,7 +1499,9 @@ static int tile_m_for(const ConvParams& p, int phases, int bn, bool stem) {
     return blocks128 < 768 ? 64 : 128;
 }
 
-static int dispatch(const ConvParams& p, int phases, bool stem, hipStream_t st, int64_t* row_blocks = nullptr) {
+static int dispatch(const ConvParams& p_in, int phases, bool stem, hipStream_t st, int64_t* row_blocks = nullptr) {
+    ConvParams p = p_in;
+    p.d_HoWo = make_fastdiv((unsigned)(p.Ho * p.Wo)); p.d_Wo = make_fastdiv((unsigned)p.Wo);
     const int bn = tile_n_for(p.Cout);
     if (p.CoutPad % bn != 0) return fail(VATL_EINVAL, "CoutPad %d must be a multiple of %d for Cout %d", p.CoutPad, bn, p.Cout);
     const int var = g_var.load(std::memory_order_relaxed);
@@ -1748,6 +1751,7 @@ extern "C" int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float
     p.x_bytes = (unsigned)(xe * 4); p.x2_bytes = (unsigned)(x2e * 4); p.y_bytes = (unsigned)(ye * 4); p.w_bytes = (unsigned)(we * 4);
     if (CoutPad % 128) return fail(VATL_EINVAL, "conv1x1_dual_fwd: CoutPad %d must be a multiple of 128", CoutPad);
     const int bm = tile_m_for(p, 1, 128, false);
+    p.d_HoWo = make_fastdiv((unsigned)(p.Ho * p.Wo)); p.d_Wo = make_fastdiv((unsigned)p.Wo);
     if (bm == 64) return launch<64, 128, 32, 64, false, 4, true>(p, 1, (hipStream_t)stream);
     return launch<128, 128, 64, 64, false, 4, true>(p, 1, (hipStream_t)stream);
 }
