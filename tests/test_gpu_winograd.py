@@ -343,3 +343,37 @@ def test_winograd_data_gradient_of_the_transposed_conv(vh, case):
         t1 = s1.stats[:s1.blocks * cin * 2].view(s1.blocks, cin, 2).sum(0)
         t2 = s2.stats[:s2.blocks * cin * 2].view(s2.blocks, cin, 2).sum(0)
         assert torch.allclose(t1, t2, rtol=1e-4, atol=1e-3 * float(t2.abs().max()))
+
+
+def test_winograd_full_batch_properties(vh):
+    """BASELINE.json's batch (1024 crops per launch sequence): the properties that do not need a reference at that size — a crop's bits
+    equal its single-crop launch, linearity in the input, and a float64 spot check of eight crops — for a 3x3 layer and a transposed conv."""
+    g = torch.Generator(device="cpu").manual_seed(53)
+    n, h, w, cin, cout = 1024, 16, 12, 256, 256
+    x = torch.randn((n, h, w, cin), generator=g).to(dev())
+    x2 = torch.randn((n, h, w, cin), generator=g).to(dev())
+    wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.03).to(dev())
+    u = vh.pack_winograd_weight(wt)
+    y = vh.conv3x3_winograd_fwd(x, u, None, None, cout, False)
+    for i in (0, 517, 1023):
+        assert torch.equal(vh.conv3x3_winograd_fwd(x[i:i + 1].contiguous(), u, None, None, cout, False)[0], y[i])
+    lin = vh.conv3x3_winograd_fwd(2.0 * x - 0.5 * x2, u, None, None, cout, False)
+    y2 = vh.conv3x3_winograd_fwd(x2, u, None, None, cout, False)
+    assert rel_err(lin.cpu().numpy(), (2.0 * y - 0.5 * y2).cpu().numpy()) < 1e-5
+    pick = [3, 100, 511, 512, 640, 900, 1000, 1023]
+    ref = F.conv2d(x[pick].permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), None, 1, 1).permute(0, 2, 3, 1)
+    e = rel_err(y[pick].cpu().numpy(), ref.numpy())
+    record("winograd_full_batch_3x3", rel=e)
+    assert e < TOL
+    # transposed conv at the batch of the headline (deconv1's grid, narrower channels to keep the float64 reference cheap)
+    n, h, w, cin, cout = 1024, 8, 6, 128, 64
+    x = torch.randn((n, h, w, cin), generator=g).to(dev())
+    wd = (torch.randn((cin, cout, 4, 4), generator=g) * 0.05).to(dev())
+    ud = vh.pack_winograd_deconv_weight(wd)
+    y = vh.deconv4x4s2_winograd_fwd(x, ud, None, None, cout, False)
+    for i in (0, 700, 1023):
+        assert torch.equal(vh.deconv4x4s2_winograd_fwd(x[i:i + 1].contiguous(), ud, None, None, cout, False)[0], y[i])
+    ref = F.conv_transpose2d(x[pick].permute(0, 3, 1, 2).double().cpu(), wd.double().cpu(), None, 2, 1).permute(0, 2, 3, 1)
+    e = rel_err(y[pick].cpu().numpy(), ref.numpy())
+    record("winograd_full_batch_deconv", rel=e)
+    assert e < TOL
