@@ -1604,7 +1604,7 @@ extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 8 && (value == 0 || value == 1)) return conv3x3_halo_enable(value);
     if (knob == 9 && (value == 0 || value == 1)) { g_splitk_policy.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 16 && vatl_crop_tune_px(value) == 0) return 0;
-    if (knob == 17 && value >= 0 && value <= 31) return wino_set_ablate(value);
+    if (knob == 17 && value >= 0 && value <= 63) return wino_set_ablate(value);
     if (knob == 18 && value >= 0 && value <= (1 << 20)) return wino_set_group_kb(value);
     if (knob == 19 && value >= 1 && value <= (1 << 20)) return wino_wgrad_set_blocks(value);
     if (knob == 12 && (value == 0 || value == 1)) { g_streamk.store(value, std::memory_order_relaxed); return 0; }

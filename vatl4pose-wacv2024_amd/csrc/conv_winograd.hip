@@ -68,9 +68,6 @@ struct WinoParams {
     int relu;
     int stages;                       // Cin / 16
     int nhp;                          // 32-channel groups per filter tile of the packing (1 if Cout <= 32, else 2)
-    int RW;                           // slots per tile row = MO TW + 4 - MO
-    int ns;                           // slots staged per input row i (upper bound over the launch's blocks)
-    int ndma, stage_floats;           // LDS-DMA instructions per stage (1 KB each), floats per stage
     int pad_y, pad_x;                 // tile (ty, tx) reads input rows MO ty - pad_y + i (deconv: 1 - phase bit, set in the kernel)
     int OH, OW, os, ooy, oox;         // output pixel of grid point (y, x) = (y os + ooy, x os + oox) in an OH x OW image
     int deconv;                       // four sub-pixel phases py * 2 + px, each with its own filter
@@ -84,7 +81,7 @@ struct WinoParams {
     unsigned x_bytes, u_bytes, y_bytes;
     // divisions by launch constants (common.h: fdiv): a block's setup has ~30 of them per lane, which for the short layers (Cin = 32 / 64:
     // 64 / 128 MFMAs per wave and block) cost as much as the MFMAs when done as integer divisions
-    FastDivU d_ns, d_RW, d_TH, d_TW, d_tpi, d_grp, d_rn, d_rn_last, d_ntiles;
+    FastDivU d_TH, d_TW, d_tpi, d_grp, d_rn, d_rn_last, d_ntiles;
 };
 
 constexpr unsigned WOOB = 0xFFFFFFFFu;
@@ -99,8 +96,17 @@ __device__ __forceinline__ void wbuf_store4(__amdgpu_buffer_rsrc_t r, unsigned b
 
 constexpr int W_TB = 32;                        // tiles per block
 constexpr int W_CK = 16;                        // channels per LDS stage
-constexpr int W_NLD = 8;                        // LDS-DMA instructions per wave per stage, at most (ns <= 128)
+constexpr int W_NQ = W_TB + 1;                  // entries of a column array: one per tile + the halo of the last tile
+constexpr int W_ZERO = 16;                      // floats of the zero pixel in front of the stages
 constexpr int W_LDP = 32;                       // row stride of the output-transform tiles in LDS
+// LDS stage: [4 input rows i][MO column arrays r][33 entries q][16 channels]; entry (r, q) = column r of tile q (= column MO + r of tile q - 1)
+template <int MO> struct WinoStage {
+    static constexpr int ROWE = MO * W_NQ;                 // entries per input row
+    static constexpr int ITEMS = 4 * ROWE * 4;             // 16-byte pieces
+    static constexpr int NDMA = (ITEMS + 63) / 64;         // wave-wide LDS-DMA instructions (1 KB each; the last one is partly used)
+    static constexpr int FLOATS = NDMA * 256;
+    static constexpr int NLD = (NDMA + 3) / 4;             // per wave
+};
 
 typedef __attribute__((address_space(3))) void wlds_void;
 
@@ -108,7 +114,9 @@ typedef __attribute__((address_space(3))) void wlds_void;
 template <int MO, bool BNB, bool GATHER>
 __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) {
     constexpr int NT = 256, BN = 32, NW = 4;
-    float* Rs = smem;                                      // [2][4 rows][ns slots][16 channels], chunk-swizzled
+    using ST = WinoStage<MO>;
+    constexpr int W_NLD = ST::NLD, STAGE = ST::FLOATS, ROWF = ST::ROWE * W_CK;   // DMA instructions per wave, floats per stage / per input row
+    float* Rs = smem + W_ZERO;                             // [2][4 rows][MO arrays][33 entries][16 channels], chunk-swizzled
 
     const int tid = threadIdx.x, lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -138,33 +146,42 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ubase_ptr), 0, p.u_bytes, 0x00020000);
 
     // ---- staging by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write pass).  The destination of a wave instruction is
-    // lane-linear (base + lane * 16 bytes), so the chunk swizzle is applied on the SOURCE side: LDS position q = (pixel q >> 2, chunk
-    // position q & 3) receives the pixel's global chunk (q & 3) ^ ((slot >> 2) & 3);  pixel = (input row i, slot).  Outside the image /
-    // launch the offset is out of range and the DMA writes zeros: image borders need no special case in the reader.
-    const int gr0 = fdiv(m0, p.d_TW);                      // global tile row (image, ty) of the block's first tile
-    const int pos0 = MO * (m0 - gr0 * p.TW);               // its first column slot inside that row
+    // lane-linear (base + lane * 16 bytes), so the chunk swizzle is applied on the SOURCE side: LDS position p = (entry p >> 2, chunk
+    // position p & 3) receives the entry's global chunk (p & 3) ^ ((q >> 2) & 3).
+    // Column arrays: pixel column j of tile t (x = MO tx + j - pad) lives in array r = j % MO at entry q = t + j / MO — the tile index
+    // is FLAT, so consecutive tiles are consecutive 64-byte entries even across tile-row ends and the 16 lanes of a ds_read_b128 group
+    // ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}) hit 16 different 16-byte bank slots (with one slot per distinct pixel column —
+    // stride MO between tiles and a gap at row ends — every fragment read was a 3-way bank conflict: SQ_LDS_BANK_CONFLICT 65 % of the
+    // LDS cycles).  At a row end entry (r, q) is asked for by two tiles: column r of tile q (first of its row: x = r - pad) and
+    // column MO + r of tile q - 1 (last of its row: x = MO TW + r - pad) — never both inside the image; the entry holds whichever is,
+    // and a tile whose column is outside the image reads the zero pixel instead.
     unsigned goff[W_NLD];                                  // byte offset of the lane's piece in the first stage (WOOB: zeros)
     auto set_goff = [&](int ph) {                          // ph: input phase of the gather mode (0 otherwise)
         const int gy = ph >> 1, gx = ph & 1;
         const int py_ = GATHER ? gy : pad_y, px_ = GATHER ? gx : pad_x;
 #pragma unroll
         for (int u = 0; u < W_NLD; ++u) {
-            const int q = (xi + NW * u) * 64 + lane;
+            const int pz = (xi + NW * u) * 64 + lane;
             goff[u] = WOOB;
-            if (xi + NW * u >= p.ndma) continue;           // (wave-uniform) no such staging instruction
-            const int cpos = q & 3, pix = q >> 2;
-            const int i = fdiv(pix, p.d_ns), slot = pix - i * p.ns;
-            if (i < 4) {
-                const int chunk = cpos ^ ((slot >> 2) & 3);
-                const int P = slot + pos0;
-                const int rr = fdiv(P, p.d_RW), pos = P - rr * p.RW;
-                const int gr = gr0 + rr;
-                const int b = fdiv(gr, p.d_TH), ty = gr - b * p.TH;
-                const int yy = MO * ty - py_ + i, xx = pos - px_;
-                if (b < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
-                    if (GATHER) goff[u] = (unsigned)(((b * 2 * p.H + 2 * yy + gy) * 2 * p.W + 2 * xx + gx) * p.Cin + chunk * 4) << 2;
-                    else goff[u] = (unsigned)(((b * p.H + yy) * p.W + xx) * p.Cin + chunk * 4) << 2;
-                }
+            if (pz >= ST::ITEMS) continue;
+            const int cpos = pz & 3, e = pz >> 2;
+            const int i = e / ST::ROWE, re = e - i * ST::ROWE;
+            const int r = re / W_NQ, q = re - r * W_NQ;
+            const int chunk = cpos ^ ((q >> 2) & 3);
+            int m = m0 + q;                                // column r of tile m ...
+            int gr = fdiv(m, p.d_TW), tx = m - gr * p.TW;
+            int xx = MO * tx + r - px_;
+            if (m >= p.Mtiles || (tx == 0 && xx < 0)) {    // ... or, when that is outside, column MO + r of the tile before (a row end / the halo)
+                m -= 1;
+                if (m < 0) continue;
+                gr = fdiv(m, p.d_TW); tx = m - gr * p.TW;
+                xx = MO * tx + MO + r - px_;
+            }
+            const int b = fdiv(gr, p.d_TH), ty = gr - b * p.TH;
+            const int yy = MO * ty - py_ + i;
+            if (m < p.Mtiles && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+                if (GATHER) goff[u] = (unsigned)(((b * 2 * p.H + 2 * yy + gy) * 2 * p.W + 2 * xx + gx) * p.Cin + chunk * 4) << 2;
+                else goff[u] = (unsigned)(((b * p.H + yy) * p.W + xx) * p.Cin + chunk * 4) << 2;
             }
         }
     };
@@ -178,27 +195,36 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
         }
 #pragma unroll
         for (int u = 0; u < W_NLD; ++u)
-            if (xi + NW * u < p.ndma)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (wlds_void*)(Rs + buf * p.stage_floats + (xi + NW * u) * 256), 16,
+            if (xi + NW * u < ST::NDMA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (wlds_void*)(Rs + buf * STAGE + (xi + NW * u) * 256), 16,
                                                          goff[u] != WOOB ? goff[u] + (unsigned)cst * (W_CK * 4) : WOOB, 0, 0, 0);
     };
 
-    // ---- fragment addressing: lane = (tile l & 31, channel quad l >> 5).  ra[j]: float index (relative to the stage, input row 0,
-    // first 8-channel step) of column j of the lane's tile; the second step of a stage is the same index ^ 8.
+    // ---- fragment addressing: lane = (tile l & 31, channel quad l >> 5).  ra[px][j]: float index (relative to Rs, input row 0, stage 0,
+    // first 8-channel step) of column j of the lane's tile; the second step of a stage is the same index ^ 8; -W_ZERO = the zero pixel
+    // (column outside the image).  The gather mode has two horizontal paddings (input phase & 1).
     const int h = lane >> 5;
-    int ra[4];
+    int ra[GATHER ? 2 : 1][4];
     {
-        const int m = min(m0 + (lane & 31), p.Mtiles - 1);
+        const int tl = lane & 31;
+        const int m = min(m0 + tl, p.Mtiles - 1);
         const int gr = fdiv(m, p.d_TW), tx = m - gr * p.TW;
-        const int sbase = (gr - gr0) * p.RW + MO * tx - pos0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ra[j] = (sbase + j) * W_CK + ((h ^ (((sbase + j) >> 2) & 3)) << 2);
+        for (int v = 0; v < (GATHER ? 2 : 1); ++v) {
+            const int px_ = GATHER ? v : pad_x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = MO * tx + j - px_;
+                const int q = tl + j / MO;
+                ra[v][j] = (unsigned)xx < (unsigned)p.W ? ((j % MO) * W_NQ + q) * W_CK + ((h ^ ((q >> 2) & 3)) << 2) : -W_ZERO;
+            }
+        }
     }
     // row transform of this wave: t = d[ia] + sgn * d[ib]   (B^T rows: d0 - d2, d1 + d2, d2 - d1, d1 - d3)
     const int ia = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
     const int ib = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
     const float sgn = xi == 1 ? 1.f : -1.f;
-    const int roa = ia * p.ns * W_CK, rob = ib * p.ns * W_CK;
+    const int roa = ia * ROWF, rob = ib * ROWF;
 
 #ifdef VATL_ABLATION
     const int abl = p.ablate;
@@ -229,13 +255,14 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
 
+    if (tid < W_ZERO / 4) *reinterpret_cast<f32x4*>(&smem[tid * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 ua[4], ub[4];
     stage_dma(0, 0);
     u_load(ua, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMA pieces have landed
     __syncthreads();
 
-    auto step_mfma = [&](const float* Rb, int x8, const f32x4 (&uu)[4]) {
+    auto step_mfma = [&](const float* Rb, int x8, const f32x4 (&uu)[4], int pv) {
         f32x4 tc[4];
         if (abl & 2) {
 #pragma unroll
@@ -243,8 +270,18 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 da = *reinterpret_cast<const f32x4*>(Rb + roa + (ra[j] ^ x8));
-                const f32x4 db = *reinterpret_cast<const f32x4*>(Rb + rob + (ra[j] ^ x8));
+                const int a = ra[GATHER ? pv : 0][j];
+                const bool z = a < 0;                      // the zero pixel has no rows / stages / steps
+#ifdef VATL_ABLATION
+                if (abl & 32) {        // lane-linear fragment addresses (bank-conflict probe)
+                    const f32x4 da = *reinterpret_cast<const f32x4*>(Rb + lane * 4 + j * 256);
+                    const f32x4 db = *reinterpret_cast<const f32x4*>(Rb + lane * 4 + j * 256 + 1024);
+                    tc[j] = da + sgn * db;
+                    continue;
+                }
+#endif
+                const f32x4 da = *reinterpret_cast<const f32x4*>(z ? smem : Rb + roa + (a ^ x8));
+                const f32x4 db = *reinterpret_cast<const f32x4*>(z ? smem : Rb + rob + (a ^ x8));
                 tc[j] = da + sgn * db;
             }
         }
@@ -259,17 +296,18 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
 
     for (int st = 0; st < p.stages; ++st) {
         const int buf = st & 1;
-        const float* Rb = Rs + buf * p.stage_floats;
+        const float* Rb = Rs + buf * STAGE;
+        const int pv = GATHER ? (st / p.spp) & 1 : 0;     // horizontal padding of this stage's input phase
         // the scheduler barriers keep the requests where they are written: without them hipcc sinks the filter loads to just before
         // their first MFMA (latency fully exposed)
         if (st + 1 < p.stages && !(abl & 8)) stage_dma(buf ^ 1, st + 1);
         u_load(ub, 2 * st + 1);
         __builtin_amdgcn_sched_barrier(0);
-        step_mfma(Rb, 0, ua);
+        step_mfma(Rb, 0, ua, pv);
         __builtin_amdgcn_sched_barrier(0);
         u_load(ua, 2 * st + 2);
         __builtin_amdgcn_sched_barrier(0);
-        step_mfma(Rb, 8, ub);
+        step_mfma(Rb, 8, ub, pv);
         __builtin_amdgcn_sched_barrier(0);
         if (!(abl & 16)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next stage have landed
@@ -446,7 +484,7 @@ template <int MO, bool BNB, bool GATHER = false>
 static int launch_wino(const WinoParams& p, int phases, hipStream_t st) {
     auto kern = winograd_kernel<MO, BNB, GATHER>;
     if (int rc = ensure_dynamic_lds((const void*)kern, kWinoMaxLds, g_wino_lds_done[GATHER ? 4 + (BNB ? 1 : 0) : (MO - 2) * 2 + (BNB ? 1 : 0)], "winograd")) return rc;
-    const int loop = 2 * p.stage_floats, epi = 4 * MO * W_TB * W_LDP, sta = 2 * 256 * 4;
+    const int loop = W_ZERO + 2 * WinoStage<MO>::FLOATS, epi = 4 * MO * W_TB * W_LDP, sta = 2 * 256 * 4;
     const int smem = std::max(loop, std::max(epi, sta)) * (int)sizeof(float);
     if (smem > kWinoMaxLds) return fail(VATL_EINVAL, "winograd: %d bytes of LDS per block", smem);
     hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles * phases), dim3(256), smem, st, p);
@@ -512,11 +550,6 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
     p.nhp = wino_nh(Cout);
     p.spp = Cin / W_CK;
     p.stages = gather ? 4 * p.spp : p.spp;
-    p.RW = MO * p.TW + 4 - MO;
-    p.ns = 31 * MO + 4 + (4 - MO) * ((p.TW + 30) / p.TW);  // slots a block of 32 consecutive tiles can touch (header comment)
-    p.ndma = (4 * p.ns * 4 + 63) / 64;
-    p.stage_floats = p.ndma * 256;
-    if (p.ndma > 4 * W_NLD) return fail(VATL_EINVAL, "winograd: %d staging instructions per stage (image width %d)", p.ndma, W);
     p.pad_y = 1; p.pad_x = 1; p.OH = H * os; p.OW = W * os; p.os = os; p.ooy = 0; p.oox = 0;
     p.deconv = deconv; p.gather = gather; p.u_phase_floats = ue;
     p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.u_bytes = (unsigned)(ue * 4 * (gather ? 4 : 1));
@@ -528,7 +561,7 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
     const int gkb = g_wino_group_kb.load(std::memory_order_relaxed);
     p.rn = std::max(1, std::min(p.n_tiles * phases, std::max(gkb > 0 ? 2 : 1, gkb / (2 * Cin * (gather ? 4 : 1)))));
     const int units = p.n_tiles * phases;
-    p.d_ns = make_fastdiv(p.ns); p.d_RW = make_fastdiv(p.RW); p.d_TH = make_fastdiv(p.TH); p.d_TW = make_fastdiv(p.TW); p.d_tpi = make_fastdiv(p.tpi);
+    p.d_TH = make_fastdiv(p.TH); p.d_TW = make_fastdiv(p.TW); p.d_tpi = make_fastdiv(p.tpi);
     p.d_grp = make_fastdiv((unsigned)(p.m_tiles * p.rn)); p.d_rn = make_fastdiv(p.rn); p.d_ntiles = make_fastdiv(p.n_tiles);
     p.d_rn_last = make_fastdiv(units % p.rn ? units % p.rn : p.rn);
     if ((long long)p.m_tiles * units >= (1LL << 31)) return fail(VATL_EINVAL, "winograd: too many blocks");
