@@ -27,11 +27,12 @@
 //   * B operand (U): packed in MFMA fragment order, a wave's 16-byte-per-lane load is 1 KB contiguous; straight from L2 into registers
 //     one 8-channel step ahead (no LDS: every wave needs a different slice).
 //   * A operand (V): the raw input pixels of the block's tiles are staged in LDS 16 channels at a time by LDS-DMA (double buffer, one
-//     stage ahead), de-duplicated along the tile row: per input row i of the tiles, one slot per distinct pixel column — column j of
-//     tile (row r, tx) is slot (r - r0) * (MO TW + 4 - MO) + MO tx + j - MO tx0, so neighbours share their 4 - MO common columns and
-//     pixels outside the image are slots that the DMA filled with zeros.  A wave needs two of the four tile rows (row transform) and
-//     forms its four V_p = column transform in registers: 8 ds_read_b128 and 8 vector adds per 16 MFMAs.  The 16-byte read of a lane
-//     is four consecutive channels = four MFMA k-steps (the same k permutation on both operands).
+//     stage ahead), de-duplicated along the tile row: per input row i of the tiles, MO column arrays — column j of tile t is entry
+//     t + j / MO of array j % MO, with a FLAT tile index, so neighbouring tiles share their 4 - MO common columns and consecutive tiles
+//     are consecutive 64-byte entries (bank-conflict-free ds_read_b128 for the hardware's lane groups; the details are at the loader).
+//     A wave needs two of the four tile rows (row transform) and forms its four V_p = column transform in registers: 8 ds_read_b128
+//     and 8 vector adds per 16 MFMAs.  The 16-byte read of a lane is four consecutive channels = four MFMA k-steps (the same k
+//     permutation on both operands).
 //   * Output transform: the nu sum happens in registers (4 accumulator tiles -> MO), the xi sum through LDS (the staging buffers are
 //     free by then): every wave writes its partial tiles, every thread then combines the four xi for whole 16-byte channel groups and
 //     stores NHWC channel runs, with scale / bias / residual / ReLU, the BatchNorm statistics of the training forward, or the
