@@ -301,8 +301,10 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
         const int pv = GATHER ? (st / p.spp) & 1 : 0;     // horizontal padding of this stage's input phase
         // the scheduler barriers keep the requests where they are written: without them hipcc sinks the filter loads to just before
         // their first MFMA (latency fully exposed)
-        if (st + 1 < p.stages && !(abl & 8)) stage_dma(buf ^ 1, st + 1);
+        // (the filter loads first: VMEM loads retire in order, so fragments requested AFTER the staging DMA would make the second step wait
+        // for the whole DMA; this way the DMA has both steps to land)
         u_load(ub, 2 * st + 1);
+        if (st + 1 < p.stages && !(abl & 8)) stage_dma(buf ^ 1, st + 1);
         __builtin_amdgcn_sched_barrier(0);
         step_mfma(Rb, 0, ua, pv);
         __builtin_amdgcn_sched_barrier(0);
