@@ -285,7 +285,9 @@ def _allreduce_alone_ms(arena, dist_on):
     return round((time.perf_counter() - t0) / 5 * 1e3, 3)
 
 
-def extra_finetune(dev, name, cfg, hw, batch, gflop_fwd, groups, world, dist_on, steps=8, warmup=2):
+def extra_finetune(dev, name, cfg, hw, batch, gflop_fwd, groups, world, dist_on, steps=8, warmup=4):
+    # (warm-up 4: the first step records the weight re-pack plan and creates the optimizer state, the next ones let the caching allocator settle
+    # under the two-stream pattern — with two warm-up steps one run in two still had a ~20 ms allocation step among its timed ones)
     from active_learning.optim import AdamW
     m = build_net(cfg, hw, dev).train()
     lr = 2.5e-4                                              # al_simple_posetrack.yaml:62-69: lr x{10, 1, 5}, weight decay 0.7
