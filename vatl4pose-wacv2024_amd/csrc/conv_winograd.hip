@@ -113,19 +113,20 @@ typedef __attribute__((address_space(3))) void wlds_void;
 
 // (body in a __device__ function: with the DMA builtin inside the __global__ template hipcc 7.2 drops the kernel's host stub)
 template <int MO, bool BNB, bool GATHER>
-__device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) {
+__device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, const int bid, const int nblk) {
     constexpr int NT = 256, BN = 32, NW = 4;
     using ST = WinoStage<MO>;
     constexpr int W_NLD = ST::NLD, STAGE = ST::FLOATS, ROWF = ST::ROWE * W_CK;   // DMA instructions per wave, floats per stage / per input row
     float* Rs = smem + W_ZERO;                             // [2][4 rows][MO arrays][33 entries][16 channels], chunk-swizzled
 
-    const int tid = threadIdx.x, lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tid_ = threadIdx.x;
+    if constexpr (GATHER) asm volatile("" : "+v"(tid_));   // (part of the gather instantiations' loop form, see winograd_kernel)
+    const int tid = tid_, lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // XCD-aware tile order: block b runs on XCD b % 8; each XCD gets a contiguous run of the sequence
     //     for (group of rn filter slices) for (m-tile) for (slice in the group)        slice = (phase, 32 output channels)
     // so the blocks that are resident together read the same input tiles (fetched from HBM once per group instead of once per slice)
     // while the group's filter slices (rn * Cin * 2 KB <= 2 MB) stay in that XCD's L2 for the whole sweep over the m-tiles.
-    const int nblk = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, loc = bid >> 3, q8 = nblk >> 3, r8 = nblk & 7;
     const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
     const int units = p.n_tiles * (p.deconv ? 4 : 1);      // (gather mode: deconv = 0, the four input phases are part of the reduction)
@@ -145,6 +146,24 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
     }
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ubase_ptr), 0, p.u_bytes, 0x00020000);
+
+#ifdef VATL_ABLATION
+    const int abl = p.ablate;
+#else
+    constexpr int abl = 0;
+#endif
+    // The first requests of the block go out as early as their addresses exist (the first filter fragments here, the first stage right
+    // after its offsets, the write-out's operands before the accumulators go through LDS): a block with two to four stages (32 / 64
+    // input channels) is not much longer than these latencies.  Not in the gather instantiations: their blocks run 64 - 128 stages and
+    // they are short of registers as it is.
+    constexpr bool EARLY = !GATHER;
+    f32x4 ua[4], ub[4];
+    if constexpr (EARLY) {
+        const int ut0 = n_tile / p.nhp;
+        const unsigned u0 = (unsigned)((((ut0 * p.stages * 2) * 16 + 4 * xi) * p.nhp + (n_tile - ut0 * p.nhp)) * 64 + lane) << 4;
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) ua[nu] = wbuf_load4(ur, (abl & 4) ? WOOB : u0 + nu * (p.nhp * 1024u));
+    }
 
     // ---- staging by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write pass).  The destination of a wave instruction is
     // lane-linear (base + lane * 16 bytes), so the chunk swizzle is applied on the SOURCE side: LDS position p = (entry p >> 2, chunk
@@ -201,6 +220,11 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
                                                          goff[u] != WOOB ? goff[u] + (unsigned)cst * (W_CK * 4) : WOOB, 0, 0, 0);
     };
 
+    if constexpr (EARLY) {
+        if (tid < W_ZERO / 4) *reinterpret_cast<f32x4*>(&smem[tid * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        stage_dma(0, 0);                                   // in flight while the rest of the prologue runs
+    }
+
     // ---- fragment addressing: lane = (tile l & 31, channel quad l >> 5).  ra[px][j]: float index (relative to Rs, input row 0, stage 0,
     // first 8-channel step) of column j of the lane's tile; the second step of a stage is the same index ^ 8; -W_ZERO = the zero pixel
     // (column outside the image).  The gather mode has two horizontal paddings (input phase & 1).
@@ -227,11 +251,6 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
     const float sgn = xi == 1 ? 1.f : -1.f;
     const int roa = ia * ROWF, rob = ib * ROWF;
 
-#ifdef VATL_ABLATION
-    const int abl = p.ablate;
-#else
-    constexpr int abl = 0;
-#endif
     // ---- U fragments: [n_tile][step][position][nh][lane][4]; the packing groups 32 p.nhp channels per filter tile ----------------------
     const int steps = p.stages * 2;
     const int ut = n_tile / p.nhp, nh_g = n_tile - ut * p.nhp;
@@ -256,10 +275,11 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
 
-    if (tid < W_ZERO / 4) *reinterpret_cast<f32x4*>(&smem[tid * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 ua[4], ub[4];
-    stage_dma(0, 0);
-    u_load(ua, 0);
+    if constexpr (!EARLY) {
+        if (tid < W_ZERO / 4) *reinterpret_cast<f32x4*>(&smem[tid * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        stage_dma(0, 0);
+        u_load(ua, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMA pieces have landed
     __syncthreads();
 
@@ -330,7 +350,67 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
         return;
     }
 #endif
+    constexpr int C4 = BN / 4;                             // channel quads per tile row
+    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
     // ---- output transform -----------------------------------------------------------------------------------------------------------------
+    // What the write-out needs from global memory (store offsets, skip-connection values, per-channel constants) is requested FIRST, so
+    // that it is in flight while the accumulators go through LDS: at the end of the block these latencies are not hidden by anything else.
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bz : p.x), 0, BNB ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bmy : p.x), 0, (BNB && p.bmy) ? p.y_bytes : 0u, 0x00020000);
+    const int c4 = tid % C4;
+    const int n = n0 + c4 * 4;
+    const bool nv = n < p.Cout;
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, nul = {0.f, 0.f, 0.f, 0.f};
+    const float lo = p.relu ? 0.f : -INFINITY;
+    f32x4 sc = one, bi = nul, mu = nul, is = nul, msc = nul, mbi = one;       // no mask: 0 * z + 1 > 0
+    auto request_consts = [&]() {
+        if (nv && p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        if (nv && p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (BNB && nv) {
+            mu = *reinterpret_cast<const f32x4*>(p.bmu + n); is = *reinterpret_cast<const f32x4*>(p.bis + n);
+            if (p.bsc) { msc = *reinterpret_cast<const f32x4*>(p.bsc + n); mbi = *reinterpret_cast<const f32x4*>(p.bbi + n); }
+        }
+    };
+    unsigned off[MO][MO];                                  // [pass u][output row a] of the thread's (tile, output column, channel quad)
+    f32x4 rs[MO][MO];
+    constexpr bool EARLY_Z = BNB && MO == 2;               // the BatchNorm-backward operands too, where the registers allow (F(3x3,2x2): 3 x 36 more)
+    f32x4 zq[EARLY_Z ? MO : 1][EARLY_Z ? MO : 1], yq[EARLY_Z ? MO : 1][EARLY_Z ? MO : 1];
+    auto request_out = [&](const int u) {                  // pass u: store offsets, skip-connection values (BatchNorm-backward operands)
+    {
+        const int rest = (tid + NT * u) / C4;              // 0 .. 32 MO - 1
+        const int tl = rest / MO, bq = rest - tl * MO;
+        const int m = m0 + tl;
+#pragma unroll
+        for (int a = 0; a < MO; ++a) off[u][a] = WOOB;
+        if (nv && m < p.Mtiles) {
+            const int b = fdiv(m, p.d_tpi), r = m - b * p.tpi;
+            const int ty = fdiv(r, p.d_TW), tx = r - ty * p.TW;
+            const int xx = MO * tx + bq;
+            if (xx < p.W) {
+#pragma unroll
+                for (int a = 0; a < MO; ++a) {
+                    const int yy = MO * ty + a;
+                    if (yy < p.H) off[u][a] = (unsigned)(((b * p.OH + yy * p.os + ooy) * p.OW + xx * p.os + oox) * p.Cout + n) << 2;
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < MO; ++a) rs[u][a] = p.res ? wbuf_load4(rr, off[u][a]) : nul;
+        if constexpr (EARLY_Z) {
+#pragma unroll
+            for (int a = 0; a < MO; ++a) { zq[u][a] = wbuf_load4(zr, off[u][a]); yq[u][a] = p.bmy ? wbuf_load4(mr, off[u][a]) : nul; }
+        }
+    }
+    };
+    if constexpr (EARLY) {
+        request_consts();
+#pragma unroll
+        for (int u = 0; u < MO; ++u) request_out(u);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
     // nu sum in registers (rows of A^T):  MO = 2: P0 = M0 + M1 + M2, P1 = M1 - M2 - M3;   MO = 3: P0 = M0 + M1 + M2, P1 = M1 - M2,
     // P2 = M1 + M2 + M3.   Ps[xi][b][tile][n] in LDS
     float* Ps = smem;
@@ -350,49 +430,14 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
         }
     }
     __syncthreads();
+    if constexpr (!EARLY) request_consts();
 
     // xi sum (the same rows of A^T) per (tile, output column b, channel quad); 16-byte stores of NHWC channel runs
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? p.y_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bz : p.x), 0, BNB ? p.y_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bmy : p.x), 0, (BNB && p.bmy) ? p.y_bytes : 0u, 0x00020000);
-    constexpr int C4 = BN / 4;                             // channel quads per tile row
-    const int c4 = tid % C4;
-    const int n = n0 + c4 * 4;
-    const bool nv = n < p.Cout;
-    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, nul = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 sc = (nv && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + n) : one;
-    const f32x4 bi = (nv && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + n) : nul;
-    const float lo = p.relu ? 0.f : -INFINITY;
-    f32x4 ssum = nul, ssq = nul;
-    f32x4 mu = nul, is = nul, msc = nul, mbi = one;       // no mask: 0 * z + 1 > 0
-    if (BNB && nv) {
-        mu = *reinterpret_cast<const f32x4*>(p.bmu + n); is = *reinterpret_cast<const f32x4*>(p.bis + n);
-        if (p.bsc) { msc = *reinterpret_cast<const f32x4*>(p.bsc + n); mbi = *reinterpret_cast<const f32x4*>(p.bbi + n); }
-    }
 #pragma unroll
     for (int u = 0; u < MO; ++u) {
-        const int rest = (tid + NT * u) / C4;              // 0 .. 32 MO - 1
+        if constexpr (!EARLY) request_out(u);
+        const int rest = (tid + NT * u) / C4;
         const int tl = rest / MO, bq = rest - tl * MO;
-        const int m = m0 + tl;
-        unsigned off[MO];
-#pragma unroll
-        for (int a = 0; a < MO; ++a) off[a] = WOOB;
-        if (nv && m < p.Mtiles) {
-            const int b = fdiv(m, p.d_tpi), r = m - b * p.tpi;
-            const int ty = fdiv(r, p.d_TW), tx = r - ty * p.TW;
-            const int xx = MO * tx + bq;
-            if (xx < p.W) {
-#pragma unroll
-                for (int a = 0; a < MO; ++a) {
-                    const int yy = MO * ty + a;
-                    if (yy < p.H) off[a] = (unsigned)(((b * p.OH + yy * p.os + ooy) * p.OW + xx * p.os + oox) * p.Cout + n) << 2;
-                }
-            }
-        }
-        f32x4 rs[MO];
-#pragma unroll
-        for (int a = 0; a < MO; ++a) rs[a] = p.res ? wbuf_load4(rr, off[a]) : nul;
         f32x4 pq[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) pq[k] = *reinterpret_cast<const f32x4*>(&Ps[((k * MO + bq) * W_TB + tl) * W_LDP + c4 * 4]);
@@ -407,28 +452,31 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
         if constexpr (BNB) {
             f32x4 zt[MO], yt[MO];
 #pragma unroll
-            for (int a = 0; a < MO; ++a) { zt[a] = wbuf_load4(zr, off[a]); yt[a] = p.bmy ? wbuf_load4(mr, off[a]) : nul; }
+            for (int a = 0; a < MO; ++a) {
+                if constexpr (EARLY_Z) { zt[a] = zq[u][a]; yt[a] = yq[u][a]; }
+                else { zt[a] = wbuf_load4(zr, off[u][a]); yt[a] = p.bmy ? wbuf_load4(mr, off[u][a]) : nul; }
+            }
 #pragma unroll
             for (int a = 0; a < MO; ++a) {
                 f32x4 gq;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float d = yv[a][c] + rs[a][c];
+                    const float d = yv[a][c] + rs[u][a][c];
                     const bool on = p.bmy ? yt[a][c] > 0.f : fmaf(zt[a][c], msc[c], mbi[c]) > 0.f;
-                    gq[c] = (on && off[a] != WOOB) ? d : 0.f;
+                    gq[c] = (on && off[u][a] != WOOB) ? d : 0.f;
                     ssum[c] += gq[c];
                     ssq[c] += gq[c] * ((zt[a][c] - mu[c]) * is[c]);
                 }
-                wbuf_store4(yr, off[a], gq);
+                wbuf_store4(yr, off[u][a], gq);
             }
         } else {
 #pragma unroll
             for (int a = 0; a < MO; ++a) {
                 f32x4 o;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = fmaxf(yv[a][c] * sc[c] + bi[c] + rs[a][c], lo);
-                wbuf_store4(yr, off[a], o);
-                if (p.stats && off[a] != WOOB) {
+                for (int c = 0; c < 4; ++c) o[c] = fmaxf(yv[a][c] * sc[c] + bi[c] + rs[u][a][c], lo);
+                wbuf_store4(yr, off[u][a], o);
+                if (p.stats && off[u][a] != WOOB) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { ssum[c] += o[c]; ssq[c] += o[c] * o[c]; }
                 }
@@ -467,7 +515,24 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem) 
 template <int MO, bool BNB, bool GATHER>
 __global__ __launch_bounds__(256, 3) void winograd_kernel(WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    winograd_body<MO, BNB, GATHER>(p, smem);
+    if constexpr (GATHER) {
+        // Written as a loop over the tiles of this block — which runs exactly once, the grid has one block per tile — with the parameter
+        // block read through an opaque pointer to the kernel-argument segment (WinoParams is the only argument) and an opaque thread id.
+        // In this form hipcc 7.2 splits the stage loop of the gather mode by input phase: a 409-instruction inner loop without spill
+        // traffic, the re-loads (34 scratch loads, 80 lane reads per trip in the plain form) only at the four phase changes.  deconv3's
+        // data gradient at 120 crops 1.34 -> 1.11 ms, deconv2's 0.71 -> 0.61, deconv1's 0.37 -> 0.31 (same box, alternating).  The other
+        // instantiations are 2 - 3 % slower in this form and stay plain.
+        typedef const __attribute__((address_space(4))) WinoParams* KArg;
+        const int total = gridDim.x;
+        for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
+            KArg pp = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(pp));
+            winograd_body<MO, BNB, GATHER>(*(const WinoParams*)pp, smem, bid, total);
+            __syncthreads();
+        }
+    } else {
+        winograd_body<MO, BNB, GATHER>(p, smem, blockIdx.x, gridDim.x);
+    }
 }
 
 // U = G g G^T (winograd_pack.h): one block per (32 output channels, 8 input channels) (x 4 phases for the transposed conv)
