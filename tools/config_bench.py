@@ -93,7 +93,7 @@ def cfg3(dev):
     x = torch.rand((b, 3, 256, 192), device=dev, generator=g) - 0.45
     labels = torch.rand((b, 17, 64, 48), device=dev, generator=g) * 0.1
     masks = (torch.rand((b, 17, 1, 1), device=dev, generator=g) > 0.2).float()
-    dt = timed(train_step_fn(m, opt, x, labels, masks), 10, 2)
+    dt = timed(train_step_fn(m, opt, x, labels, masks), 10, 4)     # four warm-up steps: see bench.py extra_finetune
     print(json.dumps({"config": "cfg3 fine-tune step, SimpleBaseline-R50 B=120", "ms_per_step": round(dt * 1e3, 2), "crops_per_s": round(b / dt, 1),
                       "conv_tflops": round(3 * 10.853e9 * b / dt / 1e12, 2)}), flush=True)
     m.eval()
@@ -161,7 +161,7 @@ def cfg5(dev):
     x = torch.rand((b, 3, 384, 288), device=dev, generator=g) - 0.45
     labels = torch.rand((b, 17, 96, 72), device=dev, generator=g) * 0.1
     masks = (torch.rand((b, 17, 1, 1), device=dev, generator=g) > 0.2).float()
-    dt = timed(train_step_fn(m, opt, x, labels, masks), 5, 2)
+    dt = timed(train_step_fn(m, opt, x, labels, masks), 5, 4)
     print(json.dumps({"config": "cfg5 fine-tune step, FastPose-R152 384x288 B=32 (one rank's share)", "ms_per_step": round(dt * 1e3, 2),
                       "crops_per_s": round(b / dt, 1), "conv_tflops": round(3 * 59.192e9 * b / dt / 1e12, 2),
                       "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}), flush=True)

@@ -2,7 +2,7 @@
 """Fine-tune step benchmark (BASELINE.json configs[2]): SimpleBaseline-R50,
 B = 120 crops, forward in train mode + masked MSE + backward + AdamW (3 param groups).
 
-    python tools/train_bench.py [--batch 120] [--steps 5] [--warmup 2]
+    python tools/train_bench.py [--batch 120] [--steps 5] [--warmup 4]
 Prints one JSON line: steps/s, crops/s and the conv-path TFLOP/s (3 x 10.853 GFLOP per crop).
 """
 import argparse
@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=120)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--wgrad-blocks", type=int, default=0, help="vatl_tune_set(3, v): target block count of the wgrad launches")
     ap.add_argument("--model", default="simplepose", choices=["simplepose", "fastpose", "hrnet"], help="backbone (autograd path for fastpose / hrnet)")
     a = ap.parse_args()
