@@ -333,8 +333,8 @@ int vatl_bn_train_bwd_relu_pool(const float* dpool, const uint8_t* idx, const fl
                                 float* dbeta, int N, int H, int W, int C, float* coef3C, double* workspace, void* stream);
 /* Every weight re-pack of one fine-tune step in ONE launch (the per-tensor entry points vatl_pack_conv_weight,
  * vatl_pack_dgrad_weight, vatl_pack_deconv4x4s2_weight produce the same bytes one launch each).  jobs_device: device
- * array of njobs descriptors sorted by first_block = the running sum of ceil(elements / 1024) (kinds 3 / 4: elements / 4096) over the
- * preceding jobs;
+ * array of njobs descriptors sorted by first_block = the running sum of the jobs' block counts over the preceding jobs — kinds 0 / 2:
+ * ceil(elements / 1024); kind 1: ceil(a / 32) * c * ceil(b / 32) (one 32 x 32 tile of one tap per block); kinds 3 .. 6: elements / 4096;
  * total_blocks = that sum over all jobs.  kind 0: conv forward layout, (a, b, c) = (CoutPad, Spad, CinPad);
  * kind 1: data-gradient layout, (a, b, c) = (CinPad, CoutK, ntaps) with the taps in tap_r / tap_s;
  * kind 2: ConvTranspose2d(4,2,1) layout, src (Cin,Cout,4,4), a = CoutPad;

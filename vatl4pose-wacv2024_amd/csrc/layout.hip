@@ -354,8 +354,9 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __r
 
 // Every weight re-pack of a fine-tune step in ONE launch (the trainers need ~60 .. 180 packed copies per step — forward
 // layouts of the 3x3 / 7x7 / transposed convs, data-gradient layouts of every conv — and each used to be its own 5 us
-// launch).  jobs: device array sorted by first_block; a block of 256 threads makes 1024 consecutive elements of one job (4096 of a
-// Winograd filter transform, kinds 3 / 4).
+// launch).  jobs: device array sorted by first_block; a block of 256 threads makes 1024 consecutive elements of one job (kinds 0 / 2),
+// one 32 x 32 tile of one tap (kind 1: ceil(CinPad / 32) * ntaps * ceil(CoutK / 32) blocks) or 4096 elements of a Winograd filter
+// transform (kinds 3 .. 6).
 // Element arithmetic = pack_conv_weight_kernel / pack_dgrad_weight_kernel / pack_deconv_weight_kernel.
 __global__ __launch_bounds__(256) void pack_multi_kernel(const VatlPackJob* __restrict__ jobs, int njobs) {
     __shared__ int sj;
@@ -377,38 +378,55 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const VatlPackJob* __re
         wino_pack_block(w, out, kind - 3, pc, Cout, Cin, pb, (long long)blockIdx.x - J->first_block, threadIdx.x);   // 4096 elements per block
         return;
     }
-    const long long base = ((long long)blockIdx.x - J->first_block) * 1024;
-    long long total;
-    if (kind == 0) total = (long long)pa * R * pb * pc;            // [CoutPad][R][Spad][CinPad]
-    else if (kind == 1) total = (long long)pa * pc * pb;           // [CinPad][ntaps][CoutK]
-    else total = 16LL * pa * Cin;                                  // [phase][CoutPad][ty][tx][Cin]
+    const unsigned bl = (unsigned)((long long)blockIdx.x - J->first_block);
+    if (kind == 1) {
+        // data-gradient layout [CinPad][ntaps][CoutK] = a transpose of OIHW: a block makes one 32 (input channels) x 32 (output channels)
+        // tile of one tap through LDS, so that the reads run along the input channels of a filter row and the writes along the output
+        // channels (one element per thread with 64-bit index arithmetic read a different cache line per lane: 305 us of the R50 step)
+        __shared__ float tile[32][33];
+        const unsigned tiles_n = (unsigned)(pb + 31) >> 5;
+        const unsigned n_t = bl % tiles_n, t = bl / tiles_n;
+        const unsigned tp = t % (unsigned)pc, c_t = t / (unsigned)pc;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        const int tap = J->tap_r[tp] * S + J->tap_s[tp], RS = R * S;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int n = (int)n_t * 32 + ty + 8 * k, c = (int)c_t * 32 + tx;
+            tile[ty + 8 * k][tx] = (c < Cin && n < Cout) ? w[((size_t)n * Cin + c) * RS + tap] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = (int)c_t * 32 + ty + 8 * k, n = (int)n_t * 32 + tx;
+            if (c < pa && n < pb) out[((size_t)c * pc + tp) * pb + n] = tile[tx][ty + 8 * k];
+        }
+        return;
+    }
+    // kinds 0 / 2 (forward layouts of the strided 3x3 / 7x7 convs and of the implicit-GEMM transposed convs): a few layers; 32-bit index arithmetic
+    const unsigned base = bl * 1024u;
+    const unsigned total = kind == 0 ? (unsigned)pa * R * pb * pc       // [CoutPad][R][Spad][CinPad]
+                                     : 16u * pa * Cin;                  // [phase][CoutPad][ty][tx][Cin]
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const long long i = base + e * 256 + threadIdx.x;
+        const unsigned i = base + e * 256 + threadIdx.x;
         if (i >= total) continue;
         float v = 0.f;
         if (kind == 0) {
-            const int c = (int)(i % pc);
-            long long t = i / pc;
-            const int s_ = (int)(t % pb); t /= pb;
-            const int r = (int)(t % R);
-            const int o = (int)(t / R);
-            if (o < Cout && s_ < S && c < Cin) v = w[(((long long)o * Cin + c) * R + r) * S + s_];
-        } else if (kind == 1) {
-            const int n = (int)(i % pb);
-            long long t = i / pb;
-            const int tp = (int)(t % pc);
-            const int c = (int)(t / pc);
-            if (c < Cin && n < Cout) v = w[(((long long)n * Cin + c) * R + J->tap_r[tp]) * S + J->tap_s[tp]];
+            const unsigned c = i % (unsigned)pc;
+            unsigned t = i / (unsigned)pc;
+            const unsigned s_ = t % (unsigned)pb; t /= (unsigned)pb;
+            const unsigned r = t % (unsigned)R;
+            const unsigned o = t / (unsigned)R;
+            if ((int)o < Cout && (int)s_ < S && (int)c < Cin) v = w[(((size_t)o * Cin + c) * R + r) * S + s_];
         } else {
-            const int c = (int)(i % Cin);
-            long long t = i / Cin;
+            const unsigned c = i % (unsigned)Cin;
+            unsigned t = i / (unsigned)Cin;
             const int tx = (int)(t & 1); t >>= 1;
             const int ty = (int)(t & 1); t >>= 1;
-            const int o = (int)(t % pa);
-            const int ph = (int)(t / pa);
+            const unsigned o = t % (unsigned)pa;
+            const int ph = (int)(t / (unsigned)pa);
             const int ky = 3 - (ph >> 1) - 2 * ty, kx = 3 - (ph & 1) - 2 * tx;
-            if (o < Cout) v = w[(((long long)c * Cout + o) * 4 + ky) * 4 + kx];
+            if ((int)o < Cout) v = w[(((size_t)c * Cout + o) * 4 + ky) * 4 + kx];
         }
         out[i] = v;
     }

@@ -312,7 +312,10 @@ class PackPlan:
             jb.kind, jb.Cout, jb.Cin, jb.R, jb.S, jb.a, jb.b, jb.c = f[:8]
             for t, (tr, ts) in enumerate(f[8]):
                 jb.tap_r[t], jb.tap_s[t] = tr, ts
-            blocks += (dst.numel() + 1023) // 1024 if f[0] < 3 else dst.numel() // 4096     # Winograd filters: 4096 elements per block
+            if f[0] == 1:                                    # data-gradient layout [a = CinPad][c = taps][b = CoutK]: 32 x 32 tiles of one tap
+                blocks += ((f[5] + 31) // 32) * f[7] * ((f[6] + 31) // 32)
+            else:
+                blocks += (dst.numel() + 1023) // 1024 if f[0] < 3 else dst.numel() // 4096     # Winograd filters: 4096 elements per block
         dev = next(iter(self.jobs.values()))[1].device
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.table = host.to(dev)
