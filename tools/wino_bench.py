@@ -42,10 +42,13 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--check", type=int, default=8)
     ap.add_argument("--group-kb", type=int, default=-1, help="vatl_tune_set(18, v): KB of filter slices per group of the Winograd tile order")
+    ap.add_argument("--halves", type=int, default=0, help="vatl_tune_set(21, v): 32-channel filter halves per Winograd block (1, or 2 where the layer allows)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     if a.group_kb >= 0:
         vh.tune_set(18, a.group_kb)
+    if a.halves:
+        vh.tune_set(21, a.halves)
     warm = torch.randn((4096, 4096), device=dev)
     for _ in range(100):
         warm @ warm

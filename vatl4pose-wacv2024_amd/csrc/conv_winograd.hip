@@ -112,9 +112,9 @@ template <int MO> struct WinoStage {
 typedef __attribute__((address_space(3))) void wlds_void;
 
 // (body in a __device__ function: with the DMA builtin inside the __global__ template hipcc 7.2 drops the kernel's host stub)
-template <int MO, bool BNB, bool GATHER>
+template <int MO, bool BNB, bool GATHER, int NB>
 __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, const int bid, const int nblk) {
-    constexpr int NT = 256, BN = 32, NW = 4;
+    constexpr int NT = 256, BN = 32 * NB, NW = 4;       // NB: 32-channel halves of the filter tile per block (2: the staged pixels and their transform serve 64 output channels)
     using ST = WinoStage<MO>;
     constexpr int W_NLD = ST::NLD, STAGE = ST::FLOATS, ROWF = ST::ROWE * W_CK;   // DMA instructions per wave, floats per stage / per input row
     float* Rs = smem + W_ZERO;                             // [2][4 rows][MO arrays][33 entries][16 channels], chunk-swizzled
@@ -159,8 +159,8 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
     constexpr bool EARLY = !GATHER;
     f32x4 ua[4], ub[4];
     if constexpr (EARLY) {
-        const int ut0 = n_tile / p.nhp;
-        const unsigned u0 = (unsigned)((((ut0 * p.stages * 2) * 16 + 4 * xi) * p.nhp + (n_tile - ut0 * p.nhp)) * 64 + lane) << 4;
+        const int hn0 = n_tile * NB, ut0 = hn0 / p.nhp;
+        const unsigned u0 = (unsigned)((((ut0 * p.stages * 2) * 16 + 4 * xi) * p.nhp + (hn0 - ut0 * p.nhp)) * 64 + lane) << 4;
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) ua[nu] = wbuf_load4(ur, (abl & 4) ? WOOB : u0 + nu * (p.nhp * 1024u));
     }
@@ -253,7 +253,8 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
 
     // ---- U fragments: [n_tile][step][position][nh][lane][4]; the packing groups 32 p.nhp channels per filter tile ----------------------
     const int steps = p.stages * 2;
-    const int ut = n_tile / p.nhp, nh_g = n_tile - ut * p.nhp;
+    const int hn = n_tile * NB;                            // first 32-channel half of this block's filter tile (NB = 2: the second one follows 1 KB later)
+    const int ut = hn / p.nhp, nh_g = hn - ut * p.nhp;
     const int usteps = GATHER ? 2 * p.spp : steps;        // steps of one packed filter
     const unsigned ubase = (unsigned)((((ut * usteps) * 16 + 4 * xi) * p.nhp + nh_g) * 64 + lane) << 4;   // bytes; + step * ustep + nu * unu
     const unsigned ustep = 16u * p.nhp * 1024u, unu = p.nhp * 1024u;
@@ -269,11 +270,14 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
         for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? off + nu * unu : WOOB);
     };
 
-    f32x16 acc[4];
+    f32x16 accs[NB][4];
 #pragma unroll
-    for (int nu = 0; nu < 4; ++nu)
+    for (int hh = 0; hh < NB; ++hh)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
+        for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accs[hh][nu][e] = 0.f;
+    f32x16 (&acc)[4] = accs[0];
 
     if constexpr (!EARLY) {
         if (tid < W_ZERO / 4) *reinterpret_cast<f32x4*>(&smem[tid * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -283,7 +287,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's DMA pieces have landed
     __syncthreads();
 
-    auto step_mfma = [&](const float* Rb, int x8, const f32x4 (&uu)[4], int pv) {
+    auto make_v = [&](f32x4 (&v)[4], const float* Rb, int x8, int pv) {      // V = B^T d B of the lane's tile: this wave's four positions, four channels
         f32x4 tc[4];
         if (abl & 2) {
 #pragma unroll
@@ -306,15 +310,59 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
                 tc[j] = da + sgn * db;
             }
         }
-        f32x4 v[4];
         v[0] = tc[0] - tc[2]; v[1] = tc[1] + tc[2]; v[2] = tc[2] - tc[1]; v[3] = tc[1] - tc[3];
+    };
+    auto mfma_group = [&](f32x16 (&ac)[4], const f32x4 (&v)[4], const f32x4 (&uu)[4]) {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu)
-                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][tt], uu[nu][tt], acc[nu], 0, 0, 0);
+                ac[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][tt], uu[nu][tt], ac[nu], 0, 0, 0);
+    };
+    auto step_mfma = [&](const float* Rb, int x8, const f32x4 (&uu)[4], int pv) {
+        f32x4 v[4];
+        make_v(v, Rb, x8, pv);
+        mfma_group(acc, v, uu);
     };
 
+    if constexpr (NB == 2) {
+        // Two filter halves per block: one V per step serves both, the two fragment sets alternate between the halves with a look-ahead of
+        // one group of 16 MFMAs: (step 0, half 0) = ua [requested in the previous stage], (step 0, half 1) = ub, (step 1, half 0) = ua, ..
+        auto u_load_h = [&](f32x4 (&dst)[4], int step, int half) {
+            const bool live = step < steps && !(abl & 4);
+            const unsigned off = ubase + (unsigned)half * 1024u + (unsigned)step * ustep;
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? off + nu * unu : WOOB);
+        };
+        for (int st = 0; st < p.stages; ++st) {
+            const int buf = st & 1;
+            const float* Rb = Rs + buf * STAGE;
+            f32x4 v[4];
+            u_load_h(ub, 2 * st, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            make_v(v, Rb, 0, 0);
+            mfma_group(accs[0], v, ua);
+            __builtin_amdgcn_sched_barrier(0);
+            u_load_h(ua, 2 * st + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(accs[NB - 1], v, ub);
+            __builtin_amdgcn_sched_barrier(0);
+            u_load_h(ub, 2 * st + 1, 1);
+            if (st + 1 < p.stages && !(abl & 8)) stage_dma(buf ^ 1, st + 1);     // (behind the fragments of this stage's second step: loads retire in order)
+            __builtin_amdgcn_sched_barrier(0);
+            make_v(v, Rb, 8, 0);
+            mfma_group(accs[0], v, ua);
+            __builtin_amdgcn_sched_barrier(0);
+            u_load_h(ua, 2 * st + 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(accs[NB - 1], v, ub);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(abl & 16)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    } else
     for (int st = 0; st < p.stages; ++st) {
         const int buf = st & 1;
         const float* Rb = Rs + buf * STAGE;
@@ -350,170 +398,176 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
         return;
     }
 #endif
-    constexpr int C4 = BN / 4;                             // channel quads per tile row
-    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
-    // ---- output transform -----------------------------------------------------------------------------------------------------------------
-    // What the write-out needs from global memory (store offsets, skip-connection values, per-channel constants) is requested FIRST, so
-    // that it is in flight while the accumulators go through LDS: at the end of the block these latencies are not hidden by anything else.
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? p.y_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bz : p.x), 0, BNB ? p.y_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bmy : p.x), 0, (BNB && p.bmy) ? p.y_bytes : 0u, 0x00020000);
-    const int c4 = tid % C4;
-    const int n = n0 + c4 * 4;
-    const bool nv = n < p.Cout;
-    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, nul = {0.f, 0.f, 0.f, 0.f};
-    const float lo = p.relu ? 0.f : -INFINITY;
-    f32x4 sc = one, bi = nul, mu = nul, is = nul, msc = nul, mbi = one;       // no mask: 0 * z + 1 > 0
-    auto request_consts = [&]() {
-        if (nv && p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-        if (nv && p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (BNB && nv) {
-            mu = *reinterpret_cast<const f32x4*>(p.bmu + n); is = *reinterpret_cast<const f32x4*>(p.bis + n);
-            if (p.bsc) { msc = *reinterpret_cast<const f32x4*>(p.bsc + n); mbi = *reinterpret_cast<const f32x4*>(p.bbi + n); }
+    constexpr int C4 = 32 / 4;                             // channel quads per tile row of one 32-channel half
+#pragma unroll
+    for (int hh = 0; hh < NB; ++hh) {                      // one filter half at a time through the same LDS tiles
+        const int n0h = n0 + 32 * hh;
+        f32x16 (&acch)[4] = accs[hh];
+        f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+        // ---- output transform -----------------------------------------------------------------------------------------------------------------
+        // What the write-out needs from global memory (store offsets, skip-connection values, per-channel constants) is requested FIRST, so
+        // that it is in flight while the accumulators go through LDS: at the end of the block these latencies are not hidden by anything else.
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res), 0, p.res ? p.y_bytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bz : p.x), 0, BNB ? p.y_bytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bmy : p.x), 0, (BNB && p.bmy) ? p.y_bytes : 0u, 0x00020000);
+        const int c4 = tid % C4;
+        const int n = n0h + c4 * 4;
+        const bool nv = n < p.Cout;
+        const f32x4 one = {1.f, 1.f, 1.f, 1.f}, nul = {0.f, 0.f, 0.f, 0.f};
+        const float lo = p.relu ? 0.f : -INFINITY;
+        f32x4 sc = one, bi = nul, mu = nul, is = nul, msc = nul, mbi = one;       // no mask: 0 * z + 1 > 0
+        auto request_consts = [&]() {
+            if (nv && p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+            if (nv && p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (BNB && nv) {
+                mu = *reinterpret_cast<const f32x4*>(p.bmu + n); is = *reinterpret_cast<const f32x4*>(p.bis + n);
+                if (p.bsc) { msc = *reinterpret_cast<const f32x4*>(p.bsc + n); mbi = *reinterpret_cast<const f32x4*>(p.bbi + n); }
+            }
+        };
+        unsigned off[MO][MO];                                  // [pass u][output row a] of the thread's (tile, output column, channel quad)
+        f32x4 rs[MO][MO];
+        constexpr bool EARLY_Z = BNB && MO == 2;               // the BatchNorm-backward operands too, where the registers allow (F(3x3,2x2): 3 x 36 more)
+        f32x4 zq[EARLY_Z ? MO : 1][EARLY_Z ? MO : 1], yq[EARLY_Z ? MO : 1][EARLY_Z ? MO : 1];
+        auto request_out = [&](const int u) {                  // pass u: store offsets, skip-connection values (BatchNorm-backward operands)
+        {
+            const int rest = (tid + NT * u) / C4;              // 0 .. 32 MO - 1
+            const int tl = rest / MO, bq = rest - tl * MO;
+            const int m = m0 + tl;
+    #pragma unroll
+            for (int a = 0; a < MO; ++a) off[u][a] = WOOB;
+            if (nv && m < p.Mtiles) {
+                const int b = fdiv(m, p.d_tpi), r = m - b * p.tpi;
+                const int ty = fdiv(r, p.d_TW), tx = r - ty * p.TW;
+                const int xx = MO * tx + bq;
+                if (xx < p.W) {
+    #pragma unroll
+                    for (int a = 0; a < MO; ++a) {
+                        const int yy = MO * ty + a;
+                        if (yy < p.H) off[u][a] = (unsigned)(((b * p.OH + yy * p.os + ooy) * p.OW + xx * p.os + oox) * p.Cout + n) << 2;
+                    }
+                }
+            }
+    #pragma unroll
+            for (int a = 0; a < MO; ++a) rs[u][a] = p.res ? wbuf_load4(rr, off[u][a]) : nul;
+            if constexpr (EARLY_Z) {
+    #pragma unroll
+                for (int a = 0; a < MO; ++a) { zq[u][a] = wbuf_load4(zr, off[u][a]); yq[u][a] = p.bmy ? wbuf_load4(mr, off[u][a]) : nul; }
+            }
         }
-    };
-    unsigned off[MO][MO];                                  // [pass u][output row a] of the thread's (tile, output column, channel quad)
-    f32x4 rs[MO][MO];
-    constexpr bool EARLY_Z = BNB && MO == 2;               // the BatchNorm-backward operands too, where the registers allow (F(3x3,2x2): 3 x 36 more)
-    f32x4 zq[EARLY_Z ? MO : 1][EARLY_Z ? MO : 1], yq[EARLY_Z ? MO : 1][EARLY_Z ? MO : 1];
-    auto request_out = [&](const int u) {                  // pass u: store offsets, skip-connection values (BatchNorm-backward operands)
-    {
-        const int rest = (tid + NT * u) / C4;              // 0 .. 32 MO - 1
-        const int tl = rest / MO, bq = rest - tl * MO;
-        const int m = m0 + tl;
-#pragma unroll
-        for (int a = 0; a < MO; ++a) off[u][a] = WOOB;
-        if (nv && m < p.Mtiles) {
-            const int b = fdiv(m, p.d_tpi), r = m - b * p.tpi;
-            const int ty = fdiv(r, p.d_TW), tx = r - ty * p.TW;
-            const int xx = MO * tx + bq;
-            if (xx < p.W) {
-#pragma unroll
-                for (int a = 0; a < MO; ++a) {
-                    const int yy = MO * ty + a;
-                    if (yy < p.H) off[u][a] = (unsigned)(((b * p.OH + yy * p.os + ooy) * p.OW + xx * p.os + oox) * p.Cout + n) << 2;
+        };
+        if constexpr (EARLY) {
+            request_consts();
+    #pragma unroll
+            for (int u = 0; u < MO; ++u) request_out(u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // nu sum in registers (rows of A^T):  MO = 2: P0 = M0 + M1 + M2, P1 = M1 - M2 - M3;   MO = 3: P0 = M0 + M1 + M2, P1 = M1 - M2,
+        // P2 = M1 + M2 + M3.   Ps[xi][b][tile][n] in LDS
+        float* Ps = smem;
+        {
+            const int cl = lane & 31;
+    #pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const float m0v = acch[0][e], m1v = acch[1][e], m2v = acch[2][e], m3v = acch[3][e];
+                Ps[((xi * MO + 0) * W_TB + row) * W_LDP + cl] = m0v + m1v + m2v;
+                if (MO == 2) {
+                    Ps[((xi * MO + 1) * W_TB + row) * W_LDP + cl] = m1v - m2v - m3v;
+                } else {
+                    Ps[((xi * MO + 1) * W_TB + row) * W_LDP + cl] = m1v - m2v;
+                    Ps[((xi * MO + MO - 1) * W_TB + row) * W_LDP + cl] = m1v + m2v + m3v;
                 }
             }
         }
-#pragma unroll
-        for (int a = 0; a < MO; ++a) rs[u][a] = p.res ? wbuf_load4(rr, off[u][a]) : nul;
-        if constexpr (EARLY_Z) {
-#pragma unroll
-            for (int a = 0; a < MO; ++a) { zq[u][a] = wbuf_load4(zr, off[u][a]); yq[u][a] = p.bmy ? wbuf_load4(mr, off[u][a]) : nul; }
-        }
-    }
-    };
-    if constexpr (EARLY) {
-        request_consts();
-#pragma unroll
-        for (int u = 0; u < MO; ++u) request_out(u);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+        __syncthreads();
+        if constexpr (!EARLY) request_consts();
 
-    // nu sum in registers (rows of A^T):  MO = 2: P0 = M0 + M1 + M2, P1 = M1 - M2 - M3;   MO = 3: P0 = M0 + M1 + M2, P1 = M1 - M2,
-    // P2 = M1 + M2 + M3.   Ps[xi][b][tile][n] in LDS
-    float* Ps = smem;
-    {
-        const int cl = lane & 31;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-            const float m0v = acc[0][e], m1v = acc[1][e], m2v = acc[2][e], m3v = acc[3][e];
-            Ps[((xi * MO + 0) * W_TB + row) * W_LDP + cl] = m0v + m1v + m2v;
+        // xi sum (the same rows of A^T) per (tile, output column b, channel quad); 16-byte stores of NHWC channel runs
+    #pragma unroll
+        for (int u = 0; u < MO; ++u) {
+            if constexpr (!EARLY) request_out(u);
+            const int rest = (tid + NT * u) / C4;
+            const int tl = rest / MO, bq = rest - tl * MO;
+            f32x4 pq[4];
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) pq[k] = *reinterpret_cast<const f32x4*>(&Ps[((k * MO + bq) * W_TB + tl) * W_LDP + c4 * 4]);
+            f32x4 yv[MO];
+            yv[0] = pq[0] + pq[1] + pq[2];
             if (MO == 2) {
-                Ps[((xi * MO + 1) * W_TB + row) * W_LDP + cl] = m1v - m2v - m3v;
+                yv[1] = pq[1] - pq[2] - pq[3];
             } else {
-                Ps[((xi * MO + 1) * W_TB + row) * W_LDP + cl] = m1v - m2v;
-                Ps[((xi * MO + MO - 1) * W_TB + row) * W_LDP + cl] = m1v + m2v + m3v;
+                yv[1] = pq[1] - pq[2];
+                yv[MO - 1] = pq[1] + pq[2] + pq[3];
+            }
+            if constexpr (BNB) {
+                f32x4 zt[MO], yt[MO];
+    #pragma unroll
+                for (int a = 0; a < MO; ++a) {
+                    if constexpr (EARLY_Z) { zt[a] = zq[u][a]; yt[a] = yq[u][a]; }
+                    else { zt[a] = wbuf_load4(zr, off[u][a]); yt[a] = p.bmy ? wbuf_load4(mr, off[u][a]) : nul; }
+                }
+    #pragma unroll
+                for (int a = 0; a < MO; ++a) {
+                    f32x4 gq;
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float d = yv[a][c] + rs[u][a][c];
+                        const bool on = p.bmy ? yt[a][c] > 0.f : fmaf(zt[a][c], msc[c], mbi[c]) > 0.f;
+                        gq[c] = (on && off[u][a] != WOOB) ? d : 0.f;
+                        ssum[c] += gq[c];
+                        ssq[c] += gq[c] * ((zt[a][c] - mu[c]) * is[c]);
+                    }
+                    wbuf_store4(yr, off[u][a], gq);
+                }
+            } else {
+    #pragma unroll
+                for (int a = 0; a < MO; ++a) {
+                    f32x4 o;
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = fmaxf(yv[a][c] * sc[c] + bi[c] + rs[u][a][c], lo);
+                    wbuf_store4(yr, off[u][a], o);
+                    if (p.stats && off[u][a] != WOOB) {
+    #pragma unroll
+                        for (int c = 0; c < 4; ++c) { ssum[c] += o[c]; ssq[c] += o[c] * o[c]; }
+                    }
+                }
             }
         }
-    }
-    __syncthreads();
-    if constexpr (!EARLY) request_consts();
-
-    // xi sum (the same rows of A^T) per (tile, output column b, channel quad); 16-byte stores of NHWC channel runs
-#pragma unroll
-    for (int u = 0; u < MO; ++u) {
-        if constexpr (!EARLY) request_out(u);
-        const int rest = (tid + NT * u) / C4;
-        const int tl = rest / MO, bq = rest - tl * MO;
-        f32x4 pq[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pq[k] = *reinterpret_cast<const f32x4*>(&Ps[((k * MO + bq) * W_TB + tl) * W_LDP + c4 * 4]);
-        f32x4 yv[MO];
-        yv[0] = pq[0] + pq[1] + pq[2];
-        if (MO == 2) {
-            yv[1] = pq[1] - pq[2] - pq[3];
-        } else {
-            yv[1] = pq[1] - pq[2];
-            yv[MO - 1] = pq[1] + pq[2] + pq[3];
-        }
-        if constexpr (BNB) {
-            f32x4 zt[MO], yt[MO];
-#pragma unroll
-            for (int a = 0; a < MO; ++a) {
-                if constexpr (EARLY_Z) { zt[a] = zq[u][a]; yt[a] = yq[u][a]; }
-                else { zt[a] = wbuf_load4(zr, off[u][a]); yt[a] = p.bmy ? wbuf_load4(mr, off[u][a]) : nul; }
-            }
-#pragma unroll
-            for (int a = 0; a < MO; ++a) {
-                f32x4 gq;
-#pragma unroll
+        if (p.stats) {
+            // BatchNorm batch statistics of the pixels just stored: one (sum, sum^2) double pair per (row block, channel), fixed order
+            __syncthreads();
+            f32x4* sh = reinterpret_cast<f32x4*>(smem);
+            sh[tid] = ssum; sh[NT + tid] = ssq;
+            __syncthreads();
+            if (tid < C4) {
+                double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+    #pragma unroll 2
+                for (int k = 0; k < NT / C4; ++k) {
+                    const f32x4 a = sh[k * C4 + tid], b = sh[NT + k * C4 + tid];
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c) { ds[c] += a[c]; dq[c] += b[c]; }
+                }
+                const long long rb = (long long)phase * p.m_tiles + m_tile;
+    #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float d = yv[a][c] + rs[u][a][c];
-                    const bool on = p.bmy ? yt[a][c] > 0.f : fmaf(zt[a][c], msc[c], mbi[c]) > 0.f;
-                    gq[c] = (on && off[u][a] != WOOB) ? d : 0.f;
-                    ssum[c] += gq[c];
-                    ssq[c] += gq[c] * ((zt[a][c] - mu[c]) * is[c]);
-                }
-                wbuf_store4(yr, off[u][a], gq);
-            }
-        } else {
-#pragma unroll
-            for (int a = 0; a < MO; ++a) {
-                f32x4 o;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = fmaxf(yv[a][c] * sc[c] + bi[c] + rs[u][a][c], lo);
-                wbuf_store4(yr, off[u][a], o);
-                if (p.stats && off[u][a] != WOOB) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { ssum[c] += o[c]; ssq[c] += o[c] * o[c]; }
+                    const int nn = n0h + tid * 4 + c;
+                    if (nn < p.Cout) {
+                        p.stats[(rb * p.Cout + nn) * 2 + 0] = ds[c];
+                        p.stats[(rb * p.Cout + nn) * 2 + 1] = dq[c];
+                    }
                 }
             }
         }
-    }
-    if (p.stats) {
-        // BatchNorm batch statistics of the pixels just stored: one (sum, sum^2) double pair per (row block, channel), fixed order
-        __syncthreads();
-        f32x4* sh = reinterpret_cast<f32x4*>(smem);
-        sh[tid] = ssum; sh[NT + tid] = ssq;
-        __syncthreads();
-        if (tid < C4) {
-            double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
-#pragma unroll 2
-            for (int k = 0; k < NT / C4; ++k) {
-                const f32x4 a = sh[k * C4 + tid], b = sh[NT + k * C4 + tid];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { ds[c] += a[c]; dq[c] += b[c]; }
-            }
-            const long long rb = (long long)phase * p.m_tiles + m_tile;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int nn = n0 + tid * 4 + c;
-                if (nn < p.Cout) {
-                    p.stats[(rb * p.Cout + nn) * 2 + 0] = ds[c];
-                    p.stats[(rb * p.Cout + nn) * 2 + 1] = dq[c];
-                }
-            }
-        }
+        if (NB > 1 && hh + 1 < NB) __syncthreads();       // the next half's tiles go where this one's were read
     }
 }
 
 // GATHER: the data gradient of the transposed conv (reduction over the four pixel phases of dz x channels); a separate instantiation —
 // its phase changes keep the loader's geometry live across the stage loop, which costs the other variants 37 spilled registers
-template <int MO, bool BNB, bool GATHER>
-__global__ __launch_bounds__(256, 3) void winograd_kernel(WinoParams p) {
+template <int MO, bool BNB, bool GATHER, int NB = 1>
+__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void winograd_kernel(WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if constexpr (GATHER) {
         // Written as a loop over the tiles of this block — which runs exactly once, the grid has one block per tile — with the parameter
@@ -527,11 +581,11 @@ __global__ __launch_bounds__(256, 3) void winograd_kernel(WinoParams p) {
         for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
             KArg pp = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(pp));
-            winograd_body<MO, BNB, GATHER>(*(const WinoParams*)pp, smem, bid, total);
+            winograd_body<MO, BNB, GATHER, 1>(*(const WinoParams*)pp, smem, bid, total);
             __syncthreads();
         }
     } else {
-        winograd_body<MO, BNB, GATHER>(p, smem, blockIdx.x, gridDim.x);
+        winograd_body<MO, BNB, GATHER, NB>(p, smem, blockIdx.x, gridDim.x);
     }
 }
 
@@ -540,7 +594,9 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     wino_pack_block(w, out, mode, w_i, Cout, Cin, NH, blockIdx.x, threadIdx.x);
 }
 
-static std::atomic<unsigned> g_wino_lds_done[6];   // (MO - 2) * 2 + BNB, + 4 for the gather instantiations
+static std::atomic<unsigned> g_wino_lds_done[10];  // (MO - 2) * 2 + BNB, + 4 for the gather instantiations, + 6 for the two-half blocks
+static std::atomic<int> g_wino_halves{2};          // vatl_tune_set(21, v): filter halves per block where the layer allows two (1 = always one)
+int wino_set_halves(int v) { g_wino_halves.store(v, std::memory_order_relaxed); return 0; }
 static std::atomic<int> g_wino_ablate{0};
 static std::atomic<int> g_wino_group_kb{2048};     // vatl_tune_set(18, v): KB of filter slices per group of the tile order (0 = one slice)
 int wino_set_group_kb(int v) { g_wino_group_kb.store(v, std::memory_order_relaxed); return 0; }
@@ -548,10 +604,10 @@ int wino_set_ablate(int bits) { g_wino_ablate.store(bits, std::memory_order_rela
 
 constexpr int kWinoMaxLds = 64 * 1024;            // upper bound of a block's dynamic LDS (ns <= 128: two 32 KB stages)
 
-template <int MO, bool BNB, bool GATHER = false>
+template <int MO, bool BNB, bool GATHER = false, int NB = 1>
 static int launch_wino(const WinoParams& p, int phases, hipStream_t st) {
-    auto kern = winograd_kernel<MO, BNB, GATHER>;
-    if (int rc = ensure_dynamic_lds((const void*)kern, kWinoMaxLds, g_wino_lds_done[GATHER ? 4 + (BNB ? 1 : 0) : (MO - 2) * 2 + (BNB ? 1 : 0)], "winograd")) return rc;
+    auto kern = winograd_kernel<MO, BNB, GATHER, NB>;
+    if (int rc = ensure_dynamic_lds((const void*)kern, kWinoMaxLds, g_wino_lds_done[(NB == 2 ? 6 : 0) + (GATHER ? 4 + (BNB ? 1 : 0) : (MO - 2) * 2 + (BNB ? 1 : 0))], "winograd")) return rc;
     const int loop = W_ZERO + 2 * WinoStage<MO>::FLOATS, epi = 4 * MO * W_TB * W_LDP, sta = 2 * 256 * 4;
     const int smem = std::max(loop, std::max(epi, sta)) * (int)sizeof(float);
     if (smem > kWinoMaxLds) return fail(VATL_EINVAL, "winograd: %d bytes of LDS per block", smem);
@@ -622,12 +678,15 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
     p.deconv = deconv; p.gather = gather; p.u_phase_floats = ue;
     p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.u_bytes = (unsigned)(ue * 4 * (gather ? 4 : 1));
     p.ablate = g_wino_ablate.load(std::memory_order_relaxed);
-    p.m_tiles = cdiv(mt, W_TB); p.n_tiles = cdiv(Cout, 32);
+    // two filter halves per block where the padded filter has an even number of them (packed in pairs: nhp = 2) — not in the gather mode
+    const bool two = !gather && p.nhp == 2 && vatl_winograd_cout_pad(Cout) % 64 == 0 && g_wino_halves.load(std::memory_order_relaxed) == 2;
+    const int NBh = two ? 2 : 1;
+    p.m_tiles = cdiv(mt, W_TB); p.n_tiles = cdiv(Cout, 32 * NBh);
     if (row_blocks_used) *row_blocks_used = (int64_t)p.m_tiles * phases;
     // a slice is Cin * 2 KB (x 4 input phases in the gather mode); at least two per group (deconv1, Cin = 2048: 4 MB slices, 4326 -> 4135 us
     // with two), unless the knob says 0
     const int gkb = g_wino_group_kb.load(std::memory_order_relaxed);
-    p.rn = std::max(1, std::min(p.n_tiles * phases, std::max(gkb > 0 ? 2 : 1, gkb / (2 * Cin * (gather ? 4 : 1)))));
+    p.rn = std::max(1, std::min(p.n_tiles * phases, std::max(gkb > 0 ? 2 : 1, gkb / (2 * Cin * NBh * (gather ? 4 : 1)))));
     const int units = p.n_tiles * phases;
     p.d_TH = make_fastdiv(p.TH); p.d_TW = make_fastdiv(p.TW); p.d_tpi = make_fastdiv(p.tpi);
     p.d_grp = make_fastdiv((unsigned)(p.m_tiles * p.rn)); p.d_rn = make_fastdiv(p.rn); p.d_ntiles = make_fastdiv(p.n_tiles);
@@ -638,9 +697,11 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
         if (deconv) return fail(VATL_EINVAL, "winograd: the BatchNorm-backward epilogue exists for the data-gradient launches only");
         p.bz = fuse->z; p.bmy = fuse->mask_y; p.bsc = fuse->scale; p.bbi = fuse->bias; p.bmu = fuse->mean; p.bis = fuse->invstd;
         if (gather) return launch_wino<3, true, true>(p, phases, st);
+        if (two) return MO == 2 ? launch_wino<2, true, false, 2>(p, phases, st) : launch_wino<3, true, false, 2>(p, phases, st);
         return MO == 2 ? launch_wino<2, true>(p, phases, st) : launch_wino<3, true>(p, phases, st);
     }
     if (gather) return launch_wino<3, false, true>(p, phases, st);
+    if (two) return MO == 2 ? launch_wino<2, false, false, 2>(p, phases, st) : launch_wino<3, false, false, 2>(p, phases, st);
     return MO == 2 ? launch_wino<2, false>(p, phases, st) : launch_wino<3, false>(p, phases, st);
 }
 

@@ -148,6 +148,8 @@ def lib() -> C.CDLL:
             l.vatl_tune_set(0, int(os.environ["VATL_CONV_VAR"]))
         if os.environ.get("VATL_WINO_GROUP_KB"):     # tile-order knob of the Winograd kernel (results are identical)
             l.vatl_tune_set(18, int(os.environ["VATL_WINO_GROUP_KB"]))
+        if os.environ.get("VATL_WINO_HALVES"):       # 32-channel filter halves per Winograd block: 1, or 2 where the layer allows (results are identical)
+            l.vatl_tune_set(21, int(os.environ["VATL_WINO_HALVES"]))
     return _lib
 
 
