@@ -678,10 +678,17 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
     p.deconv = deconv; p.gather = gather; p.u_phase_floats = ue;
     p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4); p.u_bytes = (unsigned)(ue * 4 * (gather ? 4 : 1));
     p.ablate = g_wino_ablate.load(std::memory_order_relaxed);
-    // two filter halves per block where the padded filter has an even number of them (packed in pairs: nhp = 2) — not in the gather mode
-    const bool two = !gather && p.nhp == 2 && vatl_winograd_cout_pad(Cout) % 64 == 0 && g_wino_halves.load(std::memory_order_relaxed) == 2;
+    // Two filter halves per block (one staged input and one input transform for 64 output channels, 128 accumulator registers, two blocks
+    // per CU) where the padded filter has an even number of halves (packed in pairs: nhp = 2) and the launch still has enough blocks for the
+    // 512 slots that leaves: at 1024 crops every layer gains 5 - 12 %; small launches lose (120 crops: l4.c2 360 blocks 134 -> 154 us,
+    // deconv1 368 blocks 494 -> 578; 32 crops: l2.c2 384 blocks 42 -> 47) where 432 blocks and more win (R152 l3.c2 at 32 crops 96 -> 86 us,
+    // l3.c2 at 120 crops, 720 blocks, 151 -> 134).  Not in the gather mode (register budget).
+    p.m_tiles = cdiv(mt, W_TB);
+    const int hv = g_wino_halves.load(std::memory_order_relaxed);          // 1: never, 2: with the block-count floor, 3: wherever possible
+    const bool two = !gather && p.nhp == 2 && vatl_winograd_cout_pad(Cout) % 64 == 0 && hv >= 2 &&
+                     (hv == 3 || (long long)p.m_tiles * cdiv(Cout, 64) * phases >= 400);
     const int NBh = two ? 2 : 1;
-    p.m_tiles = cdiv(mt, W_TB); p.n_tiles = cdiv(Cout, 32 * NBh);
+    p.n_tiles = cdiv(Cout, 32 * NBh);
     if (row_blocks_used) *row_blocks_used = (int64_t)p.m_tiles * phases;
     // a slice is Cin * 2 KB (x 4 input phases in the gather mode); at least two per group (deconv1, Cin = 2048: 4 MB slices, 4326 -> 4135 us
     // with two), unless the knob says 0
