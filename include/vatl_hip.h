@@ -90,7 +90,8 @@ int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float* w, const 
  * look-ahead of the persistent 1x1 kernel in k-tiles (1, or 2 = default; bit-identical results), 12 = stream-K route (see
  * vatl_set_streamk_workspace_thread; 1 = default, 0 = off), 16 = pixels per thread of the crop warp kernel (8 = default, 4), 18 = KB of filter slices per group of the Winograd
  * kernel's tile order (default 2048; 0 = one slice), 19 = target block count of the Winograd weight-gradient launches (default 1024; the transposed
- * convs use 4x that).  Knob 0 values 10..13, knob 4 (wgrad ablation bits), knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) and knob 17
+ * convs use 4x that), 21 = 32-channel filter halves per Winograd block (1 = one, 2 = default: two where the filter has an even number of halves and the launch keeps
+ * >= 400 blocks, 3 = two wherever the filter allows; bit-identical results).  Knob 0 values 10..13, knob 4 (wgrad ablation bits), knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) and knob 17
  * (Winograd ablation bits: 1 no output transform, 2 no LDS reads, 4 no filter loads, 8 no staging DMA, 16 no barriers) are profiling
  * ablations that compute WRONG results: they are not compiled into the product library at all (every such call returns
  * VATL_EINVAL); the profiling variant built with -DVATL_ABLATION (build.py --ablation -> libvatl_hip_ablation.so, loaded
