@@ -330,17 +330,22 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
         // one group of 16 MFMAs: (step 0, half 0) = ua [requested in the previous stage], (step 0, half 1) = ub, (step 1, half 0) = ua, ..
         auto u_load_h = [&](f32x4 (&dst)[4], int step, int half) {
             const bool live = step < steps && !(abl & 4);
-            const unsigned off = ubase + (unsigned)half * 1024u + (unsigned)step * ustep;
+            unsigned off = ubase + (unsigned)half * 1024u + (unsigned)step * ustep;
+            if constexpr (GATHER) {
+                const int ph = step / (2 * p.spp);
+                off = ubase + (unsigned)half * 1024u + (unsigned)ph * uphase + (unsigned)(step - ph * 2 * p.spp) * ustep;
+            }
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? off + nu * unu : WOOB);
         };
         for (int st = 0; st < p.stages; ++st) {
             const int buf = st & 1;
             const float* Rb = Rs + buf * STAGE;
+            const int pv = GATHER ? (st / p.spp) & 1 : 0;
             f32x4 v[4];
             u_load_h(ub, 2 * st, 1);
             __builtin_amdgcn_sched_barrier(0);
-            make_v(v, Rb, 0, 0);
+            make_v(v, Rb, 0, pv);
             mfma_group(accs[0], v, ua);
             __builtin_amdgcn_sched_barrier(0);
             u_load_h(ua, 2 * st + 1, 0);
@@ -350,7 +355,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
             u_load_h(ub, 2 * st + 1, 1);
             if (st + 1 < p.stages && !(abl & 8)) stage_dma(buf ^ 1, st + 1);     // (behind the fragments of this stage's second step: loads retire in order)
             __builtin_amdgcn_sched_barrier(0);
-            make_v(v, Rb, 8, 0);
+            make_v(v, Rb, 8, pv);
             mfma_group(accs[0], v, ua);
             __builtin_amdgcn_sched_barrier(0);
             u_load_h(ua, 2 * st + 2, 0);
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void winograd_kernel(WinoPara
         for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
             KArg pp = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(pp));
-            winograd_body<MO, BNB, GATHER, 1>(*(const WinoParams*)pp, smem, bid, total);
+            winograd_body<MO, BNB, GATHER, NB>(*(const WinoParams*)pp, smem, bid, total);
             __syncthreads();
         }
     } else {
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
     wino_pack_block(w, out, mode, w_i, Cout, Cin, NH, blockIdx.x, threadIdx.x);
 }
 
-static std::atomic<unsigned> g_wino_lds_done[10];  // (MO - 2) * 2 + BNB, + 4 for the gather instantiations, + 6 for the two-half blocks
+static std::atomic<unsigned> g_wino_lds_done[12];  // (MO - 2) * 2 + BNB, + 4 for the gather instantiations, + 6 for the two-half blocks
 static std::atomic<int> g_wino_halves{2};          // vatl_tune_set(21, v): filter halves per block where the layer allows two (1 = always one)
 int wino_set_halves(int v) { g_wino_halves.store(v, std::memory_order_relaxed); return 0; }
 static std::atomic<int> g_wino_ablate{0};
@@ -682,10 +687,11 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
     // per CU) where the padded filter has an even number of halves (packed in pairs: nhp = 2) and the launch still has enough blocks for the
     // 512 slots that leaves: at 1024 crops every layer gains 5 - 12 %; small launches lose (120 crops: l4.c2 360 blocks 134 -> 154 us,
     // deconv1 368 blocks 494 -> 578; 32 crops: l2.c2 384 blocks 42 -> 47) where 432 blocks and more win (R152 l3.c2 at 32 crops 96 -> 86 us,
-    // l3.c2 at 120 crops, 720 blocks, 151 -> 134).  Not in the gather mode (register budget).
+    // l3.c2 at 120 crops, 720 blocks, 151 -> 134).  The gather instantiations too (256 VGPRs, 13 spilled against 27 - 31 in the small shape: deconv3's
+    // data gradient at 120 crops 1.11 -> 1.04 ms, deconv1's 0.61 -> 0.56).
     p.m_tiles = cdiv(mt, W_TB);
     const int hv = g_wino_halves.load(std::memory_order_relaxed);          // 1: never, 2: with the block-count floor, 3: wherever possible
-    const bool two = !gather && p.nhp == 2 && vatl_winograd_cout_pad(Cout) % 64 == 0 && hv >= 2 &&
+    const bool two = p.nhp == 2 && vatl_winograd_cout_pad(Cout) % 64 == 0 && hv >= 2 &&
                      (hv == 3 || (long long)p.m_tiles * cdiv(Cout, 64) * phases >= 400);
     const int NBh = two ? 2 : 1;
     p.n_tiles = cdiv(Cout, 32 * NBh);
@@ -703,11 +709,11 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
     if (fuse) {
         if (deconv) return fail(VATL_EINVAL, "winograd: the BatchNorm-backward epilogue exists for the data-gradient launches only");
         p.bz = fuse->z; p.bmy = fuse->mask_y; p.bsc = fuse->scale; p.bbi = fuse->bias; p.bmu = fuse->mean; p.bis = fuse->invstd;
-        if (gather) return launch_wino<3, true, true>(p, phases, st);
+        if (gather) return two ? launch_wino<3, true, true, 2>(p, phases, st) : launch_wino<3, true, true>(p, phases, st);
         if (two) return MO == 2 ? launch_wino<2, true, false, 2>(p, phases, st) : launch_wino<3, true, false, 2>(p, phases, st);
         return MO == 2 ? launch_wino<2, true>(p, phases, st) : launch_wino<3, true>(p, phases, st);
     }
-    if (gather) return launch_wino<3, false, true>(p, phases, st);
+    if (gather) return two ? launch_wino<3, false, true, 2>(p, phases, st) : launch_wino<3, false, true>(p, phases, st);
     if (two) return MO == 2 ? launch_wino<2, false, false, 2>(p, phases, st) : launch_wino<3, false, false, 2>(p, phases, st);
     return MO == 2 ? launch_wino<2, false>(p, phases, st) : launch_wino<3, false>(p, phases, st);
 }
