@@ -377,3 +377,58 @@ def test_winograd_full_batch_properties(vh):
     e = rel_err(y[pick].cpu().numpy(), ref.numpy())
     record("winograd_full_batch_deconv", rel=e)
     assert e < TOL
+
+
+def test_two_half_blocks_give_the_bits_of_the_small_shape(vh):
+    """vatl_tune_set(21, v): 32 tiles x 64 channels per block (two filter halves, taken by default only where a launch keeps >= 400
+    blocks) against 32 x 32 — same products, same summation order per output: every epilogue must give identical bits.  Forced on
+    (v = 3) for shapes far below the default floor, including Cout = 96 / 192 (odd / even half counts) and tail tiles."""
+    g = torch.Generator(device="cpu").manual_seed(77)
+
+    def both(fn):
+        outs = []
+        for v in (1, 3):
+            vh.tune_set(21, v)
+            try:
+                outs.append(fn())
+            finally:
+                vh.tune_set(21, 2)
+        return outs
+
+    for n, h, w, cin, cout in ((3, 16, 12, 64, 64), (2, 13, 9, 32, 128), (5, 8, 6, 128, 192), (2, 10, 6, 48, 96), (1, 7, 5, 16, 256)):
+        x = torch.randn((n, h, w, cin), generator=g).to(dev())
+        wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.05).to(dev())
+        sc, bi = (torch.rand(cout, generator=g) + 0.5).to(dev()), torch.randn(cout, generator=g).to(dev())
+        r = torch.randn((n, h, w, cout), generator=g).to(dev())
+        u = vh.pack_winograd_weight(wt)
+        a, b = both(lambda: vh.conv3x3_winograd_fwd(x, u, sc, bi, cout, True, residual=r))
+        assert torch.equal(a, b)
+        (ya, sa, ba), (yb, sb, bb) = both(lambda: vh.conv3x3_winograd_fwd_stats(x, u, cout))
+        assert torch.equal(ya, yb) and ba == bb and torch.equal(sa[:ba * cout * 2], sb[:bb * cout * 2])
+        # data gradient with the BatchNorm-backward epilogue (u of the rotated / transposed filter: cin <-> cout)
+        if cin % 4 == 0:
+            ud = vh.pack_winograd_weight(wt, data_gradient=True)
+            dz = torch.randn((n, h, w, cout), generator=g).to(dev())
+            z = torch.randn((n, h, w, cin), generator=g).to(dev())
+            mean, invstd = z.reshape(-1, cin).mean(0), 1.0 / (z.reshape(-1, cin).var(0, unbiased=False) + 1e-5).sqrt()
+            s2, b2 = (torch.rand(cin, generator=g) + 0.5).to(dev()), (torch.randn(cin, generator=g) * 0.3).to(dev())
+
+            def bnb():
+                spec = vh.BnBwdSpec(z, mean, invstd, scale=s2, bias=b2)
+                gq = vh.conv3x3_winograd_fwd_bnbwd(dz, ud, cin, spec)
+                return gq, spec.stats[:spec.blocks * cin * 2].clone()
+            (ga, ta), (gb, tb) = both(bnb)
+            assert torch.equal(ga, gb) and torch.equal(ta, tb)
+    for n, h, w, cin, cout in ((2, 8, 6, 64, 64), (3, 5, 3, 32, 128), (1, 16, 12, 128, 192)):
+        x = torch.randn((n, h, w, cin), generator=g).to(dev())
+        wt = (torch.randn((cin, cout, 4, 4), generator=g) * 0.05).to(dev())
+        sc, bi = (torch.rand(cout, generator=g) + 0.5).to(dev()), torch.randn(cout, generator=g).to(dev())
+        u = vh.pack_winograd_deconv_weight(wt)
+        a, b = both(lambda: vh.deconv4x4s2_winograd_fwd(x, u, sc, bi, cout, True))
+        assert torch.equal(a, b)
+        # its data gradient (gather mode): reduction over cout, output channels = cin
+        ug = vh.pack_winograd_deconv_dgrad_weight(wt)
+        dy = torch.randn((n, 2 * h, 2 * w, cout), generator=g).to(dev())
+        a, b = both(lambda: vh.deconv4x4s2_winograd_dgrad(dy, ug, cin))
+        assert torch.equal(a, b)
+    record("winograd_two_half_blocks_bit_identical", ok=True)
