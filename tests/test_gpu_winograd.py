@@ -432,3 +432,37 @@ def test_two_half_blocks_give_the_bits_of_the_small_shape(vh):
         a, b = both(lambda: vh.deconv4x4s2_winograd_dgrad(dy, ug, cin))
         assert torch.equal(a, b)
     record("winograd_two_half_blocks_bit_identical", ok=True)
+
+
+def test_two_half_blocks_random_shapes(vh):
+    """Seeded sweep over odd sizes for the block-shape identity: 3x3 forward (+ residual / ReLU / folded affine at random) and the
+    transposed conv's forward and data gradient, both shapes forced (knob 21 = 1 / 3)."""
+    rng = np.random.RandomState(2024)
+    g = torch.Generator(device="cpu").manual_seed(2024)
+    for k in range(16):
+        n, h, w = int(rng.randint(1, 7)), int(rng.randint(1, 20)), int(rng.randint(1, 20))
+        cin, cout = 16 * int(rng.randint(1, 7)), 64 * int(rng.randint(1, 4))
+        x = torch.randn((n, h, w, cin), generator=g).to(dev())
+        outs = []
+        if k % 2 == 0:
+            wt = (torch.randn((cout, cin, 3, 3), generator=g) * 0.05).to(dev())
+            u = vh.pack_winograd_weight(wt)
+            sc = (torch.rand(cout, generator=g) + 0.5).to(dev()) if rng.rand() < 0.5 else None
+            bi = torch.randn(cout, generator=g).to(dev()) if sc is not None else None
+            r = torch.randn((n, h, w, cout), generator=g).to(dev()) if rng.rand() < 0.5 else None
+            relu = bool(rng.rand() < 0.5)
+            fn = lambda: (vh.conv3x3_winograd_fwd(x, u, sc, bi, cout, relu, residual=r),)      # noqa: E731
+        else:
+            wt = (torch.randn((cin, cout, 4, 4), generator=g) * 0.05).to(dev())
+            u, ug = vh.pack_winograd_deconv_weight(wt), vh.pack_winograd_deconv_dgrad_weight(wt)
+            dy = torch.randn((n, 2 * h, 2 * w, cout), generator=g).to(dev())
+            fn = lambda: (vh.deconv4x4s2_winograd_fwd(x, u, None, None, cout, False), vh.deconv4x4s2_winograd_dgrad(dy, ug, cin))   # noqa: E731
+        for v in (1, 3):
+            vh.tune_set(21, v)
+            try:
+                outs.append(fn())
+            finally:
+                vh.tune_set(21, 2)
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), (k, n, h, w, cin, cout)
+    record("winograd_two_half_blocks_random", shapes=16)
