@@ -328,6 +328,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
     if constexpr (NB == 2) {
         // Two filter halves per block: one V per step serves both, the two fragment sets alternate between the halves with a look-ahead of
         // one group of 16 MFMAs: (step 0, half 0) = ua [requested in the previous stage], (step 0, half 1) = ub, (step 1, half 0) = ua, ..
+        constexpr bool V_AHEAD = !GATHER && (MO == 2 || !BNB);   // 16 more registers: the gather instantiations and F(3x3,2x2) with the BatchNorm-backward epilogue have none to spare
         auto u_load_h = [&](f32x4 (&dst)[4], int step, int half) {
             const bool live = step < steps && !(abl & 4);
             unsigned off = ubase + (unsigned)half * 1024u + (unsigned)step * ustep;
@@ -342,11 +343,12 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
             const int buf = st & 1;
             const float* Rb = Rs + buf * STAGE;
             const int pv = GATHER ? (st / p.spp) & 1 : 0;
-            f32x4 v[4];
+            f32x4 v[4], v1[4];
             u_load_h(ub, 2 * st, 1);
             __builtin_amdgcn_sched_barrier(0);
             make_v(v, Rb, 0, pv);
             mfma_group(accs[0], v, ua);
+            if constexpr (V_AHEAD) make_v(v1, Rb, 8, pv);  // the second step's V in the shadow of the first group's MFMAs (no scheduling barrier in between)
             __builtin_amdgcn_sched_barrier(0);
             u_load_h(ua, 2 * st + 1, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -355,7 +357,10 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
             u_load_h(ub, 2 * st + 1, 1);
             if (st + 1 < p.stages && !(abl & 8)) stage_dma(buf ^ 1, st + 1);     // (behind the fragments of this stage's second step: loads retire in order)
             __builtin_amdgcn_sched_barrier(0);
-            make_v(v, Rb, 8, pv);
+            if constexpr (V_AHEAD) {
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) v[nu] = v1[nu];
+            } else make_v(v, Rb, 8, pv);
             mfma_group(accs[0], v, ua);
             __builtin_amdgcn_sched_barrier(0);
             u_load_h(ua, 2 * st + 2, 0);
