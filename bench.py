@@ -73,18 +73,71 @@ def make_video(dev, seed):
     return x, bbox, (pos != 0).to(torch.uint8), (pos != FRAMES // TRACKS - 1).to(torch.uint8)
 
 
-def one_step(model, x, bbox, is_prev, is_next, hm_buf):
+def one_step(model, x, bbox, is_prev, is_next, hm_buf, batch=None):
     from active_learning.scoring import score_batch
     from alphapose.models import hip_engine
+    batch = batch or BATCH
     with torch.no_grad():
-        for i in range(0, FRAMES, BATCH):
-            hip_engine.forward_into(model, x[i:i + BATCH], hm_buf[i:i + BATCH])
+        for i in range(0, FRAMES, batch):
+            hip_engine.forward_into(model, x[i:i + batch], hm_buf[i:i + batch])
         return score_batch(hm_buf, bbox, is_prev, is_next, thc_norm="L1")
 
 
+def headline_variants(model, x, bbox, is_prev, is_next, hm_buf, steps=3):
+    """Beside the headline (one 1024-crop launch sequence per video, one forward per frame): the same step in batches of 256 (SURVEY.md
+    §8d item 2's sketch), and the §8d item 3 pair — the reference-faithful evaluation that forwards the prev / current / next crops of
+    every item (ActiveLearning.py:277, 294, 296) against the de-duplicated stream, THC compared bit for bit."""
+    import vatl_hip as vh
+    from active_learning.scoring import score_batch
+    from alphapose.models import hip_engine
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    out = {}
+    d256 = timed(lambda: one_step(model, x, bbox, is_prev, is_next, hm_buf, batch=256))
+    out["batch256_frames_per_s"] = round(FRAMES / d256, 1)
+    out["batch256_ms_per_step"] = round(d256 * 1e3, 3)
+    a = one_step(model, x, bbox, is_prev, is_next, hm_buf)
+    thc_dedup = a.thc.clone()
+    d1 = timed(lambda: one_step(model, x, bbox, is_prev, is_next, hm_buf))
+    prev_x = torch.cat([torch.zeros_like(x[:1]), x[:-1]]) * is_prev.view(-1, 1, 1, 1)
+    next_x = torch.cat([x[1:], torch.zeros_like(x[:1])]) * is_next.view(-1, 1, 1, 1)
+    hp, hn = torch.empty_like(hm_buf), torch.empty_like(hm_buf)
+
+    def faithful():                                   # three forwards per item, THC from explicit neighbour heat-maps
+        with torch.no_grad():
+            hip_engine.forward_into(model, x, hm_buf)
+            hip_engine.forward_into(model, prev_x, hp)
+            hip_engine.forward_into(model, next_x, hn)
+            s = score_batch(hm_buf, bbox, is_prev, is_next, thc_norm=None)
+            tp, tn = vh.thc_pairs(hm_buf, hp, "L1"), vh.thc_pairs(hm_buf, hn, "L1")
+            one = (is_prev ^ is_next).float()
+            s.thc = (tp * is_prev + tn * is_next) * (1 + one)
+            return s
+    b = faithful()
+    torch.cuda.synchronize()
+    out["thc_bit_identical"] = bool(torch.equal(thc_dedup, b.thc))
+    d3 = timed(faithful)
+    out["dedup_frames_per_s"] = round(FRAMES / d1, 1)
+    out["faithful_3fwd_frames_per_s"] = round(FRAMES / d3, 1)
+    del prev_x, next_x, hp, hn
+    torch.cuda.empty_cache()
+    return out
+
+
 def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
-    """Time every conv/deconv implicit-GEMM launch of one step with HIP events on the
-    launch stream (torch's current stream) and relate the sum to the algorithmic FLOPs."""
+    """Time every conv / deconv launch of one step with HIP events on the launch stream (torch's current stream) and relate the sum
+    to (a) the MFMA FLOPs those launches really execute — counted by the library itself, tile padding included
+    (vatl_flop_meter_begin / _end) — and (b) the algorithmic (direct-sum) FLOPs of the step.  `frac` is (a): the fraction of the
+    fp32 matrix pipe's peak that is busy; it cannot exceed 1.  (b) is `algorithmic_frac`: 16 of the 53 launches are Winograd
+    kernels that reach their direct-sum FLOPs with 2.25x fewer multiplies, so it can."""
     import vatl_hip as vh
     events, wino = [], []
     orig_c, orig_d, orig_u, orig_w, orig_dw = vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd, vh.conv3x3_winograd_fwd, vh.deconv4x4s2_winograd_fwd
@@ -103,18 +156,18 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
     vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd = wrap(orig_c), wrap(orig_d), wrap(orig_u)
     vh.conv3x3_winograd_fwd, vh.deconv4x4s2_winograd_fwd = wrap(orig_w, 9), wrap(orig_dw, 4)
     try:
-        one_step(model, x, bbox, is_prev, is_next, hm_buf)
+        with vh.flop_meter() as fm:
+            one_step(model, x, bbox, is_prev, is_next, hm_buf)
         torch.cuda.synchronize()
     finally:
         vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd, vh.conv3x3_winograd_fwd, vh.deconv4x4s2_winograd_fwd = orig_c, orig_d, orig_u, orig_w, orig_dw
     ms = sum(a.elapsed_time(b) for a, b in events)
-    flops = GFLOP_PER_CROP * 1e9 * FRAMES
-    achieved = flops / (ms * 1e-3) / 1e12
-    # the Winograd launches issue 16 multiplies per output tile and channel pair where the direct sum has 36 (2x2 outputs x 9 taps /
-    # 3x3 outputs x 4 taps): what the matrix pipe actually executes is `flops` minus 5/9 of their direct-sum FLOPs (tile padding aside)
+    flops = GFLOP_PER_CROP * 1e9 * x.shape[0]
+    algorithmic = flops / (ms * 1e-3) / 1e12
+    executed = fm.total                                    # what the matrix pipe multiplies: padded tiles, 16 / 36 of the direct sum on the Winograd launches
+    achieved = executed / (ms * 1e-3) / 1e12
     wino_flops = sum(f for _, _, f in wino)
     wino_ms = sum(a.elapsed_time(b) for a, b, _ in wino)
-    executed = flops - wino_flops * 5.0 / 9.0
     traffic, traffic_source = None, None               # HBM bytes of the same launches, from the committed PMC passes
     try:
         pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
@@ -125,16 +178,22 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": (traffic / len(events)) if traffic else None,
-            "kernel": "conv_igemm_kernel + gemm1x1_persistent2_kernel + winograd_kernel (all conv/deconv launches of one step; 4 of them fuse a projection shortcut with the block's last conv; the 13 3x3 stride-1 layers run as Winograd F(2x2,3x3), the 3 transposed convs as F(3x3,2x2) on their four phases)", "launches": len(events),
-            # `achieved` / `frac` count ALGORITHMIC (direct-sum) FLOPs, as the contract asks; the Winograd launches reach them with 2.25x
-            # fewer multiplies, so their own algorithmic rate can exceed the pipe's peak.  `executed_frac` = MFMA FLOPs actually issued
-            # / time / peak: the occupancy of the matrix pipe.
-            "executed_flops_per_step": executed, "executed_frac": round(executed / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA, 4),
+            "metered_launches": fm.direct_launches + fm.winograd_launches, "kernel": "conv_igemm_kernel + gemm1x1_persistent2_kernel + winograd_kernel (all conv/deconv launches of one step; 4 of them fuse a projection shortcut with the block's last conv; the 13 3x3 stride-1 layers run as Winograd F(2x2,3x3), the 3 transposed convs as F(3x3,2x2) on their four phases)", "launches": len(events),
+            # `achieved` / `frac`: MFMA FLOPs the launches EXECUTE (counted per launch by libvatl_hip.so: 2 x padded M x padded N x padded K; the
+            # Winograd launches their 16 transform-domain GEMMs) / event-timed duration / peak = how busy the matrix pipe is.
+            # `algorithmic_*`: the step's direct-sum FLOPs (10.853 GFLOP x frames) over the same time; the Winograd launches deliver
+            # theirs with 2.25x fewer multiplies, so this ratio may exceed 1 — it is a throughput figure, not a roofline fraction.
+            "executed_flops_per_step": executed, "executed_direct_flops": fm.direct, "executed_winograd_flops": fm.winograd,
+            "algorithmic_achieved": round(algorithmic, 2), "algorithmic_frac": round(algorithmic / PEAK_FP32_MFMA, 4),
             "winograd": {"launches": len(wino), "ms": round(wino_ms, 3), "algorithmic_tflops": round(wino_flops / (wino_ms * 1e-3) / 1e12, 2) if wino_ms else None,
-                         "executed_tflops": round(wino_flops * 4 / 9 / (wino_ms * 1e-3) / 1e12, 2) if wino_ms else None},
+                         "executed_tflops": round(fm.winograd / (wino_ms * 1e-3) / 1e12, 2) if wino_ms else None,
+                         "executed_frac": round(fm.winograd / (wino_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA, 4) if wino_ms else None},
+            "implicit_gemm": {"launches": len(events) - len(wino), "ms": round(ms - wino_ms, 3),
+                              "executed_tflops": round(fm.direct / ((ms - wino_ms) * 1e-3) / 1e12, 2),
+                              "executed_frac": round(fm.direct / ((ms - wino_ms) * 1e-3) / 1e12 / PEAK_FP32_MFMA, 4)},
             "avg_launch_us": round(ms * 1e3 / len(events), 2), "flops_per_step": flops,
             # the step's conv launches have different shapes: `achieved` is sum(flops) / sum(duration); per-launch averages for reference
-            "flops_per_launch": flops / len(events), "traffic_per_step": traffic, "traffic_source": traffic_source,
+            "flops_per_launch": executed / len(events), "traffic_per_step": traffic, "traffic_source": traffic_source,
             "traffic_note": "`traffic` = HBM bytes per launch (average over the step's conv launches, like `achieved`); source: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE x2 on gfx950) around this same command (tools/profile_round.sh), summed over the conv launches of one step — read from `traffic_source`, the newest committed summary: the counters cannot be sampled from inside the process, so this field does not move with the run"}
 
 
@@ -310,8 +369,17 @@ def extra_finetune(dev, name, cfg, hw, batch, gflop_fwd, groups, world, dist_on,
         if alone:
             hidden = round(max(0.0, min(1.0, 1.0 - (dt * 1e3 - local_ms) / alone)), 4)
     tf = 3 * gflop_fwd * 1e9 * batch / dt / 1e12              # fwd + dgrad + wgrad of every conv, per GPU
+    import vatl_hip as vh
+    with vh.flop_meter() as fm:                              # one more (untimed) step: the MFMA FLOPs its launches execute, padding included
+        step()
+    torch.cuda.synchronize()
+    ex = fm.total / dt / 1e12
     out = {"workload": name, "batch_per_gpu": batch, "ms_per_step": round(dt * 1e3, 3), "crops_per_s": round(batch * world / dt, 1),
-           "conv_tflops_per_gpu": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA, 4), "flops_counted": "algorithmic (direct-sum)",
+           # executed_*: what the matrix pipe multiplies (library meter) / the WHOLE step time / peak — the roofline fraction of the step;
+           # algorithmic_*: 3 x forward direct-sum FLOPs / the same time (the Winograd launches reach theirs with 2.25x fewer multiplies)
+           "executed_tflops_per_gpu": round(ex, 2), "executed_frac": round(ex / PEAK_FP32_MFMA, 4),
+           "executed_winograd_share": round(fm.winograd / fm.total, 4) if fm.total else None,
+           "algorithmic_tflops_per_gpu": round(tf, 2), "algorithmic_frac": round(tf / PEAK_FP32_MFMA, 4),
            "grad_bytes": arena.total * 4, "allreduce_buckets": buckets, "allreduce_bucket_bytes": arena.bucket * 4,
            "allreduce_alone_ms": alone, "step_without_allreduce_ms": local_ms, "overlap_hidden_frac": hidden,
            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
@@ -356,12 +424,18 @@ def extra_hrnet_shard(dev, world, rank, dist_on, steps=3, warmup=1):
 
     dt = _timed(run, steps, warmup, dist_on)
     tf = GFLOP_FWD["hrnet_w32"] * 1e9 * n / dt / 1e12
+    import vatl_hip as vh
+    with vh.flop_meter() as fm:
+        run()
+    torch.cuda.synchronize()
+    ex = fm.total / dt / 1e12
     out = {"workload": "HRNet-W32 256x192 inference + decode + local-peak + THC-L1 + WPU (AE 42-d, z=4), 1024-frame shard per GPU + halo",
            "frames_per_gpu": FRAMES, "halo_frames": front + back, "ms_per_pass": round(dt * 1e3, 3), "frames_per_s": round(FRAMES * world / dt, 1),
-           "conv_tflops_per_gpu": round(tf, 2), "frac_of_fp32_mfma_peak": round(tf / PEAK_FP32_MFMA, 4),
-           # direct-sum (algorithmic) FLOPs / whole pass time: every conv of the HRNet branches is a 3x3 on the Winograd route (16 multiplies
-           # where the direct sum has 36), so this ratio can exceed 1; the matrix pipe executes ~4/9 of these FLOPs
-           "flops_counted": "algorithmic (direct-sum)"}
+           # executed_*: MFMA FLOPs the launches execute (library meter, padding included) / whole pass time / peak; algorithmic_*: direct-sum
+           # FLOPs over the same time — nearly every conv of the HRNet branches is a 3x3 on the Winograd route, so that ratio can exceed 1
+           "executed_tflops_per_gpu": round(ex, 2), "executed_frac": round(ex / PEAK_FP32_MFMA, 4),
+           "executed_winograd_share": round(fm.winograd / fm.total, 4) if fm.total else None,
+           "algorithmic_tflops_per_gpu": round(tf, 2), "algorithmic_frac": round(tf / PEAK_FP32_MFMA, 4)}
     del m, x, hm
     torch.cuda.empty_cache()
     return out
@@ -492,9 +566,10 @@ def main():
 
     roof = conv_roofline(model, x, bbox, is_prev, is_next, hm_buf) if rank == 0 else None
     if roof is not None:
-        # the whole step (conv + pool + layout + scorers + launch gaps) against the same conv FLOPs: value per GPU x GFLOP / peak
-        per_gpu = a.steps * FRAMES / dt
-        roof["e2e_frac"] = round(per_gpu * GFLOP_PER_CROP * 1e9 / 1e12 / PEAK_FP32_MFMA, 4)
+        # the whole step (conv + pool + layout + scorers + launch gaps) against the FLOPs its conv launches execute: the step-level roofline fraction
+        roof["e2e_frac"] = round(roof["executed_flops_per_step"] * a.steps / dt / 1e12 / PEAK_FP32_MFMA, 4)
+        roof["e2e_algorithmic_frac"] = round(a.steps * FRAMES / dt * GFLOP_PER_CROP * 1e9 / 1e12 / PEAK_FP32_MFMA, 4)
+    variants = headline_variants(model, x, bbox, is_prev, is_next, hm_buf) if (rank == 0 and not a.no_extra) else None
     devices = [torch.cuda.get_device_name(dev)]
     if dist:                                            # what actually ran: one entry per rank, gathered (not assumed from --gpus)
         box = [None] * world
@@ -518,6 +593,7 @@ def main():
             "world_size_seen": td.get_world_size() if dist else 1, "rank_devices": devices,
         }
         if extra is not None:
+            extra["headline_variants"] = variants
             line["extra"] = extra
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

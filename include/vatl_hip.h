@@ -33,6 +33,15 @@ extern "C" {
 int         vatl_version(void);
 const char* vatl_last_error(void);
 
+/* Executed-FLOP meter of the CALLING HOST THREAD (thread-local, off by default): between _begin and _end every
+ * matrix-core launch this thread makes adds the multiply-adds its grid really executes on the MFMA pipe, tile
+ * padding included (2 * padded rows * padded columns * padded reduction), split into direct-sum launches
+ * (implicit GEMM, weight gradients) and Winograd transform-domain launches.  bench.py divides these by the
+ * measured time: the roofline fraction of the fp32 matrix pipe (the reference has no counterpart; its convs are
+ * cuDNN calls behind nn.Conv2d, Resnet.py:63-100).  Any of the four outputs may be NULL. */
+int vatl_flop_meter_begin(void);
+int vatl_flop_meter_end(double* direct_flops, double* winograd_flops, int64_t* direct_launches, int64_t* winograd_launches);
+
 /* ------------------------------------------------------------------------ *
  * Layout and parameter preparation (done once per weight version)
  * ------------------------------------------------------------------------ */

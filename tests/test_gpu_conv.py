@@ -545,3 +545,130 @@ def test_streamk_route_matches_the_whole_tile_kernels(vh):
     for a, b in zip(zs, zb):                                      # z, mean, invstd, scale, bias
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
     record("streamk", worst=max(rel_err(b.cpu().numpy(), a.cpu().numpy()) for a, b in zip(base, sk1)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The route the headline times (hip_engine.forward_into: Winograd for every eligible 3x3 / transposed conv, no split-K),
+# pinned DIRECTLY to the reference's golden heat-maps and arg-max (simplepose.py:82-86, fastpose.py:52-59, hrnet.py:421-456)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _count_winograd(vh, monkeypatch):
+    calls = {"conv": 0, "deconv": 0, "splitk": 0}
+    oc, od = vh.conv3x3_winograd_fwd, vh.deconv4x4s2_winograd_fwd
+    monkeypatch.setattr(vh, "conv3x3_winograd_fwd", lambda *a, **k: (calls.__setitem__("conv", calls["conv"] + 1), oc(*a, **k))[1])
+    monkeypatch.setattr(vh, "deconv4x4s2_winograd_fwd", lambda *a, **k: (calls.__setitem__("deconv", calls["deconv"] + 1), od(*a, **k))[1])
+    return calls
+
+
+def _eligible(m, head):
+    """(3x3 / stride 1 / pad 1 convs, transposed 4x4 / stride 2 convs) the plan must send through the Winograd kernels: every one
+    except the layer that writes the NCHW heat-maps."""
+    c = sum(1 for mod in m.modules() if isinstance(mod, torch.nn.Conv2d) and mod is not head and mod.kernel_size == (3, 3)
+            and mod.stride == (1, 1) and mod.padding == (1, 1) and mod.in_channels % 16 == 0 and mod.out_channels % 4 == 0)
+    d = sum(1 for mod in m.modules() if isinstance(mod, torch.nn.ConvTranspose2d))
+    return c, d
+
+
+STREAM_CASES = [("simplepose_r50", (13, 3)), ("fastpose_r50", (15, 0)), ("hrnet_w32", (213, 0)), ("fastpose_r152_384", (49, 0))]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES, ids=[c[0] for c in STREAM_CASES])
+def test_stream_route_vs_reference_golden(vh, monkeypatch, case):
+    """The bench / ActiveLearning.eval_and_query route: forward_into (+ score_batch) on the golden inputs.  Heat-maps within 1e-4 of
+    the REFERENCE's output, arg-max identical, decode / local-peak / THC of the HIP heat-maps equal to the oracle's scorers run on the
+    reference's heat-maps (indices exact), and the expected number of Winograd launches really happened (no split-K, no implicit-GEMM
+    stand-in for an eligible layer)."""
+    import os
+    from active_learning.scoring import score_batch
+    from alphapose.models import builder, hip_engine
+    from alphapose.utils.config import edict
+    from oracle import scorers
+    name, (want_conv, want_deconv) = case
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    hw = (256, 192)
+    if name == "simplepose_r50":
+        g = np.load(os.path.join(gdir, "simplepose_r50.npz")); ref = g["heatmaps"]; m = _build_simplepose(); head = m.final_layer
+    elif name == "fastpose_r50":
+        g = np.load(os.path.join(gdir, "fastpose_hrnet.npz")); ref = g["fastpose_heatmaps"]
+        m = _build({"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50}); head = m.conv_out
+    elif name == "hrnet_w32":
+        g = np.load(os.path.join(gdir, "fastpose_hrnet.npz")); ref = g["hrnet_heatmaps"]; m = _build(HRNET_CFG); head = m.final_layer
+    else:
+        g = np.load(os.path.join(gdir, "fastpose_r152_384.npz")); ref = g["heatmaps"]; hw = (384, 288)
+        preset = edict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": [384, 288], "HEATMAP_SIZE": [96, 72]})
+        m = builder.build_sppe(edict({"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 152}), preset_cfg=preset)
+        m.load_state_dict(synth.state_dict_for(m), strict=True)
+        m = m.to(dev()).eval(); head = m.conv_out
+    n = ref.shape[0]
+    assert _eligible(m, head) == (want_conv, want_deconv)
+    x = to_dev(synth.crops(n, hw=hw) if hw != (256, 192) else synth.crops(n))
+    bb = synth.bboxes(n)
+    calls = _count_winograd(vh, monkeypatch)
+    out = torch.empty(ref.shape, device=dev())
+    ip = torch.tensor([0] + [1] * (n - 1), device=dev(), dtype=torch.uint8)
+    inx = torch.tensor([1] * (n - 1) + [0], device=dev(), dtype=torch.uint8)
+    with torch.no_grad():
+        assert not vh.latency_mode()
+        hip_engine.forward_into(m, x, out)
+        s = score_batch(out, to_dev(bb), ip, inx, thc_norm="L1")
+    torch.cuda.synchronize()
+    assert (calls["conv"], calls["deconv"]) == (want_conv, want_deconv), calls
+    hm = out.cpu().numpy()
+    e = rel_err(hm, ref)
+    record(f"stream_route_{name}", rel=e, winograd_conv=calls["conv"], winograd_deconv=calls["deconv"])
+    assert e < 1e-4                                                                   # north_star: heat-maps within 1e-4 rel fp32
+    ref_idx = ref.reshape(n, 17, -1).argmax(2)
+    assert np.array_equal(hm.reshape(n, 17, -1).argmax(2), ref_idx)                   # integer peak indices bit-exact
+    assert np.array_equal(s.argmax.cpu().numpy(), ref_idx)                            # ... and through the decode kernel
+    import warnings
+    for i in range(n):                                                                # scorers of the HIP stream vs the oracle on the REFERENCE's maps
+        d = scorers.decode_heatmaps(ref[i], bb[i])
+        assert np.array_equal(s.argmax[i].cpu().numpy(), d["idx"])
+        np.testing.assert_allclose(s.keypoints[i, :, :2].cpu().numpy(), d["coords"], rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(s.keypoints[i, :, 2].cpu().numpy(), d["maxvals"].reshape(-1), rtol=1e-4, atol=1e-6 + 1e-4 * np.abs(ref).max())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            lp = scorers.localpeak_mean(ref[i])
+            lp_own = scorers.localpeak_mean(hm[i])
+        if np.isfinite(lp):
+            np.testing.assert_allclose(float(s.localpeak[i]), lp_own, rtol=1e-5)       # the kernel on its own maps: exact peak set
+            np.testing.assert_allclose(float(s.localpeak[i]), lp, rtol=1e-2)           # vs the reference's maps: a borderline peak may enter / leave the set
+    if n > 1:
+        want = scorers.thc_item(ref[0], None, ref[1], False, True, "L1")
+        np.testing.assert_allclose(float(s.thc[0]), want, rtol=1e-3)
+
+
+def test_full_video_stream_spot_checks(vh):
+    """bench.py's step on a 1024-frame video: the heat-maps of spot frames are BIT-identical to their solo forward_into (a frame's bits
+    do not depend on the launch it shares), and the stream's decode / THC agree with the oracle run on those spot heat-maps."""
+    from active_learning.scoring import score_batch
+    from alphapose.models import hip_engine
+    from oracle import scorers
+    m = _build_simplepose()
+    n = 1024
+    g = torch.Generator(device=dev()); g.manual_seed(5)
+    x = torch.rand((n, 3, 256, 192), device=dev(), generator=g) - 0.45
+    base = to_dev(synth.crops(8, seed=3))
+    spots = [0, 1, 255, 256, 511, 777, 1022, 1023]
+    for k, i in enumerate(spots):
+        x[i] = base[k]
+    w = 60 + 180 * torch.rand(n, device=dev(), generator=g)
+    bbox = torch.stack([torch.full_like(w, 100.0), torch.full_like(w, 50.0), 100 + w, 50 + w * 4 / 3], 1).contiguous()
+    pos = torch.arange(n, device=dev()) % 256
+    ip, inx = (pos != 0).to(torch.uint8), (pos != 255).to(torch.uint8)
+    hm = torch.empty((n, 17, 64, 48), device=dev())
+    with torch.no_grad():
+        hip_engine.forward_into(m, x, hm)
+        s = score_batch(hm, bbox, ip, inx, thc_norm="L1")
+        solo = torch.empty((1, 17, 64, 48), device=dev())
+        for i in spots:
+            hip_engine.forward_into(m, x[i:i + 1], solo)
+            assert torch.equal(solo[0], hm[i]), i
+    hmc, bbc = hm.cpu().numpy(), bbox.cpu().numpy()
+    for i in spots:
+        d = scorers.decode_heatmaps(hmc[i], bbc[i])
+        assert np.array_equal(s.argmax[i].cpu().numpy(), d["idx"])
+        np.testing.assert_allclose(s.keypoints[i, :, :2].cpu().numpy(), d["coords"], rtol=1e-5, atol=1e-4)
+        prev = hmc[i - 1] if ip[i] else None
+        nxt = hmc[i + 1] if inx[i] else None
+        np.testing.assert_allclose(float(s.thc[i]), scorers.thc_item(hmc[i], prev, nxt, bool(ip[i]), bool(inx[i]), "L1"), rtol=1e-5)

@@ -220,7 +220,9 @@ def test_peak_local_max_pinned_on_real_scikit_image():
                 tied_differ += not same
             else:
                 assert same, (n, j, loc.tolist(), g["loc"][n, j, :k].tolist())
-    assert int((~g["tied"]).sum()) >= 390 and tied_differ <= int(g["tied"].sum())
+    # 16 of the 408 planes have exactly equal candidate maxima; on 4 of them scikit-image 0.18.3's unstable argsort orders the equal values
+    # differently from the stable order the oracle (and the reference's 0.24 pin) uses — counted, documented in tests/golden/README.md
+    assert int((~g["tied"]).sum()) == 392 and int(g["tied"].sum()) == 16 and tied_differ == 4
     free = ~g["item_tied"]
     assert free.sum() >= 20
     mpe = np.array([scorers.mpe_item(h) for h in hm]); mar = np.array([scorers.margin_item(h) for h in hm])

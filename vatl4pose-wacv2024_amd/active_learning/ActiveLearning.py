@@ -102,6 +102,15 @@ class ActiveLearning:
         if D.have_workers() and D.is_main():
             payload = {k: v for k, v in (("eval_dataset", eval_dataset), ("train_dataset", train_dataset)) if v is not None}
             D.command("new", cfg, opt, D.dump_payload(payload) if payload else "")
+        try:                                           # after the ('new', ...) broadcast the workers are building their replicas and will wait in the
+            self._build(cfg, opt, eval_dataset, train_dataset, ngpu, world)   # barrier below: a failure here must not be followed by an 'exit' broadcast
+        except BaseException:
+            if D.mirrored():
+                D.mark_failed()
+            raise
+
+    def _build(self, cfg, opt, eval_dataset, train_dataset, ngpu, world):
+        from . import distributed as D
         self.device = torch.device("cuda", torch.cuda.current_device())
         # the reference's DataParallel scatters every mini-batch over opt.num_gpu replicas (:233); `replicas` keeps that
         # partition (and with it the per-replica BatchNorm statistics) whatever the number of processes actually running

@@ -39,8 +39,10 @@ STAGE1_CHUNK = int(os.environ.get("VATL_STAGE1_CHUNK", "0"))   # measured neutra
 
 # 3x3 / stride 1 / pad 1 layers run as Winograd F(2x2, 3x3) (csrc/conv_winograd.hip: 2.25x fewer multiplies, fp32).  The choice depends
 # on the layer's geometry only — never on the batch — so a crop's heat-map bits do not depend on how it was batched.  The one exception is the
-# small-batch module call (`model(x)` with <= 16 crops, run_module_nchw below), which has always had its own bits (split-K): it stays on
-# the implicit GEMM for every batch size it serves (vh.latency_mode()).  VATL_WINOGRAD=0 = the implicit GEMM everywhere.
+# small-batch module call (`model(x)` with <= 16 crops, run_module_nchw below): since round 3 it runs with split-K BY DEFAULT (before that
+# split-K was opt-in through VATL_SPLITK_MB) and stays on the implicit GEMM for every batch size it serves (vh.latency_mode()), so
+# `model(x)` gives one set of bits for <= 16 crops and the stream route's bits above; both hold the 1e-4 / arg-max contract, and
+# VATL_SPLITK_AUTO=0 makes the module call take the stream route at every size.  VATL_WINOGRAD=0 = the implicit GEMM everywhere.
 WINOGRAD = os.environ.get("VATL_WINOGRAD", "1") != "0"
 
 

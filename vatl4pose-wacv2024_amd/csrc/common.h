@@ -14,6 +14,12 @@ namespace vatl {
 char* err_buf();
 int fail(int code, const char* fmt, ...);
 
+// Executed-MFMA-FLOP meter of the calling host thread (vatl_flop_meter_begin / vatl_flop_meter_end): every matrix-core launch adds
+// what its grid really multiplies — 2 * padded rows * padded columns * padded reduction length, tile padding included — under
+// kind 0 (direct sums: implicit GEMM, weight gradients) or kind 1 (Winograd transform-domain GEMMs).  Thread-local like the
+// split-K scope: nothing global, off unless the thread asked for it.
+void meter_add(int kind, double flops);
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(VATL_ELAUNCH, "%s: %s", what, hipGetErrorString(e));

@@ -622,6 +622,7 @@ static int launch_wino(const WinoParams& p, int phases, hipStream_t st) {
     const int smem = std::max(loop, std::max(epi, sta)) * (int)sizeof(float);
     if (smem > kWinoMaxLds) return fail(VATL_EINVAL, "winograd: %d bytes of LDS per block", smem);
     hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles * phases), dim3(256), smem, st, p);
+    meter_add(1, 2.0 * ((double)p.m_tiles * W_TB) * ((double)p.n_tiles * 32 * NB) * 16.0 * ((double)p.stages * W_CK) * phases);
     return check_launch("winograd");
 }
 

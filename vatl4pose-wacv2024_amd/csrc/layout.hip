@@ -17,6 +17,20 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+static thread_local bool tl_meter_on = false;
+static thread_local double tl_meter_flops[2] = {0.0, 0.0};
+static thread_local long long tl_meter_launches[2] = {0, 0};
+void meter_add(int kind, double flops) {
+    if (!tl_meter_on) return;
+    tl_meter_flops[kind & 1] += flops;
+    tl_meter_launches[kind & 1] += 1;
+}
+void meter_begin() { tl_meter_on = true; tl_meter_flops[0] = tl_meter_flops[1] = 0.0; tl_meter_launches[0] = tl_meter_launches[1] = 0; }
+void meter_end(double* flops, long long* launches) {
+    for (int k = 0; k < 2; ++k) { flops[k] = tl_meter_flops[k]; launches[k] = tl_meter_launches[k]; }
+    tl_meter_on = false;
+}
+
 // Cpad % 4 == 0, Cpad > 4 (the 17 -> 32 channel gradient of the heat-map head): one thread per (pixel, four channels), the channel
 // group fastest, so a wave writes 1 KB of contiguous NHWC rows (the per-pixel version below wrote 4 bytes per lane 128 bytes apart:
 // 165 us for 120 x 17 x 64 x 48 at 0.44 TB/s)
@@ -510,6 +524,18 @@ using namespace vatl;
 
 extern "C" int vatl_version(void) { return VATL_VERSION; }
 extern "C" const char* vatl_last_error(void) { return err_buf(); }
+
+namespace vatl { void meter_begin(); void meter_end(double*, long long*); }
+extern "C" int vatl_flop_meter_begin(void) { vatl::meter_begin(); return 0; }
+extern "C" int vatl_flop_meter_end(double* direct_flops, double* winograd_flops, int64_t* direct_launches, int64_t* winograd_launches) {
+    double f[2]; long long n[2];
+    vatl::meter_end(f, n);
+    if (direct_flops) *direct_flops = f[0];
+    if (winograd_flops) *winograd_flops = f[1];
+    if (direct_launches) *direct_launches = n[0];
+    if (winograd_launches) *winograd_launches = n[1];
+    return 0;
+}
 
 extern "C" int vatl_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int Cpad, void* stream) {
     if (!src || !dst || Cpad < C) return fail(VATL_EINVAL, "nchw_to_nhwc: bad arguments");

@@ -336,6 +336,7 @@ static int winograd_wgrad_impl(const float* x, const float* g, float* dw, float*
     const int smem = 2 * p.stage_floats * (int)sizeof(float);
     if (smem > kWWMaxLds) return fail(VATL_EINVAL, "winograd_wgrad: %d bytes of LDS per block", smem);
     hipLaunchKernelGGL(kern, dim3((unsigned)((long long)q.n_tiles * q.c_tiles * q.phases * q.splits)), dim3(256), smem, st, p);
+    meter_add(1, 2.0 * (double)p.CnPad * p.CxPad * 16.0 * q.phases * (double)((mt + kWWTK - 1) / kWWTK * kWWTK));
     if (int rc = check_launch("winograd_wgrad")) return rc;
     hipLaunchKernelGGL(winograd_wgrad_finish_kernel<MO>, dim3((unsigned)((long long)q.phases * Cn * ((Cx + 63) / 64))), dim3(256), 0, st, workspace, dw, Cn, Cx,
                        p.CnPad, p.CxPad, q.splits);

@@ -26,6 +26,8 @@ _i64 = C.c_int64
 SIGNATURES = {
     "vatl_version": (_i, []),
     "vatl_last_error": (C.c_char_p, []),
+    "vatl_flop_meter_begin": (_i, []),
+    "vatl_flop_meter_end": (_i, [_p, _p, _p, _p]),
     "vatl_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "vatl_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vatl_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -193,6 +195,25 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+class flop_meter:
+    """`with vh.flop_meter() as fm: ...` — executed MFMA FLOPs (tile padding included) of the matrix-core launches the calling host
+    thread makes inside the block: fm.direct (implicit GEMM / weight gradients), fm.winograd (transform-domain GEMMs), fm.total, and the
+    launch counts.  Thread-local in the library (vatl_flop_meter_begin / _end); used by bench.py for roofline.frac."""
+
+    def __enter__(self):
+        _check(lib().vatl_flop_meter_begin(), "flop_meter_begin")
+        self.direct = self.winograd = self.total = 0.0
+        self.direct_launches = self.winograd_launches = 0
+        return self
+
+    def __exit__(self, *exc):
+        d, w, nd, nw = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_int64(0)
+        _check(lib().vatl_flop_meter_end(C.byref(d), C.byref(w), C.byref(nd), C.byref(nw)), "flop_meter_end")
+        self.direct, self.winograd, self.total = d.value, w.value, d.value + w.value
+        self.direct_launches, self.winograd_launches = nd.value, nw.value
+        return False
+
+
 def tune_set(knob: int, value: int):
     _check(lib().vatl_tune_set(knob, value), "vatl_tune_set")
 
@@ -215,7 +236,11 @@ def enable_splitk(megabytes: int = 64, device=None):
         _splitk_buf[idx] = buf
 
 
-_splitk_scratch = {}                                 # (host thread, device index) -> workspace of the automatic small-batch mode
+_splitk_scratch = {}                                 # device index -> free list of workspaces of the automatic small-batch mode
+_splitk_scratch_lock = __import__("threading").Lock()
+# the batch-invariant cut sizes a layer's split from what a 16-crop batch needs (conv_igemm.hip: launch): the largest is SimplePose's last
+# transposed conv, 3 slices x 16 crops x 64 x 48 x 256 floats = 151 MB; a smaller workspace only makes that layer run unsplit
+SPLITK_SCRATCH_MB = int(os.environ.get("VATL_SPLITK_SCRATCH_MB", "256"))
 
 
 class splitk_scope:
@@ -223,22 +248,30 @@ class splitk_scope:
     alphapose/models/hip_engine.py: run_module_nchw), with the batch-invariant cut, and removed afterwards: the evaluation stream
     — whose crops must have batch-size-independent bits — never sees it, other host threads (DataParallel replicas) are not
     affected and share no buffer with this one.  A device on which split-K was switched on explicitly (``enable_splitk``) is
-    left alone."""
+    left alone.  Workspaces live in a per-DEVICE free list: a scope takes one (allocating only when every buffer of the device
+    is in use by another thread's open scope) and puts it back on exit, so a thread-per-call caller does not accumulate buffers."""
 
-    def __init__(self, device, megabytes: int = 256):
+    def __init__(self, device, megabytes: int | None = None):
         self.idx = device.index if device.index is not None else torch.cuda.current_device()
-        self.mb = megabytes
+        self.mb = megabytes or SPLITK_SCRATCH_MB
         self.active = False
+        self.buf = None
 
     def __enter__(self):
         if self.idx in _splitk_buf:
             return self
-        import threading
-        key = (threading.get_ident(), self.idx)
-        buf = _splitk_scratch.get(key)
-        if buf is None:
-            buf = _splitk_scratch[key] = torch.empty(self.mb * (1 << 18), device=torch.device("cuda", self.idx), dtype=torch.float32)
-        _check(lib().vatl_set_splitk_workspace_thread(_ptr(buf), buf.numel()), "vatl_set_splitk_workspace_thread")
+        want = self.mb * (1 << 18)
+        with _splitk_scratch_lock:
+            free = _splitk_scratch.setdefault(self.idx, [])
+            hit = next((e for e in free if e[0].numel() >= want), None)
+            if hit is not None:
+                free.remove(hit)
+        if hit is not None:
+            self.buf = hit[0]
+            torch.cuda.current_stream(self.idx).wait_event(hit[1])      # the previous user's launches (possibly another thread's stream) are done with it
+        else:
+            self.buf = torch.empty(want, device=torch.device("cuda", self.idx), dtype=torch.float32)
+        _check(lib().vatl_set_splitk_workspace_thread(_ptr(self.buf), self.buf.numel()), "vatl_set_splitk_workspace_thread")
         self.active = True
         _tls.latency_mode = getattr(_tls, "latency_mode", 0) + 1
         return self
@@ -247,6 +280,12 @@ class splitk_scope:
         if self.active:
             _tls.latency_mode -= 1
             _check(lib().vatl_set_splitk_workspace_thread(None, 0), "vatl_set_splitk_workspace_thread")
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.idx))
+            with _splitk_scratch_lock:
+                _splitk_scratch[self.idx].append((self.buf, ev))
+            self.buf = None
+            self.active = False
         return False
 
 
