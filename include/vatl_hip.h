@@ -173,6 +173,12 @@ int vatl_gap_bwd(const float* dy, float* dx, int N, int HW, int C, void* stream)
  * idx (N,J) int32 flat arg-max (may be NULL). */
 int vatl_decode_argmax_affine(const float* hm, const float* bbox, float* coords, float* maxvals, int32_t* idx,
                               int N, int J, int H, int W, void* stream);
+/* The same decode writing the reference's key-point rows directly — kpts (N,J,3) fp32 = (x, y, score) per joint, the
+ * np.concatenate((pose_coords, pose_scores), axis=1) of ActiveLearning.py:304-306 — plus the two per-item scores made from
+ * them: hp (N) = -np.sum(pose_scores) (the 'HP' uncertainty, :329-330; NumPy's float32 pairwise order, bit-identical) and
+ * pose_score (N) = np.mean + 1.25 np.max (the json "score", :314).  idx, hp, pose_score may be NULL. */
+int vatl_decode_pose(const float* hm, const float* bbox, float* kpts, int32_t* idx, float* hp, float* pose_score,
+                     int N, int J, int H, int W, void* stream);
 
 /* compute_thc (ActiveLearning.py:747-760) for P pairs: out[i] = sum|a_i-b_i|/J
  * (norm 1) or sum (a_i-b_i)^2/J (norm 2); a_i = a + i*stride_a, b likewise

@@ -33,6 +33,31 @@ def test_decode_golden(vh, golden_scorers):
     assert exact == 1.0                                                                   # and in fact bit-identical here
 
 
+def test_decode_pose_rows_and_item_scores(vh, golden_scorers):
+    """vatl_decode_pose: the interleaved (x, y, score) rows equal the separate decode bit for bit; HP = -np.sum(scores) is BIT-identical to
+    NumPy's float32 pairwise sum (17 joints, and 5 / 8 / 136 / 300 joints for the other branches of the summation order); the json score
+    = mean + 1.25 max within float32 rounding (ActiveLearning.py:304-314, 329-330)."""
+    g = golden_scorers
+    hm, bb = to_dev(g["hm"]), to_dev(g["bbox"])
+    coords, maxv, idx = vh.decode(hm, bb)
+    kpts, idx2, hp, ps = vh.decode_pose(hm, bb)
+    assert torch.equal(kpts[..., :2], coords) and torch.equal(kpts[..., 2], maxv) and torch.equal(idx2, idx)
+    assert np.array_equal(kpts.cpu().numpy().reshape(len(bb), -1), g["kp"].astype(np.float32))
+    mv = g["maxvals"][..., 0].astype(np.float32)
+    want_hp = np.array([-np.sum(mv[i]) for i in range(mv.shape[0])], np.float32)
+    assert np.array_equal(hp.cpu().numpy(), want_hp)
+    for i in range(mv.shape[0]):
+        np.testing.assert_allclose(float(ps[i]), scorers.pose_score(g["maxvals"][i]), rtol=1e-6)
+    r = np.random.RandomState(9)
+    for j in (5, 8, 136, 300):
+        h = r.standard_normal((3, j, 8, 12)).astype(np.float32) * 3
+        k, _, hp, ps = vh.decode_pose(to_dev(h), to_dev(synth.bboxes(3, seed=2)))
+        sc = h.reshape(3, j, -1).max(2)
+        assert np.array_equal(k[..., 2].cpu().numpy(), sc)
+        assert np.array_equal(hp.cpu().numpy(), np.array([-np.sum(sc[i]) for i in range(3)], np.float32)), j
+        np.testing.assert_allclose(ps.cpu().numpy(), [scorers.pose_score(sc[i][:, None]) for i in range(3)], rtol=1e-6)
+
+
 def test_decode_random_vs_oracle(vh):
     r = np.random.RandomState(1)
     hm = r.standard_normal((32, 17, 64, 48)).astype(np.float32)

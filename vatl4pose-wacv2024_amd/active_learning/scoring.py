@@ -39,15 +39,13 @@ def score_batch(heatmaps: torch.Tensor, bboxes: torch.Tensor, is_prev: torch.Ten
                 is_next: torch.Tensor | None = None, thc_norm: str | None = "L1", ae_flat: torch.Tensor | None = None,
                 ae_dims=(42, 4), wpu_only38: bool = False) -> Scores:
     """heatmaps (N,J,H,W) fp32 on the device, bboxes (N,4) crop boxes xyxy."""
-    coords, maxv, idx = vh.decode(heatmaps, bboxes)
-    kpts = torch.cat([coords, maxv.unsqueeze(-1)], dim=2)
+    kpts, idx, hp, pose_score = vh.decode_pose(heatmaps, bboxes)     # key-point rows + HP + json score: two launches, no torch glue kernels
     lp, _ = vh.localpeak_mean(heatmaps)
-    out = Scores(keypoints=kpts, argmax=idx, hp=-maxv.sum(dim=1), pose_score=maxv.mean(dim=1) + 1.25 * maxv.max(dim=1).values,
-                 localpeak=lp)
+    out = Scores(keypoints=kpts, argmax=idx, hp=hp, pose_score=pose_score, localpeak=lp)
     if thc_norm is not None and is_prev is not None:
         out.thc = vh.thc_stream(heatmaps, is_prev.to(torch.uint8), is_next.to(torch.uint8), thc_norm)
     if ae_flat is not None:
-        out.wpu, out.wpu_status = vh.hybrid_ae_wpu(kpts.contiguous(), bboxes, ae_flat, ae_dims[0], ae_dims[1], wpu_only38)
+        out.wpu, out.wpu_status = vh.hybrid_ae_wpu(kpts, bboxes, ae_flat, ae_dims[0], ae_dims[1], wpu_only38)
     return out
 
 

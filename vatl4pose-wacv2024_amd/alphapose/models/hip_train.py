@@ -203,6 +203,15 @@ def _planned(kind):
     return deco
 
 
+def _wino_wgrad_fits(xshape, mo: int) -> bool:
+    """winograd_wgrad_impl addresses tiles with 20 bits (csrc/winograd_wgrad.hip: N * ceil(H / MO) * ceil(W / MO) < 2^20, N * tile rows < 2^20):
+    batches beyond that (> 1365 crops at 64 x 48) take the implicit-GEMM weight gradient instead of failing mid-step.  (The forward / data
+    gradient kernels share their only limit, 2^30 elements per tensor, with the implicit GEMM: nothing to fall back to there.)"""
+    n, h, w = int(xshape[0]), int(xshape[1]), int(xshape[2])
+    th, tw = -(-h // mo), -(-w // mo)
+    return n * th * tw < (1 << 20) and n * th < (1 << 20)
+
+
 class _ConvBN:
     """Conv2d (bias-free) + BatchNorm2d(train) (+ residual) (+ ReLU)."""
 
@@ -296,7 +305,7 @@ class _ConvBN:
         grads[self.bn.bias] = dbeta
         cin_w = 3 if self.cin == 3 else self.cin
         ow = _gout(grads, self.conv.weight)
-        if self.wino and min(self.cin, self.cout) >= _WINOGRAD_WGRAD_MIN_C:      # transform-domain weight gradient (csrc/winograd_wgrad.hip)
+        if self.wino and min(self.cin, self.cout) >= _WINOGRAD_WGRAD_MIN_C and _wino_wgrad_fits(x.shape, 2):      # transform-domain weight gradient (csrc/winograd_wgrad.hip)
             grads[self.conv.weight] = _side.run(lambda: vh.conv3x3_winograd_wgrad(x, dz, out=ow), x, dz)
         else:
             grads[self.conv.weight] = _side.run(lambda: vh.conv2d_wgrad(x, dz, self.cout, cin_w, self.r, self.s, self.stride, self.pad, out=ow), x, dz)
@@ -377,7 +386,7 @@ class _DeconvBN:
         grads[self.bn.weight] = dgamma
         grads[self.bn.bias] = dbeta
         ow = _gout(grads, self.dc.weight)
-        if _WINOGRAD and min(self.cin, self.cout) >= _WINOGRAD_WGRAD_MIN_C:      # transform-domain weight gradient (1.04 - 1.16x at B = 120)
+        if _WINOGRAD and min(self.cin, self.cout) >= _WINOGRAD_WGRAD_MIN_C and _wino_wgrad_fits(x.shape, 3):      # transform-domain weight gradient (1.04 - 1.16x at B = 120)
             grads[self.dc.weight] = _side.run(lambda: vh.deconv4x4s2_winograd_wgrad(x, dz, out=ow), x, dz)
         else:
             grads[self.dc.weight] = _side.run(lambda: vh.deconv4x4s2_wgrad(x, dz, out=ow), x, dz)

@@ -18,7 +18,9 @@ __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi)
 // quarter-pixel shift + inverse crop affine + stores of one plane's result (one thread)
 __device__ __forceinline__ void decode_finish(const float* __restrict__ src, const float* __restrict__ bbox, float* __restrict__ coords,
                                               float* __restrict__ maxvals, int32_t* __restrict__ idx_out, long long plane, int item,
-                                              float best, int bidx, int H, int W) {
+                                              float best, int bidx, int H, int W, int cs = 2, int ms = 1, int mo = 0) {
+    // cs / ms / mo: element stride of a plane's coordinate pair / score and the score's offset — (2, 1, 0) for separate (N,J,2) + (N,J)
+    // arrays, (3, 3, 2) with coords == maxvals for the interleaved (N,J,3) key-point rows of vatl_decode_pose
     int px = bidx % W, py = bidx / W;
     if (!(best > 0.f)) { px = 0; py = 0; }                      // pred_mask: maxval <= 0 zeroes the coords
     float u = (float)px, v = (float)py;
@@ -38,15 +40,15 @@ __device__ __forceinline__ void decode_finish(const float* __restrict__ src, con
     const float top32 = (float)(cy + bw * -0.5);
     const float d32 = cy32 - top32;
     const double g = (double)d32 / (W * 0.5);
-    coords[plane * 2 + 0] = (float)((double)cx32 + ((double)u - W * 0.5) * g);
-    coords[plane * 2 + 1] = (float)((double)cy32 + ((double)v - H * 0.5) * g);
-    maxvals[plane] = best;
+    coords[plane * cs + 0] = (float)((double)cx32 + ((double)u - W * 0.5) * g);
+    coords[plane * cs + 1] = (float)((double)cy32 + ((double)v - H * 0.5) * g);
+    maxvals[plane * ms + mo] = best;
     if (idx_out) idx_out[plane] = bidx;
 }
 
 __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ hm, const float* __restrict__ bbox,
                                                      float* __restrict__ coords, float* __restrict__ maxvals,
-                                                     int32_t* __restrict__ idx_out, int J, int H, int W) {
+                                                     int32_t* __restrict__ idx_out, int J, int H, int W, int cs, int ms, int mo) {
     const int item = blockIdx.x / J;
     const int HW = H * W;
     const float* src = hm + (long long)blockIdx.x * HW;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
     if (tid != 0) return;
     for (int w = 1; w < 4; ++w) argmax_merge(best, bidx, sv[w], si[w]);
 
-    decode_finish(src, bbox, coords, maxvals, idx_out, (long long)blockIdx.x, item, best, bidx, H, W);
+    decode_finish(src, bbox, coords, maxvals, idx_out, (long long)blockIdx.x, item, best, bidx, H, W, cs, ms, mo);
 }
 
 // One WAVE per plane, the plane in registers (NV float4 per lane, every load in flight at once, no LDS, no block barrier): used
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
 template <int NV>
 __global__ __launch_bounds__(256) void decode_wave_kernel(const float* __restrict__ hm, const float* __restrict__ bbox,
                                                           float* __restrict__ coords, float* __restrict__ maxvals,
-                                                          int32_t* __restrict__ idx_out, int planes, int J, int H, int W) {
+                                                          int32_t* __restrict__ idx_out, int planes, int J, int H, int W, int cs, int ms, int mo) {
     const int lane = threadIdx.x & 63;
     const long long plane = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (plane >= planes) return;
@@ -113,7 +115,49 @@ __global__ __launch_bounds__(256) void decode_wave_kernel(const float* __restric
         const int oi = __shfl_xor(bidx, o, 64);
         argmax_merge(best, bidx, ov, oi);
     }
-    if (lane == 0) decode_finish(src, bbox, coords, maxvals, idx_out, plane, (int)(plane / J), best, bidx, H, W);
+    if (lane == 0) decode_finish(src, bbox, coords, maxvals, idx_out, plane, (int)(plane / J), best, bidx, H, W, cs, ms, mo);
+}
+
+// Per-item pose scores from the interleaved key-point rows: HP = -np.sum(scores) (ActiveLearning.py:329-330) and the json "score" =
+// np.mean(scores) + 1.25 np.max(scores) (:314), with NumPy's float32 pairwise summation order (8 running sums over the leading multiple
+// of 8, combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the tail added in order; halves of a run longer than 128 summed separately) —
+// HP is bit-identical to the reference's float32 np.sum, not merely close.  One thread per item.
+__device__ float np_pairwise_sum(const float* a, int n, int stride) {
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; ++i) r += a[i * stride];
+        return r;
+    }
+    if (n <= 128) {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = a[j * stride];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] += a[(i + j) * stride];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i * stride];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2, stride) + np_pairwise_sum(a + (long long)n2 * stride, n - n2, stride);
+}
+
+__global__ void pose_scores_kernel(const float* __restrict__ kpts, float* __restrict__ hp, float* __restrict__ pose_score, int N, int J) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float* sc = kpts + (long long)i * J * 3 + 2;
+    const float sum = np_pairwise_sum(sc, J, 3);
+    float mx = sc[0];
+    for (int j = 1; j < J; ++j) {                              // np.max: NaN propagates
+        const float v = sc[j * 3];
+        if (v > mx || v != v) mx = (mx != mx) ? mx : v;
+    }
+    if (hp) hp[i] = -sum;
+    // float(np.mean(s) + 1.25 * np.max(s)): float32 mean (pairwise sum / J), the rest in double, stored as float32
+    if (pose_score) pose_score[i] = (float)((double)(sum / (float)J) + 1.25 * (double)mx);
 }
 
 // --------------------------------------------------------------------------
@@ -464,19 +508,36 @@ __global__ __launch_bounds__(256) void wpu_kernel(const float* __restrict__ kpts
 
 using namespace vatl;
 
+static int decode_launch(const float* hm, const float* bbox, float* coords, float* maxvals, int32_t* idx, int N, int J, int H, int W, int cs, int ms,
+                         int mo, hipStream_t st) {
+    const long long planes = (long long)N * J;
+    const bool aligned = (((uintptr_t)hm) & 15) == 0 && planes <= 0x7FFFFFFF;
+    if (aligned && H * W == 64 * 12 * 4)
+        hipLaunchKernelGGL(decode_wave_kernel<12>, dim3(cdiv(planes, 4)), dim3(256), 0, st, hm, bbox, coords, maxvals, idx, (int)planes, J, H, W, cs, ms, mo);
+    else if (aligned && H * W == 64 * 27 * 4)
+        hipLaunchKernelGGL(decode_wave_kernel<27>, dim3(cdiv(planes, 4)), dim3(256), 0, st, hm, bbox, coords, maxvals, idx, (int)planes, J, H, W, cs, ms, mo);
+    else
+        hipLaunchKernelGGL(decode_kernel, dim3(N * J), dim3(256), 0, st, hm, bbox, coords, maxvals, idx, J, H, W, cs, ms, mo);
+    return check_launch("decode_argmax_affine");
+}
+
 extern "C" int vatl_decode_argmax_affine(const float* hm, const float* bbox, float* coords, float* maxvals, int32_t* idx,
                                          int N, int J, int H, int W, void* stream) {
     if (N <= 0) return 0;
     if (!hm || !bbox || !coords || !maxvals) return fail(VATL_EINVAL, "decode_argmax_affine: null pointer");
-    const long long planes = (long long)N * J;
-    const bool aligned = (((uintptr_t)hm) & 15) == 0 && planes <= 0x7FFFFFFF;
-    if (aligned && H * W == 64 * 12 * 4)
-        hipLaunchKernelGGL(decode_wave_kernel<12>, dim3(cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream, hm, bbox, coords, maxvals, idx, (int)planes, J, H, W);
-    else if (aligned && H * W == 64 * 27 * 4)
-        hipLaunchKernelGGL(decode_wave_kernel<27>, dim3(cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream, hm, bbox, coords, maxvals, idx, (int)planes, J, H, W);
-    else
-        hipLaunchKernelGGL(decode_kernel, dim3(N * J), dim3(256), 0, (hipStream_t)stream, hm, bbox, coords, maxvals, idx, J, H, W);
-    return check_launch("decode_argmax_affine");
+    return decode_launch(hm, bbox, coords, maxvals, idx, N, J, H, W, 2, 1, 0, (hipStream_t)stream);
+}
+
+extern "C" int vatl_decode_pose(const float* hm, const float* bbox, float* kpts, int32_t* idx, float* hp, float* pose_score, int N, int J, int H, int W,
+                                void* stream) {
+    if (N <= 0) return 0;
+    if (!hm || !bbox || !kpts) return fail(VATL_EINVAL, "decode_pose: null pointer");
+    if (int rc = decode_launch(hm, bbox, kpts, kpts, idx, N, J, H, W, 3, 3, 2, (hipStream_t)stream)) return rc;
+    if (hp || pose_score) {
+        hipLaunchKernelGGL(pose_scores_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, kpts, hp, pose_score, N, J);
+        return check_launch("pose_scores");
+    }
+    return 0;
 }
 
 extern "C" int vatl_thc_pairs(const float* a, const float* b, int64_t stride_a, int64_t stride_b, float* out,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "vatl_upsample_nearest_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vatl_gap_bwd": (_i, [_p, _p, _i, _i, _i, _p]),
     "vatl_decode_argmax_affine": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vatl_decode_pose": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_thc_pairs": (_i, [_p, _p, _i64, _i64, _p, _i, _i, _i, _i, _p]),
     "vatl_thc_combine": (_i, [_p, _p, _p, _p, _i, _p]),
     "vatl_localpeak_mean": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
@@ -719,6 +720,18 @@ def decode(hm: torch.Tensor, bbox: torch.Tensor):
     _check(lib().vatl_decode_argmax_affine(_ptr(hm), _ptr(bbox), _ptr(coords), _ptr(maxv), _ptr(idx, torch.int32), n, j, h, w, _stream()),
            "vatl_decode_argmax_affine")
     return coords, maxv, idx
+
+
+def decode_pose(hm: torch.Tensor, bbox: torch.Tensor):
+    """-> kpts (N,J,3) f32 rows (x, y, score), idx (N,J) i32, hp (N) = -sum of scores, pose_score (N) = mean + 1.25 max: the decode and the
+    per-item scores of ActiveLearning.py:304-314, 329-330 in two launches (no cat / neg / sum / max / mean kernels around them)."""
+    n, j, h, w = hm.shape
+    kpts = torch.empty((n, j, 3), device=hm.device, dtype=torch.float32)
+    idx = torch.empty((n, j), device=hm.device, dtype=torch.int32)
+    hp = torch.empty((n,), device=hm.device, dtype=torch.float32)
+    ps = torch.empty((n,), device=hm.device, dtype=torch.float32)
+    _check(lib().vatl_decode_pose(_ptr(hm), _ptr(bbox), _ptr(kpts), _ptr(idx, torch.int32), _ptr(hp), _ptr(ps), n, j, h, w, _stream()), "vatl_decode_pose")
+    return kpts, idx, hp, ps
 
 
 def thc_pairs(a: torch.Tensor, b: torch.Tensor, norm: str = "L1") -> torch.Tensor:
