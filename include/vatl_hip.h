@@ -491,6 +491,11 @@ int64_t vatl_winograd_weight_floats(int Cout, int Cin);
 int vatl_pack_winograd_weight(const float* w, float* u, int Cout, int Cin, int data_gradient, void* stream);
 int vatl_conv3x3_winograd_fwd(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y,
                               int N, int H, int W, int Cin, int Cout, int relu, void* stream);
+/* Which kernel the calling thread's last vatl_conv3x3_winograd_fwd launch took: 0 = one block per (32-tile group, filter tile);
+ * 1 = the persistent route (blocks keep a group of the period lcm(tiles per image, 32) and walk whole periods: the layers with
+ * <= 128 input channels, whose blocks are otherwise shorter than their own set-up); 2 = persistent + a plain launch for the
+ * images that do not fill a period.  All three give the same bits; tests use this to prove which one ran. */
+int vatl_winograd_last_route(void);
 int64_t vatl_winograd_stats_row_blocks(int64_t N, int H, int W);
 int vatl_conv3x3_winograd_fwd_stats(const float* x, const float* u, float* y, double* stats, int64_t* row_blocks_used, int N, int H, int W,
                                     int Cin, int Cout, void* stream);

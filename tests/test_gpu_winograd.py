@@ -466,3 +466,41 @@ def test_two_half_blocks_random_shapes(vh):
         for a, b in zip(*outs):
             assert torch.equal(a, b), (k, n, h, w, cin, cout)
     record("winograd_two_half_blocks_random", shapes=16)
+
+
+def test_persistent_route_gives_the_bits_of_the_plain_kernel(vh):
+    """winograd_persist_kernel (short blocks: <= 128 input channels): a block keeps one 32-tile group of the period lcm(tiles per image, 32)
+    and walks the periods by base address; images that do not fill a period go through the plain kernel.  Same per-tile arithmetic and
+    summation order: bit-identical to the plain kernel (vatl_tune_set(22, 0)), with scale / bias / residual / ReLU, one and two filter
+    halves per block, periods of 1 / 2 / 8 / 16 images, partial tiles at the image border, and a remainder."""
+    lib = vh.lib()
+    g = torch.Generator(device="cpu").manual_seed(31)
+    #        n,  h,  w, cin, cout, residual, expected route (1 persistent, 2 persistent + tail launch, 0 plain, None: whatever the block-count rule picks)
+    cases = [(64, 64, 48, 32, 32, True, 1), (1024, 32, 24, 64, 64, True, 1), (4101, 8, 6, 32, 32, True, 2), (1025, 16, 12, 32, 32, False, 2),
+             (8199, 5, 4, 32, 32, True, 2), (2041, 16, 12, 64, 64, True, 2), (517, 16, 12, 128, 128, False, None), (40, 13, 9, 32, 48, True, 0),
+             (24, 16, 12, 256, 256, False, 0)]
+    took = []
+    for n, h, w, cin, cout, res, want in cases:
+        x = torch.randn((n, h, w, cin), generator=g).to(dev())
+        wt = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev())
+        sc = (torch.rand(cout, generator=g) + 0.5).to(dev()); bi = torch.randn(cout, generator=g).to(dev())
+        r = torch.randn((n, h, w, cout), generator=g).to(dev()) if res else None
+        u = vh.pack_winograd_weight(wt)
+        y = vh.conv3x3_winograd_fwd(x, u, sc, bi, cout, True, residual=r)
+        route = lib.vatl_winograd_last_route()
+        y2 = vh.conv3x3_winograd_fwd(x, u, None, None, cout, False)
+        vh.tune_set(22, 0)
+        try:
+            p = vh.conv3x3_winograd_fwd(x, u, sc, bi, cout, True, residual=r)
+            assert lib.vatl_winograd_last_route() == 0
+            p2 = vh.conv3x3_winograd_fwd(x, u, None, None, cout, False)
+        finally:
+            vh.tune_set(22, 8)
+        assert want is None or route == want, (n, h, w, cin, cout, route)
+        assert torch.equal(y, p) and torch.equal(y2, p2), (n, h, w, cin, cout, route)
+        took.append(route)
+        k = min(n, 3)                                       # and against float64 (last images of the batch: the tail launch / the last period)
+        ref = F.conv2d(x[-k:].permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), padding=1).permute(0, 2, 3, 1)
+        assert rel_err(y2[-k:].cpu().numpy(), ref.numpy()) < TOL
+    record("winograd_persistent_route", routes=took)
+    assert took.count(1) >= 2 and took.count(2) >= 4, took       # whole periods only, and periods + a plain launch for the remainder

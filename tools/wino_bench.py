@@ -43,8 +43,11 @@ def main():
     ap.add_argument("--check", type=int, default=8)
     ap.add_argument("--group-kb", type=int, default=-1, help="vatl_tune_set(18, v): KB of filter slices per group of the Winograd tile order")
     ap.add_argument("--halves", type=int, default=0, help="vatl_tune_set(21, v): 32-channel filter halves per Winograd block (1, or 2 where the layer allows)")
+    ap.add_argument("--persist", type=int, default=-1, help="vatl_tune_set(22, v): layers with at most v 16-channel stages take the persistent Winograd route (0 = never)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    if a.persist >= 0:
+        vh.tune_set(22, a.persist)
     if a.group_kb >= 0:
         vh.tune_set(18, a.group_kb)
     if a.halves:

@@ -1580,6 +1580,7 @@ int conv3x3_halo_enable(int on);
 int wino_set_ablate(int bits);                                 // conv_winograd.hip
 int wino_set_group_kb(int v);
 int wino_set_halves(int v);
+int wino_set_persist(int v);
 int wino_wgrad_set_blocks(int v);                              // winograd_wgrad.hip
 
 }
@@ -1612,6 +1613,7 @@ extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 17 && value >= 0 && value <= 63) return wino_set_ablate(value);
     if (knob == 18 && value >= 0 && value <= (1 << 20)) return wino_set_group_kb(value);
     if (knob == 21 && value >= 1 && value <= 3) return wino_set_halves(value);
+    if (knob == 22 && value >= 0 && value <= 4096) return wino_set_persist(value);
     if (knob == 19 && value >= 1 && value <= (1 << 20)) return wino_wgrad_set_blocks(value);
     if (knob == 12 && (value == 0 || value == 1)) { g_streamk.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 10 && (value == 1 || value == 2)) { g_persist_dist.store(value, std::memory_order_relaxed); return 0; }

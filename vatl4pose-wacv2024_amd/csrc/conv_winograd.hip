@@ -76,6 +76,11 @@ struct WinoParams {
                                       // phase (p, q) are x[2 y + p][2 x + q] of an (N, 2H, 2W, Cin) tensor, read with pad (p, q)
     int spp;                          // gather: 16-channel stages per phase (Cin / 16); stages = 4 spp
     int rn;                           // filter slices per group of the tile order (see the kernel)
+    // persistent route (winograd_persist_kernel): the launch covers `periods` runs of `pg` 32-tile groups = lcm(tiles per image, 32) tiles =
+    // a whole number of images, so that the geometry of a group repeats from period to period; a block keeps one (group, filter tile) of the
+    // period and walks `chunk` consecutive periods, advancing its buffer bases by the period's bytes
+    int pg, periods, chunk;
+    long long x_period_floats, y_period_floats;
     long long u_phase_floats;         // deconv: floats of one phase's packed filter
     int ablate;                       // profiling library only (vatl_tune_set(17, bits), wrong results): 1 no output transform, 2 no LDS
                                       // reads / input transform, 4 no filter loads, 8 no staging DMA, 16 no barriers
@@ -223,6 +228,10 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
     if constexpr (EARLY) {
         if (tid < W_ZERO / 4) *reinterpret_cast<f32x4*>(&smem[tid * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
         stage_dma(0, 0);                                   // in flight while the rest of the prologue runs
+        // ... and the second stage with it (its buffer is free: nothing has been staged yet).  Requested inside stage 0 it had one
+        // group of MFMAs to land, and the blocks of the short layers (32 / 64 input channels: two to four stages) waited for it a second
+        // time at the end of that stage: one memory latency less on the serial chain of every block.
+        if (p.stages > 1 && !(abl & 8)) stage_dma(1, 1);
     }
 
     // ---- fragment addressing: lane = (tile l & 31, channel quad l >> 5).  ra[px][j]: float index (relative to Rs, input row 0, stage 0,
@@ -355,7 +364,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
             mfma_group(accs[NB - 1], v, ub);
             __builtin_amdgcn_sched_barrier(0);
             u_load_h(ub, 2 * st + 1, 1);
-            if (st + 1 < p.stages && !(abl & 8)) stage_dma(buf ^ 1, st + 1);     // (behind the fragments of this stage's second step: loads retire in order)
+            if (st + 1 < p.stages && (!EARLY || st > 0) && !(abl & 8)) stage_dma(buf ^ 1, st + 1);     // (behind the fragments of this stage's second step: loads retire in order)
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (V_AHEAD) {
 #pragma unroll
@@ -382,7 +391,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
         // (the filter loads first: VMEM loads retire in order, so fragments requested AFTER the staging DMA would make the second step wait
         // for the whole DMA; this way the DMA has both steps to land)
         u_load(ub, 2 * st + 1);
-        if (st + 1 < p.stages && !(abl & 8)) stage_dma(buf ^ 1, st + 1);
+        if (st + 1 < p.stages && (!EARLY || st > 0) && !(abl & 8)) stage_dma(buf ^ 1, st + 1);
         __builtin_amdgcn_sched_barrier(0);
         step_mfma(Rb, 0, ua, pv);
         __builtin_amdgcn_sched_barrier(0);
@@ -574,6 +583,299 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
     }
 }
 
+// Persistent variant for the 3x3 layers (MO = 2) whose blocks are short — 32 .. 128 input channels: two to eight stages — i.e. every
+// branch conv of HRNet and the first stages of the ResNets.  Measured on those layers (profiles/r04_notes.md): the tensors can sit in the
+// Infinity Cache or stream from HBM, with or without the skip-connection read, and a launch takes the same time — what the blocks spend
+// beside their MFMAs is INSTRUCTIONS: ~900 before the first MFMA (tile decode, ~30 magic-number divisions per lane for the staging and store
+// offsets) and ~700 after the last one, for 64 .. 256 MFMAs per wave.  All of that geometry depends on the tile's position inside its image
+// only.  With a launch cut into periods of lcm(tiles per image, 32) tiles (a whole number of images AND of 32-tile groups) group g of every
+// period has the same geometry, so a block computes it ONCE — staging offsets, fragment addresses, store offsets, masks — keeps it in
+// registers and walks the periods by advancing the base addresses of its buffer descriptors (scalar work).  Per-tile arithmetic, stage
+// order and summation order are those of winograd_body: bit-identical results.
+template <int NB>
+__device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float* smem) {
+    constexpr int MO = 2, NT = 256, BN = 32 * NB, NW = 4;
+    using ST = WinoStage<MO>;
+    constexpr int W_NLD = ST::NLD, STAGE = ST::FLOATS, ROWF = ST::ROWE * W_CK;
+    float* Rs = smem + W_ZERO;
+    const int tid = threadIdx.x, lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // block -> (part, group of the period, filter tile); consecutive ids of the sequence on one XCD (block b runs on XCD b % 8), the
+    // filter tile fastest: the blocks that read the same staged pixels are neighbours in time and share an L2
+    const int bid = blockIdx.x, nblk = gridDim.x;
+    const int xcd = bid & 7, loc = bid >> 3, q8 = nblk >> 3, r8 = nblk & 7;
+    const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    const int units = p.pg * p.n_tiles;
+    const int part = fdiv(t, p.d_grp), unit = t - part * units;
+    const int slot = fdiv(unit, p.d_ntiles), n_tile = unit - slot * p.n_tiles;
+    const int it0 = part * p.chunk, it1 = min(it0 + p.chunk, p.periods);
+    if (it0 >= it1) return;
+    const int m0 = slot * W_TB, n0 = n_tile * BN;
+    const int Lt = p.pg * W_TB;                            // tiles of one period (whole images): the geometry below is that of period 0
+
+    // ---- staging offsets (see winograd_body: one slot per distinct pixel column of a tile row, chunk swizzle on the source side) ----
+    // The geometry of the block — staging offsets, fragment addresses, store offsets: 16 words per thread — is parked in LDS behind the stage
+    // buffers and read back at the top of every period (staging / fragment part) and before the write-out (store part): as plain loop invariants
+    // these 13 values stay live across the MFMA loop AND the write-out, and the two-half kernel spilled 22 - 53 registers into the stage loop.
+    static_assert(W_NLD <= 8, "geometry record layout");
+    wu32x4* Gs = reinterpret_cast<wu32x4*>(smem + W_ZERO + 2 * STAGE);          // [4][256 threads] x 16 bytes: goff[0..3] | goff[4..7] | ra[0..3] | off[0..3]
+    unsigned g0[8] = {WOOB, WOOB, WOOB, WOOB, WOOB, WOOB, WOOB, WOOB};
+#pragma unroll
+    for (int u = 0; u < W_NLD; ++u) {
+        const int pz = (xi + NW * u) * 64 + lane;
+        if (pz >= ST::ITEMS) continue;
+        const int cpos = pz & 3, e = pz >> 2;
+        const int i = e / ST::ROWE, re = e - i * ST::ROWE;
+        const int r = re / W_NQ, q = re - r * W_NQ;
+        const int chunk = cpos ^ ((q >> 2) & 3);
+        int m = m0 + q;
+        int gr = fdiv(m, p.d_TW), tx = m - gr * p.TW;
+        int xx = MO * tx + r - 1;
+        if (m >= Lt || (tx == 0 && xx < 0)) {
+            m -= 1;
+            if (m < 0) continue;
+            gr = fdiv(m, p.d_TW); tx = m - gr * p.TW;
+            xx = MO * tx + MO + r - 1;
+        }
+        const int b = fdiv(gr, p.d_TH), ty = gr - b * p.TH;
+        const int yy = MO * ty - 1 + i;
+        if (m < Lt && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+            g0[u] = (unsigned)(((b * p.H + yy) * p.W + xx) * p.Cin + chunk * 4) << 2;
+    }
+    Gs[tid] = wu32x4{g0[0], g0[1], g0[2], g0[3]};
+    Gs[NT + tid] = wu32x4{g0[4], g0[5], g0[6], g0[7]};
+    // ---- fragment addressing ----
+    const int h = lane >> 5;
+    {
+        int ra[4];
+        const int tl = lane & 31;
+        const int m = m0 + tl;                             // < Lt: a period holds whole groups
+        const int gr = fdiv(m, p.d_TW), tx = m - gr * p.TW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xx = MO * tx + j - 1;
+            const int q = tl + j / MO;
+            ra[j] = (unsigned)xx < (unsigned)p.W ? ((j % MO) * W_NQ + q) * W_CK + ((h ^ ((q >> 2) & 3)) << 2) : -W_ZERO;
+        }
+        Gs[2 * NT + tid] = wu32x4{(unsigned)ra[0], (unsigned)ra[1], (unsigned)ra[2], (unsigned)ra[3]};
+    }
+    const int ia = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
+    const int ib = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
+    const float sgn = xi == 1 ? 1.f : -1.f;
+    const int roa = ia * ROWF, rob = ib * ROWF;
+    // ---- filter fragments ----
+    const int steps = p.stages * 2;
+    const int hn = n_tile * NB;
+    const int ut = hn / p.nhp, nh_g = hn - ut * p.nhp;
+    const unsigned ubase = (unsigned)((((ut * steps) * 16 + 4 * xi) * p.nhp + nh_g) * 64 + lane) << 4;
+    const unsigned ustep = 16u * p.nhp * 1024u, unu = p.nhp * 1024u;
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+    // ---- write-out: per pass u the thread's (tile, output column, channel quad); store offsets of the first filter half (the second: + 128 bytes) ----
+    constexpr int C4 = 32 / 4;
+    const int c4 = tid % C4;
+    {
+        wu32x4 o4;
+#pragma unroll
+        for (int u = 0; u < MO; ++u) {
+            const int rest = (tid + NT * u) / C4;
+            const int tl = rest / MO, bq = rest - tl * MO;
+            const int m = m0 + tl;
+            const int b = fdiv(m, p.d_tpi), r = m - b * p.tpi;
+            const int ty = fdiv(r, p.d_TW), tx = r - ty * p.TW;
+            const int xx = MO * tx + bq;
+#pragma unroll
+            for (int a = 0; a < MO; ++a) {
+                const int yy = MO * ty + a;
+                o4[u * MO + a] = (xx < p.W && yy < p.H) ? (unsigned)(((b * p.H + yy) * p.W + xx) * p.Cout + n0 + c4 * 4) << 2 : WOOB;
+            }
+        }
+        Gs[3 * NT + tid] = o4;
+    }
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, nul = {0.f, 0.f, 0.f, 0.f};
+    const float lo = p.relu ? 0.f : -INFINITY;
+    bool nvh[NB];
+#pragma unroll
+    for (int hh = 0; hh < NB; ++hh) nvh[hh] = n0 + 32 * hh + c4 * 4 < p.Cout;
+
+    auto mfma_group = [&](f32x16 (&ac)[4], const f32x4 (&v)[4], const f32x4 (&uu)[4]) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu)
+                ac[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][tt], uu[nu][tt], ac[nu], 0, 0, 0);
+    };
+    auto u_load_h = [&](f32x4 (&dst)[4], int step, int half) {
+        const bool live = step < steps;
+        const unsigned o = ubase + (unsigned)half * 1024u + (unsigned)step * ustep;
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? o + nu * unu : WOOB);
+    };
+
+    for (int it = it0; it < it1; ++it) {
+        // the period's tensors: base pointers advance, offsets stay (32-bit offsets inside a period-aligned window of the tensor)
+        const float* xb = p.x + (long long)it * p.x_period_floats;
+        float* yb = p.y + (long long)it * p.y_period_floats;
+        const float* rb = p.res ? p.res + (long long)it * p.y_period_floats : nullptr;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, p.x_bytes, 0x00020000);
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));                    // (opaque: the reads below are per period, not hoisted)
+        unsigned goff[8];
+        int ra[4];
+        {
+            const wu32x4 ga = Gs[tid_o], gb = Gs[NT + tid_o], gc = Gs[2 * NT + tid_o];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { goff[k] = ga[k]; goff[4 + k] = gb[k]; ra[k] = (int)gc[k]; }
+        }
+        auto make_v = [&](f32x4 (&v)[4], const float* Rb, int x8) {
+            f32x4 tc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int a = ra[j];
+                const bool z = a < 0;
+                const f32x4 da = *reinterpret_cast<const f32x4*>(z ? smem : Rb + roa + (a ^ x8));
+                const f32x4 db = *reinterpret_cast<const f32x4*>(z ? smem : Rb + rob + (a ^ x8));
+                tc[j] = da + sgn * db;
+            }
+            v[0] = tc[0] - tc[2]; v[1] = tc[1] + tc[2]; v[2] = tc[2] - tc[1]; v[3] = tc[1] - tc[3];
+        };
+        auto stage_dma = [&](int buf, int st) {
+#pragma unroll
+            for (int u = 0; u < W_NLD; ++u)
+                if (xi + NW * u < ST::NDMA)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (wlds_void*)(Rs + buf * STAGE + (xi + NW * u) * 256), 16,
+                                                             goff[u] != WOOB ? goff[u] + (unsigned)st * (W_CK * 4) : WOOB, 0, 0, 0);
+        };
+        f32x4 ua[4], ub[4];
+        u_load_h(ua, 0, 0);
+        stage_dma(0, 0);
+        if (p.stages > 1) stage_dma(1, 1);
+        if (tid < W_ZERO / 4) *reinterpret_cast<f32x4*>(&smem[tid * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};   // (the output-transform tiles of the period before lay over the zero pixel)
+        f32x16 accs[NB][4];
+#pragma unroll
+        for (int hh = 0; hh < NB; ++hh)
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) accs[hh][nu][e] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        if constexpr (NB == 2) {
+            for (int st = 0; st < p.stages; ++st) {
+                const int buf = st & 1;
+                const float* Rb = Rs + buf * STAGE;
+                f32x4 v[4], v1[4];
+                u_load_h(ub, 2 * st, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                make_v(v, Rb, 0);
+                mfma_group(accs[0], v, ua);
+                make_v(v1, Rb, 8);
+                __builtin_amdgcn_sched_barrier(0);
+                u_load_h(ua, 2 * st + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(accs[NB - 1], v, ub);
+                __builtin_amdgcn_sched_barrier(0);
+                u_load_h(ub, 2 * st + 1, 1);
+                if (st + 1 < p.stages && st > 0) stage_dma(buf ^ 1, st + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) v[nu] = v1[nu];
+                mfma_group(accs[0], v, ua);
+                __builtin_amdgcn_sched_barrier(0);
+                u_load_h(ua, 2 * st + 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(accs[NB - 1], v, ub);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        } else {
+            for (int st = 0; st < p.stages; ++st) {
+                const int buf = st & 1;
+                const float* Rb = Rs + buf * STAGE;
+                f32x4 v[4];
+                u_load_h(ub, 2 * st + 1, 0);
+                if (st + 1 < p.stages && st > 0) stage_dma(buf ^ 1, st + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                make_v(v, Rb, 0);
+                mfma_group(accs[0], v, ua);
+                __builtin_amdgcn_sched_barrier(0);
+                u_load_h(ua, 2 * st + 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                make_v(v, Rb, 8);
+                mfma_group(accs[0], v, ub);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(yb, 0, p.y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rb), 0, rb ? p.y_bytes : 0u, 0x00020000);
+        // (the write-out's LDS addresses are formed from the opaque copy of the thread id too: as loop invariants hipcc would keep all ~40 of
+        // them in registers across the MFMA loop)
+        const int lane_o = tid_o & 63, c4o = tid_o % C4;
+        const wu32x4 o4 = Gs[3 * NT + tid_o];
+        unsigned off[MO][MO];
+#pragma unroll
+        for (int u = 0; u < MO; ++u)
+#pragma unroll
+            for (int a = 0; a < MO; ++a) off[u][a] = o4[u * MO + a];
+#pragma unroll
+        for (int hh = 0; hh < NB; ++hh) {
+            f32x16 (&acch)[4] = accs[hh];
+            const unsigned hoff = (unsigned)hh * 128u;
+            const int nq = n0 + 32 * hh + c4o * 4;
+            const f32x4 sc = (nvh[hh] && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + nq) : one;
+            const f32x4 bi = (nvh[hh] && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + nq) : nul;
+            f32x4 rs[MO][MO];
+#pragma unroll
+            for (int u = 0; u < MO; ++u)
+#pragma unroll
+                for (int a = 0; a < MO; ++a)
+                    rs[u][a] = rb ? wbuf_load4(rr, (nvh[hh] && off[u][a] != WOOB) ? off[u][a] + hoff : WOOB) : nul;
+            __builtin_amdgcn_sched_barrier(0);
+            float* Ps = smem;
+            {
+                const int cl = lane_o & 31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * (lane_o >> 5);
+                    const float m0v = acch[0][e], m1v = acch[1][e], m2v = acch[2][e], m3v = acch[3][e];
+                    Ps[((xi * MO + 0) * W_TB + row) * W_LDP + cl] = m0v + m1v + m2v;
+                    Ps[((xi * MO + 1) * W_TB + row) * W_LDP + cl] = m1v - m2v - m3v;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < MO; ++u) {
+                const int rest = (tid_o + NT * u) / C4;
+                const int tl = rest / MO, bq = rest - tl * MO;
+                f32x4 pq[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pq[k] = *reinterpret_cast<const f32x4*>(&Ps[((k * MO + bq) * W_TB + tl) * W_LDP + c4o * 4]);
+                f32x4 yv[MO];
+                yv[0] = pq[0] + pq[1] + pq[2];
+                yv[1] = pq[1] - pq[2] - pq[3];
+#pragma unroll
+                for (int a = 0; a < MO; ++a) {
+                    f32x4 o;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = fmaxf(yv[a][c] * sc[c] + bi[c] + rs[u][a][c], lo);
+                    wbuf_store4(yr, (nvh[hh] && off[u][a] != WOOB) ? off[u][a] + hoff : WOOB, o);
+                }
+            }
+            __syncthreads();                               // the next half's / the next period's stage goes where these tiles were read
+        }
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void winograd_persist_kernel(WinoParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    winograd_persist_body<NB>(p, smem);
+}
+
 // GATHER: the data gradient of the transposed conv (reduction over the four pixel phases of dz x channels); a separate instantiation —
 // its phase changes keep the loader's geometry live across the stage loop, which costs the other variants 37 spilled registers
 template <int MO, bool BNB, bool GATHER, int NB = 1>
@@ -612,6 +914,10 @@ static std::atomic<int> g_wino_group_kb{2048};     // vatl_tune_set(18, v): KB o
 int wino_set_group_kb(int v) { g_wino_group_kb.store(v, std::memory_order_relaxed); return 0; }
 int wino_set_ablate(int bits) { g_wino_ablate.store(bits, std::memory_order_relaxed); return 0; }
 
+static std::atomic<int> g_wino_persist{8};         // vatl_tune_set(22, v): 3x3 layers with at most v 16-channel stages take the persistent route (0 = never)
+int wino_set_persist(int v) { g_wino_persist.store(v, std::memory_order_relaxed); return 0; }
+static std::atomic<unsigned> g_wino_persist_lds_done[2];
+
 constexpr int kWinoMaxLds = 64 * 1024;            // upper bound of a block's dynamic LDS (ns <= 128: two 32 KB stages)
 
 template <int MO, bool BNB, bool GATHER = false, int NB = 1>
@@ -624,6 +930,64 @@ static int launch_wino(const WinoParams& p, int phases, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles * phases), dim3(256), smem, st, p);
     meter_add(1, 2.0 * ((double)p.m_tiles * W_TB) * ((double)p.n_tiles * 32 * NB) * 16.0 * ((double)p.stages * W_CK) * phases);
     return check_launch("winograd");
+}
+
+static thread_local int tl_wino_route = 0;         // what the calling thread's last F(2x2,3x3) forward launch took (vatl_winograd_last_route)
+
+static long long gcd_ll(long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a; }
+
+// The persistent route of a forward F(2x2,3x3) launch: images [0, periods * Pi) in ONE launch of blocks that each keep a (group, filter tile) of
+// the period; returns the number of images it covered (0: not taken, the caller runs the plain kernel on everything; otherwise the caller runs
+// the plain kernel on the remaining N % Pi images).  Taken when the blocks are short (<= g_wino_persist stages) and a grid of whole rounds of
+// resident blocks can be cut with >= 90 % of its slots busy and >= 2 periods per block.
+static int launch_wino_persist(const WinoParams& base, int N, bool two, hipStream_t st, int* covered) {
+    *covered = 0;
+    const int maxst = g_wino_persist.load(std::memory_order_relaxed);
+    if (maxst <= 0 || base.stages > maxst || base.deconv || base.gather || base.stats || base.bz) return 0;
+    const long long Lt = (long long)base.tpi / gcd_ll(base.tpi, W_TB) * W_TB;          // lcm(tiles per image, 32)
+    const int Pi = (int)(Lt / base.tpi), Pg = (int)(Lt / W_TB);
+    const int periods = N / Pi;
+    if (periods < 8 || Pg > 4096) return 0;
+    const int NBh = two ? 2 : 1;
+    const int n_tiles = cdiv(base.Cout, 32 * NBh);
+    const int units = Pg * n_tiles, slots = two ? 512 : 768;
+    if (units > slots) return 0;
+    // whole rounds of resident blocks: k rounds -> at most k * slots / units parts; keep the cut with the best slot occupancy
+    int best_chunk = 0, best_parts = 0;
+    double best_eff = 0.0;
+    for (int k = 1; k <= 4; ++k) {
+        const int np_max = std::min(periods, k * slots / units);
+        if (np_max < 1) continue;
+        const int chunk = cdiv(periods, np_max), parts = cdiv(periods, chunk);
+        if (chunk < 2) break;
+        const int rounds = cdiv((long long)parts * units, slots);
+        const double eff = (double)periods * units / ((double)rounds * slots * chunk);
+        if (eff > best_eff + 0.02) { best_eff = eff; best_chunk = chunk; best_parts = parts; }
+    }
+    if (best_eff < 0.9) return 0;
+    WinoParams p = base;
+    p.N = Pi; p.Mtiles = (int)Lt;
+    p.pg = Pg; p.periods = periods; p.chunk = best_chunk;
+    p.n_tiles = n_tiles; p.m_tiles = Pg;
+    p.x_period_floats = (long long)Pi * base.H * base.W * base.Cin;
+    p.y_period_floats = (long long)Pi * base.H * base.W * base.Cout;
+    p.x_bytes = (unsigned)(p.x_period_floats * 4); p.y_bytes = (unsigned)(p.y_period_floats * 4);
+    p.d_grp = make_fastdiv((unsigned)units); p.d_ntiles = make_fastdiv((unsigned)n_tiles);
+    const int loop = W_ZERO + 2 * WinoStage<2>::FLOATS, epi = 4 * 2 * W_TB * W_LDP;
+    const int smem = (std::max(loop, epi) + 4 * 256 * 4) * (int)sizeof(float);  // + the geometry records of the 256 threads (behind the stage buffers)
+    const unsigned grid = (unsigned)(best_parts * units);
+    if (two) {
+        auto kern = winograd_persist_kernel<2>;
+        if (int rc = ensure_dynamic_lds((const void*)kern, kWinoMaxLds, g_wino_persist_lds_done[1], "winograd_persist")) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p);
+    } else {
+        auto kern = winograd_persist_kernel<1>;
+        if (int rc = ensure_dynamic_lds((const void*)kern, kWinoMaxLds, g_wino_persist_lds_done[0], "winograd_persist")) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p);
+    }
+    meter_add(1, 2.0 * ((double)periods * Lt) * ((double)n_tiles * 32 * NBh) * 16.0 * ((double)base.stages * W_CK));
+    *covered = periods * Pi;
+    return check_launch("winograd_persist");
 }
 
 }  // namespace vatl
@@ -701,6 +1065,22 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
                      (hv == 3 || (long long)p.m_tiles * cdiv(Cout, 64) * phases >= 400);
     const int NBh = two ? 2 : 1;
     p.n_tiles = cdiv(Cout, 32 * NBh);
+    hipStream_t st = (hipStream_t)stream;
+    if (MO == 2 && !fuse && !stats && !gather) {
+        // short blocks: the persistent route (geometry computed once per block, periods of whole images walked by base address); the images
+        // that do not fill a period go through the plain kernel below
+        p.d_TH = make_fastdiv(p.TH); p.d_TW = make_fastdiv(p.TW); p.d_tpi = make_fastdiv(p.tpi);
+        int covered = 0;
+        if (int rc = launch_wino_persist(p, N, two, st, &covered)) return rc;
+        tl_wino_route = covered == 0 ? 0 : (covered == N ? 1 : 2);
+        if (covered == N) return 0;
+        if (covered > 0) {
+            const int rc = winograd_impl(MO, x + (long long)covered * H * W * Cin, u, scale, bias, residual ? residual + (long long)covered * H * W * Cout : nullptr,
+                                 y + (long long)covered * H * W * Cout, nullptr, nullptr, N - covered, H, W, Cin, Cout, relu, stream);
+            tl_wino_route = 2;
+            return rc;
+        }
+    }
     if (row_blocks_used) *row_blocks_used = (int64_t)p.m_tiles * phases;
     // a slice is Cin * 2 KB (x 4 input phases in the gather mode); at least two per group (deconv1, Cin = 2048: 4 MB slices, 4326 -> 4135 us
     // with two), unless the knob says 0
@@ -711,7 +1091,6 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
     p.d_grp = make_fastdiv((unsigned)(p.m_tiles * p.rn)); p.d_rn = make_fastdiv(p.rn); p.d_ntiles = make_fastdiv(p.n_tiles);
     p.d_rn_last = make_fastdiv(units % p.rn ? units % p.rn : p.rn);
     if ((long long)p.m_tiles * units >= (1LL << 31)) return fail(VATL_EINVAL, "winograd: too many blocks");
-    hipStream_t st = (hipStream_t)stream;
     if (fuse) {
         if (deconv) return fail(VATL_EINVAL, "winograd: the BatchNorm-backward epilogue exists for the data-gradient launches only");
         p.bz = fuse->z; p.bmy = fuse->mask_y; p.bsc = fuse->scale; p.bbi = fuse->bias; p.bmu = fuse->mean; p.bis = fuse->invstd;
@@ -728,6 +1107,8 @@ extern "C" int vatl_conv3x3_winograd_fwd(const float* x, const float* u, const f
                                          int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
     return winograd_impl(2, x, u, scale, bias, residual, y, nullptr, nullptr, N, H, W, Cin, Cout, relu, stream);
 }
+
+extern "C" int vatl_winograd_last_route(void) { return tl_wino_route; }
 
 extern "C" int64_t vatl_winograd_stats_row_blocks(int64_t N, int H, int W) { return (N * ((H + 1) / 2) * ((W + 1) / 2) + W_TB - 1) / W_TB; }
 

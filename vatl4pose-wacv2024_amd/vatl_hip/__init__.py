@@ -81,6 +81,7 @@ SIGNATURES = {
     "vatl_winograd_weight_floats": (_i64, [_i, _i]),
     "vatl_pack_winograd_weight": (_i, [_p, _p, _i, _i, _i, _p]),
     "vatl_conv3x3_winograd_fwd": (_i, [_p] * 6 + [_i] * 6 + [_p]),
+    "vatl_winograd_last_route": (_i, []),
     "vatl_winograd_stats_row_blocks": (_i64, [_i64, _i, _i]),
     "vatl_conv3x3_winograd_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "vatl_conv3x3_winograd_fwd_bnbwd": (_i, [_p] * 4 + [_i] * 5 + [_p] * 9),
