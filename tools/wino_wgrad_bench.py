@@ -21,8 +21,11 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--layers", default="")
     ap.add_argument("--blocks", default="", help="comma list of target block counts to A/B (vatl_tune_set(19, v))")
+    ap.add_argument("--halves", type=int, default=0, help="vatl_tune_set(23, v): gradient-channel halves per block of the Winograd weight-gradient kernel (1 or 2)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    if a.halves:
+        vh.tune_set(23, a.halves)
     warm = torch.randn((4096, 4096), device=dev)
     for _ in range(100):
         warm @ warm

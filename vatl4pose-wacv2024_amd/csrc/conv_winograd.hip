@@ -719,12 +719,11 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, p.x_bytes, 0x00020000);
         int tid_o = tid;
         asm volatile("" : "+v"(tid_o));                    // (opaque: the reads below are per period, not hoisted)
-        unsigned goff[8];
         int ra[4];
         {
-            const wu32x4 ga = Gs[tid_o], gb = Gs[NT + tid_o], gc = Gs[2 * NT + tid_o];
+            const wu32x4 gc = Gs[2 * NT + tid_o];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { goff[k] = ga[k]; goff[4 + k] = gb[k]; ra[k] = (int)gc[k]; }
+            for (int k = 0; k < 4; ++k) ra[k] = (int)gc[k];
         }
         auto make_v = [&](f32x4 (&v)[4], const float* Rb, int x8) {
             f32x4 tc[4];
@@ -738,7 +737,13 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
             }
             v[0] = tc[0] - tc[2]; v[1] = tc[1] + tc[2]; v[2] = tc[2] - tc[1]; v[3] = tc[1] - tc[3];
         };
-        auto stage_dma = [&](int buf, int st) {
+        auto stage_dma = [&](int buf, int st) {            // (the staging offsets are read from the record at every use: 5 fewer registers live across the stage loop)
+            int tid_p = tid_o;
+            asm volatile("" : "+v"(tid_p));
+            const wu32x4 ga = Gs[tid_p], gb = Gs[NT + tid_p];
+            unsigned goff[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { goff[k] = ga[k]; goff[4 + k] = gb[k]; }
 #pragma unroll
             for (int u = 0; u < W_NLD; ++u)
                 if (xi + NW * u < ST::NDMA)
@@ -964,7 +969,9 @@ static int launch_wino_persist(const WinoParams& base, int N, bool two, hipStrea
         const double eff = (double)periods * units / ((double)rounds * slots * chunk);
         if (eff > best_eff + 0.02) { best_eff = eff; best_chunk = chunk; best_parts = parts; }
     }
-    if (best_eff < 0.9) return 0;
+    // measured (tools/exp_persist.py, profiles/r04_notes.md): two- to four-stage blocks gain 4 - 7 % wherever the cut keeps the slots busy; five to eight
+    // stages gain 3 - 5 % with long walks and an even cut, and lose 3 - 4 % with two periods per block (hr.b128) or an uneven cut (r152.l2.c2)
+    if (best_eff < 0.9 || (base.stages > 4 && (best_eff < 0.95 || best_chunk < 8))) return 0;
     WinoParams p = base;
     p.N = Pi; p.Mtiles = (int)Lt;
     p.pg = Pg; p.periods = periods; p.chunk = best_chunk;

@@ -44,11 +44,16 @@ struct WinoWgradParams {
 constexpr unsigned WWOOB = 0xFFFFFFFFu;
 typedef __attribute__((address_space(3))) void wwlds_void;
 
-template <int MO, int TK>
+// NBN = 2: 64 output channels per block (two 32-channel halves, 128 accumulator registers, two blocks per CU).  The kernel is bound by
+// vector-instruction issue, not by the matrix pipe (36 % busy in round 3: ~9 vector instructions per MFMA — tile addressing, the 8 + 4 LDS
+// reads and both transforms of every tile pair); with two halves the input side V = B^T d B of a tile pair — the expensive one — and the
+// tile addressing are formed once for twice the MFMAs, only the cheap gradient side Z = A dY A^T is formed per half.
+template <int MO, int TK, int NBN>
 __device__ __forceinline__ void winograd_wgrad_body(const WinoWgradParams& p, float* smem) {
     constexpr int NS = MO == 2 ? 3 : 2;                    // accumulator sets after the nu side of G
     constexpr int GP = TK * MO;                            // gradient pixels per stage row
-    constexpr int NLX = 6, NLG = (MO * GP * 8 + 255) / 256;   // DMA instructions per wave per stage, at most (x: ns <= 48)
+    constexpr int GC = 32 * NBN;                           // gradient channels staged per pixel
+    constexpr int NLX = 6, NLG = (MO * GP * 8 * NBN + 255) / 256;   // DMA instructions per wave per stage, at most (x: ns <= 48)
     const int tid = threadIdx.x, lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // block -> (n tile, c tile, phase, split), the channel tiles fastest: the blocks of one split read the same pixels
@@ -58,7 +63,7 @@ __device__ __forceinline__ void winograd_wgrad_body(const WinoWgradParams& p, fl
     const int phases = p.deconv ? 4 : 1;
     const int phase = bid % phases;
     const int split = bid / phases;
-    const int n0 = n_tile * 32, c0 = c_tile * 32;
+    const int n0 = n_tile * GC, c0 = c_tile * 32;
     const int py = phase >> 1, px = phase & 1;
     const int pad_y = p.deconv ? 1 - py : 1, pad_x = p.deconv ? 1 - px : 1;
     const int ooy = p.deconv ? py : 0, oox = p.deconv ? px : 0;
@@ -80,9 +85,9 @@ __device__ __forceinline__ void winograd_wgrad_body(const WinoWgradParams& p, fl
 #pragma unroll
     for (int u = 0; u < NLG; ++u) {
         const int q = (xi + 4 * u) * 64 + lane;
-        const int pix = q >> 3;
+        const int pix = q / (8 * NBN);
         const int a = pix / GP, sl = pix - a * GP;
-        gi_a[u] = a; gi_t[u] = sl / MO; gi_b[u] = sl - gi_t[u] * MO; gi_c[u] = n0 + (q & 7) * 4;
+        gi_a[u] = a; gi_t[u] = sl / MO; gi_b[u] = sl - gi_t[u] * MO; gi_c[u] = n0 + (q % (8 * NBN)) * 4;
     }
     auto stage_dma = [&](int buf, int t0) {
         float* Xs = smem + buf * p.stage_floats;
@@ -133,11 +138,13 @@ __device__ __forceinline__ void winograd_wgrad_body(const WinoWgradParams& p, fl
     const int ch = lane & 31, kh = lane >> 5;
     const int roa = ia * p.ns * 32, rob = ib * p.ns * 32;
 
-    f32x16 acc[4];
+    f32x16 acc[NBN][4];
 #pragma unroll
-    for (int nu = 0; nu < 4; ++nu)
+    for (int hh = 0; hh < NBN; ++hh)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[nu][e] = 0.f;
+        for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[hh][nu][e] = 0.f;
 
     if (t_begin < t_end) {
         stage_dma(0, t_begin);
@@ -166,20 +173,23 @@ __device__ __forceinline__ void winograd_wgrad_body(const WinoWgradParams& p, fl
 #pragma unroll
             for (int j = 0; j < 4; ++j) tc[j] = Xs[roa + sb + j * 32] + vs * Xs[rob + sb + j * 32];
             const float v0 = tc[0] - tc[2], v1 = tc[1] + tc[2], v2 = tc[2] - tc[1], v3 = tc[1] - tc[3];
-            float zr[MO];
 #pragma unroll
-            for (int b = 0; b < MO; ++b) {
-                float z = za[0] * Gs[(0 * GP + tk * MO + b) * 32 + ch] + za[1] * Gs[(1 * GP + tk * MO + b) * 32 + ch];
-                if (MO == 3) z += za[2] * Gs[(2 * GP + tk * MO + b) * 32 + ch];
-                zr[b] = z;
+            for (int hh = 0; hh < NBN; ++hh) {
+                float zr[MO];
+#pragma unroll
+                for (int b = 0; b < MO; ++b) {
+                    float z = za[0] * Gs[(0 * GP + tk * MO + b) * GC + 32 * hh + ch] + za[1] * Gs[(1 * GP + tk * MO + b) * GC + 32 * hh + ch];
+                    if (MO == 3) z += za[2] * Gs[(2 * GP + tk * MO + b) * GC + 32 * hh + ch];
+                    zr[b] = z;
+                }
+                float z0, z1, z2, z3;
+                if (MO == 2) { z0 = zr[0]; z1 = zr[0] + zr[1]; z2 = zr[0] - zr[1]; z3 = -zr[1]; }
+                else { z0 = zr[0]; z1 = zr[0] + zr[1] + zr[MO - 1]; z2 = zr[0] - zr[1] + zr[MO - 1]; z3 = zr[MO - 1]; }
+                acc[hh][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, v0, acc[hh][0], 0, 0, 0);
+                acc[hh][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, v1, acc[hh][1], 0, 0, 0);
+                acc[hh][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(z2, v2, acc[hh][2], 0, 0, 0);
+                acc[hh][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(z3, v3, acc[hh][3], 0, 0, 0);
             }
-            float z0, z1, z2, z3;
-            if (MO == 2) { z0 = zr[0]; z1 = zr[0] + zr[1]; z2 = zr[0] - zr[1]; z3 = -zr[1]; }
-            else { z0 = zr[0]; z1 = zr[0] + zr[1] + zr[MO - 1]; z2 = zr[0] - zr[1] + zr[MO - 1]; z3 = zr[MO - 1]; }
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, v0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, v1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(z2, v2, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(z3, v3, acc[3], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -192,9 +202,11 @@ __device__ __forceinline__ void winograd_wgrad_body(const WinoWgradParams& p, fl
     float* out = p.part + ((((long long)split * phases + phase) * NS) * 4 + xi) * ((long long)p.CnPad * p.CxPad);
     const long long set_stride = 4LL * p.CnPad * p.CxPad;
 #pragma unroll
+    for (int hh = 0; hh < NBN; ++hh)
+#pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int row = n0 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const float d0 = acc[0][e], d1 = acc[1][e], d2 = acc[2][e], d3 = acc[3][e];
+        const int row = n0 + 32 * hh + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const float d0 = acc[hh][0][e], d1 = acc[hh][1][e], d2 = acc[hh][2][e], d3 = acc[hh][3][e];
         float* o = out + (long long)row * p.CxPad + c0 + ch;
         o[0] = d0 + 0.5f * (d1 + d2);
         if (MO == 2) { o[set_stride] = 0.5f * (d1 - d2); o[2 * set_stride] = 0.5f * (d1 + d2) + d3; }
@@ -202,10 +214,10 @@ __device__ __forceinline__ void winograd_wgrad_body(const WinoWgradParams& p, fl
     }
 }
 
-template <int MO, int TK>
-__global__ __launch_bounds__(256, 3) void winograd_wgrad_kernel(WinoWgradParams p) {
+template <int MO, int TK, int NBN = 1>
+__global__ __launch_bounds__(256, NBN == 2 ? 2 : 3) void winograd_wgrad_kernel(WinoWgradParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    winograd_wgrad_body<MO, TK>(p, smem);
+    winograd_wgrad_body<MO, TK, NBN>(p, smem);
 }
 
 // Sum of the split partials in split order + the xi side of G^T . G, written in the filter's own layout:
@@ -278,18 +290,28 @@ __global__ __launch_bounds__(256) void winograd_wgrad_finish_kernel(const float*
     }
 }
 
-static std::atomic<unsigned> g_ww_lds_done[2];
+static std::atomic<unsigned> g_ww_lds_done[4];
+static std::atomic<int> g_ww_halves{2};            // vatl_tune_set(23, v): 32-channel gradient halves per block where the layer allows (1 or 2)
+int wino_wgrad_set_halves(int v) { g_ww_halves.store(v, std::memory_order_relaxed); return 0; }
+
 static std::atomic<int> g_ww_blocks{1024};         // target block count of a launch (vatl_tune_set(19, v))
 int wino_wgrad_set_blocks(int v) { g_ww_blocks.store(v, std::memory_order_relaxed); return 0; }
 
 constexpr int kWWTK = 8;
 constexpr int kWWMaxLds = 64 * 1024;
 
-struct WWPlan { int n_tiles, c_tiles, splits, tps, phases, ns; long long floats; };
+struct WWPlan { int n_tiles, c_tiles, splits, tps, phases, ns, nbn; long long floats; };
 
 static WWPlan ww_plan(int MO, int Cn, int Cx, long long Mtiles, int TW) {
     WWPlan q{};
-    q.n_tiles = cdiv(Cn, 32); q.c_tiles = cdiv(Cx, 32); q.phases = MO == 3 ? 4 : 1;
+    q.ns = (kWWTK - 1) * MO + 4 + (4 - MO) * ((TW + kWWTK - 2) / TW);
+    // two gradient halves per block where the channel count allows and both stages still fit the block's LDS
+    // (measured at B = 120, tools/wino_wgrad_bench.py --halves: 3x3 layers with 256 / 512 channels +3 .. +10 %, 128 channels -3 %, the transposed convs
+    // +-2 %: the second half's registers cost the third and fourth resident block, which is most of what the shared transform saves)
+    int nbn = (g_ww_halves.load(std::memory_order_relaxed) >= 2 && MO == 2 && Cn % 64 == 0 && Cn >= 256 && Cx >= 256) ? 2 : 1;
+    if (nbn == 2 && 2 * ((4 * q.ns * 8 + 63) / 64 + (MO * kWWTK * MO * 16 + 63) / 64) * 1024 > kWWMaxLds) nbn = 1;
+    q.nbn = nbn;
+    q.n_tiles = cdiv(Cn, 32 * nbn); q.c_tiles = cdiv(Cx, 32); q.phases = MO == 3 ? 4 : 1;
     const long long per_split = (long long)q.n_tiles * q.c_tiles * q.phases;
     // target block count: the knob for the 3x3 layers, 4x that for the transposed convs (B = 120, tools/wino_wgrad_bench.py: deconv3 1.03x
     // over the implicit GEMM at 1024 blocks, 1.13x at 2048, 1.16x at 4096; the 3x3 layers peak at 1024)
@@ -299,9 +321,8 @@ static WWPlan ww_plan(int MO, int Cn, int Cx, long long Mtiles, int TW) {
     const long long sps = (stages + want - 1) / want;      // stages per split
     q.tps = (int)(sps * kWWTK);
     q.splits = (int)((Mtiles + q.tps - 1) / q.tps);
-    q.ns = (kWWTK - 1) * MO + 4 + (4 - MO) * ((TW + kWWTK - 2) / TW);
     const int NS = MO == 2 ? 3 : 2;
-    q.floats = (long long)q.splits * q.phases * NS * 4 * (q.n_tiles * 32LL) * (q.c_tiles * 32LL);
+    q.floats = (long long)q.splits * q.phases * NS * 4 * (q.n_tiles * 32LL * nbn) * (q.c_tiles * 32LL);
     return q;
 }
 
@@ -321,21 +342,29 @@ static int winograd_wgrad_impl(const float* x, const float* g, float* dw, float*
     p.Mtiles = (int)mt;
     const WWPlan q = ww_plan(MO, Cn, Cx, mt, p.TW);
     p.n_tiles = q.n_tiles; p.c_tiles = q.c_tiles; p.splits = q.splits; p.tps = q.tps;
-    p.CnPad = q.n_tiles * 32; p.CxPad = q.c_tiles * 32;
+    const int nbn = q.nbn;
+    p.CnPad = q.n_tiles * 32 * nbn; p.CxPad = q.c_tiles * 32;
     p.RW = MO * p.TW + 4 - MO; p.ns = q.ns;
     p.ndma_x = (4 * p.ns * 8 + 63) / 64;
-    p.ndma_g = (MO * kWWTK * MO * 8 + 63) / 64;
+    p.ndma_g = (MO * kWWTK * MO * 8 * nbn + 63) / 64;
     p.g_floats_off = p.ndma_x * 256;
     p.stage_floats = (p.ndma_x + p.ndma_g) * 256;
     if (p.ndma_x > 24 || p.RW > 4096 || p.TH > 4096) return fail(VATL_EINVAL, "winograd_wgrad: image %dx%d outside the range of this route", H, W);
     p.OH = H * os; p.OW = W * os; p.os = os; p.deconv = MO == 3;
     p.inv_TW = 1.0f / (float)p.TW; p.inv_TH = 1.0f / (float)p.TH; p.inv_RW = 1.0f / (float)p.RW; p.inv_ns = 1.0f / (float)p.ns;
     p.x_bytes = (unsigned)(xe * 4); p.g_bytes = (unsigned)(ge * 4);
-    auto kern = winograd_wgrad_kernel<MO, kWWTK>;
-    if (int rc = ensure_dynamic_lds((const void*)kern, kWWMaxLds, g_ww_lds_done[MO - 2], "winograd_wgrad")) return rc;
     const int smem = 2 * p.stage_floats * (int)sizeof(float);
     if (smem > kWWMaxLds) return fail(VATL_EINVAL, "winograd_wgrad: %d bytes of LDS per block", smem);
-    hipLaunchKernelGGL(kern, dim3((unsigned)((long long)q.n_tiles * q.c_tiles * q.phases * q.splits)), dim3(256), smem, st, p);
+    const dim3 grid((unsigned)((long long)q.n_tiles * q.c_tiles * q.phases * q.splits));
+    if (nbn == 2) {
+        auto kern = winograd_wgrad_kernel<MO, kWWTK, 2>;
+        if (int rc = ensure_dynamic_lds((const void*)kern, kWWMaxLds, g_ww_lds_done[2 + MO - 2], "winograd_wgrad")) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+    } else {
+        auto kern = winograd_wgrad_kernel<MO, kWWTK, 1>;
+        if (int rc = ensure_dynamic_lds((const void*)kern, kWWMaxLds, g_ww_lds_done[MO - 2], "winograd_wgrad")) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+    }
     meter_add(1, 2.0 * (double)p.CnPad * p.CxPad * 16.0 * q.phases * (double)((mt + kWWTK - 1) / kWWTK * kWWTK));
     if (int rc = check_launch("winograd_wgrad")) return rc;
     hipLaunchKernelGGL(winograd_wgrad_finish_kernel<MO>, dim3((unsigned)((long long)q.phases * Cn * ((Cx + 63) / 64))), dim3(256), 0, st, workspace, dw, Cn, Cx,

@@ -154,6 +154,8 @@ def lib() -> C.CDLL:
             l.vatl_tune_set(18, int(os.environ["VATL_WINO_GROUP_KB"]))
         if os.environ.get("VATL_WINO_HALVES"):       # 32-channel filter halves per Winograd block: 1, or 2 where the layer allows (results are identical)
             l.vatl_tune_set(21, int(os.environ["VATL_WINO_HALVES"]))
+        if os.environ.get("VATL_WINO_PERSIST"):      # 3x3 layers with at most this many 16-channel stages take the persistent Winograd route; 0 = never (results are identical)
+            l.vatl_tune_set(22, int(os.environ["VATL_WINO_PERSIST"]))
     return _lib
 
 
