@@ -175,50 +175,119 @@ __global__ __launch_bounds__(256) void peaks5_wave_kernel(const float* __restric
                                                           long long planes) {
     constexpr int D = 5, H = 64;
     static_assert(W % 4 == 0 && W > 2 * D && W <= 64, "row of W floats per lane");
+    // Round 4: the 11 x 11 maximum filter as two in-register passes of the doubling scheme (windows of 2, 4, 8, then 8 + 4 overlapping = 11:
+    // 4 max operations per pixel and pass instead of 10), the COLUMN pass on a transposed copy of the plane — written row-wise to a
+    // wave-private LDS tile (pitch W + 4 floats: conflict-free both ways), read column-wise (lane = column), filtered, written back and
+    // read row-wise again — instead of six lane shuffles and eight max / select operations per pixel.  Round 3's kernel was bound by its
+    // ~1200 vector and ~290 LDS-permute instructions per plane (2.1 TB/s); this one issues ~600 + ~150.  Same window maxima (max is
+    // associative; fmaxf treats a NaN as missing in any order), same candidates, same greedy selection.
+    constexpr int P = W + 4;
+    extern __shared__ __attribute__((aligned(16))) float tile_all[];
     const int lane = threadIdx.x & 63;
+    float* tile = tile_all + (threadIdx.x >> 6) * (H * P);
     const long long plane = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (plane >= planes) return;
-    // (staging the plane through a padded LDS tile for fully coalesced HBM reads measured SLOWER, 505 us against 437 us per 4096
-    // items: the kernel is bound by its ~500 max / compare operations and ~290 lane shuffles per plane, not by the row-strided loads)
     const float* src = hm + plane * (H * W) + lane * W;
     float v[W];
 #pragma unroll
     for (int k = 0; k < W / 4; ++k) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * k);
         v[4 * k] = t[0]; v[4 * k + 1] = t[1]; v[4 * k + 2] = t[2]; v[4 * k + 3] = t[3];
+        *reinterpret_cast<f32x4*>(tile + lane * P + 4 * k) = t;
     }
     float mn = v[0];
 #pragma unroll
     for (int x = 1; x < W; ++x) mn = fminf(mn, v[x]);
     mn = -wave_max(-mn);
-    // row pass: h[x] = max v[max(0,x-D) .. min(W-1,x+D)]
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // column pass (lane = column x < W): c[y] = max over rows y - 5 .. y + 5 inside the plane
+    if (lane < W) {
+        float c[H];
+#pragma unroll
+        for (int y = 0; y < H; ++y) c[y] = tile[y * P + lane];
+        float a2[H], a4[H], a8[H];                         // maxima of the windows [y, y + 2), [y, y + 4), [y, y + 8) clipped at the last row
+#pragma unroll
+        for (int y = 0; y < H; ++y) a2[y] = y + 1 < H ? fmaxf(c[y], c[y + 1]) : c[y];
+#pragma unroll
+        for (int y = 0; y < H; ++y) a4[y] = y + 2 < H ? fmaxf(a2[y], a2[y + 2]) : a2[y];
+#pragma unroll
+        for (int y = 0; y < H; ++y) a8[y] = y + 4 < H ? fmaxf(a4[y], a4[y + 4]) : a4[y];
+#pragma unroll
+        for (int y = 0; y < H; ++y) {
+            // rows y - 5 .. y + 5 = [s, s + 8) U [y + 2, y + 6) with s = y - 5; at the top the window starts at row 0 and is shorter
+            float m;
+            if (y >= D) m = y + 2 < H ? fmaxf(a8[y - D], a4[y + 2]) : a8[y - D];
+            else if (y + D + 1 >= 8) m = fmaxf(a8[0], a4[y + 2]);                  // [0, 8) U [y + 2, y + 6)   (y = 2 .. 4)
+            else m = fmaxf(a4[0], a4[y + 2]);                                       // [0, 4) U [y + 2, y + 6)   (y = 0, 1: windows of 6 / 7 rows)
+            tile[y * P + lane] = m;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // row pass (lane = row y) on the column maxima
     float h[W];
 #pragma unroll
-    for (int x = 0; x < W; ++x) {
-        float m = v[x];
-#pragma unroll
-        for (int d = 1; d <= D; ++d) {
-            if (x - d >= 0) m = fmaxf(m, v[x - d]);
-            if (x + d < W) m = fmaxf(m, v[x + d]);
-        }
-        h[x] = m;
+    for (int k = 0; k < W / 4; ++k) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tile + lane * P + 4 * k);
+        h[4 * k] = t[0]; h[4 * k + 1] = t[1]; h[4 * k + 2] = t[2]; h[4 * k + 3] = t[3];
     }
-    // column pass across lanes
-    auto dn = [&](float a, int k) { const float t = __shfl(a, (lane + k) & 63, 64); return lane + k < H ? t : -INFINITY; };
-    auto up = [&](float a, int k) { const float t = __shfl(a, (lane - k) & 63, 64); return lane - k >= 0 ? t : -INFINITY; };
-    const bool row_in = lane >= D && lane < H - D;
     float cand[W];
+    {
+        float b2[W], b4[W], b8[W];
 #pragma unroll
-    for (int x = 0; x < W; ++x) {
-        const float c2 = fmaxf(h[x], dn(h[x], 1));           // rows y .. y+1
-        const float c4 = fmaxf(c2, dn(c2, 2));               // y .. y+3
-        const float e2 = fmaxf(h[x], up(h[x], 1));           // y-1 .. y
-        const float e4 = fmaxf(e2, up(e2, 2));               // y-3 .. y
-        const float m = fmaxf(fmaxf(c4, dn(c2, 4)), fmaxf(e4, up(e2, 4)));   // y .. y+5 and y-5 .. y
-        const bool inside = row_in && x >= D && x < W - D;
-        cand[x] = (inside && v[x] == m && v[x] > mn) ? v[x] : -INFINITY;
+        for (int x = 0; x < W; ++x) b2[x] = x + 1 < W ? fmaxf(h[x], h[x + 1]) : h[x];
+#pragma unroll
+        for (int x = 0; x < W; ++x) b4[x] = x + 2 < W ? fmaxf(b2[x], b2[x + 2]) : b2[x];
+#pragma unroll
+        for (int x = 0; x < W; ++x) b8[x] = x + 4 < W ? fmaxf(b4[x], b4[x + 4]) : b4[x];
+        const bool row_in = lane >= D && lane < H - D;
+#pragma unroll
+        for (int x = D; x < W - D; ++x) {                  // candidates exist inside the border only: there the window is never clipped on the left
+            const float m = fmaxf(b8[x - D], b4[x + 2]);
+            cand[x] = (row_in && v[x] == m && v[x] > mn) ? v[x] : -INFINITY;
+        }
+#pragma unroll
+        for (int x = 0; x < D; ++x) { cand[x] = -INFINITY; cand[W - 1 - x] = -INFINITY; }
     }
     float pv[5]; int pi[5]; int n = 0;
+    // Greedy selection.  A plane has few candidates (maxima of 11 x 11 windows: typically 10 - 25): they are compacted into a list of at most
+    // 64 — one per lane, in LDS where the tile was — and the five rounds run on ONE value per lane (wave arg-max + one distance test) instead
+    // of re-scanning 48 registers per lane and round, which was two thirds of this kernel's vector instructions.  Planes with more than 64
+    // candidates (plateaus of equal values) take the register scan below.  Same order either way: value descending, flat index ascending.
+    int mine = 0;
+#pragma unroll
+    for (int x = D; x < W - D; ++x) mine += cand[x] > -INFINITY ? 1 : 0;
+    int incl = mine;                                       // inclusive prefix sum over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    const int total = __shfl(incl, 63, 64);
+    if (total <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                   // every lane has read its row of the tile
+        int pos = incl - mine;
+#pragma unroll
+        for (int x = D; x < W - D; ++x)
+            if (cand[x] > -INFINITY) { tile[pos] = cand[x]; reinterpret_cast<int*>(tile)[64 + pos] = lane * W + x; ++pos; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float cv = lane < total ? tile[lane] : -INFINITY;
+        const int ci = lane < total ? reinterpret_cast<const int*>(tile)[64 + lane] : 0x7FFFFFFF;
+        const int cy = ci / W, cx = ci - cy * W;
+#pragma unroll 1
+        for (int k = 0; k < 5; ++k) {
+            float bv = cv; int bi = cv > -INFINITY ? ci : 0x7FFFFFFF;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (bv == -INFINITY) break;
+            pv[n] = bv; pi[n] = bi; ++n;
+            const int by = bi / W, bx = bi - by * W;
+            if (abs(cy - by) < D && abs(cx - bx) < D) cv = -INFINITY;
+        }
+    } else {
 #pragma unroll 1
     for (int k = 0; k < 5; ++k) {
         float bv = -INFINITY; int bi = 0x7FFFFFFF;
@@ -238,6 +307,7 @@ __global__ __launch_bounds__(256) void peaks5_wave_kernel(const float* __restric
             for (int x = 0; x < W; ++x)
                 if (abs(x - bx) < D) cand[x] = -INFINITY;
         }
+    }
     }
     if (lane == 0) {
         npeaks[plane] = n;
@@ -376,8 +446,8 @@ extern "C" int vatl_peaks5(const float* hm, float* peak_val, int32_t* peak_idx, 
     if (min_distance < 1 || H <= 2 * min_distance || W <= 2 * min_distance) return fail(VATL_EINVAL, "peaks5: %dx%d plane too small for min_distance %d", H, W, min_distance);
     if (H == 64 && W == 48 && min_distance == 5 && (((uintptr_t)hm) & 15) == 0) {      // the shipped heat-map size: one wave per plane
         const long long planes = (long long)N * J;
-        hipLaunchKernelGGL(peaks5_wave_kernel<48>, dim3((unsigned)cdiv(planes, 4)), dim3(256), 0, (hipStream_t)stream, hm, peak_val, peak_idx, npeaks, mpe,
-                           margin, planes);
+        hipLaunchKernelGGL(peaks5_wave_kernel<48>, dim3((unsigned)cdiv(planes, 4)), dim3(256), 4 * 64 * (48 + 4) * sizeof(float), (hipStream_t)stream, hm, peak_val,
+                           peak_idx, npeaks, mpe, margin, planes);
         return check_launch("peaks5");
     }
     const size_t smem = 2 * (size_t)H * W * sizeof(float);
