@@ -644,7 +644,7 @@ def gen_hostaug(out: str):
 # MPE / Margin pinned on the real scikit-image found in this image (row a13)
 # ----------------------------------------------------------------------------
 
-SKIMAGE_ROOT = "/opt/conda/lib/python3.9/site-packages/skimage"
+SKIMAGE_ROOT = os.environ.get("VATL_SKIMAGE_ROOT", "/opt/conda/lib/python3.9/site-packages/skimage")   # a scikit-image SOURCE tree (0.18.3 in the build image; the reference pins 0.24: regenerate with VATL_SKIMAGE_ROOT=<its tree> when one is at hand)
 
 
 def load_real_skimage_peak(root: str = SKIMAGE_ROOT):
