@@ -44,14 +44,15 @@ def main():
             f = lambda: vh.conv3x3_winograd_fwd(x, u, sc, bi, cout, True, residual=r, out=y)
             ts = {}
             for rep in range(2):
-                for v in (0, 128):
-                    vh.tune_set(22, v)
+                for v, pf in ((0, 0), (128, 0), (128, 3)):
+                    vh.tune_set(22, v); vh.tune_set(24, pf)
                     t = timed(f, 10)
-                    ts.setdefault(v, []).append(t)
-                    route = lib.vatl_winograd_last_route()
-            vh.tune_set(22, 8)
-            a, c = min(ts[0]), min(ts[128])
-            print(f"{name:11s} B={b:5d} plain {a:8.1f} us  persistent {c:8.1f} us (route {route})  {a / c:5.2f}x", flush=True)
+                    ts.setdefault((v, pf), []).append(t)
+                    if v:
+                        route = lib.vatl_winograd_last_route()
+            vh.tune_set(22, 8); vh.tune_set(24, 2)
+            a, c, d = min(ts[(0, 0)]), min(ts[(128, 0)]), min(ts[(128, 3)])
+            print(f"{name:11s} B={b:5d} plain {a:8.1f} us  persistent {c:8.1f} us ({a / c:4.2f}x)  persistent + prefetch {d:8.1f} us ({a / d:4.2f}x)  route {route}", flush=True)
 
 
 if __name__ == "__main__":

@@ -592,7 +592,11 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
 // period has the same geometry, so a block computes it ONCE — staging offsets, fragment addresses, store offsets, masks — keeps it in
 // registers and walks the periods by advancing the base addresses of its buffer descriptors (scalar work).  Per-tile arithmetic, stage
 // order and summation order are those of winograd_body: bit-identical results.
-template <int NB>
+// PF (two blocks per CU): the output-transform tiles get their own LDS region instead of lying over the stage buffers, so the first two stages and
+// the first filter fragments of the NEXT period are requested right after the last stage of this one and land while its write-out runs; without
+// it every period starts by waiting for its first loads (s_waitcnt share of the wave time 24 -> 36 % against the plain kernel, which hides them
+// behind its 440 set-up instructions).
+template <int NB, bool PF>
 __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float* smem) {
     constexpr int MO = 2, NT = 256, BN = 32 * NB, NW = 4;
     using ST = WinoStage<MO>;
@@ -617,8 +621,10 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
     // The geometry of the block — staging offsets, fragment addresses, store offsets: 16 words per thread — is parked in LDS behind the stage
     // buffers and read back at the top of every period (staging / fragment part) and before the write-out (store part): as plain loop invariants
     // these 13 values stay live across the MFMA loop AND the write-out, and the two-half kernel spilled 22 - 53 registers into the stage loop.
-    static_assert(W_NLD <= 8, "geometry record layout");
-    wu32x4* Gs = reinterpret_cast<wu32x4*>(smem + W_ZERO + 2 * STAGE);          // [4][256 threads] x 16 bytes: goff[0..3] | goff[4..7] | ra[0..3] | off[0..3]
+    static_assert(W_NLD <= 5, "geometry record layout");
+    constexpr int PS_FLOATS = 4 * MO * W_TB * W_LDP;
+    float* const Ps = PF ? smem + W_ZERO + 2 * STAGE : smem;                     // output-transform tiles [xi][b][tile][32 channels]
+    wu32x4* Gs = reinterpret_cast<wu32x4*>(smem + W_ZERO + 2 * STAGE + (PF ? PS_FLOATS : 0));   // [3][256 threads] x 16 bytes: goff[0..3] | goff[4], ra[0..3] as 16-bit pairs | off[0..3]
     unsigned g0[8] = {WOOB, WOOB, WOOB, WOOB, WOOB, WOOB, WOOB, WOOB};
 #pragma unroll
     for (int u = 0; u < W_NLD; ++u) {
@@ -643,7 +649,6 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
             g0[u] = (unsigned)(((b * p.H + yy) * p.W + xx) * p.Cin + chunk * 4) << 2;
     }
     Gs[tid] = wu32x4{g0[0], g0[1], g0[2], g0[3]};
-    Gs[NT + tid] = wu32x4{g0[4], g0[5], g0[6], g0[7]};
     // ---- fragment addressing ----
     const int h = lane >> 5;
     {
@@ -657,7 +662,7 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
             const int q = tl + j / MO;
             ra[j] = (unsigned)xx < (unsigned)p.W ? ((j % MO) * W_NQ + q) * W_CK + ((h ^ ((q >> 2) & 3)) << 2) : -W_ZERO;
         }
-        Gs[2 * NT + tid] = wu32x4{(unsigned)ra[0], (unsigned)ra[1], (unsigned)ra[2], (unsigned)ra[3]};
+        Gs[NT + tid] = wu32x4{g0[4], ((unsigned)ra[0] & 0xFFFFu) | ((unsigned)ra[1] << 16), ((unsigned)ra[2] & 0xFFFFu) | ((unsigned)ra[3] << 16), 0u};
     }
     const int ia = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
     const int ib = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
@@ -689,7 +694,7 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
                 o4[u * MO + a] = (xx < p.W && yy < p.H) ? (unsigned)(((b * p.H + yy) * p.W + xx) * p.Cout + n0 + c4 * 4) << 2 : WOOB;
             }
         }
-        Gs[3 * NT + tid] = o4;
+        Gs[2 * NT + tid] = o4;
     }
     const f32x4 one = {1.f, 1.f, 1.f, 1.f}, nul = {0.f, 0.f, 0.f, 0.f};
     const float lo = p.relu ? 0.f : -INFINITY;
@@ -711,6 +716,33 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
         for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? o + nu * unu : WOOB);
     };
 
+    // requests of a period's first two stages + first filter fragments (PF: issued during the write-out of the period before)
+    f32x4 ua[4], ub[4];
+    auto first_requests = [&](int it) {
+        const __amdgpu_buffer_rsrc_t xq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (long long)it * p.x_period_floats), 0, p.x_bytes, 0x00020000);
+        u_load_h(ua, 0, 0);
+        int tid_p = tid;
+        asm volatile("" : "+v"(tid_p));
+        const wu32x4 ga = Gs[tid_p], gb = Gs[NT + tid_p];
+        unsigned goff[5];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) goff[k] = ga[k];
+        goff[4] = gb[0];
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+            if (st < p.stages) {
+#pragma unroll
+                for (int u = 0; u < W_NLD; ++u)
+                    if (xi + NW * u < ST::NDMA)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xq, (wlds_void*)(Rs + st * STAGE + (xi + NW * u) * 256), 16,
+                                                                 goff[u] != WOOB ? goff[u] + (unsigned)st * (W_CK * 4) : WOOB, 0, 0, 0);
+            }
+    };
+    if constexpr (PF) {
+        if (tid < W_ZERO / 4) *reinterpret_cast<f32x4*>(&smem[tid * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        first_requests(it0);
+    }
+
     for (int it = it0; it < it1; ++it) {
         // the period's tensors: base pointers advance, offsets stay (32-bit offsets inside a period-aligned window of the tensor)
         const float* xb = p.x + (long long)it * p.x_period_floats;
@@ -721,9 +753,9 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
         asm volatile("" : "+v"(tid_o));                    // (opaque: the reads below are per period, not hoisted)
         int ra[4];
         {
-            const wu32x4 gc = Gs[2 * NT + tid_o];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ra[k] = (int)gc[k];
+            const wu32x4 gc = Gs[NT + tid_o];
+            ra[0] = (int)(short)(gc[1] & 0xFFFFu); ra[1] = (int)(short)(gc[1] >> 16);
+            ra[2] = (int)(short)(gc[2] & 0xFFFFu); ra[3] = (int)(short)(gc[2] >> 16);
         }
         auto make_v = [&](f32x4 (&v)[4], const float* Rb, int x8) {
             f32x4 tc[4];
@@ -741,20 +773,22 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
             int tid_p = tid_o;
             asm volatile("" : "+v"(tid_p));
             const wu32x4 ga = Gs[tid_p], gb = Gs[NT + tid_p];
-            unsigned goff[8];
+            unsigned goff[5];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { goff[k] = ga[k]; goff[4 + k] = gb[k]; }
+            for (int k = 0; k < 4; ++k) goff[k] = ga[k];
+            goff[4] = gb[0];
 #pragma unroll
             for (int u = 0; u < W_NLD; ++u)
                 if (xi + NW * u < ST::NDMA)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (wlds_void*)(Rs + buf * STAGE + (xi + NW * u) * 256), 16,
                                                              goff[u] != WOOB ? goff[u] + (unsigned)st * (W_CK * 4) : WOOB, 0, 0, 0);
         };
-        f32x4 ua[4], ub[4];
-        u_load_h(ua, 0, 0);
-        stage_dma(0, 0);
-        if (p.stages > 1) stage_dma(1, 1);
-        if (tid < W_ZERO / 4) *reinterpret_cast<f32x4*>(&smem[tid * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};   // (the output-transform tiles of the period before lay over the zero pixel)
+        if constexpr (!PF) {
+            u_load_h(ua, 0, 0);
+            stage_dma(0, 0);
+            if (p.stages > 1) stage_dma(1, 1);
+            if (tid < W_ZERO / 4) *reinterpret_cast<f32x4*>(&smem[tid * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};   // (the output-transform tiles of the period before lay over the zero pixel)
+        }
         f32x16 accs[NB][4];
 #pragma unroll
         for (int hh = 0; hh < NB; ++hh)
@@ -820,7 +854,7 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
         // (the write-out's LDS addresses are formed from the opaque copy of the thread id too: as loop invariants hipcc would keep all ~40 of
         // them in registers across the MFMA loop)
         const int lane_o = tid_o & 63, c4o = tid_o % C4;
-        const wu32x4 o4 = Gs[3 * NT + tid_o];
+        const wu32x4 o4 = Gs[2 * NT + tid_o];
         unsigned off[MO][MO];
 #pragma unroll
         for (int u = 0; u < MO; ++u)
@@ -840,7 +874,10 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
                 for (int a = 0; a < MO; ++a)
                     rs[u][a] = rb ? wbuf_load4(rr, (nvh[hh] && off[u][a] != WOOB) ? off[u][a] + hoff : WOOB) : nul;
             __builtin_amdgcn_sched_barrier(0);
-            float* Ps = smem;
+            if constexpr (PF) {                            // the stage buffers are free (barrier after the last stage), this half's skip-connection values are requested
+                if (hh == 0 && it + 1 < it1) first_requests(it + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             {
                 const int cl = lane_o & 31;
 #pragma unroll
@@ -875,10 +912,10 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
     }
 }
 
-template <int NB>
-__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void winograd_persist_kernel(WinoParams p) {
+template <int NB, bool PF>
+__global__ __launch_bounds__(256, (NB == 2 || PF) ? 2 : 3) void winograd_persist_kernel(WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    winograd_persist_body<NB>(p, smem);
+    winograd_persist_body<NB, PF>(p, smem);
 }
 
 // GATHER: the data gradient of the transposed conv (reduction over the four pixel phases of dz x channels); a separate instantiation —
@@ -921,7 +958,9 @@ int wino_set_ablate(int bits) { g_wino_ablate.store(bits, std::memory_order_rela
 
 static std::atomic<int> g_wino_persist{8};         // vatl_tune_set(22, v): 3x3 layers with at most v 16-channel stages take the persistent route (0 = never)
 int wino_set_persist(int v) { g_wino_persist.store(v, std::memory_order_relaxed); return 0; }
-static std::atomic<unsigned> g_wino_persist_lds_done[2];
+static std::atomic<unsigned> g_wino_persist_lds_done[4];
+static std::atomic<int> g_wino_persist_pf{2};      // vatl_tune_set(24, bits): 1 = prefetching variant for one-half blocks (two blocks per CU instead of three), 2 = for two-half blocks
+int wino_set_persist_pf(int v) { g_wino_persist_pf.store(v, std::memory_order_relaxed); return 0; }
 
 constexpr int kWinoMaxLds = 64 * 1024;            // upper bound of a block's dynamic LDS (ns <= 128: two 32 KB stages)
 
@@ -955,7 +994,7 @@ static int launch_wino_persist(const WinoParams& base, int N, bool two, hipStrea
     if (periods < 8 || Pg > 4096) return 0;
     const int NBh = two ? 2 : 1;
     const int n_tiles = cdiv(base.Cout, 32 * NBh);
-    const int units = Pg * n_tiles, slots = two ? 512 : 768;
+    const int units = Pg * n_tiles, slots = (two || (g_wino_persist_pf.load(std::memory_order_relaxed) & 1)) ? 512 : 768;
     if (units > slots) return 0;
     // whole rounds of resident blocks: k rounds -> at most k * slots / units parts; keep the cut with the best slot occupancy
     int best_chunk = 0, best_parts = 0;
@@ -981,17 +1020,18 @@ static int launch_wino_persist(const WinoParams& base, int N, bool two, hipStrea
     p.x_bytes = (unsigned)(p.x_period_floats * 4); p.y_bytes = (unsigned)(p.y_period_floats * 4);
     p.d_grp = make_fastdiv((unsigned)units); p.d_ntiles = make_fastdiv((unsigned)n_tiles);
     const int loop = W_ZERO + 2 * WinoStage<2>::FLOATS, epi = 4 * 2 * W_TB * W_LDP;
-    const int smem = (std::max(loop, epi) + 4 * 256 * 4) * (int)sizeof(float);  // + the geometry records of the 256 threads (behind the stage buffers)
+    const int pfbits = g_wino_persist_pf.load(std::memory_order_relaxed);
+    const bool pf = two ? (pfbits & 2) != 0 : (pfbits & 1) != 0;
+    // geometry records of the 256 threads behind the stage buffers (PF: behind the output-transform tiles, which then have a region of their own)
+    const int smem = ((pf ? loop + epi : std::max(loop, epi)) + 3 * 256 * 4) * (int)sizeof(float);
     const unsigned grid = (unsigned)(best_parts * units);
-    if (two) {
-        auto kern = winograd_persist_kernel<2>;
-        if (int rc = ensure_dynamic_lds((const void*)kern, kWinoMaxLds, g_wino_persist_lds_done[1], "winograd_persist")) return rc;
+    auto go = [&](auto kern, int slot) -> int {
+        if (int rc = ensure_dynamic_lds((const void*)kern, 96 * 1024, g_wino_persist_lds_done[slot], "winograd_persist")) return rc;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p);
-    } else {
-        auto kern = winograd_persist_kernel<1>;
-        if (int rc = ensure_dynamic_lds((const void*)kern, kWinoMaxLds, g_wino_persist_lds_done[0], "winograd_persist")) return rc;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, p);
-    }
+        return 0;
+    };
+    if (int rc = two ? (pf ? go(winograd_persist_kernel<2, true>, 3) : go(winograd_persist_kernel<2, false>, 1))
+                     : (pf ? go(winograd_persist_kernel<1, true>, 2) : go(winograd_persist_kernel<1, false>, 0))) return rc;
     meter_add(1, 2.0 * ((double)periods * Lt) * ((double)n_tiles * 32 * NBh) * 16.0 * ((double)base.stages * W_CK));
     *covered = periods * Pi;
     return check_launch("winograd_persist");

@@ -156,6 +156,8 @@ def lib() -> C.CDLL:
             l.vatl_tune_set(21, int(os.environ["VATL_WINO_HALVES"]))
         if os.environ.get("VATL_WINO_PERSIST"):      # 3x3 layers with at most this many 16-channel stages take the persistent Winograd route; 0 = never (results are identical)
             l.vatl_tune_set(22, int(os.environ["VATL_WINO_PERSIST"]))
+        if os.environ.get("VATL_WINO_PERSIST_PF"):   # bit 0 / 1: the prefetching variant of the persistent route for one- / two-half blocks (results are identical)
+            l.vatl_tune_set(24, int(os.environ["VATL_WINO_PERSIST_PF"]))
     return _lib
 
 
