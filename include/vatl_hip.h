@@ -61,6 +61,17 @@ int vatl_pack_conv_weight(const float* w_oihw, float* w_packed, int Cout, int Ci
  * filters [phase=py*2+px][CoutPad][ty][tx][Cin] with ky = 3-py-2*ty, kx = 3-px-2*tx.
  * simplepose.py:39-46. */
 int vatl_pack_deconv4x4s2_weight(const float* w_iohw, float* w_packed, int Cin, int Cout, int CoutPad, void* stream);
+/* The ResNet stem for inference in one launch: NCHW crops -> conv 7x7 / stride 2 / pad 3 (3 -> 64, bias-free) -> folded BatchNorm ->
+ * ReLU -> max-pool 3x3 / stride 2 / pad 1 -> NHWC (N, H/4, W/4, 64)  (Resnet.py:155-158, 171-172: conv1, bn1, relu, maxpool).  The
+ * filter is packed once by vatl_pack_stem_pool_weight from the (64,3,7,7) OIHW weight into vatl_stem_pool_weight_floats() floats;
+ * scale / bias = vatl_bn_fold of bn1.  Served sizes: vatl_stem_pool_supported(H, W) != 0 (W / 2 in {32, 64, 96}, H % 4 == 0; 256x192
+ * crops: yes, 384x288: no — callers keep vatl_nchw_to_nhwc + vatl_conv2d_fwd + vatl_maxpool3x3s2_fwd there).  x must be 8-byte aligned. */
+int64_t vatl_stem_pool_weight_floats(void);
+int vatl_pack_stem_pool_weight(const float* w_oihw, float* packed, void* stream);
+int vatl_stem_pool_supported(int H, int W);
+int vatl_stem7x7s2_pool_fwd(const float* x_nchw, const float* w_packed, const float* scale, const float* bias, float* y_nhwc,
+                            int N, int H, int W, void* stream);
+
 /* Eval-mode BatchNorm2d as a per-channel affine: scale = gamma/sqrt(var+eps),
  * bias = beta - mean*scale (Resnet.py:67,98,100,155; simplepose.py:41,44,47).
  * gamma/beta may be NULL (then 1 / 0); conv_bias (may be NULL) is folded in:

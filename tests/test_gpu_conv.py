@@ -672,3 +672,50 @@ def test_full_video_stream_spot_checks(vh):
         prev = hmc[i - 1] if ip[i] else None
         nxt = hmc[i + 1] if inx[i] else None
         np.testing.assert_allclose(float(s.thc[i]), scorers.thc_item(hmc[i], prev, nxt, bool(ip[i]), bool(inx[i]), "L1"), rtol=1e-5)
+
+
+def test_fused_stem_pool_kernel_vs_float64_and_the_three_launch_path(vh):
+    """vatl_stem7x7s2_pool_fwd: NCHW crops -> conv7x7/2 + folded BN + ReLU + maxpool3x3/2 -> NHWC in one launch (csrc/stem_pool.hip), against float64
+    (conv + affine + relu + max_pool2d of torch on the CPU) and against the three-launch path it replaces (same values to fp32 rounding: K is summed in
+    another order), for the three served widths, batch sizes that take 1 .. 16 row bands per image, and with a crop's bits independent of its batch."""
+    g = torch.Generator(device="cpu").manual_seed(41)
+    w = (torch.randn((64, 3, 7, 7), generator=g) * (2.0 / 147) ** 0.5)
+    sc = torch.rand(64, generator=g) + 0.5
+    bi = torch.randn(64, generator=g) * 0.5
+    wd, scd, bid = w.to(dev()), sc.to(dev()), bi.to(dev())
+    pw = vh.pack_stem_pool_weight(wd)
+    wp = vh.pack_conv_weight(torch.cat([wd, torch.zeros((64, 1, 7, 7), device=dev())], 1)) if False else None
+    for n, h, wdt in ((3, 256, 192), (40, 64, 128), (1, 32, 64), (600, 16, 192), (5, 256, 192)):
+        assert vh.stem_pool_supported(h, wdt)
+        x = torch.rand((n, 3, h, wdt), generator=g) - 0.45
+        got = vh.stem_pool_fwd(x.to(dev()), pw, scd, bid)
+        assert got.shape == (n, h // 4, wdt // 4, 64)
+        k = min(n, 3)
+        ref = F.conv2d(x[:k].double(), w.double(), None, 2, 3) * sc.double().view(1, -1, 1, 1) + bi.double().view(1, -1, 1, 1)
+        ref = F.max_pool2d(ref.clamp_min(0), 3, 2, 1).permute(0, 2, 3, 1).numpy()
+        e = rel_err(got[:k].cpu().numpy(), ref)
+        record(f"stem_pool_{n}x{h}x{wdt}", rel=e)
+        assert e < TOL, (n, h, wdt, e)
+        solo = vh.stem_pool_fwd(x[n - 1:n].contiguous().to(dev()), pw, scd, bid)       # another band cut, same bits
+        assert torch.equal(solo[0], got[n - 1])
+    assert not vh.stem_pool_supported(384, 288) and not vh.stem_pool_supported(256, 200) and not vh.stem_pool_supported(258, 192)
+    with pytest.raises(vh.VatlError):
+        vh.stem_pool_fwd(torch.zeros((1, 3, 384, 288), device=dev()), pw, scd, bid)
+    # the plan: fused stem on and off give the same heat-maps to rounding, arg-max identical
+    from alphapose.models import hip_engine
+    m = _build_simplepose()
+    xs = to_dev(synth.crops(20))
+    out_f, out_3 = torch.empty((20, 17, 64, 48), device=dev()), torch.empty((20, 17, 64, 48), device=dev())
+    with torch.no_grad():
+        hip_engine.forward_into(m, xs, out_f)
+        plan = hip_engine._plan_for(m, dev())
+        keep, plan.trunk.stem_pw = plan.trunk.stem_pw, None
+        assert keep is not None
+        try:
+            hip_engine.forward_into(m, xs, out_3)
+        finally:
+            plan.trunk.stem_pw = keep
+    assert not torch.equal(out_f, out_3)                    # (another summation order really ran)
+    e = rel_err(out_f.cpu().numpy(), out_3.cpu().numpy())
+    record("stem_pool_plan_vs_three_launches", rel=e)
+    assert e < 1e-5 and torch.equal(out_f.flatten(2).argmax(2), out_3.flatten(2).argmax(2))

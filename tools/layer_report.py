@@ -48,10 +48,10 @@ def layers(B, fused=False):
 def main():
     path = sys.argv[1]
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "gemm1x1_persistent" in r["Kernel_Name"] or "winograd_kernel" in r["Kernel_Name"] or "winograd_persist_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "gemm1x1_persistent" in r["Kernel_Name"] or "winograd_kernel" in r["Kernel_Name"] or "winograd_persist_kernel" in r["Kernel_Name"] or "stem_pool_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     import re
-    is_stem = lambda name: bool(re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, true", name))
+    is_stem = lambda name: bool(re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, true", name)) or "stem_pool_kernel" in name   # (the fused stem launch includes bn1 + relu + maxpool)
     per_step = sum(1 for r in rows if is_stem(r["Kernel_Name"]))                                     # one stem launch per forward
     fused = per_step > 0 and len(rows) // per_step == 53
     L = layers(B, fused)

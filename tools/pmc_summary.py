@@ -38,7 +38,7 @@ def main():
         kernels[k] = {"launches_per_step": n // steps,
                       "read_bytes_per_step": int(fetch[k][1] * 1024 * 2 / steps),      # x2: gfx950 FETCH_SIZE correction
                       "write_bytes_per_step": int(write[k][1] * 1024 / steps)}
-    conv = [v for k, v in kernels.items() if "conv_igemm" in k or "gemm1x1_persistent" in k or "winograd_kernel" in k or "winograd_persist_kernel" in k]   # all conv launches
+    conv = [v for k, v in kernels.items() if "conv_igemm" in k or "gemm1x1_persistent" in k or "winograd_kernel" in k or "winograd_persist_kernel" in k or "stem_pool_kernel" in k]   # all conv launches
     cal = kernels.get("vatl::nchw_to_nhwc_kernel")
     summary = {
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0, 1024 frames/step",

@@ -122,16 +122,36 @@ class _BottleneckPlan:
         return self.c3(y, relu=True, residual=skip, out=out)        # relu(bn3(conv3) + skip)
 
 
+# conv1 + bn1 + relu + maxpool of the ResNet trunk as ONE launch that reads the NCHW crops directly (csrc/stem_pool.hip: K = 168 instead of the 224 of the
+# 4-channel implicit GEMM, no 3.2 GB stem activation per 1024 crops, no layout pass) where the input size allows (256x192: yes; 384x288: no).  Not in the
+# small-batch module calls (vh.latency_mode(): a handful of crops leaves most of its per-image blocks without work).  VATL_FUSE_STEM=0 = three launches.
+FUSE_STEM = os.environ.get("VATL_FUSE_STEM", "1") != "0"
+
+
+def _stem_pool_weight(net):
+    c = net.conv1
+    ok = (FUSE_STEM and tuple(c.weight.shape) == (64, 3, 7, 7) and c.stride == (2, 2) and c.padding == (3, 3) and c.bias is None
+          and isinstance(net.maxpool, nn.MaxPool2d) and net.maxpool.kernel_size in (3, (3, 3)) and net.maxpool.stride in (2, (2, 2))
+          and net.maxpool.padding in (1, (1, 1)) and not net.maxpool.ceil_mode)
+    return vh.pack_stem_pool_weight(c.weight.detach()) if ok else None
+
+
 class _TrunkPlan:
     def __init__(self, net):
         self.stem = _Conv(net.conv1, net.bn1)
+        self.stem_pw = _stem_pool_weight(net)
         self.blocks = [_BottleneckPlan(b) for stage in net.stages() for b in stage]
         self.n_stage1 = len(net.stages()[0])
 
-    def _stage1(self, x_nchw, out=None):
+    def _stem(self, x_nchw):
+        if self.stem_pw is not None and not vh.latency_mode() and vh.stem_pool_supported(x_nchw.shape[2], x_nchw.shape[3]):
+            return vh.stem_pool_fwd(x_nchw, self.stem_pw, self.stem.scale, self.stem.bias)
         x = vh.nchw_to_nhwc(x_nchw, 4)                              # 3 -> 4 channels (zero), 16-byte pixels
         x = self.stem(x, relu=True)
-        x = vh.maxpool3x3s2_fwd(x)
+        return vh.maxpool3x3s2_fwd(x)
+
+    def _stage1(self, x_nchw, out=None):
+        x = self._stem(x_nchw)
         for k, b in enumerate(self.blocks[:self.n_stage1]):
             last = k == self.n_stage1 - 1
             x = b(x, out=out) if (last and out is not None and type(b) is _BottleneckPlan) else b(x)
@@ -203,6 +223,7 @@ class _SEBottleneckPlan(_BottleneckPlan):
 class _SETrunkPlan(_TrunkPlan):
     def __init__(self, net):
         self.stem = _Conv(net.conv1, net.bn1)
+        self.stem_pw = _stem_pool_weight(net)
         self.blocks = [(_SEBottleneckPlan(b) if getattr(b, "reduc", False) else _BottleneckPlan(b))
                        for stage in net.stages() for b in stage]
         self.n_stage1 = len(net.stages()[0])

@@ -34,6 +34,10 @@ SIGNATURES = {
     "vatl_pack_deconv4x4s2_weight": (_i, [_p, _p, _i, _i, _i, _p]),
     "vatl_pack_conv1x1_dual_weight": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_conv1x1_dual_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vatl_stem_pool_weight_floats": (_i64, []),
+    "vatl_pack_stem_pool_weight": (_i, [_p, _p, _p]),
+    "vatl_stem_pool_supported": (_i, [_i, _i]),
+    "vatl_stem7x7s2_pool_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vatl_bn_fold": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _i, _p]),
     "vatl_tune_set": (_i, [_i, _i]),
     "vatl_set_splitk_workspace": (_i, [_p, _i64]),
@@ -498,6 +502,30 @@ def conv2d_fwd(x, w_packed, scale, bias, cout: int, r: int, s: int, stride: int,
     y = out if out is not None else torch.empty(shape, device=x.device, dtype=torch.float32)
     _check(lib().vatl_conv2d_fwd(_ptr(x), _ptr(w_packed), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(y), n, h, w, cin, cout,
                                  w_packed.shape[0], r, s, stride, pad, int(relu), int(out_nchw), _stream()), "vatl_conv2d_fwd")
+    return y
+
+
+def pack_stem_pool_weight(w: torch.Tensor) -> torch.Tensor:
+    """(64,3,7,7) OIHW stem filter -> the fragment order of vatl_stem7x7s2_pool_fwd."""
+    if tuple(w.shape) != (64, 3, 7, 7):
+        raise VatlError(f"pack_stem_pool_weight: expected a (64,3,7,7) filter, got {tuple(w.shape)}")
+    w = w.detach().float().contiguous()
+    out = torch.empty(int(lib().vatl_stem_pool_weight_floats()), device=w.device, dtype=torch.float32)
+    _check(lib().vatl_pack_stem_pool_weight(_ptr(w), _ptr(out), _stream()), "vatl_pack_stem_pool_weight")
+    return out
+
+
+def stem_pool_supported(h: int, w: int) -> bool:
+    return bool(lib().vatl_stem_pool_supported(int(h), int(w)))
+
+
+def stem_pool_fwd(x_nchw: torch.Tensor, w_packed: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, out=None) -> torch.Tensor:
+    """NCHW crops (N,3,H,W) -> conv7x7/2 + folded BN + ReLU + maxpool3x3/2 -> NHWC (N,H/4,W/4,64) in one launch (Resnet.py:155-158, 171-172)."""
+    n, c, h, w = x_nchw.shape
+    if c != 3:
+        raise VatlError(f"stem_pool_fwd: expected 3 input channels, got {c}")
+    y = out if out is not None else torch.empty((n, h // 4, w // 4, 64), device=x_nchw.device, dtype=torch.float32)
+    _check(lib().vatl_stem7x7s2_pool_fwd(_ptr(x_nchw), _ptr(w_packed), _ptr(scale), _ptr(bias), _ptr(y), n, h, w, _stream()), "vatl_stem7x7s2_pool_fwd")
     return y
 
 
