@@ -71,6 +71,13 @@ int vatl_pack_stem_pool_weight(const float* w_oihw, float* packed, void* stream)
 int vatl_stem_pool_supported(int H, int W);
 int vatl_stem7x7s2_pool_fwd(const float* x_nchw, const float* w_packed, const float* scale, const float* bias, float* y_nhwc,
                             int N, int H, int W, void* stream);
+/* HRNet's first stem layer the same way: NCHW crops -> conv 3x3 / stride 2 / pad 1 (3 -> 64) -> folded BatchNorm -> ReLU -> NHWC
+ * (N, H/2, W/2, 64)  (hrnet.py:109-110, 426-428: conv1, bn1, relu).  Filter (64,3,3,3) packed by vatl_pack_stem3_weight into
+ * vatl_stem3_weight_floats() floats; same served sizes (vatl_stem_pool_supported). */
+int64_t vatl_stem3_weight_floats(void);
+int vatl_pack_stem3_weight(const float* w_oihw, float* packed, void* stream);
+int vatl_stem3x3s2_fwd(const float* x_nchw, const float* w_packed, const float* scale, const float* bias, float* y_nhwc,
+                       int N, int H, int W, void* stream);
 
 /* Eval-mode BatchNorm2d as a per-channel affine: scale = gamma/sqrt(var+eps),
  * bias = beta - mean*scale (Resnet.py:67,98,100,155; simplepose.py:41,44,47).

@@ -698,6 +698,20 @@ def test_fused_stem_pool_kernel_vs_float64_and_the_three_launch_path(vh):
         assert e < TOL, (n, h, wdt, e)
         solo = vh.stem_pool_fwd(x[n - 1:n].contiguous().to(dev()), pw, scd, bid)       # another band cut, same bits
         assert torch.equal(solo[0], got[n - 1])
+    # HRNet's conv1 (3x3 / stride 2 / pad 1) + bn1 + relu through the same sliding block, no pooling: (N, H/2, W/2, 64)
+    w3 = (torch.randn((64, 3, 3, 3), generator=g) * (2.0 / 27) ** 0.5)
+    pw3 = vh.pack_stem3_weight(w3.to(dev()))
+    for n, h, wdt in ((3, 256, 192), (33, 64, 128), (2, 32, 64), (700, 8, 64)):
+        x = torch.rand((n, 3, h, wdt), generator=g) - 0.45
+        got = vh.stem3_fwd(x.to(dev()), pw3, scd, bid)
+        assert got.shape == (n, h // 2, wdt // 2, 64)
+        k = min(n, 3)
+        ref = (F.conv2d(x[-k:].double(), w3.double(), None, 2, 1) * sc.double().view(1, -1, 1, 1) + bi.double().view(1, -1, 1, 1)).clamp_min(0)
+        e = rel_err(got[-k:].cpu().numpy(), ref.permute(0, 2, 3, 1).numpy())
+        record(f"stem3_{n}x{h}x{wdt}", rel=e)
+        assert e < TOL, (n, h, wdt, e)
+        solo = vh.stem3_fwd(x[:1].contiguous().to(dev()), pw3, scd, bid)
+        assert torch.equal(solo[0], got[0])
     assert not vh.stem_pool_supported(384, 288) and not vh.stem_pool_supported(256, 200) and not vh.stem_pool_supported(258, 192)
     with pytest.raises(vh.VatlError):
         vh.stem_pool_fwd(torch.zeros((1, 3, 384, 288), device=dev()), pw, scd, bid)

@@ -314,6 +314,9 @@ class _HRModulePlan:
 class _HRNetPlan:
     def __init__(self, m):
         self.stem1, self.stem2 = _Conv(m.conv1, m.bn1), _Conv(m.conv2, m.bn2)
+        c = m.conv1
+        ok = FUSE_STEM and tuple(c.weight.shape) == (64, 3, 3, 3) and c.stride == (2, 2) and c.padding == (1, 1) and c.bias is None
+        self.stem1_pw = vh.pack_stem3_weight(c.weight.detach()) if ok else None
         self.layer1 = [_block_plan(b) for b in m.layer1]
         self.stages = []
         for s in (2, 3, 4):
@@ -322,8 +325,11 @@ class _HRNetPlan:
         self.head = _Conv(m.final_layer, None)
 
     def __call__(self, x_nchw, out=None):
-        x = vh.nchw_to_nhwc(x_nchw, 4)
-        x = self.stem2(self.stem1(x, relu=True), relu=True)
+        if self.stem1_pw is not None and not vh.latency_mode() and vh.stem_pool_supported(x_nchw.shape[2], x_nchw.shape[3]):
+            x = vh.stem3_fwd(x_nchw, self.stem1_pw, self.stem1.scale, self.stem1.bias)       # conv1 + bn1 + relu straight from the NCHW crops
+        else:
+            x = self.stem1(vh.nchw_to_nhwc(x_nchw, 4), relu=True)
+        x = self.stem2(x, relu=True)
         for b in self.layer1:
             x = b(x)
         ys = [x]

@@ -18,17 +18,19 @@
 
 namespace vatl {
 
-constexpr int SP_RING = 13;                      // input rows resident: 9 in use (two stem rows: 2 * 2 + 7 - 2) + 4 arriving
 constexpr int SP_ZREG = 512;                     // floats of the zero region (reads of the padded tap land here whatever their immediate offset)
 
-template <int TPR> struct StemPoolLds {
+// KS = 7 (pad 3, + max-pool): the ResNet stem.  KS = 3 (pad 1, no pooling): HRNet's first stem conv (hrnet.py:109-110, 426-428) — the same sliding block
+// with K = 3 channels x 3 rows x 4 taps (3 + 1 zero) = 36 instead of the 96 of the 4-channel implicit GEMM, writing the stem rows themselves.
+template <int TPR, int KS> struct StemPoolLds {
+    static constexpr int RING = KS + 6;          // input rows resident: KS + 2 in use (two stem rows) + 4 arriving
     static constexpr int WO = 32 * TPR;          // stem output columns
     static constexpr int IW = WO + 4;            // entries of an even / odd pixel array: index q + 2 <-> pixel 2q (even) / 2q + 1 (odd); two zeros on either side
     static constexpr int ROW = 3 * 2 * IW;       // floats of one ring slot: [channel][parity][IW]
-    static constexpr int IN = SP_RING * ROW;
+    static constexpr int IN = RING * ROW;
     static constexpr int STG = 33 * 32;          // per wave: [1 + 32 pixels][32 channels]
     static constexpr int HP = 2 * (WO / 2) * 64; // horizontally pooled rows of this step: [stem row parity][pooled column][64 channels]
-    static constexpr int FLOATS = SP_ZREG + IN + 4 * STG + HP;
+    static constexpr int FLOATS = SP_ZREG + IN + (KS == 7 ? 4 * STG + HP : 0);
 };
 
 struct StemPoolParams {
@@ -41,10 +43,13 @@ struct StemPoolParams {
     int bands, steps_per_band;   // a block = (image, band of pooled rows)
 };
 
-template <int TPR>
+template <int TPR, int KS>
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolParams p) {
-    using L = StemPoolLds<TPR>;
-    constexpr int WO = L::WO, IW = L::IW, ROW = L::ROW, PW = WO / 2;
+    using L = StemPoolLds<TPR, KS>;
+    constexpr int WO = L::WO, IW = L::IW, ROW = L::ROW, PW = WO / 2, SP_RING = L::RING;
+    constexpr bool POOL = KS == 7;
+    constexpr int PAD = KS / 2, NPAIR = (KS + 1) / 2, NW = 3 * KS * NPAIR;   // k-pairs per (channel, filter row); filter values per lane
+    constexpr int OO = 2 - (PAD + 1) / 2, EO = 2 - (PAD - 1) / 2;           // pair i: half 0 reads the odd array at ox + i + OO, half 1 the even array at ox + i + EO
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Zr = smem;                            // zeros
     float* In = smem + SP_ZREG;
@@ -58,14 +63,14 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolParams p) {
     const int HO = p.H >> 1, PH = p.H >> 2;      // stem rows, pooled rows
     const int i_first = band * p.steps_per_band, i_end = min(i_first + p.steps_per_band, PH);
     if (i_first >= i_end) return;
-    const int i_begin = i_first > 0 ? i_first - 1 : 0;   // a band that does not start at the top first recomputes the odd stem row above it (results not stored)
+    const int i_begin = (POOL && i_first > 0) ? i_first - 1 : i_first;   // a pooling band that does not start at the top first recomputes the odd stem row above it (results not stored)
 
     // ---- filter fragments of this wave's 32 channels: 84 k-pairs, lane half 0 = the odd-pixel taps (kx = 2 i), half 1 = the even-pixel taps (kx = 2 i + 1; i = 3: zero)
-    float wr[84];
+    float wr[NW];
     {
-        const float* wp = p.w + (long long)nh * 84 * 64 + lane;
+        const float* wp = p.w + (long long)nh * NW * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < 84; ++k) wr[k] = wp[k * 64];
+        for (int k = 0; k < NW; ++k) wr[k] = wp[k * 64];
     }
     const int ch = 32 * nh + m;                  // (as MFMA column: this lane's output channel)
     const float sc = p.scale[ch], bi = p.bias[ch];
@@ -109,16 +114,16 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolParams p) {
         }
     };
     f32x2 rg[NP4];
-    // prologue: rows 4 i_begin - 3 .. 4 i_begin + 5 (nine rows, three passes)
-    for (int r0 = 4 * i_begin - 3; r0 < 4 * i_begin + 6; r0 += 4) {
-        const int nr = min(4, 4 * i_begin + 6 - r0);
+    // prologue: rows 4 i_begin - PAD .. 4 i_begin + 1 + KS - PAD (KS + 2 rows)
+    for (int r0 = 4 * i_begin - PAD; r0 < 4 * i_begin + 2 + KS - PAD; r0 += 4) {
+        const int nr = min(4, 4 * i_begin + 2 + KS - PAD - r0);
         load_rows(rg, r0, nr);
         store_rows(rg, r0, nr);
     }
     __syncthreads();
 
-    // per-lane read base inside a ring slot: half 0 reads the ODD array at 32 t + m + i, half 1 the EVEN array at 32 t + m + i + 1
-    const int lbase = (h == 0 ? IW : 0) + m + h;
+    // per-lane read base inside a ring slot: half 0 reads the ODD array at 32 t + m + i + OO, half 1 the EVEN array at 32 t + m + i + EO
+    const int lbase = (h == 0 ? IW + OO : EO) + m;
     f32x4 carry[3];                              // horizontally pooled odd stem row of the step before: this thread's (pooled column, 4 channels) x 3
 #pragma unroll
     for (int k = 0; k < 3; ++k) carry[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -127,12 +132,12 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolParams p) {
     for (int i = i_begin; i < i_end; ++i) {
         // rows of the next step, in flight while this one is multiplied
         const bool more = i + 1 < i_end;
-        if (more) load_rows(rg, 4 * i + 6, 4);
+        if (more) load_rows(rg, 4 * i + 2 + KS - PAD, 4);
         const int oy = 2 * i + rsel;             // this wave's stem row
-        int rb[7], rbp[7];                       // float index of (filter row ky, channel 0, tile 0, pair 0) for this lane; rbp: the same for the padded pair (half 1 -> zero region)
+        int rb[KS], rbp[KS];                     // float index of (filter row ky, channel 0, tile 0, pair 0) for this lane; rbp: the same for the padded pair (half 1 -> zero region)
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-            int slot = (2 * oy + ky - 3) % SP_RING; if (slot < 0) slot += SP_RING;
+        for (int ky = 0; ky < KS; ++ky) {
+            int slot = (2 * oy + ky - PAD) % SP_RING; if (slot < 0) slot += SP_RING;
             rb[ky] = SP_ZREG + slot * ROW + lbase;
             rbp[ky] = h ? 0 : rb[ky];
         }
@@ -144,15 +149,31 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolParams p) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int ky = 0; ky < 7; ++ky)
+            for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
                 for (int t = 0; t < TPR; ++t) {
                     const int o = c * 2 * IW + 32 * t;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(smem[rb[ky] + o + k], wr[(c * 7 + ky) * 4 + k], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(smem[rbp[ky] + o + 3], wr[(c * 7 + ky) * 4 + 3], acc[t], 0, 0, 0);
+                    for (int k = 0; k < NPAIR - 1; ++k)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(smem[rb[ky] + o + k], wr[(c * KS + ky) * NPAIR + k], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(smem[rbp[ky] + o + NPAIR - 1], wr[(c * KS + ky) * NPAIR + NPAIR - 1], acc[t], 0, 0, 0);
                 }
+
+        if constexpr (!POOL) {
+            // ---- folded BatchNorm + ReLU, stored as the stem row itself: (N, H / 2, W / 2, 64); a lane's 32 neighbours write 128 contiguous bytes of a pixel
+            float* yrow = p.y + (((long long)b * HO + oy) * WO) * 64 + ch;
+#pragma unroll
+            for (int t = 0; t < TPR; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int px = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    yrow[px * 64] = fmaxf(fmaf(acc[t][e], sc, bi), 0.f);
+                }
+            __syncthreads();                     // every wave is done reading this step's input rows
+            if (more) store_rows(rg, 4 * i + 2 + KS - PAD, 4);
+            __syncthreads();
+            continue;
+        }
 
         // ---- folded BatchNorm + ReLU, horizontal 3-window maximum with stride 2 through the wave's LDS tile (row 0 = the pixel left of the tile)
         if (lane < 32) stg[lane] = 0.f;          // left of the image: neutral
@@ -181,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolParams p) {
         __syncthreads();                         // both stem rows of the step are in Hp; every wave is done reading this step's input rows
 
         // ---- vertical maximum (odd row of the step before, even row, odd row) and store; the next step's input rows go to LDS
-        if (more) store_rows(rg, 4 * i + 6, 4);
+        if (more) store_rows(rg, 4 * i + 2 + KS - PAD, 4);
         {
             constexpr int V4 = PW * 16;          // float4 pieces of one pooled row
 #pragma unroll
@@ -208,59 +229,77 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolParams p) {
 using namespace vatl;
 
 extern "C" int64_t vatl_stem_pool_weight_floats(void) { return 2 * 84 * 64; }
+extern "C" int64_t vatl_stem3_weight_floats(void) { return 2 * 18 * 64; }
 
-// w (64, 3, 7, 7) OIHW -> [channel half][k = (c * 7 + ky) * 4 + i][lane = 32 half + n]: half 0 = w[n][c][ky][2 i], half 1 = w[n][c][ky][2 i + 1] (i = 3: 0)
-__global__ void stem_pool_pack_kernel(const float* __restrict__ w, float* __restrict__ out) {
+// w (64, 3, KS, KS) OIHW -> [channel half][k = (c * KS + ky) * NPAIR + i][lane = 32 half + n]: half 0 = w[n][c][ky][2 i], half 1 = w[n][c][ky][2 i + 1] (beyond the filter: 0)
+__global__ void stem_pool_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int KS) {
+    const int NPAIR = (KS + 1) / 2, NW = 3 * KS * NPAIR;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 2 * 84 * 64) return;
-    const int lane = idx & 63, k = (idx >> 6) % 84, nhalf = idx / (84 * 64);
-    const int i = k & 3, cky = k >> 2, c = cky / 7, ky = cky - 7 * c;
+    if (idx >= 2 * NW * 64) return;
+    const int lane = idx & 63, k = (idx >> 6) % NW, nhalf = idx / (NW * 64);
+    const int i = k % NPAIR, cky = k / NPAIR, c = cky / KS, ky = cky - KS * c;
     const int n = 32 * nhalf + (lane & 31), hh = lane >> 5;
     const int kx = 2 * i + hh;
-    out[idx] = kx < 7 ? w[((n * 3 + c) * 7 + ky) * 7 + kx] : 0.f;
+    out[idx] = kx < KS ? w[((n * 3 + c) * KS + ky) * KS + kx] : 0.f;
 }
 
 extern "C" int vatl_pack_stem_pool_weight(const float* w_oihw, float* packed, void* stream) {
     if (!w_oihw || !packed) return fail(VATL_EINVAL, "pack_stem_pool_weight: null pointer");
-    hipLaunchKernelGGL(stem_pool_pack_kernel, dim3((2 * 84 * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, packed);
+    hipLaunchKernelGGL(stem_pool_pack_kernel, dim3((2 * 84 * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, 7);
     return check_launch("stem_pool_pack");
 }
 
-// 1 when the fused kernel serves this input size (W / 2 a multiple of 32 up to 96 columns, H a multiple of 4), else 0 (the caller keeps the three-launch path)
+extern "C" int vatl_pack_stem3_weight(const float* w_oihw, float* packed, void* stream) {
+    if (!w_oihw || !packed) return fail(VATL_EINVAL, "pack_stem3_weight: null pointer");
+    hipLaunchKernelGGL(stem_pool_pack_kernel, dim3((2 * 18 * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, 3);
+    return check_launch("stem3_pack");
+}
+
+// 1 when the fused kernels serve this input size (W / 2 a multiple of 32 up to 96 columns, H a multiple of 4), else 0 (the caller keeps the generic path)
 extern "C" int vatl_stem_pool_supported(int H, int W) {
     const int wo = W / 2;
     return (H > 0 && W > 0 && (H & 3) == 0 && (W & 3) == 0 && wo % 32 == 0 && wo >= 32 && wo <= 96) ? 1 : 0;
 }
 
-template <int TPR>
+template <int TPR, int KS>
 static int launch_stem_pool(const StemPoolParams& p, hipStream_t st) {
-    auto kern = stem_pool_kernel<TPR>;
+    auto kern = stem_pool_kernel<TPR, KS>;
     static std::atomic<unsigned> configured{0};
-    constexpr int smem = StemPoolLds<TPR>::FLOATS * (int)sizeof(float);
+    constexpr int smem = StemPoolLds<TPR, KS>::FLOATS * (int)sizeof(float);
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, configured, "stem_pool")) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.N * p.bands)), dim3(256), smem, st, p);
-    // executed MFMA FLOPs: every pooled-row step multiplies 2 stem rows x (W / 2) pixels x 64 channels x K = 168 (+ one recomputed step per band below the first)
-    const double steps = (double)p.N * ((p.H >> 2) + (p.bands - 1));
-    meter_add(0, 2.0 * steps * 2.0 * (p.W / 2) * 64.0 * 168.0);
+    // executed MFMA FLOPs: every step multiplies 2 stem rows x (W / 2) pixels x 64 channels x K = 3 KS (KS + 1) (+ one recomputed step per pooling band below the first)
+    const double steps = (double)p.N * ((p.H >> 2) + (KS == 7 ? p.bands - 1 : 0));
+    meter_add(0, 2.0 * steps * 2.0 * (p.W / 2) * 64.0 * (3.0 * KS * (KS + 1)));
     return check_launch("stem_pool");
 }
 
-extern "C" int vatl_stem7x7s2_pool_fwd(const float* x_nchw, const float* w_packed, const float* scale, const float* bias, float* y_nhwc, int N, int H, int W,
-                                       void* stream) {
+template <int KS>
+static int stem_impl(const float* x_nchw, const float* w_packed, const float* scale, const float* bias, float* y_nhwc, int N, int H, int W, void* stream, const char* what) {
     if (N <= 0) return 0;
-    if (!x_nchw || !w_packed || !scale || !bias || !y_nhwc) return fail(VATL_EINVAL, "stem7x7s2_pool_fwd: null pointer");
-    if (!vatl_stem_pool_supported(H, W)) return fail(VATL_EINVAL, "stem7x7s2_pool_fwd: %dx%d input not served by the fused kernel (W / 2 must be 32, 64 or 96, H %% 4 == 0)", H, W);
-    if ((((uintptr_t)x_nchw) & 7) != 0) return fail(VATL_EINVAL, "stem7x7s2_pool_fwd: input must be 8-byte aligned");
+    if (!x_nchw || !w_packed || !scale || !bias || !y_nhwc) return fail(VATL_EINVAL, "%s: null pointer", what);
+    if (!vatl_stem_pool_supported(H, W)) return fail(VATL_EINVAL, "%s: %dx%d input not served by the fused kernel (W / 2 must be 32, 64 or 96, H %% 4 == 0)", what, H, W);
+    if ((((uintptr_t)x_nchw) & 7) != 0) return fail(VATL_EINVAL, "%s: input must be 8-byte aligned", what);
     StemPoolParams p{};
     p.x = x_nchw; p.w = w_packed; p.scale = scale; p.bias = bias; p.y = y_nhwc; p.N = N; p.H = H; p.W = W;
-    // one block per image once the images alone fill the 512 block slots; fewer images are cut into bands of pooled rows (each band re-computes one stem row)
+    // one block per image once the images alone fill the 512 block slots; fewer images are cut into bands of row pairs (a pooling band re-computes one stem row)
     const int PH = H >> 2;
     int bands = 1;
     while ((long long)N * bands < 512 && bands * 2 <= PH / 4) bands *= 2;
     p.bands = bands; p.steps_per_band = (PH + bands - 1) / bands;
     hipStream_t st = (hipStream_t)stream;
     const int tpr = W / 64;
-    if (tpr == 1) return launch_stem_pool<1>(p, st);
-    if (tpr == 2) return launch_stem_pool<2>(p, st);
-    return launch_stem_pool<3>(p, st);
+    if (tpr == 1) return launch_stem_pool<1, KS>(p, st);
+    if (tpr == 2) return launch_stem_pool<2, KS>(p, st);
+    return launch_stem_pool<3, KS>(p, st);
+}
+
+extern "C" int vatl_stem7x7s2_pool_fwd(const float* x_nchw, const float* w_packed, const float* scale, const float* bias, float* y_nhwc, int N, int H, int W,
+                                       void* stream) {
+    return stem_impl<7>(x_nchw, w_packed, scale, bias, y_nhwc, N, H, W, stream, "stem7x7s2_pool_fwd");
+}
+
+// conv 3x3 / stride 2 / pad 1 (3 -> 64) + folded BatchNorm + ReLU from NCHW crops to NHWC (N, H / 2, W / 2, 64): HRNet's conv1 + bn1 + relu (hrnet.py:109-110, 426-428)
+extern "C" int vatl_stem3x3s2_fwd(const float* x_nchw, const float* w_packed, const float* scale, const float* bias, float* y_nhwc, int N, int H, int W, void* stream) {
+    return stem_impl<3>(x_nchw, w_packed, scale, bias, y_nhwc, N, H, W, stream, "stem3x3s2_fwd");
 }

@@ -38,6 +38,9 @@ SIGNATURES = {
     "vatl_pack_stem_pool_weight": (_i, [_p, _p, _p]),
     "vatl_stem_pool_supported": (_i, [_i, _i]),
     "vatl_stem7x7s2_pool_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "vatl_stem3_weight_floats": (_i64, []),
+    "vatl_pack_stem3_weight": (_i, [_p, _p, _p]),
+    "vatl_stem3x3s2_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "vatl_bn_fold": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, _i, _p]),
     "vatl_tune_set": (_i, [_i, _i]),
     "vatl_set_splitk_workspace": (_i, [_p, _i64]),
@@ -513,6 +516,26 @@ def pack_stem_pool_weight(w: torch.Tensor) -> torch.Tensor:
     out = torch.empty(int(lib().vatl_stem_pool_weight_floats()), device=w.device, dtype=torch.float32)
     _check(lib().vatl_pack_stem_pool_weight(_ptr(w), _ptr(out), _stream()), "vatl_pack_stem_pool_weight")
     return out
+
+
+def pack_stem3_weight(w: torch.Tensor) -> torch.Tensor:
+    """(64,3,3,3) OIHW filter of HRNet's conv1 -> the fragment order of vatl_stem3x3s2_fwd."""
+    if tuple(w.shape) != (64, 3, 3, 3):
+        raise VatlError(f"pack_stem3_weight: expected a (64,3,3,3) filter, got {tuple(w.shape)}")
+    w = w.detach().float().contiguous()
+    out = torch.empty(int(lib().vatl_stem3_weight_floats()), device=w.device, dtype=torch.float32)
+    _check(lib().vatl_pack_stem3_weight(_ptr(w), _ptr(out), _stream()), "vatl_pack_stem3_weight")
+    return out
+
+
+def stem3_fwd(x_nchw: torch.Tensor, w_packed: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """NCHW crops (N,3,H,W) -> conv3x3/2 + folded BN + ReLU -> NHWC (N,H/2,W/2,64) in one launch (hrnet.py:109-110, 426-428)."""
+    n, c, h, w = x_nchw.shape
+    if c != 3:
+        raise VatlError(f"stem3_fwd: expected 3 input channels, got {c}")
+    y = torch.empty((n, h // 2, w // 2, 64), device=x_nchw.device, dtype=torch.float32)
+    _check(lib().vatl_stem3x3s2_fwd(_ptr(x_nchw), _ptr(w_packed), _ptr(scale), _ptr(bias), _ptr(y), n, h, w, _stream()), "vatl_stem3x3s2_fwd")
+    return y
 
 
 def stem_pool_supported(h: int, w: int) -> bool:
