@@ -39,11 +39,15 @@ def main():
                       "read_bytes_per_step": int(fetch[k][1] * 1024 * 2 / steps),      # x2: gfx950 FETCH_SIZE correction
                       "write_bytes_per_step": int(write[k][1] * 1024 / steps)}
     conv = [v for k, v in kernels.items() if "conv_igemm" in k or "gemm1x1_persistent" in k or "winograd_kernel" in k or "winograd_persist_kernel" in k or "stem_pool_kernel" in k]   # all conv launches
-    cal = kernels.get("vatl::nchw_to_nhwc_kernel")
+    cal, cal_name = kernels.get("vatl::nchw_to_nhwc_kernel"), "nchw_to_nhwc_kernel"
+    if cal is None:                     # round 4: the fused stem reads the NCHW crops itself (same known read volume; it writes the pooled 64-channel rows: N x 64 x 48 x 64 x 4 bytes)
+        for k, v in kernels.items():
+            if "stem_pool_kernel<3, 7>" in k:
+                cal, cal_name = v, "stem_pool_kernel<3, 7>"
     summary = {
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0, 1024 frames/step",
         "fetch_correction": 2.0,
-        "calibration": {"kernel": "nchw_to_nhwc_kernel", "expected_read_bytes": 1024 * 3 * 256 * 192 * 4,
+        "calibration": {"kernel": cal_name, "expected_read_bytes": 1024 * 3 * 256 * 192 * 4,
                         "measured_read_bytes_corrected": cal["read_bytes_per_step"] if cal else None,
                         "expected_write_bytes": 1024 * 4 * 256 * 192 * 4, "measured_write_bytes": cal["write_bytes_per_step"] if cal else None},
         "conv_igemm": {"launches_per_step": sum(v["launches_per_step"] for v in conv),
