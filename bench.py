@@ -136,12 +136,15 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
     """Time every conv / deconv launch of one step with HIP events on the launch stream (torch's current stream) and relate the sum
     to (a) the MFMA FLOPs those launches really execute — counted by the library itself, tile padding included
     (vatl_flop_meter_begin / _end) — and (b) the algorithmic (direct-sum) FLOPs of the step.  `frac` is (a): the fraction of the
-    fp32 matrix pipe's peak that is busy; it cannot exceed 1.  (b) is `algorithmic_frac`: 16 of the 53 launches are Winograd
+    fp32 matrix pipe's peak that is busy; it cannot exceed 1.  (b) is `algorithmic_frac`: 16 of the step's launches are Winograd
     kernels that reach their direct-sum FLOPs with 2.25x fewer multiplies, so it can."""
     import vatl_hip as vh
     events, wino = [], []
-    orig_c, orig_d, orig_u, orig_w, orig_dw = vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd, vh.conv3x3_winograd_fwd, vh.deconv4x4s2_winograd_fwd
-    orig_s = vh.stem_pool_fwd                               # (the fused stem: conv1 + bn1 + relu + maxpool in one launch — its pooling is inside the timed launch)
+    # every entry point of the step that launches MFMA work (the library meters their FLOPs; a launch missing here would count FLOPs without time: checked below)
+    timed_names = {"conv2d_fwd": 0, "deconv4x4s2_fwd": 0, "conv1x1_dual_fwd": 0, "conv3x3_winograd_fwd": 9, "deconv4x4s2_winograd_fwd": 4,
+                   "stem_pool_fwd": 0,               # the fused stem: conv1 + bn1 + relu + maxpool in one launch — its pooling is inside the timed launch
+                   "bottleneck_chain_fwd": 0}        # conv3 + skip of one bottleneck and conv1 of the next in one launch
+    originals = {n: getattr(vh, n) for n in timed_names}
 
     def wrap(fn, is_wino=0):
         def inner(*a, **k):
@@ -154,16 +157,17 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
                 wino.append((e0, e1, 2.0 * r.numel() * is_wino * a[0].shape[-1]))
             return r
         return inner
-    vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd = wrap(orig_c), wrap(orig_d), wrap(orig_u)
-    vh.conv3x3_winograd_fwd, vh.deconv4x4s2_winograd_fwd = wrap(orig_w, 9), wrap(orig_dw, 4)
-    vh.stem_pool_fwd = wrap(orig_s)
+    for n, taps in timed_names.items():
+        setattr(vh, n, wrap(originals[n], taps))
     try:
         with vh.flop_meter() as fm:
             one_step(model, x, bbox, is_prev, is_next, hm_buf)
         torch.cuda.synchronize()
     finally:
-        vh.conv2d_fwd, vh.deconv4x4s2_fwd, vh.conv1x1_dual_fwd, vh.conv3x3_winograd_fwd, vh.deconv4x4s2_winograd_fwd = orig_c, orig_d, orig_u, orig_w, orig_dw
-        vh.stem_pool_fwd = orig_s
+        for n, fn in originals.items():
+            setattr(vh, n, fn)
+    if fm.direct_launches + fm.winograd_launches != len(events):
+        raise RuntimeError(f"conv_roofline: {fm.direct_launches + fm.winograd_launches} metered MFMA launches but {len(events)} timed ones — an entry point is missing from timed_names")
     ms = sum(a.elapsed_time(b) for a, b in events)
     flops = GFLOP_PER_CROP * 1e9 * x.shape[0]
     algorithmic = flops / (ms * 1e-3) / 1e12
@@ -181,7 +185,7 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": (traffic / len(events)) if traffic else None,
-            "metered_launches": fm.direct_launches + fm.winograd_launches, "kernel": "stem_pool_kernel + conv_igemm_kernel + gemm1x1_persistent2_kernel + winograd_kernel / winograd_persist_kernel (all conv/deconv launches of one step; the stem launch includes bn1 + relu + maxpool; 4 launches fuse a projection shortcut with the block's last conv; the 13 3x3 stride-1 layers run as Winograd F(2x2,3x3), the 3 transposed convs as F(3x3,2x2) on their four phases)", "launches": len(events),
+            "metered_launches": fm.direct_launches + fm.winograd_launches, "kernel": "stem_pool_kernel + conv_igemm_kernel + gemm1x1_persistent2_kernel + winograd_kernel / winograd_persist_kernel (all conv/deconv launches of one step; the stem launch includes bn1 + relu + maxpool; 4 launches fuse a projection shortcut with the block's last conv, 1 chains a block's last conv with the next block's first; the 13 3x3 stride-1 layers run as Winograd F(2x2,3x3), the 3 transposed convs as F(3x3,2x2) on their four phases)", "launches": len(events),
             # `achieved` / `frac`: MFMA FLOPs the launches EXECUTE (counted per launch by libvatl_hip.so: 2 x padded M x padded N x padded K; the
             # Winograd launches their 16 transform-domain GEMMs) / event-timed duration / peak = how busy the matrix pipe is.
             # `algorithmic_*`: the step's direct-sum FLOPs (10.853 GFLOP x frames) over the same time; the Winograd launches deliver

@@ -108,6 +108,18 @@ int vatl_pack_conv1x1_dual_weight(const float* w1, const float* scale1, const fl
 int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo,
                           int C1, int H2, int W2, int C2, int stride2, int Cout, int CoutPad, int relu, void* stream);
 
+/* Last 1x1 conv of a bottleneck (+ bn3 + identity skip + ReLU, Resnet.py:120-128) chained with the NEXT bottleneck's first 1x1 conv
+ * (+ bn1 + ReLU, Resnet.py:104-108) in one launch (csrc/bottleneck_chain.hip): t = relu(scale3 * (a W3^T) + bias3 + skip) is written
+ * (it is the next block's skip connection) and y1 = relu(scale1 * (t W1^T) + bias1) is computed from the tile still in LDS, so the
+ * Cout-channel tensor is not re-read.  a (M, Cmid), skip / t (M, Cout), y1 (M, Cnext): NHWC pixels as rows; w3 [Cout][Cmid] and
+ * w1 [Cnext][Cout] in the vatl_pack_conv_weight layout of 1x1 filters; scale / bias may be NULL (1 / 0), skip may be NULL.
+ * Cnext == 0 (w1, y1 NULL): the first GEMM alone.  t has the bits of vatl_conv2d_fwd; y1 sums K in four fixed pieces.
+ * vatl_bottleneck_chain_supported: 1 for the shapes served (Cmid 64, Cout 256, Cnext 64 or 0, (M + 32) * 256 < 2^30). */
+int vatl_bottleneck_chain_supported(int Cmid, int Cout, int Cnext, int64_t M);
+int vatl_bottleneck_chain_fwd(const float* a, const float* w3, const float* scale3, const float* bias3, const float* skip, float* t,
+                              const float* w1, const float* scale1, const float* bias1, float* y1, int64_t M, int Cmid, int Cout,
+                              int Cnext, void* stream);
+
 /* Tuning knobs (benchmarks / A-B tests only).  Results are identical for every setting of
  * knob 0 = k-loop schedule of the conv kernel, values 0, 2, 4, 5 (see csrc/conv_igemm.hip), 1 = tile order, 2 = block
  * stagger, 3 = target block count of the weight-gradient launches (number of pixel splits), 5 = rows of the conv block

@@ -326,6 +326,69 @@ def test_conv1x1_dual_matches_two_launches(vh, stride):
     assert got.shape == (n, ho, wo, cout) and e_two < 2e-6 and e_64 < 2e-6
 
 
+def test_bottleneck_chain_vs_two_launches_and_float64(vh):
+    """vatl_bottleneck_chain_fwd: conv3 + bn3 + skip + relu of one bottleneck and conv1 + bn1 + relu of the next in one launch (csrc/bottleneck_chain.hip).
+    t must have the bits of the tiled implicit GEMM (it IS the network's activation and the next skip connection); y1 sums K in four fixed pieces: fp32
+    rounding of the two-launch value, checked against float64 too.  Ragged pixel counts (partial 32-row tiles, a single pixel), the first GEMM alone,
+    no skip, and a crop's bits independent of the batch it sits in."""
+    r = np.random.RandomState(77)
+    w3 = (r.standard_normal((256, 64, 1, 1)) / 8).astype(np.float32); w1 = (r.standard_normal((64, 256, 1, 1)) / 16).astype(np.float32)
+    s3, b3 = r.uniform(0.5, 1.5, 256).astype(np.float32), r.standard_normal(256).astype(np.float32)
+    s1, b1 = r.uniform(0.5, 1.5, 64).astype(np.float32), r.standard_normal(64).astype(np.float32)
+    w3p, w1p = vh.pack_conv_weight(to_dev(w3)), vh.pack_conv_weight(to_dev(w1))
+    s3d, b3d, s1d, b1d = to_dev(s3), to_dev(b3), to_dev(s1), to_dev(b1)
+    assert vh.bottleneck_chain_supported(64, 256, 64, 1024 * 64 * 48) and vh.bottleneck_chain_supported(64, 256, 0, 100)
+    assert not vh.bottleneck_chain_supported(128, 512, 128, 100) and not vh.bottleneck_chain_supported(64, 256, 128, 100)
+    assert not vh.bottleneck_chain_supported(64, 256, 64, 1 << 22)
+    for n, h, w in ((2, 64, 48), (1, 5, 7), (1, 1, 1), (3, 16, 12), (70, 8, 6), (1, 1, 33)):
+        a = r.standard_normal((n, h, w, 64)).astype(np.float32)
+        skip = r.standard_normal((n, h, w, 256)).astype(np.float32)
+        ad, sd = to_dev(a), to_dev(skip)
+        t_two = vh.conv2d_fwd(ad, w3p, s3d, b3d, 256, 1, 1, 1, 0, True, residual=sd)
+        y_two = vh.conv2d_fwd(t_two, w1p, s1d, b1d, 64, 1, 1, 1, 0, True)
+        t, y1 = vh.bottleneck_chain_fwd(ad, w3p, s3d, b3d, sd, w1p, s1d, b1d)
+        assert torch.equal(t, t_two), (n, h, w)
+        t64 = np.maximum((a.astype(np.float64) @ w3[:, :, 0, 0].T.astype(np.float64)) * s3 + b3 + skip, 0)
+        # the float64 value of the second conv ON the fp32 tensor t the launch stored (its own input), so the bound is one GEMM's rounding
+        y64 = np.maximum((t.cpu().numpy().astype(np.float64) @ w1[:, :, 0, 0].T.astype(np.float64)) * s1 + b1, 0)
+        e_two, e_64, e_t = rel_err(y1.cpu().numpy(), y_two.cpu().numpy()), rel_err(y1.cpu().numpy(), y64), rel_err(t.cpu().numpy(), t64)
+        record(f"bottleneck_chain_{n}x{h}x{w}", y1_vs_two_launches=e_two, y1_vs_fp64=e_64, two_launches_vs_fp64=rel_err(y_two.cpu().numpy(), y64), t_vs_fp64=e_t)
+        assert e_two < 2e-6 and e_64 < 2e-6 and e_t < 2e-6
+        t1, none = vh.bottleneck_chain_fwd(ad, w3p, s3d, b3d, sd)                       # first GEMM alone
+        assert none is None and torch.equal(t1, t_two)
+        t0, y0 = vh.bottleneck_chain_fwd(ad, w3p, None, None, None, w1p, None, None)   # no folded BN, no skip
+        t0_two = vh.conv2d_fwd(ad, w3p, None, None, 256, 1, 1, 1, 0, True)
+        assert torch.equal(t0, t0_two) and rel_err(y0.cpu().numpy(), vh.conv2d_fwd(t0_two, w1p, None, None, 64, 1, 1, 1, 0, True).cpu().numpy()) < 2e-6
+        if n > 1:                                                                       # bits of a crop do not depend on its batch (32-row tiles straddle crops)
+            ts, ys = vh.bottleneck_chain_fwd(ad[1:2].contiguous(), w3p, s3d, b3d, sd[1:2].contiguous(), w1p, s1d, b1d)
+            assert torch.equal(ts, t[1:2]) and torch.equal(ys, y1[1:2])
+    with pytest.raises(vh.VatlError):
+        vh.bottleneck_chain_fwd(to_dev(r.standard_normal((1, 2, 2, 32)).astype(np.float32)), w3p[:, :, :, :32].contiguous(), s3d, b3d, None)
+
+
+def test_chained_bottlenecks_in_the_plans(vh, monkeypatch):
+    """The stream route of SimplePose-R50 / HRNet-W32 takes the chained launch where an identity-shortcut bottleneck is followed by a 256 -> 64 conv1
+    (R50 stage 1: one linked + one first-GEMM-only launch; HRNet layer1: two linked + one alone), and the pass equals the separate launches to fp32 rounding."""
+    from alphapose.models import hip_engine
+    torch.manual_seed(5)
+    calls, real = [], vh.bottleneck_chain_fwd
+    monkeypatch.setattr(vh, "bottleneck_chain_fwd", lambda *a, **k: (calls.append(len(a) > 5 and a[5] is not None), real(*a, **k))[1])
+    for cfg, calls_want in (({"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50, "NUM_DECONV_FILTERS": [256, 256, 256]}, (1, 1)), (HRNET_CFG, (2, 1))):
+        m = _build(cfg)
+        x = torch.randn((20, 3, 256, 192), device=dev())
+        calls.clear()
+        with torch.no_grad():
+            on = hip_engine.forward_into(m, x, torch.empty((20, 17, 64, 48), device=dev())).clone()
+            n_on = (sum(calls), len(calls) - sum(calls))
+            monkeypatch.setattr(hip_engine, "FUSE_CHAIN", False)
+            off = hip_engine.forward_into(m, x, torch.empty((20, 17, 64, 48), device=dev())).clone()
+            monkeypatch.setattr(hip_engine, "FUSE_CHAIN", True)
+        assert n_on == calls_want and len(calls) == sum(calls_want), (cfg["TYPE"], n_on)
+        e = rel_err(on.cpu().numpy(), off.cpu().numpy())
+        record(f"chained_bottlenecks_{cfg['TYPE']}", on_vs_off=e)
+        assert e < 1e-5 and torch.equal(on.flatten(2).argmax(-1), off.flatten(2).argmax(-1))
+
+
 def test_ablation_knobs_are_refused(vh):
     import os
     assert os.environ.get("VATL_ALLOW_ABLATION") != "1"

@@ -10,8 +10,9 @@ import csv
 import sys
 
 
-def layers(B, fused=False):
-    """fused: the first block of every stage runs conv3 + projection as one dual-source GEMM (K = C1 + C2)."""
+def layers(B, fused=False, chained=False):
+    """fused: the first block of every stage runs conv3 + projection as one dual-source GEMM (K = C1 + C2).
+    chained: in stage 1 the second block's conv3 (+ skip) and the third block's conv1 are one launch (bottleneck_chain_kernel), the third block's conv3 its first-GEMM-only form."""
     L = []
 
     def conv(name, H, W, cin, cout, k, s, res=False):
@@ -26,7 +27,9 @@ def layers(B, fused=False):
         for b in range(n):
             s = 2 if (b == 0 and si > 0) else 1
             tag = f"l{si + 1}.{'0' if b == 0 else 'n'}"
-            conv(tag + ".c1", H, W, cin, wd, 1, 1)
+            link = chained and si == 0 and b == 1                      # this block's conv3 also computes the next block's conv1
+            if not (chained and si == 0 and b == 2):
+                conv(tag + ".c1", H, W, cin, wd, 1, 1)
             conv(tag + ".c2", H, W, wd, wd, 3, s)
             if b == 0 and not fused:
                 conv(tag + ".proj", H, W, cin, 4 * wd, 1, s)
@@ -35,6 +38,9 @@ def layers(B, fused=False):
             if b == 0 and fused:
                 M = B * H * W
                 L.append((tag + ".c3+p", 2 * M * (wd + cin) * 4 * wd, M, 4 * wd, wd + cin, (M * (wd + cin) + M * 4 * wd + (wd + cin) * 4 * wd) * 4))
+            elif link:
+                M = B * H * W
+                L.append((tag + ".c3>c1", 2 * M * wd * 4 * wd * 2, M, 4 * wd, wd, (M * (wd + 4 * wd * 2 + wd) + 2 * wd * 4 * wd) * 4))
             else:
                 conv(tag + ".c3", H, W, wd, 4 * wd, 1, 1, res=True)
             cin = 4 * wd
@@ -48,13 +54,14 @@ def layers(B, fused=False):
 def main():
     path = sys.argv[1]
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "gemm1x1_persistent" in r["Kernel_Name"] or "winograd_kernel" in r["Kernel_Name"] or "winograd_persist_kernel" in r["Kernel_Name"] or "stem_pool_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "gemm1x1_persistent" in r["Kernel_Name"] or "winograd_kernel" in r["Kernel_Name"] or "winograd_persist_kernel" in r["Kernel_Name"] or "stem_pool_kernel" in r["Kernel_Name"] or "bottleneck_chain_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     import re
     is_stem = lambda name: bool(re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, true", name)) or "stem_pool_kernel" in name   # (the fused stem launch includes bn1 + relu + maxpool)
     per_step = sum(1 for r in rows if is_stem(r["Kernel_Name"]))                                     # one stem launch per forward
-    fused = per_step > 0 and len(rows) // per_step == 53
-    L = layers(B, fused)
+    chained = any("bottleneck_chain_kernel" in r["Kernel_Name"] for r in rows)
+    fused = per_step > 0 and len(rows) // per_step == (52 if chained else 53)
+    L = layers(B, fused, chained)
     last = rows[-len(L):]
     agg = {}
     for (name, fl, M, N, K, by), r in zip(L, last):

@@ -113,13 +113,48 @@ class _BottleneckPlan:
                                                self.proj.scale, self.proj.bias)
             self.dual = (w, b, self.proj.stride)
 
-    def __call__(self, x, out=None):
-        y = self.c1(x, relu=True)
+    def __call__(self, x, out=None, y1=None):
+        y = y1 if y1 is not None else self.c1(x, relu=True)         # y1: conv1 + bn1 + relu already computed by the block before (chained launch)
         y = self.c2(y, relu=True)
+        return self.tail(y, x, out=out)
+
+    def tail(self, y, x, out=None):
         if self.dual is not None:                                   # relu(bn3(conv3(y)) + bn_p(conv_p(x))) in one GEMM over K = C1 + C2
             return vh.conv1x1_dual_fwd(y, x, self.dual[0], self.dual[1], self.c3.cout, self.dual[2], True, out=out)
         skip = x if self.proj is None else self.proj(x, relu=False)
         return self.c3(y, relu=True, residual=skip, out=out)        # relu(bn3(conv3) + skip)
+
+
+# conv3 + bn3 + skip + relu of an identity-shortcut bottleneck chained with the NEXT block's conv1 + bn1 + relu in one launch (csrc/bottleneck_chain.hip, the
+# 64 -> 256 -> 64 shapes of ResNet stage 1 / HRNet layer1): the 256-channel tensor is written once and not re-read.  Not in the small-batch module calls.
+# VATL_FUSE_CHAIN=0 = the separate launches.
+FUSE_CHAIN = os.environ.get("VATL_FUSE_CHAIN", "1") != "0"
+
+
+def _run_blocks(blocks, x, out=None):
+    """Walk consecutive residual blocks; `out` receives the last block's output when that block can write into it."""
+    y1 = None
+    for k, b in enumerate(blocks):
+        last = k == len(blocks) - 1
+        o = out if last else None
+        if type(b) is not _BottleneckPlan:
+            x, y1 = b(x), None
+            continue
+        m = x.shape[0] * x.shape[1] * x.shape[2]
+        chain = (FUSE_CHAIN and b.proj is None and not vh.latency_mode() and b.c3.scale is not None
+                 and vh.bottleneck_chain_supported(b.c3.w.shape[-1], b.c3.cout, 0, m))
+        if not chain:
+            x, y1 = b(x, out=o, y1=y1), None
+            continue
+        nxt = None if last else blocks[k + 1]
+        link = (type(nxt) is _BottleneckPlan and (nxt.c1.r, nxt.c1.stride, nxt.c1.pad) == (1, 1, 0) and nxt.c1.scale is not None
+                and vh.bottleneck_chain_supported(b.c3.w.shape[-1], b.c3.cout, nxt.c1.cout, m))
+        y = b.c2(y1 if y1 is not None else b.c1(x, relu=True), relu=True)
+        if link:
+            x, y1 = vh.bottleneck_chain_fwd(y, b.c3.w, b.c3.scale, b.c3.bias, x, nxt.c1.w, nxt.c1.scale, nxt.c1.bias, out=o)
+        else:
+            x, y1 = vh.bottleneck_chain_fwd(y, b.c3.w, b.c3.scale, b.c3.bias, x, out=o)[0], None
+    return x
 
 
 # conv1 + bn1 + relu + maxpool of the ResNet trunk as ONE launch that reads the NCHW crops directly (csrc/stem_pool.hip: K = 168 instead of the 224 of the
@@ -151,11 +186,7 @@ class _TrunkPlan:
         return vh.maxpool3x3s2_fwd(x)
 
     def _stage1(self, x_nchw, out=None):
-        x = self._stem(x_nchw)
-        for k, b in enumerate(self.blocks[:self.n_stage1]):
-            last = k == self.n_stage1 - 1
-            x = b(x, out=out) if (last and out is not None and type(b) is _BottleneckPlan) else b(x)
-        return x
+        return _run_blocks(self.blocks[:self.n_stage1], self._stem(x_nchw), out=out)
 
     def __call__(self, x_nchw):
         n = x_nchw.shape[0]
@@ -329,9 +360,7 @@ class _HRNetPlan:
             x = vh.stem3_fwd(x_nchw, self.stem1_pw, self.stem1.scale, self.stem1.bias)       # conv1 + bn1 + relu straight from the NCHW crops
         else:
             x = self.stem1(vh.nchw_to_nhwc(x_nchw, 4), relu=True)
-        x = self.stem2(x, relu=True)
-        for b in self.layer1:
-            x = b(x)
+        x = _run_blocks(self.layer1, self.stem2(x, relu=True))
         ys = [x]
         for trans, mods in self.stages:
             xs = [ys[i] if t is None else t(ys[-1]) for i, t in enumerate(trans)]

@@ -34,6 +34,8 @@ SIGNATURES = {
     "vatl_pack_deconv4x4s2_weight": (_i, [_p, _p, _i, _i, _i, _p]),
     "vatl_pack_conv1x1_dual_weight": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_conv1x1_dual_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vatl_bottleneck_chain_supported": (_i, [_i, _i, _i, _i64]),
+    "vatl_bottleneck_chain_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     "vatl_stem_pool_weight_floats": (_i64, []),
     "vatl_pack_stem_pool_weight": (_i, [_p, _p, _p]),
     "vatl_stem_pool_supported": (_i, [_i, _i]),
@@ -464,6 +466,25 @@ def conv1x1_dual_fwd(a, x, w_packed, bias, cout: int, stride2: int, relu: bool, 
     _check(lib().vatl_conv1x1_dual_fwd(_ptr(a), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(y), n, ho, wo, c1, h2, w2, c2, stride2, cout,
                                        w_packed.shape[0], int(relu), _stream()), "vatl_conv1x1_dual_fwd")
     return y
+
+
+def bottleneck_chain_supported(cmid: int, cout: int, cnext: int, m: int) -> bool:
+    return bool(lib().vatl_bottleneck_chain_supported(cmid, cout, cnext, m))
+
+
+def bottleneck_chain_fwd(a, w3, scale3, bias3, skip, w1=None, scale1=None, bias1=None, out=None, y1_out=None):
+    """t = relu(bn3(conv3(a)) + skip) and, when w1 is given, y1 = relu(bn1(conv1_next(t))) in one launch: a (N,H,W,Cmid), skip (N,H,W,Cout) NHWC,
+    w3 / w1 = packed 1x1 filters (pack_conv_weight).  Returns (t, y1) (y1 None without w1)."""
+    n, h, w_, cmid = a.shape
+    cout = w3.shape[0]
+    cnext = 0 if w1 is None else w1.shape[0]
+    assert w3.numel() == cout * cmid and (w1 is None or w1.numel() == cnext * cout) and (skip is None or tuple(skip.shape) == (n, h, w_, cout))
+    t = out if out is not None else torch.empty((n, h, w_, cout), device=a.device, dtype=torch.float32)
+    assert t.is_contiguous() and a.is_contiguous() and (skip is None or skip.is_contiguous())
+    y1 = None if w1 is None else (y1_out if y1_out is not None else torch.empty((n, h, w_, cnext), device=a.device, dtype=torch.float32))
+    _check(lib().vatl_bottleneck_chain_fwd(_ptr(a), _ptr(w3), _ptr(scale3), _ptr(bias3), _ptr(skip), _ptr(t), _ptr(w1), _ptr(scale1), _ptr(bias1), _ptr(y1),
+                                           n * h * w_, cmid, cout, cnext, _stream()), "vatl_bottleneck_chain_fwd")
+    return t, y1
 
 
 def pack_deconv_weight(w: torch.Tensor) -> torch.Tensor:
