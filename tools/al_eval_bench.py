@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--retrain", action="store_true", help="also time one fine-tune epoch over all items")
     ap.add_argument("--representativeness", default="None")
     ap.add_argument("--filter", default="None")
+    ap.add_argument("--cprofile", action="store_true", help="cProfile the rounds after the first and print the 30 most expensive functions (own time)")
     a = ap.parse_args()
     from active_learning import ActiveLearning
     from alphapose.datasets import FrameVideo
@@ -53,11 +54,19 @@ def main():
         torch.manual_seed(0); np.random.seed(0)
         al = ActiveLearning(cfg, opt, eval_dataset=ev, train_dataset=tr)
         times = []
-        for _ in range(a.rounds):
+        prof = None
+        for r in range(a.rounds):
             al.unlabeled_id = list(range(len(ev))); al.labeled_id = []
+            if a.cprofile and r == 1:
+                import cProfile
+                prof = cProfile.Profile(); prof.enable()
             torch.cuda.synchronize(); t0 = time.perf_counter()
             al.eval_and_query()
             torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof).sort_stats("tottime").print_stats(30)
         if a.retrain:
             al.retrain_id = list(range(len(ev))); al.labeled_id = list(range(len(ev))); al.retrain_epoch = 1
             rt = []

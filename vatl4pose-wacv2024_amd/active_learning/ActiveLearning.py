@@ -210,7 +210,7 @@ class ActiveLearning:
         return ae
 
     # ------------------------------------------------------------------ hot loop 1
-    def _heatmaps(self, inps, emb_out=None):
+    def _heatmaps(self, inps, emb_out=None, out=None):
         m = self.model
         x = inps[:, 0].to(self.device, non_blocking=True)
         from alphapose.models import hip_engine
@@ -221,11 +221,11 @@ class ActiveLearning:
             t = t.to(self.device)
             return hip_engine.forward_into(m, t, torch.empty((t.shape[0], self.cfg.DATA_PRESET.NUM_JOINTS, *self.hm_size), device=self.device))
         with torch.no_grad():
+            cur = out if out is not None else torch.empty((x.shape[0], self.cfg.DATA_PRESET.NUM_JOINTS, *self.hm_size), device=self.device)
             if emb_out is not None:                   # heat-maps and get_embedding from one trunk pass
-                cur = torch.empty((x.shape[0], self.cfg.DATA_PRESET.NUM_JOINTS, *self.hm_size), device=self.device)
                 hip_engine.forward_with_embedding(m, x, cur, emb_out)
             else:
-                cur = heatmaps(x)
+                hip_engine.forward_into(m, x, cur)
             if not self.get_prenext or self.dedup:
                 return cur, None, None
             return cur, heatmaps(inps[:, 1]), heatmaps(inps[:, 2])
@@ -238,10 +238,12 @@ class ActiveLearning:
         # the shard's heat-maps stay on the device (209 KB per item) and are scored in one pass, so THC/TPC
         # neighbours across loader batches need no special casing
         hm_all = torch.empty((n, J, hh, hw), device=self.device)
-        bb_all = torch.empty((n, 4), device=self.device)
-        ip_all = torch.zeros(n, dtype=torch.uint8, device=self.device)
-        in_all = torch.zeros(n, dtype=torch.uint8, device=self.device)
         thc_ref = torch.zeros(n, device=self.device)
+        # per-item host columns are collected on the host and uploaded ONCE after the loop (pinned, non-blocking): an upload from pageable
+        # memory inside the loop would block the host until the batch's forward pass has finished, and the next batch's crops are prepared
+        # by the host — the loop must only enqueue
+        bb_h = np.zeros((n, 4), np.float32)
+        ip_h, in_h = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
         gt_all = np.zeros((n, 3 * J), np.float64)
         ann_all = np.zeros((n, 4), np.float64)
         ids_all = np.zeros((n, 2), np.float64)                            # image id, annotation id (exact in float64)
@@ -251,25 +253,28 @@ class ActiveLearning:
             Subset(self.eval_dataset, list(range(lo, hi))), batch_size=self.eval_loader.batch_size, shuffle=False, num_workers=0,
             collate_fn=self.collate_fn)
         for (idxs, inps, labels, label_masks, GTkpts, img_ids, ann_ids, bboxes_crop, bboxes_ann, isPrev, isNext) in loader:
-            emb_b = torch.empty((len(idxs), self.emb_dim), device=self.device) if emb_all is not None else None
-            cur, prev, nxt = self._heatmaps(inps, emb_b)
-            assert cur.dim() == 4, "the dimension of output must be 4"
             loc = np.asarray(idxs) - lo
-            idx = torch.as_tensor(loc, device=self.device)
-            ip = torch.as_tensor(isPrev, dtype=torch.uint8, device=self.device)
-            inx = torch.as_tensor(isNext, dtype=torch.uint8, device=self.device)
-            hm_all[idx] = cur
-            if emb_all is not None:                                       # ActiveLearning.py:284-286, without the second trunk pass
-                emb_all[idx] = emb_b
-            bb_all[idx] = bboxes_crop.to(self.device).float()
-            ip_all[idx], in_all[idx] = ip, inx
+            a0, b0 = int(loc[0]), int(loc[0]) + len(loc)
+            run = bool(np.array_equal(loc, np.arange(a0, b0)))           # a sequential loader hands over consecutive items: plain slices, no index tensor
+            idx = slice(a0, b0) if run else vh.upload(loc, self.device)
+            emb_b = (emb_all[idx] if run else torch.empty((len(idxs), self.emb_dim), device=self.device)) if emb_all is not None else None
+            cur, prev, nxt = self._heatmaps(inps, emb_b, out=hm_all[idx] if run else None)
+            assert cur.dim() == 4, "the dimension of output must be 4"
+            if not run:
+                hm_all[idx] = cur
+                if emb_all is not None:                                   # ActiveLearning.py:284-286, without the second trunk pass
+                    emb_all[idx] = emb_b
+            bb_h[loc] = bboxes_crop.cpu().numpy()
+            ip_h[loc], in_h[loc] = np.asarray(isPrev, np.uint8), np.asarray(isNext, np.uint8)
             if thc_norm is not None and not self.dedup:                   # reference-faithful: explicit prev/next forwards
+                ip, inx = vh.upload(ip_h[loc], self.device), vh.upload(in_h[loc], self.device)
                 tp, tn = vh.thc_pairs(cur, prev, thc_norm), vh.thc_pairs(cur, nxt, thc_norm)
                 one = (ip ^ inx).float()
                 thc_ref[idx] = (tp * ip + tn * inx) * (1 + one)
             gt_all[loc] = GTkpts.reshape(len(idxs), -1).numpy()
             ids_all[loc, 0], ids_all[loc, 1] = np.asarray(img_ids, np.float64), np.asarray(ann_ids, np.float64)
-            ann_all[loc] = np.asarray([bbox_xyxy_to_xywh(b.tolist()) for b in bboxes_ann])
+            ann_all[loc] = bbox_xyxy_to_xywh(bboxes_ann.numpy().astype(np.float64))
+        bb_all, ip_all, in_all = vh.upload(bb_h, self.device), vh.upload(ip_h, self.device), vh.upload(in_h, self.device)
         ae_flat = self.AE.packed() if self.AE is not None else None
         s = score_batch(hm_all, bb_all, ip_all, in_all, thc_norm=thc_norm if self.dedup else None, ae_flat=ae_flat,
                         ae_dims=(self.AE.input_dim, self.AE.z_dim) if self.AE is not None else (42, 4),
@@ -295,9 +300,9 @@ class ActiveLearning:
             unc[:, 0] = multi_peak_scores(hm_all, self.unc_kind).float()
         kp = s.keypoints.reshape(n, -1)
         # compute_OKS on the device (al_metric.py:42-69): no D2H of the key-points inside the evaluation loop
-        oks = vh.oks(s.keypoints.contiguous(), torch.as_tensor(gt_all, device=self.device), torch.as_tensor(ann_all, device=self.device))
+        oks = vh.oks(s.keypoints.contiguous(), vh.upload(gt_all, self.device), vh.upload(ann_all, self.device))
         # float64 side rows for the result records (ActiveLearning.py:310-327): ids, annotation box (xywh), ground truth
-        self._side = (lo, hi, torch.as_tensor(np.concatenate([ids_all, ann_all, gt_all], 1), device=self.device))
+        self._side = (lo, hi, vh.upload(np.concatenate([ids_all, ann_all, gt_all], 1), self.device))
         cols = [kp, unc, s.localpeak[:, None], oks.float()[:, None]]
         if emb_all is not None:
             cols.append(emb_all)
@@ -444,25 +449,46 @@ class ActiveLearning:
         third-party evaluate_mAP / ospa_for_loc tools can be run on them (they stay outside this package)."""
         labeled = set(self.labeled_id)
         self.kpt_json, self.kpt_json_ann, self.GT_json = [], [], []
-        for i in range(len(kp_all)):
-            kp = kp_all[i].astype(np.float32)
-            scores = kp[2::3]
-            gt = side[i, 6:].tolist()
-            rec = {"bbox": side[i, 2:6].tolist(), "image_id": int(side[i, 0]), "id": int(side[i, 1]),
-                   "score": float(np.mean(scores) + 1.25 * np.max(scores)), "category_id": 1, "keypoints": [float(x) for x in kp],
-                   "GT_keypoints": gt, "OKS": float(oks[i])}
+        kp32 = np.asarray(kp_all, np.float32)
+        conf = kp32[:, 2::3]
+        # whole columns converted once (a numpy call per item costs more than the record itself); float32 arithmetic like the per-item form
+        score = (conf.mean(1) + np.float32(1.25) * conf.max(1)).astype(np.float64).tolist()
+        kps, gts, boxes = kp32.astype(np.float64).tolist(), side[:, 6:].tolist(), side[:, 2:6].tolist()
+        img_ids, ann_ids, oks_l = side[:, 0].astype(np.int64).tolist(), side[:, 1].astype(np.int64).tolist(), np.asarray(oks, np.float64).tolist()
+        for i in range(len(kp32)):
+            rec = {"bbox": boxes[i], "image_id": img_ids[i], "id": ann_ids[i], "score": score[i], "category_id": 1, "keypoints": kps[i],
+                   "GT_keypoints": gts[i], "OKS": oks_l[i]}
             self.kpt_json.append(rec)
-            self.kpt_json_ann.append(dict(rec, keypoints=gt) if i in labeled else dict(rec))
-            self.GT_json.append(dict(rec, keypoints=gt))
+            self.kpt_json_ann.append(dict(rec, keypoints=gts[i]) if i in labeled else dict(rec))
+            self.GT_json.append(dict(rec, keypoints=gts[i]))
         work_dir = getattr(self.opt, "work_dir", None)
         from . import distributed as D
         if work_dir and D.is_main():
-            import json
             import os
             os.makedirs(work_dir, exist_ok=True)
-            for name, data in (("predicted_kpt.json", self.kpt_json), ("predicted_kpt_ann.json", self.kpt_json_ann), ("GT_kpt.json", self._gt_dict())):
+            for name, text in zip(("predicted_kpt.json", "predicted_kpt_ann.json", "GT_kpt.json"), self._records_json()):
                 with open(os.path.join(work_dir, name), "w") as f:
-                    f.write(json.dumps(data))              # one-shot dumps runs the C encoder; json.dump(f) iterates in Python (5x slower here)
+                    f.write(text)
+
+    def _records_json(self):
+        """json.dumps of ``self.kpt_json``, ``self.kpt_json_ann`` and ``self._gt_dict()`` — the same text, character for character — with every
+        record's shared fields (box, ids, score, the two key-point lists, OKS) encoded ONCE instead of once per file: the three files differ only
+        in which of the two lists a record's "keypoints" holds, and formatting ~110 floats per record is what writing them costs."""
+        import json
+        enc = json.dumps
+        pred, ann, gt = [], [], []
+        for rec, rec_ann in zip(self.kpt_json, self.kpt_json_ann):
+            kp_s, gt_s = enc(rec["keypoints"]), enc(rec["GT_keypoints"])
+            head = '{"bbox": %s, "image_id": %s, "id": %s, "score": %s, "category_id": %s, "keypoints": ' % (
+                enc(rec["bbox"]), enc(rec["image_id"]), enc(rec["id"]), enc(rec["score"]), enc(rec["category_id"]))
+            tail = ', "GT_keypoints": %s, "OKS": %s}' % (gt_s, enc(rec["OKS"]))
+            pred.append(head + kp_s + tail)
+            ann.append(head + (gt_s if rec_ann["keypoints"] is rec["GT_keypoints"] else kp_s) + tail)
+            gt.append(head + gt_s + tail)
+        g = self._gt_dict()
+        assert list(g) == ["images", "categories", "annotations"]
+        return ("[" + ", ".join(pred) + "]", "[" + ", ".join(ann) + "]",
+                '{"images": %s, "categories": %s, "annotations": [%s]}' % (enc(g["images"]), enc(g["categories"]), ", ".join(gt)))
 
     def _gt_dict(self):
         """``save_GT_dict`` (ActiveLearning.py:693-705): the ground truth in COCO layout — ``images`` / ``categories`` copied from the

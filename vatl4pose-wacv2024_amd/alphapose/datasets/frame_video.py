@@ -20,6 +20,8 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
+import vatl_hip as vh
+
 from alphapose.models.builder import DATASET
 from alphapose.utils.presets.simple_transform import FrameArena, SimpleTransform
 
@@ -100,7 +102,7 @@ class FrameVideo(Dataset):
             if rows:
                 nb = [self._labels[idxs[k] + step] for k in rows]
                 crops, _ = st.test_transform_batch(arena, [at(a["frame"]) for a in nb], np.array([a["bbox"] for a in nb], np.float64))
-                stacked[torch.as_tensor(rows, device=cur.device), slot] = crops
+                stacked[vh.upload(np.asarray(rows, np.int64), cur.device), slot] = crops
         out = []
         for k, (i, lb) in enumerate(zip(idxs, labels)):
             out.append((i, stacked[k], target[k], weight[k], torch.tensor(lb["keypoint"], dtype=torch.float32), lb["img_id"], lb["ann_id"],

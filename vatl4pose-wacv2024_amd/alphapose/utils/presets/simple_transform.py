@@ -73,8 +73,8 @@ class SimpleTransform(object):
         if mirror is not None:
             hwf[:, 2] = np.asarray(mirror).astype(np.int32)
         dev = arena.data.device
-        crops, _ = vh.crop_warp_affine(arena.data, torch.from_numpy(arena.offsets[fi]).to(dev), torch.from_numpy(hwf).to(dev),
-                                       torch.from_numpy(np.ascontiguousarray(minv)).to(dev), (inp_h, inp_w), out=out)
+        crops, _ = vh.crop_warp_affine(arena.data, vh.upload(arena.offsets[fi], dev), vh.upload(hwf, dev),
+                                       vh.upload(np.ascontiguousarray(minv), dev), (inp_h, inp_w), out=out)
         return crops, trans
 
     def test_transform_batch(self, arena: FrameArena, frame_index, boxes_xyxy):
@@ -86,8 +86,8 @@ class SimpleTransform(object):
     def targets_batch(self, joints_xy, vis):
         """``_target_generator`` (:122-158) for (B,J,2) input-pixel joints, (B,J) visibility -> target (B,J,h,w), weight (B,J,1,1)."""
         dev = _device()
-        j = torch.as_tensor(np.ascontiguousarray(joints_xy, np.float32)).to(dev)
-        v = torch.as_tensor(np.ascontiguousarray(vis, np.float32)).to(dev)
+        j = vh.upload(np.ascontiguousarray(joints_xy, np.float32), dev)
+        v = vh.upload(np.ascontiguousarray(vis, np.float32), dev)
         return vh.gaussian_targets(j, v, tuple(int(s) for s in self._heatmap_size), tuple(int(s) for s in self._input_size), float(self._sigma))
 
     # ------------------------------------------------------------------ reference per-item interface

@@ -175,6 +175,19 @@ def _check(rc: int, what: str):
         raise VatlError(f"{what} failed ({rc}): {lib().vatl_last_error().decode()}")
 
 
+def upload(host, device, dtype=None):
+    """Host array / CPU tensor -> device tensor WITHOUT draining the stream: staged through PyTorch's pinned-memory cache and copied
+    non-blocking.  (A plain `.to(device)` from pageable memory blocks the host until every launch queued before it has finished — a few
+    of those per loader batch serialise the host's batch preparation with the device's forward pass.)"""
+    t = torch.as_tensor(host)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    device = torch.device(device)
+    if device.type != "cuda" or t.numel() == 0:
+        return t.to(device)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
 def _ptr(t, dtype=torch.float32):
     if t is None:
         return None
