@@ -108,6 +108,16 @@ int vatl_pack_conv1x1_dual_weight(const float* w1, const float* scale1, const fl
 int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo,
                           int C1, int H2, int W2, int C2, int stride2, int Cout, int CoutPad, int relu, void* stream);
 
+/* 1x1 convolution with K = 128 input channels as a row-streaming GEMM (csrc/conv1x1_rows.hip): y = act(scale * (A W^T) + bias + residual) for the short-K /
+ * wide-N layers the tiled implicit GEMM runs far from both roofs (Bottleneck.conv3 of ResNet stage 2, Resnet.py:120-128; with x2: conv3 + projection
+ * shortcut of stage 1's first block as vatl_conv1x1_dual_fwd computes it, Resnet.py:104-128, 185-189).  a (M, K1), x2 (M, K2) or NULL: the K columns
+ * K1 .. K1 + K2 - 1 come from x2; w [N][128] (vatl_pack_conv_weight layout of a 1x1 filter / vatl_pack_conv1x1_dual_weight); scale / bias / residual may
+ * be NULL.  Bit-identical to vatl_conv2d_fwd / vatl_conv1x1_dual_fwd.  Served (vatl_conv1x1_rows_supported): K1 = 128, K2 = 0 or K1 = K2 = 64;
+ * N a multiple of 128, <= 4096; (M + 32) * N < 2^30. */
+int vatl_conv1x1_rows_supported(int K1, int K2, int N, int64_t M);
+int vatl_conv1x1_rows_fwd(const float* a, const float* x2, const float* w, const float* scale, const float* bias, const float* residual, float* y,
+                          int64_t M, int K1, int K2, int N, int relu, void* stream);
+
 /* Last 1x1 conv of a bottleneck (+ bn3 + identity skip + ReLU, Resnet.py:120-128) chained with the NEXT bottleneck's first 1x1 conv
  * (+ bn1 + ReLU, Resnet.py:104-108) in one launch (csrc/bottleneck_chain.hip): t = relu(scale3 * (a W3^T) + bias3 + skip) is written
  * (it is the next block's skip connection) and y1 = relu(scale1 * (t W1^T) + bias1) is computed from the tile still in LDS, so the

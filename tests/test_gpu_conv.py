@@ -366,6 +366,48 @@ def test_bottleneck_chain_vs_two_launches_and_float64(vh):
         vh.bottleneck_chain_fwd(to_dev(r.standard_normal((1, 2, 2, 32)).astype(np.float32)), w3p[:, :, :, :32].contiguous(), s3d, b3d, None)
 
 
+def test_conv1x1_rows_has_the_bits_of_the_tiled_kernels(vh):
+    """vatl_conv1x1_rows_fwd (csrc/conv1x1_rows.hip): K = 128 1x1 layers as a row-streaming GEMM — same k order as the tiled implicit GEMM, so the output must be
+    BIT-IDENTICAL to vatl_conv2d_fwd (with / without scale, bias, residual, ReLU; N = 128 .. 1024; ragged pixel counts, a single pixel, more tiles than one walk) and,
+    in the two-source form, to vatl_conv1x1_dual_fwd; plus a float64 check and the batch independence of a crop's bits."""
+    r = np.random.RandomState(91)
+    assert vh.conv1x1_rows_supported(128, 0, 512, 1024 * 32 * 24) and vh.conv1x1_rows_supported(64, 64, 256, 1024 * 64 * 48)
+    assert not vh.conv1x1_rows_supported(256, 0, 512, 100) and not vh.conv1x1_rows_supported(128, 0, 192, 100) and not vh.conv1x1_rows_supported(128, 0, 512, 1 << 21)
+    for cout in (128, 512, 1024):
+        w = (r.standard_normal((cout, 128, 1, 1)) / 11).astype(np.float32)
+        sc, bi = r.uniform(0.5, 1.5, cout).astype(np.float32), r.standard_normal(cout).astype(np.float32)
+        wp, scd, bid = vh.pack_conv_weight(to_dev(w)), to_dev(sc), to_dev(bi)
+        for n, h, wd in ((3, 32, 24), (1, 5, 7), (1, 1, 1), (70, 8, 6), (1, 1, 33), (40, 32, 24)):
+            a = r.standard_normal((n, h, wd, 128)).astype(np.float32)
+            res = r.standard_normal((n, h, wd, cout)).astype(np.float32)
+            ad, rd = to_dev(a), to_dev(res)
+            for relu, use_res, use_sb in ((True, True, True), (False, False, True), (True, False, False)):
+                s_, b_ = (scd, bid) if use_sb else (None, None)
+                want = vh.conv2d_fwd(ad, wp, s_, b_, cout, 1, 1, 1, 0, relu, residual=rd if use_res else None)
+                got = vh.conv1x1_rows_fwd(ad, wp, s_, b_, cout, relu, residual=rd if use_res else None)
+                assert torch.equal(got, want), (cout, n, h, wd, relu, use_res, use_sb)
+            if cout == 512 and n == 3:
+                ref = np.maximum((a.astype(np.float64) @ w[:, :, 0, 0].T.astype(np.float64)) * sc + bi + res, 0)
+                e = rel_err(vh.conv1x1_rows_fwd(ad, wp, scd, bid, cout, True, residual=rd).cpu().numpy(), ref)
+                record("conv1x1_rows_k128_n512", vs_fp64=e)
+                assert e < 2e-6
+                solo = vh.conv1x1_rows_fwd(ad[1:2].contiguous(), wp, scd, bid, cout, True, residual=rd[1:2].contiguous())
+                assert torch.equal(solo, vh.conv1x1_rows_fwd(ad, wp, scd, bid, cout, True, residual=rd)[1:2])
+    # two sources: conv3 + projection shortcut of a stage's first block
+    cout = 256
+    w1 = (r.standard_normal((cout, 64, 1, 1)) / 8).astype(np.float32); w2 = (r.standard_normal((cout, 64, 1, 1)) / 8).astype(np.float32)
+    s1, b1 = r.uniform(0.5, 1.5, cout).astype(np.float32), r.standard_normal(cout).astype(np.float32)
+    s2, b2 = r.uniform(0.5, 1.5, cout).astype(np.float32), r.standard_normal(cout).astype(np.float32)
+    wp, bias = vh.pack_conv1x1_dual_weight(to_dev(w1), to_dev(s1), to_dev(b1), to_dev(w2), to_dev(s2), to_dev(b2))
+    for n, h, wd in ((2, 64, 48), (1, 3, 5), (9, 16, 12)):
+        a, x = to_dev(r.standard_normal((n, h, wd, 64)).astype(np.float32)), to_dev(r.standard_normal((n, h, wd, 64)).astype(np.float32))
+        want = vh.conv1x1_dual_fwd(a, x, wp, bias, cout, 1, True)
+        got = vh.conv1x1_rows_fwd(a, wp, None, bias, cout, True, x2=x)
+        assert torch.equal(got, want), (n, h, wd)
+    with pytest.raises(vh.VatlError):
+        vh.conv1x1_rows_fwd(to_dev(r.standard_normal((1, 2, 2, 64)).astype(np.float32)), wp, None, bias, cout, True)
+
+
 def test_chained_bottlenecks_in_the_plans(vh, monkeypatch):
     """The stream route of SimplePose-R50 / HRNet-W32 takes the chained launch where an identity-shortcut bottleneck is followed by a 256 -> 64 conv1
     (R50 stage 1: one linked + one first-GEMM-only launch; HRNet layer1: two linked + one alone), and the pass equals the separate launches to fp32 rounding."""

@@ -44,6 +44,9 @@ STAGE1_CHUNK = int(os.environ.get("VATL_STAGE1_CHUNK", "0"))   # measured neutra
 # `model(x)` gives one set of bits for <= 16 crops and the stream route's bits above; both hold the 1e-4 / arg-max contract, and
 # VATL_SPLITK_AUTO=0 makes the module call take the stream route at every size.  VATL_WINOGRAD=0 = the implicit GEMM everywhere.
 WINOGRAD = os.environ.get("VATL_WINOGRAD", "1") != "0"
+# 1x1 layers with K = 128 and N a multiple of 128 (Bottleneck.conv3 of stage 2; conv3 + projection of stage 1's first block) through the row-streaming GEMM
+# (csrc/conv1x1_rows.hip: filter slice in registers, 32-pixel tiles; bit-identical to the tiled kernels).  VATL_ROWS_GEMM=0 = the tiled kernels.
+ROWS_GEMM = os.environ.get("VATL_ROWS_GEMM", "1") != "0"
 
 
 class _Conv:
@@ -69,6 +72,9 @@ class _Conv:
     def __call__(self, x, relu, residual=None, out_nchw=False, out=None):
         if self.u is not None and not out_nchw and not vh.latency_mode():
             return vh.conv3x3_winograd_fwd(x, self.u, self.scale, self.bias, self.cout, relu, residual=residual, out=out)
+        if (ROWS_GEMM and self.r == 1 and self.stride == 1 and not out_nchw and not vh.latency_mode() and x.shape[-1] == 128
+                and vh.conv1x1_rows_supported(128, 0, self.cout, x.shape[0] * x.shape[1] * x.shape[2])):
+            return vh.conv1x1_rows_fwd(x, self.w, self.scale, self.bias, self.cout, relu, residual=residual, out=out)     # K = 128, wide N: row-streaming GEMM
         return vh.conv2d_fwd(x, self.w, self.scale, self.bias, self.cout, self.r, self.s, self.stride, self.pad, relu,
                              residual=residual, out_nchw=out_nchw, out=out)
 
@@ -120,6 +126,9 @@ class _BottleneckPlan:
 
     def tail(self, y, x, out=None):
         if self.dual is not None:                                   # relu(bn3(conv3(y)) + bn_p(conv_p(x))) in one GEMM over K = C1 + C2
+            if (ROWS_GEMM and self.dual[2] == 1 and y.shape[-1] == 64 and x.shape[-1] == 64 and not vh.latency_mode()
+                    and vh.conv1x1_rows_supported(64, 64, self.c3.cout, y.shape[0] * y.shape[1] * y.shape[2])):
+                return vh.conv1x1_rows_fwd(y, self.dual[0], None, self.dual[1], self.c3.cout, True, x2=x, out=out)
             return vh.conv1x1_dual_fwd(y, x, self.dual[0], self.dual[1], self.c3.cout, self.dual[2], True, out=out)
         skip = x if self.proj is None else self.proj(x, relu=False)
         return self.c3(y, relu=True, residual=skip, out=out)        # relu(bn3(conv3) + skip)

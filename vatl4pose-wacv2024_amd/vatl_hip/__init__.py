@@ -34,6 +34,8 @@ SIGNATURES = {
     "vatl_pack_deconv4x4s2_weight": (_i, [_p, _p, _i, _i, _i, _p]),
     "vatl_pack_conv1x1_dual_weight": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_conv1x1_dual_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "vatl_conv1x1_rows_supported": (_i, [_i, _i, _i, _i64]),
+    "vatl_conv1x1_rows_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p]),
     "vatl_bottleneck_chain_supported": (_i, [_i, _i, _i, _i64]),
     "vatl_bottleneck_chain_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
     "vatl_stem_pool_weight_floats": (_i64, []),
@@ -478,6 +480,22 @@ def conv1x1_dual_fwd(a, x, w_packed, bias, cout: int, stride2: int, relu: bool, 
     y = out if out is not None else torch.empty((n, ho, wo, cout), device=a.device, dtype=torch.float32)
     _check(lib().vatl_conv1x1_dual_fwd(_ptr(a), _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(y), n, ho, wo, c1, h2, w2, c2, stride2, cout,
                                        w_packed.shape[0], int(relu), _stream()), "vatl_conv1x1_dual_fwd")
+    return y
+
+
+def conv1x1_rows_supported(k1: int, k2: int, n: int, m: int) -> bool:
+    return bool(lib().vatl_conv1x1_rows_supported(k1, k2, n, m))
+
+
+def conv1x1_rows_fwd(a, w, scale, bias, cout: int, relu: bool, residual=None, x2=None, out=None):
+    """relu?(scale * (A W^T) + bias + residual) for K = 128 input channels (a (N,H,W,128), or a (N,H,W,64) + x2 (N,H,W,64)); w [cout][128] packed."""
+    n, h, w_, k1 = a.shape
+    k2 = 0 if x2 is None else x2.shape[-1]
+    assert w.numel() >= cout * (k1 + k2) and (x2 is None or tuple(x2.shape[:3]) == (n, h, w_)) and (residual is None or tuple(residual.shape) == (n, h, w_, cout))
+    y = out if out is not None else torch.empty((n, h, w_, cout), device=a.device, dtype=torch.float32)
+    assert a.is_contiguous() and y.is_contiguous() and (x2 is None or x2.is_contiguous()) and (residual is None or residual.is_contiguous())
+    _check(lib().vatl_conv1x1_rows_fwd(_ptr(a), _ptr(x2), _ptr(w), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(y), n * h * w_, k1, k2, cout, int(relu),
+                                       _stream()), "vatl_conv1x1_rows_fwd")
     return y
 
 
