@@ -108,6 +108,16 @@ int vatl_pack_conv1x1_dual_weight(const float* w1, const float* scale1, const fl
 int vatl_conv1x1_dual_fwd(const float* a, const float* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo,
                           int C1, int H2, int W2, int C2, int stride2, int Cout, int CoutPad, int relu, void* stream);
 
+/* Winograd F(2x2,3x3) for 32 -> 32 channel 3x3 / stride 1 / pad 1 layers without cross-wave exchange (csrc/winograd_c32.hip; BasicBlock convs of HRNet's
+ * highest-resolution branch, hrnet.py:24-56): x, residual, y NHWC (N,H,W,32), H and W even; u from vatl_pack_winograd_c32_weight ((32,32,3,3) filter ->
+ * vatl_winograd_c32_weight_floats() floats); y = act(scale * conv(x) + bias + residual), scale / bias / residual may be NULL.  Same arithmetic as
+ * vatl_conv3x3_winograd_fwd up to the order of the channel sums (fp32 rounding). */
+int64_t vatl_winograd_c32_weight_floats(void);
+int vatl_pack_winograd_c32_weight(const float* w, float* u, void* stream);
+int vatl_conv3x3_winograd_c32_supported(int N, int H, int W, int Cin, int Cout);
+int vatl_conv3x3_winograd_c32_fwd(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, int N, int H, int W,
+                                  int relu, void* stream);
+
 /* 1x1 convolution with K = 128 input channels as a row-streaming GEMM (csrc/conv1x1_rows.hip): y = act(scale * (A W^T) + bias + residual) for the short-K /
  * wide-N layers the tiled implicit GEMM runs far from both roofs (Bottleneck.conv3 of ResNet stage 2, Resnet.py:120-128; with x2: conv3 + projection
  * shortcut of stage 1's first block as vatl_conv1x1_dual_fwd computes it, Resnet.py:104-128, 185-189).  a (M, K1), x2 (M, K2) or NULL: the K columns

@@ -408,6 +408,40 @@ def test_conv1x1_rows_has_the_bits_of_the_tiled_kernels(vh):
         vh.conv1x1_rows_fwd(to_dev(r.standard_normal((1, 2, 2, 64)).astype(np.float32)), wp, None, bias, cout, True)
 
 
+def test_winograd_c32_vs_float64_and_the_general_route(vh):
+    """vatl_conv3x3_winograd_c32_fwd (csrc/winograd_c32.hip): 32 -> 32 channel 3x3 / stride 1 / pad 1 layers with wave-private tiles on 16x16x4 MFMAs.  Against
+    float64 (same bound as the general Winograd kernel: the two differ only in the grouping of the channel sums) on sizes with whole and partial 8 x 2 tile
+    patches, with / without folded BN, skip connection and ReLU; a crop's bits independent of its batch and position; the plan takes it for HRNet's first branch."""
+    r = np.random.RandomState(57)
+    w = (r.standard_normal((32, 32, 3, 3)) * (2.0 / 288) ** 0.5).astype(np.float32)
+    sc, bi = r.uniform(0.5, 1.5, 32).astype(np.float32), r.standard_normal(32).astype(np.float32)
+    u32, u = vh.pack_winograd_c32_weight(to_dev(w)), vh.pack_winograd_weight(to_dev(w))
+    assert vh.conv3x3_winograd_c32_supported(1024, 64, 48, 32, 32) and not vh.conv3x3_winograd_c32_supported(4, 7, 8, 32, 32)
+    assert not vh.conv3x3_winograd_c32_supported(4, 8, 8, 64, 64)
+    wt = torch.from_numpy(w).double()
+    for n, h, wd in ((2, 64, 48), (3, 10, 22), (1, 2, 2), (5, 4, 34), (1, 96, 72), (9, 8, 6)):
+        x = r.standard_normal((n, h, wd, 32)).astype(np.float32)
+        res = r.standard_normal((n, h, wd, 32)).astype(np.float32)
+        conv = torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), wt, padding=1).permute(0, 2, 3, 1).numpy()
+        xd, rd = to_dev(x), to_dev(res)
+        for relu, use_res, use_sb in ((True, True, True), (False, False, False), (True, False, True)):
+            want = conv * (sc if use_sb else 1.0) + (bi if use_sb else 0.0) + (res if use_res else 0.0)
+            want = np.maximum(want, 0) if relu else want
+            s_, b_ = (to_dev(sc), to_dev(bi)) if use_sb else (None, None)
+            got = vh.conv3x3_winograd_c32_fwd(xd, u32, s_, b_, relu, residual=rd if use_res else None)
+            gen = vh.conv3x3_winograd_fwd(xd, u, s_, b_, 32, relu, residual=rd if use_res else None)
+            e, eg = rel_err(got.cpu().numpy(), want), rel_err(gen.cpu().numpy(), want)
+            assert e < 2e-6 and rel_err(got.cpu().numpy(), gen.cpu().numpy()) < 2e-6, (n, h, wd, relu, use_res, use_sb, e, eg)
+        record(f"winograd_c32_{n}x{h}x{wd}", vs_fp64=e, general_route_vs_fp64=eg)
+        if n > 1:
+            full = vh.conv3x3_winograd_c32_fwd(xd, u32, to_dev(sc), to_dev(bi), True, residual=rd)
+            solo = vh.conv3x3_winograd_c32_fwd(xd[1:2].contiguous(), u32, to_dev(sc), to_dev(bi), True, residual=rd[1:2].contiguous())
+            assert torch.equal(solo, full[1:2])
+            assert torch.equal(vh.conv3x3_winograd_c32_fwd(xd, u32, to_dev(sc), to_dev(bi), True, residual=rd), full)      # same bits again
+    with pytest.raises(vh.VatlError):
+        vh.conv3x3_winograd_c32_fwd(to_dev(r.standard_normal((1, 7, 8, 32)).astype(np.float32)), u32, None, None, False)
+
+
 def test_chained_bottlenecks_in_the_plans(vh, monkeypatch):
     """The stream route of SimplePose-R50 / HRNet-W32 takes the chained launch where an identity-shortcut bottleneck is followed by a 256 -> 64 conv1
     (R50 stage 1: one linked + one first-GEMM-only launch; HRNet layer1: two linked + one alone), and the pass equals the separate launches to fp32 rounding."""
@@ -661,6 +695,8 @@ def _count_winograd(vh, monkeypatch):
     calls = {"conv": 0, "deconv": 0, "splitk": 0}
     oc, od = vh.conv3x3_winograd_fwd, vh.deconv4x4s2_winograd_fwd
     monkeypatch.setattr(vh, "conv3x3_winograd_fwd", lambda *a, **k: (calls.__setitem__("conv", calls["conv"] + 1), oc(*a, **k))[1])
+    o32 = vh.conv3x3_winograd_c32_fwd                      # (the 32 -> 32 channel layers' own Winograd kernel counts as a Winograd launch)
+    monkeypatch.setattr(vh, "conv3x3_winograd_c32_fwd", lambda *a, **k: (calls.__setitem__("conv", calls["conv"] + 1), o32(*a, **k))[1])
     monkeypatch.setattr(vh, "deconv4x4s2_winograd_fwd", lambda *a, **k: (calls.__setitem__("deconv", calls["deconv"] + 1), od(*a, **k))[1])
     return calls
 

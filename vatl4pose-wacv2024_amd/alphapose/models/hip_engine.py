@@ -47,10 +47,13 @@ WINOGRAD = os.environ.get("VATL_WINOGRAD", "1") != "0"
 # 1x1 layers with K = 128 and N a multiple of 128 (Bottleneck.conv3 of stage 2; conv3 + projection of stage 1's first block) through the row-streaming GEMM
 # (csrc/conv1x1_rows.hip: filter slice in registers, 32-pixel tiles; bit-identical to the tiled kernels).  VATL_ROWS_GEMM=0 = the tiled kernels.
 ROWS_GEMM = os.environ.get("VATL_ROWS_GEMM", "1") != "0"
+# 32 -> 32 channel 3x3 layers (HRNet's highest-resolution branch) through the wave-private Winograd kernel (csrc/winograd_c32.hip: a wave owns 16 tiles with all 16
+# transform positions, no cross-wave exchange).  VATL_WINO_C32=0 = the general Winograd kernel.
+WINO_C32 = os.environ.get("VATL_WINO_C32", "1") != "0"
 
 
 class _Conv:
-    __slots__ = ("w", "u", "scale", "bias", "cout", "r", "s", "stride", "pad")
+    __slots__ = ("w", "u", "u32", "scale", "bias", "cout", "r", "s", "stride", "pad")
 
     def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d | None):
         assert conv.groups == 1 and conv.dilation == (1, 1)
@@ -61,6 +64,9 @@ class _Conv:
         self.u = None
         if WINOGRAD and (self.r, self.s, self.stride, self.pad) == (3, 3, 1, 1) and conv.in_channels % 16 == 0 and self.cout % 4 == 0:
             self.u = vh.pack_winograd_weight(conv.weight.detach())
+        self.u32 = None
+        if self.u is not None and WINO_C32 and conv.in_channels == 32 and self.cout == 32:
+            self.u32 = vh.pack_winograd_c32_weight(conv.weight.detach())
         cb = conv.bias.detach() if conv.bias is not None else None
         if bn is not None:
             self.scale, self.bias = vh.bn_fold(_d(bn.weight), _d(bn.bias), bn.running_mean, bn.running_var, bn.eps, cb)
@@ -71,6 +77,8 @@ class _Conv:
 
     def __call__(self, x, relu, residual=None, out_nchw=False, out=None):
         if self.u is not None and not out_nchw and not vh.latency_mode():
+            if self.u32 is not None and vh.conv3x3_winograd_c32_supported(x.shape[0], x.shape[1], x.shape[2], 32, 32):
+                return vh.conv3x3_winograd_c32_fwd(x, self.u32, self.scale, self.bias, relu, residual=residual, out=out)
             return vh.conv3x3_winograd_fwd(x, self.u, self.scale, self.bias, self.cout, relu, residual=residual, out=out)
         if (ROWS_GEMM and self.r == 1 and self.stride == 1 and not out_nchw and not vh.latency_mode() and x.shape[-1] == 128
                 and vh.conv1x1_rows_supported(128, 0, self.cout, x.shape[0] * x.shape[1] * x.shape[2])):
