@@ -33,7 +33,8 @@ constexpr unsigned C32_OOB = 0xFFFFFFF0u;
 constexpr int C32_U_FLOATS = 8 * 2 * 64 * 16;     // 16384
 constexpr int C32_PATCH = 7 * 256;                // floats of a wave's patch buffer: 6 x 18 pixels x 16 channels = 432 16-byte chunks, 7 requests of 64
 constexpr int C32_WAVES = 8;
-constexpr int C32_LDS_FLOATS = C32_U_FLOATS + C32_WAVES * C32_PATCH + 64;       // + scale, bias
+constexpr int C32_TAB = 8 * 64 + 16 * 64;         // staging tables: [lane][8] relative byte offsets of the 7 requests, [16 border classes][lane] validity bits
+constexpr int C32_LDS_FLOATS = C32_U_FLOATS + C32_WAVES * C32_PATCH + 64 + C32_TAB;       // + scale, bias, staging tables
 
 __global__ __launch_bounds__(512, 1) void winograd_c32_kernel(C32Params p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -57,14 +58,34 @@ __global__ __launch_bounds__(512, 1) void winograd_c32_kernel(C32Params p) {
     // ---- per-lane constants ----
     // staging: request j writes LDS chunks 64 j .. 64 j + 63; chunk id = pixel * 4 + position, position = source quad ^ ((patch column >> 2) & 3): the 16 tiles
     // of a read fall on 8 different 4-word bank groups (two-way conflicts; a padded pixel pitch of five chunks makes them 16 — measured: no faster, two more
-    // requests per stage).  One 16-bit code per request: patch row | patch column << 3 | source quad << 8 (row 7 = past the patch: requested out of range).
-    unsigned st_code[4] = {0u, 0u, 0u, 0u};
+    // requests per stage).  What a request needs per unit is origin + a per-lane constant and a yes / no for "inside the image", which depends only on whether the
+    // unit touches the top / bottom / left / right border: both live in LDS tables (written once, by wave 0), so a stage costs ~4 vector instructions per request
+    // instead of ~13 (vector instructions are paid in full next to the MFMAs on this hardware).
+    int* TabRel = reinterpret_cast<int*>(smem + C32_U_FLOATS + C32_WAVES * C32_PATCH + 64);   // [lane][8]
+    int* TabOk = TabRel + 8 * 64;                                                               // [class = top | bottom << 1 | left << 2 | right << 3][lane]: bit j
+    if (wave == 0) {
+        int okc[16];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        const int id = 64 * j + lane, px = id >> 2;
-        const int pr = px / 18, pc = px - pr * 18;
-        st_code[j >> 1] |= (unsigned)((px >= 108 ? 7 : pr) | (pc << 3) | (((id & 3) ^ ((pc >> 2) & 3)) << 8)) << (16 * (j & 1));
+        for (int c = 0; c < 16; ++c) okc[c] = 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int id = 64 * j + lane, px = id >> 2;
+            const int pr = px / 18, pc = px - pr * 18;
+            const int sq = (id & 3) ^ ((pc >> 2) & 3);
+            TabRel[lane * 8 + j] = ((pr * p.W + pc) * 32 + sq * 4) * 4;
+            // rows / columns a unit of the class may read: top: patch row 0 is image row -1; bottom: the last unit row starts at image row 4 (UH - 1) - 1; likewise left / right
+            const int ylast = p.H - (4 * (p.UH - 1) - 1), xlast = p.W - (16 * (p.UW - 1) - 1);      // patch rows / columns below these are inside the image
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const bool ok = px < 108 && (!(c & 1) || pr >= 1) && (!(c & 2) || pr < ylast) && (!(c & 4) || pc >= 1) && (!(c & 8) || pc < xlast);
+                okc[c] |= (ok ? 1 : 0) << j;
+            }
+        }
+        TabRel[lane * 8 + 7] = 0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) TabOk[c * 64 + lane] = okc[c];
     }
+    __syncthreads();
     // input transform: lane (tile t = lane % 16 at (t & 7, t >> 3) of the 8 x 2 patch, channel k4 = lane / 16 of the K-step's four).  LDS word of pixel
     // (2 tyl + i, 2 txl + j), K-step s: base + (i * 18 + j) * 16 + ((swizzle of the pixel's column ^ s) << 2): two swizzles per lane (columns j < 2 / j >= 2)
     const int t16 = lane & 15, k4 = lane >> 4;
@@ -81,14 +102,14 @@ __global__ __launch_bounds__(512, 1) void winograd_c32_kernel(C32Params p) {
     auto stage = [&](int unit, int half) {                // the 16-channel half of the unit's patch -> this wave's buffer (zeros outside the image = the padding)
         const int img = fdiv(unit, p.d_upi), rem = unit - img * p.upi;
         const int uy = fdiv(rem, p.d_uw), ux = rem - uy * p.UW;
-        const int y0 = 4 * uy - 1, x0 = 16 * ux - 1;
+        const int cls = (uy == 0 ? 1 : 0) | (uy == p.UH - 1 ? 2 : 0) | (ux == 0 ? 4 : 0) | (ux == p.UW - 1 ? 8 : 0);
+        const int okbits = TabOk[cls * 64 + lane];
+        const int4 r0 = *reinterpret_cast<const int4*>(TabRel + lane * 8), r1 = *reinterpret_cast<const int4*>(TabRel + lane * 8 + 4);
+        const int rel[7] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z};
+        const int origin = (((img * p.H + 4 * uy - 1) * p.W + 16 * ux - 1) * 32 + half * 16) * 4;        // byte offset of patch pixel (0, 0), this half (may be negative: never used then)
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
-            const int code = (int)((st_code[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
-            const int pr = code & 7, pc = (code >> 3) & 31, sq = code >> 8;
-            const int yy = y0 + pr, xx = x0 + pc;
-            const bool ok = pr != 7 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-            const unsigned off = ok ? (unsigned)((((img * p.H + yy) * p.W + xx) * 32 + half * 16 + sq * 4) * 4) : C32_OOB;
+            const unsigned off = (okbits >> j) & 1 ? (unsigned)(origin + rel[j]) : C32_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (c32_lds_void*)(Ps + j * 256), 16, off, 0, 0, 0);
         }
     };
@@ -115,26 +136,26 @@ __global__ __launch_bounds__(512, 1) void winograd_c32_kernel(C32Params p) {
             load_d(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                // V = B^T d B: rows, then columns
-                float tr[16], v[16];
+                // V = B^T d B on register PAIRS (packed fp32: two values per instruction; vector instructions are paid in full next to the MFMAs): rows as plain
+                // pair arithmetic, columns with operand selects: (v0, v1) = (t0 - t2, t1 + t2), (v2, v3) = (t2 - t1, t1 - t3) from A = (t0, t1), B = (t2, t3)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 dl[4], dh[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    tr[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
-                    tr[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
-                    tr[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
-                    tr[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
-                }
+                for (int i = 0; i < 4; ++i) { dl[i] = f32x2{d[i * 4 + 0], d[i * 4 + 1]}; dh[i] = f32x2{d[i * 4 + 2], d[i * 4 + 3]}; }
+                const f32x2 tl[4] = {dl[0] - dl[2], dl[1] + dl[2], dl[2] - dl[1], dl[1] - dl[3]};
+                const f32x2 th[4] = {dh[0] - dh[2], dh[1] + dh[2], dh[2] - dh[1], dh[1] - dh[3]};
+                float v[16];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    v[i * 4 + 0] = tr[i * 4 + 0] - tr[i * 4 + 2];
-                    v[i * 4 + 1] = tr[i * 4 + 1] + tr[i * 4 + 2];
-                    v[i * 4 + 2] = tr[i * 4 + 2] - tr[i * 4 + 1];
-                    v[i * 4 + 3] = tr[i * 4 + 1] - tr[i * 4 + 3];
+                    f32x2 v01, v23;
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(v01) : "v"(tl[i]), "v"(th[i]));
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(v23) : "v"(tl[i]), "v"(th[i]));
+                    v[i * 4 + 0] = v01.x; v[i * 4 + 1] = v01.y; v[i * 4 + 2] = v23.x; v[i * 4 + 3] = v23.y;
                 }
                 const int S = half * 4 + s;
-                f32x4 uf0[4], uf1[4];
+                f32x4 ufc[4], uf1[4];
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) uf0[qd] = Ul[((S * 2 + 0) * 4 + qd) * 64];
+                for (int qd = 0; qd < 4; ++qd) ufc[qd] = Ul[((S * 2 + 0) * 4 + qd) * 64];
                 // the next K-step's pixels are requested now and arrive behind this step's 32 MFMAs; after the half's last reads the buffer goes to the next request
                 if (s < 3) load_d(s + 1);
                 else {
@@ -146,7 +167,7 @@ __global__ __launch_bounds__(512, 1) void winograd_c32_kernel(C32Params p) {
                 for (int qd = 0; qd < 4; ++qd) uf1[qd] = Ul[((S * 2 + 1) * 4 + qd) * 64];  // (behind the first 16 MFMAs)
                 const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q], uf0[q >> 2][q & 3], (half == 0 && s == 0) ? zero4 : acc[q][0], 0, 0, 0);
+                for (int q = 0; q < 16; ++q) acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q], ufc[q >> 2][q & 3], (half == 0 && s == 0) ? zero4 : acc[q][0], 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q], uf1[q >> 2][q & 3], (half == 0 && s == 0) ? zero4 : acc[q][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);        // (nothing else hoisted over the MFMAs: 128 accumulator registers leave no room)
