@@ -150,7 +150,9 @@ int vatl_bottleneck_chain_fwd(const float* a, const float* w3, const float* scal
  * vatl_set_streamk_workspace_thread; 1 = default, 0 = off), 16 = pixels per thread of the crop warp kernel (8 = default, 4), 18 = KB of filter slices per group of the Winograd
  * kernel's tile order (default 2048; 0 = one slice), 19 = target block count of the Winograd weight-gradient launches (default 1024; the transposed
  * convs use 4x that), 21 = 32-channel filter halves per Winograd block (1 = one, 2 = default: two where the filter has an even number of halves and the launch keeps
- * >= 400 blocks, 3 = two wherever the filter allows; bit-identical results).  Knob 0 values 10..13, knob 4 (wgrad ablation bits), knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) and knob 17
+ * >= 400 blocks, 3 = two wherever the filter allows; bit-identical results), 22 = persistent Winograd route for layers of at most v 16-channel stages (default 8), 23 = gradient halves per
+ * block of the Winograd weight-gradient kernel (1, 2 = default), 24 = prefetching variant of the persistent Winograd kernel (bits), 25 = staging-address tables of the Winograd weight-gradient
+ * kernels (1 = default: written by a small kernel before the launch, into the workspace; 0 = formed per stage in the kernel; bit-identical results).  Knob 0 values 10..13, knob 4 (wgrad ablation bits), knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) and knob 17
  * (Winograd ablation bits: 1 no output transform, 2 no LDS reads, 4 no filter loads, 8 no staging DMA, 16 no barriers) are profiling
  * ablations that compute WRONG results: they are not compiled into the product library at all (every such call returns
  * VATL_EINVAL); the profiling variant built with -DVATL_ABLATION (build.py --ablation -> libvatl_hip_ablation.so, loaded

@@ -504,3 +504,24 @@ def test_persistent_route_gives_the_bits_of_the_plain_kernel(vh):
         assert rel_err(y2[-k:].cpu().numpy(), ref.numpy()) < TOL
     record("winograd_persistent_route", routes=took)
     assert took.count(1) >= 2 and took.count(2) >= 4, took       # whole periods only, and periods + a plain launch for the remainder
+
+
+def test_wgrad_address_tables_give_the_bits_of_the_in_kernel_arithmetic(vh):
+    """The Winograd weight-gradient kernels read their staging addresses from tables written by winograd_wgrad_table_kernel right before them (vatl_tune_set(25, 1),
+    default) instead of forming them per stage (two divisions and ~25 vector instructions per request): same addresses, so the same bits — 3x3 layers with one and
+    two gradient halves per block, a transposed conv (four x phases), image / tile counts that leave partial stages and splits."""
+    g = torch.Generator(device="cpu").manual_seed(15)
+    cases = [("conv", 2, 8, 6, 32, 32), ("conv", 5, 16, 12, 64, 128), ("conv", 3, 10, 14, 256, 256), ("conv", 120, 16, 12, 128, 128),
+             ("deconv", 2, 8, 6, 64, 32), ("deconv", 7, 16, 12, 128, 64), ("deconv", 3, 5, 7, 32, 32)]
+    try:
+        for kind, b, h, w, cin, cout in cases:
+            x = torch.randn((b, h, w, cin), generator=g).to(dev())
+            dy = torch.randn((b, 2 * h, 2 * w, cout) if kind == "deconv" else (b, h, w, cout), generator=g).to(dev())
+            f = (lambda: vh.deconv4x4s2_winograd_wgrad(x, dy)) if kind == "deconv" else (lambda: vh.conv3x3_winograd_wgrad(x, dy))
+            vh.tune_set(25, 0)
+            a = f().clone()
+            vh.tune_set(25, 1)
+            c = f().clone()
+            assert torch.equal(a, c), (kind, b, h, w, cin, cout)
+    finally:
+        vh.tune_set(25, 1)

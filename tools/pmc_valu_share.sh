@@ -5,7 +5,7 @@ set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"; OUT="$REPO/gpurun_out/valu"; mkdir -p "$OUT"; export TMPDIR=/tmp
 cd /tmp
 rm -rf "$OUT/p1"
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/p1" -o p -- python3 "$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-extra > "$OUT/p1.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/p1" -o p -- python3 ${VALU_CMD:-"$REPO/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-extra} > "$OUT/p1.log" 2>&1
 python3 - "$OUT/p1" <<'PY' | tee "$REPO/gpurun_out/valu_share.txt"
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)

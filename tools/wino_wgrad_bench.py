@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--blocks", default="", help="comma list of target block counts to A/B (vatl_tune_set(19, v))")
     ap.add_argument("--halves", type=int, default=0, help="vatl_tune_set(23, v): gradient-channel halves per block of the Winograd weight-gradient kernel (1 or 2)")
+    ap.add_argument("--table", default="", help="comma list of 0/1 to A/B: staging-address tables of the Winograd weight-gradient kernel (vatl_tune_set(25, v))")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     if a.halves:
@@ -32,10 +33,14 @@ def main():
     torch.cuda.synchronize()
     g = torch.Generator(device="cpu").manual_seed(5)
     names = a.layers.split(",") if a.layers else list(SHAPES) + list(DECONVS)
-    for blocks in ([int(v) for v in a.blocks.split(",")] if a.blocks else [0]):
-        if blocks:
+    settings = [("blocks", int(v)) for v in a.blocks.split(",")] if a.blocks else ([("table", int(v)) for v in a.table.split(",")] * 2 if a.table else [("", 0)])
+    for kind, blocks in settings:
+        if kind == "blocks":
             vh.tune_set(19, blocks)
             print(f"--- target blocks {blocks}")
+        elif kind == "table":
+            vh.tune_set(25, blocks)
+            print(f"--- staging-address tables {blocks}")
         for name in names:
             b = a.batch
             if name in DECONVS:

@@ -1582,6 +1582,7 @@ int wino_set_group_kb(int v);
 int wino_set_halves(int v);
 int wino_set_persist(int v);
 int wino_wgrad_set_halves(int v);
+int wino_wgrad_set_table(int v);
 int wino_set_persist_pf(int v);
 int wino_wgrad_set_blocks(int v);                              // winograd_wgrad.hip
 
@@ -1618,6 +1619,7 @@ extern "C" int vatl_tune_set(int knob, int value) {
     if (knob == 22 && value >= 0 && value <= 4096) return wino_set_persist(value);
     if (knob == 23 && value >= 1 && value <= 2) return wino_wgrad_set_halves(value);
     if (knob == 24 && value >= 0 && value <= 3) return wino_set_persist_pf(value);
+    if (knob == 25 && (value == 0 || value == 1)) return wino_wgrad_set_table(value);
     if (knob == 19 && value >= 1 && value <= (1 << 20)) return wino_wgrad_set_blocks(value);
     if (knob == 12 && (value == 0 || value == 1)) { g_streamk.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 10 && (value == 1 || value == 2)) { g_persist_dist.store(value, std::memory_order_relaxed); return 0; }

@@ -39,10 +39,54 @@ struct WinoWgradParams {
     int deconv;
     float inv_TW, inv_TH, inv_RW, inv_ns;
     unsigned x_bytes, g_bytes;
+    // staging addresses of every stage of the launch, written by winograd_wgrad_table_kernel right before it (null: computed in the kernel):
+    // tab_x [x phase][stage][ndma_x * 64] byte offsets for channel tile 0, tab_g [stage][ndma_g * 64] for channel tile 0 / phase (0, 0); 0xFFFFFFFF = zeros
+    const unsigned* tab_x;
+    const unsigned* tab_g;
+    int stages_total;
 };
 
 constexpr unsigned WWOOB = 0xFFFFFFFFu;
 typedef __attribute__((address_space(3))) void wwlds_void;
+
+// The staging addresses of a launch depend on its geometry only — and forming them in the main kernel (two divisions and ~25 vector instructions per 16-byte
+// request, ~240 per stage and lane) costs 19 - 26 % of its time: vector instructions are not hidden behind the MFMAs on this hardware (profiles/r04_notes.md;
+// with the arithmetic removed: deconv3 1648 -> 1217 us, r152.l3.c2 426 -> 347, with the arithmetic kept and the same stale addresses used: unchanged).  So a
+// small kernel writes them once per launch into the workspace and the blocks of all channel tiles and splits read them back (one 4-byte load per request).
+template <int MO, int TK, int NBN>
+__global__ __launch_bounds__(256) void winograd_wgrad_table_kernel(WinoWgradParams p, unsigned* tab_x, unsigned* tab_g) {
+    constexpr int GP = TK * MO;
+    const int sidx = blockIdx.x, xphase = blockIdx.y;
+    const int t0 = sidx * TK;
+    const int py = xphase >> 1, px = xphase & 1;
+    const int pad_y = p.deconv ? 1 - py : 1, pad_x = p.deconv ? 1 - px : 1;
+    const int gr0 = t0 / p.TW, pos0 = MO * (t0 - gr0 * p.TW);
+    const int nx = p.ndma_x * 64, ng = p.ndma_g * 64;
+    for (int q = threadIdx.x; q < nx; q += 256) {
+        const int pix = q >> 3, i = pix / p.ns, slot = pix - i * p.ns;
+        unsigned off = WWOOB;
+        if (i < 4) {
+            const int P = slot + pos0, rr = P / p.RW, pos = P - rr * p.RW;
+            const int grow = gr0 + rr, b = grow / p.TH, ty = grow - b * p.TH;
+            const int yy = MO * ty - pad_y + i, xx = pos - pad_x;
+            if (b < p.N && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) off = (unsigned)(((b * p.H + yy) * p.W + xx) * p.Cx + (q & 7) * 4) << 2;
+        }
+        tab_x[((long long)xphase * p.stages_total + sidx) * nx + q] = off;
+    }
+    if (xphase == 0) {
+        for (int q = threadIdx.x; q < ng; q += 256) {
+            const int pix = q / (8 * NBN), a = pix / GP, sl = pix - a * GP, tl = sl / MO, bcol = sl - tl * MO;
+            const int t = t0 + tl;
+            unsigned off = WWOOB;
+            if (a < MO && t < p.Mtiles) {
+                const int grow = t / p.TW, tx = t - grow * p.TW, b = grow / p.TH, ty = grow - b * p.TH;
+                const int yy = MO * ty + a, xx = MO * tx + bcol;
+                if (yy < p.H && xx < p.W) off = (unsigned)(((b * p.OH + yy * p.os) * p.OW + xx * p.os) * p.Cn + (q % (8 * NBN)) * 4) << 2;
+            }
+            tab_g[(long long)sidx * ng + q] = off;
+        }
+    }
+}
 
 // NBN = 2: 64 output channels per block (two 32-channel halves, 128 accumulator registers, two blocks per CU).  The kernel is bound by
 // vector-instruction issue, not by the matrix pipe (36 % busy in round 3: ~9 vector instructions per MFMA — tile addressing, the 8 + 4 LDS
@@ -71,6 +115,21 @@ __device__ __forceinline__ void winograd_wgrad_body(const WinoWgradParams& p, fl
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g), 0, p.g_bytes, 0x00020000);
+    // table mode: the tables hold the offsets of channel tile 0 (and gradient phase (0, 0)); this block's tile / phase is in the descriptors' base addresses
+    const bool tabled = p.tab_x != nullptr;
+    const unsigned xsh = (unsigned)c0 * 4u, gsh = (unsigned)((ooy * p.OW + oox) * p.Cn + n0) * 4u;
+    const __amdgpu_buffer_rsrc_t xrt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + c0, 0, p.x_bytes - xsh, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g) + (gsh >> 2), 0, p.g_bytes - gsh, 0x00020000);
+    const unsigned* tx_base = tabled ? p.tab_x + ((long long)(p.deconv ? phase : 0) * p.stages_total) * (p.ndma_x * 64) + xi * 64 + lane : nullptr;
+    const unsigned* tg_base = tabled ? p.tab_g + xi * 64 + lane : nullptr;
+    unsigned offx[NLX], offg[NLG];                          // the NEXT stage_dma's addresses, loaded a stage ahead
+    auto load_offsets = [&](int t0) {
+        const int sidx = t0 / TK;                           // (t0 is a multiple of TK: splits start on stage boundaries)
+#pragma unroll
+        for (int u = 0; u < NLX; ++u) offx[u] = (xi + 4 * u < p.ndma_x) ? tx_base[(long long)sidx * (p.ndma_x * 64) + u * 256] : WWOOB;
+#pragma unroll
+        for (int u = 0; u < NLG; ++u) offg[u] = (xi + 4 * u < p.ndma_g) ? tg_base[(long long)sidx * (p.ndma_g * 64) + u * 256] : WWOOB;
+    };
 
     // ---- staging items of this lane (constant over the stages): x item = (row i, slot, 16-byte chunk), gradient item = (row a, tile, col b, chunk)
     int xi_i[NLX], xi_slot[NLX], xi_c[NLX];
@@ -92,6 +151,15 @@ __device__ __forceinline__ void winograd_wgrad_body(const WinoWgradParams& p, fl
     auto stage_dma = [&](int buf, int t0) {
         float* Xs = smem + buf * p.stage_floats;
         float* Gs = Xs + p.g_floats_off;
+        if (tabled) {
+#pragma unroll
+            for (int u = 0; u < NLX; ++u)
+                if (xi + 4 * u < p.ndma_x) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrt, (wwlds_void*)(Xs + (xi + 4 * u) * 256), 16, offx[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < NLG; ++u)
+                if (xi + 4 * u < p.ndma_g) __builtin_amdgcn_raw_ptr_buffer_load_lds(grt, (wwlds_void*)(Gs + (xi + 4 * u) * 256), 16, offg[u], 0, 0, 0);
+            return;
+        }
         const int gr0 = fast_div(t0, p.inv_TW);            // global tile row (image, ty) of the stage's first tile
         const int pos0 = MO * (t0 - gr0 * p.TW);
 #pragma unroll
@@ -147,13 +215,18 @@ __device__ __forceinline__ void winograd_wgrad_body(const WinoWgradParams& p, fl
             for (int e = 0; e < 16; ++e) acc[hh][nu][e] = 0.f;
 
     if (t_begin < t_end) {
+        if (tabled) load_offsets(t_begin);
         stage_dma(0, t_begin);
+        if (tabled && t_begin + TK < t_end) load_offsets(t_begin + TK);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     int buf = 0;
     for (int t0 = t_begin; t0 < t_end; t0 += TK, buf ^= 1) {
-        if (t0 + TK < t_end) stage_dma(buf ^ 1, t0 + TK);
+        if (t0 + TK < t_end) {
+            stage_dma(buf ^ 1, t0 + TK);
+            if (tabled && t0 + 2 * TK < t_end) load_offsets(t0 + 2 * TK);        // (arrive with the stage: the wait at the end of this pass covers them)
+        }
         __builtin_amdgcn_sched_barrier(0);
         const float* Xs = smem + buf * p.stage_floats;
         const float* Gs = Xs + p.g_floats_off;
@@ -294,13 +367,16 @@ static std::atomic<unsigned> g_ww_lds_done[4];
 static std::atomic<int> g_ww_halves{2};            // vatl_tune_set(23, v): 32-channel gradient halves per block where the layer allows (1 or 2)
 int wino_wgrad_set_halves(int v) { g_ww_halves.store(v, std::memory_order_relaxed); return 0; }
 
+static std::atomic<int> g_ww_table{1};             // staging-address tables (vatl_tune_set(25, v): 0 = addresses computed in the kernel; identical results)
+int wino_wgrad_set_table(int v) { g_ww_table.store(v, std::memory_order_relaxed); return 0; }
+
 static std::atomic<int> g_ww_blocks{1024};         // target block count of a launch (vatl_tune_set(19, v))
 int wino_wgrad_set_blocks(int v) { g_ww_blocks.store(v, std::memory_order_relaxed); return 0; }
 
 constexpr int kWWTK = 8;
 constexpr int kWWMaxLds = 64 * 1024;
 
-struct WWPlan { int n_tiles, c_tiles, splits, tps, phases, ns, nbn; long long floats; };
+struct WWPlan { int n_tiles, c_tiles, splits, tps, phases, ns, nbn; long long floats, part_floats, tab_x_words, tab_g_words; };
 
 static WWPlan ww_plan(int MO, int Cn, int Cx, long long Mtiles, int TW) {
     WWPlan q{};
@@ -323,6 +399,15 @@ static WWPlan ww_plan(int MO, int Cn, int Cx, long long Mtiles, int TW) {
     q.splits = (int)((Mtiles + q.tps - 1) / q.tps);
     const int NS = MO == 2 ? 3 : 2;
     q.floats = (long long)q.splits * q.phases * NS * 4 * (q.n_tiles * 32LL * nbn) * (q.c_tiles * 32LL);
+    // + the staging-address tables (channel counts that are whole tiles only): x [phases][stages][ndma_x * 64], gradient [stages][ndma_g * 64]
+    q.part_floats = q.floats;
+    q.tab_x_words = q.tab_g_words = 0;
+    if (Cx % 32 == 0 && Cn % (32 * nbn) == 0) {
+        const long long ndx = (4 * q.ns * 8 + 63) / 64, ndg = (MO * kWWTK * MO * 8 * nbn + 63) / 64;
+        q.tab_x_words = (long long)q.phases * stages * ndx * 64;
+        q.tab_g_words = stages * ndg * 64;
+        q.floats += q.tab_x_words + q.tab_g_words;
+    }
     return q;
 }
 
@@ -356,6 +441,15 @@ static int winograd_wgrad_impl(const float* x, const float* g, float* dw, float*
     const int smem = 2 * p.stage_floats * (int)sizeof(float);
     if (smem > kWWMaxLds) return fail(VATL_EINVAL, "winograd_wgrad: %d bytes of LDS per block", smem);
     const dim3 grid((unsigned)((long long)q.n_tiles * q.c_tiles * q.phases * q.splits));
+    p.stages_total = (int)((mt + kWWTK - 1) / kWWTK);
+    if (q.tab_x_words > 0 && g_ww_table.load(std::memory_order_relaxed)) {
+        unsigned* tx = reinterpret_cast<unsigned*>(workspace + q.part_floats);
+        unsigned* tg = tx + q.tab_x_words;
+        const dim3 tgrid((unsigned)p.stages_total, (unsigned)q.phases);
+        if (nbn == 2) hipLaunchKernelGGL((winograd_wgrad_table_kernel<MO, kWWTK, 2>), tgrid, dim3(256), 0, st, p, tx, tg);
+        else          hipLaunchKernelGGL((winograd_wgrad_table_kernel<MO, kWWTK, 1>), tgrid, dim3(256), 0, st, p, tx, tg);
+        p.tab_x = tx; p.tab_g = tg;
+    }
     if (nbn == 2) {
         auto kern = winograd_wgrad_kernel<MO, kWWTK, 2>;
         if (int rc = ensure_dynamic_lds((const void*)kern, kWWMaxLds, g_ww_lds_done[2 + MO - 2], "winograd_wgrad")) return rc;

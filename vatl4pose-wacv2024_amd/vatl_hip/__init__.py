@@ -173,6 +173,8 @@ def lib() -> C.CDLL:
             l.vatl_tune_set(22, int(os.environ["VATL_WINO_PERSIST"]))
         if os.environ.get("VATL_WINO_PERSIST_PF"):   # bit 0 / 1: the prefetching variant of the persistent route for one- / two-half blocks (results are identical)
             l.vatl_tune_set(24, int(os.environ["VATL_WINO_PERSIST_PF"]))
+        if os.environ.get("VATL_WGRAD_TABLES"):               # A/B of the Winograd weight gradients' staging-address tables (0 = addresses formed in the kernel; same bits)
+            l.vatl_tune_set(25, int(os.environ["VATL_WGRAD_TABLES"]))
     return _lib
 
 
