@@ -90,6 +90,7 @@ struct WinoParams {
     FastDivU d_TH, d_TW, d_tpi, d_grp, d_rn, d_rn_last, d_ntiles;
 };
 
+constexpr unsigned WOOB_BASE = 0xF0000000u;               // out of range for every descriptor, and still so with a fragment offset added
 constexpr unsigned WOOB = 0xFFFFFFFFu;
 typedef unsigned int wu32x4 __attribute__((ext_vector_type(4)));
 
@@ -268,15 +269,18 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
     const unsigned ubase = (unsigned)((((ut * usteps) * 16 + 4 * xi) * p.nhp + nh_g) * 64 + lane) << 4;   // bytes; + step * ustep + nu * unu
     const unsigned ustep = 16u * p.nhp * 1024u, unu = p.nhp * 1024u;
     const unsigned uphase = (unsigned)(p.u_phase_floats * 4);   // gather: bytes between the filters of consecutive input phases
-    auto u_load = [&](f32x4 (&dst)[4], int step) {
-        const bool live = step < steps && !(abl & 4);
+    // (a request past the last step re-reads the last step's fragments instead of being switched off: the look-ahead of the final stage costs no
+    // per-lane select — vector instructions are paid in full next to the MFMAs, profiles/r04_notes.md)
+    auto u_load = [&](f32x4 (&dst)[4], int step_) {
+        const int step = min(step_, steps - 1);
         unsigned off = ubase + (unsigned)step * ustep;
         if constexpr (GATHER) {
             const int ph = step / (2 * p.spp);
             off = ubase + (unsigned)ph * uphase + (unsigned)(step - ph * 2 * p.spp) * ustep;
         }
+        if (abl & 4) off = WOOB_BASE;                      // (profiling ablation; abl is 0 in the product build)
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? off + nu * unu : WOOB);
+        for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, off + nu * unu);
     };
 
     f32x16 accs[NB][4];
@@ -338,15 +342,16 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
         // Two filter halves per block: one V per step serves both, the two fragment sets alternate between the halves with a look-ahead of
         // one group of 16 MFMAs: (step 0, half 0) = ua [requested in the previous stage], (step 0, half 1) = ub, (step 1, half 0) = ua, ..
         constexpr bool V_AHEAD = !GATHER && (MO == 2 || !BNB);   // 16 more registers: the gather instantiations and F(3x3,2x2) with the BatchNorm-backward epilogue have none to spare
-        auto u_load_h = [&](f32x4 (&dst)[4], int step, int half) {
-            const bool live = step < steps && !(abl & 4);
+        auto u_load_h = [&](f32x4 (&dst)[4], int step_, int half) {
+            const int step = min(step_, steps - 1);
             unsigned off = ubase + (unsigned)half * 1024u + (unsigned)step * ustep;
             if constexpr (GATHER) {
                 const int ph = step / (2 * p.spp);
                 off = ubase + (unsigned)half * 1024u + (unsigned)ph * uphase + (unsigned)(step - ph * 2 * p.spp) * ustep;
             }
+            if (abl & 4) off = WOOB_BASE;
 #pragma unroll
-            for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? off + nu * unu : WOOB);
+            for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, off + nu * unu);
         };
         for (int st = 0; st < p.stages; ++st) {
             const int buf = st & 1;
@@ -709,11 +714,11 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
             for (int nu = 0; nu < 4; ++nu)
                 ac[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[nu][tt], uu[nu][tt], ac[nu], 0, 0, 0);
     };
-    auto u_load_h = [&](f32x4 (&dst)[4], int step, int half) {
-        const bool live = step < steps;
+    auto u_load_h = [&](f32x4 (&dst)[4], int step_, int half) {
+        const int step = min(step_, steps - 1);            // (past the last step: the last step's fragments again, no per-lane select)
         const unsigned o = ubase + (unsigned)half * 1024u + (unsigned)step * ustep;
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, live ? o + nu * unu : WOOB);
+        for (int nu = 0; nu < 4; ++nu) dst[nu] = wbuf_load4(ur, o + nu * unu);
     };
 
     // requests of a period's first two stages + first filter fragments (PF: issued during the write-out of the period before)
