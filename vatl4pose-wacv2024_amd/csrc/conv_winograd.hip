@@ -92,6 +92,7 @@ struct WinoParams {
 
 constexpr unsigned WOOB_BASE = 0xF0000000u;               // out of range for every descriptor, and still so with a fragment offset added
 constexpr unsigned WOOB = 0xFFFFFFFFu;
+constexpr unsigned WOOB_G = 0xFFFF0000u;                  // staging offset of a zero piece: still out of range with stage * 64 bytes added (stages < 1024, tensors <= 0xFFFF0000 bytes: checked on the host), so the per-stage offset needs no select
 typedef unsigned int wu32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 wbuf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
@@ -181,14 +182,14 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
     // LDS cycles).  At a row end entry (r, q) is asked for by two tiles: column r of tile q (first of its row: x = r - pad) and
     // column MO + r of tile q - 1 (last of its row: x = MO TW + r - pad) — never both inside the image; the entry holds whichever is,
     // and a tile whose column is outside the image reads the zero pixel instead.
-    unsigned goff[W_NLD];                                  // byte offset of the lane's piece in the first stage (WOOB: zeros)
+    unsigned goff[W_NLD];                                  // byte offset of the lane's piece in the first stage (WOOB_G: zeros)
     auto set_goff = [&](int ph) {                          // ph: input phase of the gather mode (0 otherwise)
         const int gy = ph >> 1, gx = ph & 1;
         const int py_ = GATHER ? gy : pad_y, px_ = GATHER ? gx : pad_x;
 #pragma unroll
         for (int u = 0; u < W_NLD; ++u) {
             const int pz = (xi + NW * u) * 64 + lane;
-            goff[u] = WOOB;
+            goff[u] = WOOB_G;
             if (pz >= ST::ITEMS) continue;
             const int cpos = pz & 3, e = pz >> 2;
             const int i = e / ST::ROWE, re = e - i * ST::ROWE;
@@ -223,7 +224,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
         for (int u = 0; u < W_NLD; ++u)
             if (xi + NW * u < ST::NDMA)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (wlds_void*)(Rs + buf * STAGE + (xi + NW * u) * 256), 16,
-                                                         goff[u] != WOOB ? goff[u] + (unsigned)cst * (W_CK * 4) : WOOB, 0, 0, 0);
+                                                         goff[u] + (unsigned)cst * (W_CK * 4), 0, 0, 0);
     };
 
     if constexpr (EARLY) {
@@ -630,7 +631,7 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
     constexpr int PS_FLOATS = 4 * MO * W_TB * W_LDP;
     float* const Ps = PF ? smem + W_ZERO + 2 * STAGE : smem;                     // output-transform tiles [xi][b][tile][32 channels]
     wu32x4* Gs = reinterpret_cast<wu32x4*>(smem + W_ZERO + 2 * STAGE + (PF ? PS_FLOATS : 0));   // [3][256 threads] x 16 bytes: goff[0..3] | goff[4], ra[0..3] as 16-bit pairs | off[0..3]
-    unsigned g0[8] = {WOOB, WOOB, WOOB, WOOB, WOOB, WOOB, WOOB, WOOB};
+    unsigned g0[8] = {WOOB_G, WOOB_G, WOOB_G, WOOB_G, WOOB_G, WOOB_G, WOOB_G, WOOB_G};
 #pragma unroll
     for (int u = 0; u < W_NLD; ++u) {
         const int pz = (xi + NW * u) * 64 + lane;
@@ -740,7 +741,7 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
                 for (int u = 0; u < W_NLD; ++u)
                     if (xi + NW * u < ST::NDMA)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(xq, (wlds_void*)(Rs + st * STAGE + (xi + NW * u) * 256), 16,
-                                                                 goff[u] != WOOB ? goff[u] + (unsigned)st * (W_CK * 4) : WOOB, 0, 0, 0);
+                                                                 goff[u] + (unsigned)st * (W_CK * 4), 0, 0, 0);
             }
     };
     if constexpr (PF) {
@@ -786,7 +787,7 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
             for (int u = 0; u < W_NLD; ++u)
                 if (xi + NW * u < ST::NDMA)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (wlds_void*)(Rs + buf * STAGE + (xi + NW * u) * 256), 16,
-                                                             goff[u] != WOOB ? goff[u] + (unsigned)st * (W_CK * 4) : WOOB, 0, 0, 0);
+                                                             goff[u] + (unsigned)st * (W_CK * 4), 0, 0, 0);
         };
         if constexpr (!PF) {
             u_load_h(ua, 0, 0);
@@ -1095,7 +1096,7 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
     const int phases = deconv ? 4 : 1, os = deconv ? 2 : 1;
     const long long mt = (long long)N * p.tpi, xe = (long long)N * H * W * Cin * (gather ? 4 : 1), ye = (long long)N * H * W * os * os * Cout;
     const long long ue = vatl_winograd_weight_floats(Cout, Cin);
-    if (xe >= (1LL << 30) || ye >= (1LL << 30) || ue >= (1LL << 28) || mt >= (1LL << 30))
+    if (xe > (long long)(WOOB_G / 4) || ye >= (1LL << 30) || ue >= (1LL << 28) || mt >= (1LL << 30) || Cin / W_CK >= 1024)
         return fail(VATL_EINVAL, "winograd: a tensor exceeds 2^30 elements (32-bit buffer offsets); split the batch");
     p.Mtiles = (int)mt;
     p.nhp = wino_nh(Cout);
