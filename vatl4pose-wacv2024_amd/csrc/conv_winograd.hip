@@ -109,7 +109,9 @@ constexpr int W_ZERO = 16;                      // floats of the zero pixel in f
 constexpr int W_LDP = 32;                       // row stride of the output-transform tiles in LDS
 // LDS stage: [4 input rows i][MO column arrays r][33 entries q][16 channels]; entry (r, q) = column r of tile q (= column MO + r of tile q - 1)
 template <int MO> struct WinoStage {
-    static constexpr int ROWE = MO * W_NQ;                 // entries per input row
+    static constexpr int ROWE = MO * W_NQ + 1;             // entries per input row: MO column arrays of W_NQ + ONE ZERO ENTRY (its four pieces are requested out of range by
+                                                           // every stage): the column of a tile that lies outside the image reads it — at the same index in every row, so the
+                                                           // fragment reads need no per-lane select (2 per column and step before; vector instructions are not hidden behind the MFMAs)
     static constexpr int ITEMS = 4 * ROWE * 4;             // 16-byte pieces
     static constexpr int NDMA = (ITEMS + 63) / 64;         // wave-wide LDS-DMA instructions (1 KB each; the last one is partly used)
     static constexpr int FLOATS = NDMA * 256;
@@ -194,6 +196,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
             const int cpos = pz & 3, e = pz >> 2;
             const int i = e / ST::ROWE, re = e - i * ST::ROWE;
             const int r = re / W_NQ, q = re - r * W_NQ;
+            if (r >= MO) continue;                         // the row's zero entry
             const int chunk = cpos ^ ((q >> 2) & 3);
             int m = m0 + q;                                // column r of tile m ...
             int gr = fdiv(m, p.d_TW), tx = m - gr * p.TW;
@@ -237,7 +240,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
     }
 
     // ---- fragment addressing: lane = (tile l & 31, channel quad l >> 5).  ra[px][j]: float index (relative to Rs, input row 0, stage 0,
-    // first 8-channel step) of column j of the lane's tile; the second step of a stage is the same index ^ 8; -W_ZERO = the zero pixel
+    // first 8-channel step) of column j of the lane's tile; the second step of a stage is the same index ^ 8; a column outside the image = the row's zero entry
     // (column outside the image).  The gather mode has two horizontal paddings (input phase & 1).
     const int h = lane >> 5;
     int ra[GATHER ? 2 : 1][4];
@@ -252,7 +255,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
             for (int j = 0; j < 4; ++j) {
                 const int xx = MO * tx + j - px_;
                 const int q = tl + j / MO;
-                ra[v][j] = (unsigned)xx < (unsigned)p.W ? ((j % MO) * W_NQ + q) * W_CK + ((h ^ ((q >> 2) & 3)) << 2) : -W_ZERO;
+                ra[v][j] = (unsigned)xx < (unsigned)p.W ? ((j % MO) * W_NQ + q) * W_CK + ((h ^ ((q >> 2) & 3)) << 2) : MO * W_NQ * W_CK + (h << 2);
             }
         }
     }
@@ -310,7 +313,6 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int a = ra[GATHER ? pv : 0][j];
-                const bool z = a < 0;                      // the zero pixel has no rows / stages / steps
 #ifdef VATL_ABLATION
                 if (abl & 32) {        // lane-linear fragment addresses (bank-conflict probe)
                     const f32x4 da = *reinterpret_cast<const f32x4*>(Rb + lane * 4 + j * 256);
@@ -319,8 +321,8 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
                     continue;
                 }
 #endif
-                const f32x4 da = *reinterpret_cast<const f32x4*>(z ? smem : Rb + roa + (a ^ x8));
-                const f32x4 db = *reinterpret_cast<const f32x4*>(z ? smem : Rb + rob + (a ^ x8));
+                const f32x4 da = *reinterpret_cast<const f32x4*>(Rb + roa + (a ^ x8));
+                const f32x4 db = *reinterpret_cast<const f32x4*>(Rb + rob + (a ^ x8));
                 tc[j] = da + sgn * db;
             }
         }
@@ -639,6 +641,7 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
         const int cpos = pz & 3, e = pz >> 2;
         const int i = e / ST::ROWE, re = e - i * ST::ROWE;
         const int r = re / W_NQ, q = re - r * W_NQ;
+        if (r >= MO) continue;                             // the row's zero entry
         const int chunk = cpos ^ ((q >> 2) & 3);
         int m = m0 + q;
         int gr = fdiv(m, p.d_TW), tx = m - gr * p.TW;
@@ -666,7 +669,7 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
         for (int j = 0; j < 4; ++j) {
             const int xx = MO * tx + j - 1;
             const int q = tl + j / MO;
-            ra[j] = (unsigned)xx < (unsigned)p.W ? ((j % MO) * W_NQ + q) * W_CK + ((h ^ ((q >> 2) & 3)) << 2) : -W_ZERO;
+            ra[j] = (unsigned)xx < (unsigned)p.W ? ((j % MO) * W_NQ + q) * W_CK + ((h ^ ((q >> 2) & 3)) << 2) : MO * W_NQ * W_CK + (h << 2);
         }
         Gs[NT + tid] = wu32x4{g0[4], ((unsigned)ra[0] & 0xFFFFu) | ((unsigned)ra[1] << 16), ((unsigned)ra[2] & 0xFFFFu) | ((unsigned)ra[3] << 16), 0u};
     }
@@ -768,9 +771,8 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int a = ra[j];
-                const bool z = a < 0;
-                const f32x4 da = *reinterpret_cast<const f32x4*>(z ? smem : Rb + roa + (a ^ x8));
-                const f32x4 db = *reinterpret_cast<const f32x4*>(z ? smem : Rb + rob + (a ^ x8));
+                const f32x4 da = *reinterpret_cast<const f32x4*>(Rb + roa + (a ^ x8));
+                const f32x4 db = *reinterpret_cast<const f32x4*>(Rb + rob + (a ^ x8));
                 tc[j] = da + sgn * db;
             }
             v[0] = tc[0] - tc[2]; v[1] = tc[1] + tc[2]; v[2] = tc[2] - tc[1]; v[3] = tc[1] - tc[3];
