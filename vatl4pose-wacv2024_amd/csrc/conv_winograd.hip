@@ -82,6 +82,8 @@ struct WinoParams {
     int pg, periods, chunk;
     long long x_period_floats, y_period_floats;
     long long u_phase_floats;         // deconv: floats of one phase's packed filter
+    float neg_one;                    // -1.0f, as a run-time value: a - b is written fma(b, neg_one, a), which hipcc packs two lanes per instruction (a literal -1 is folded back
+                                      // into four scalar v_sub_f32; vector instructions are paid in full next to the MFMAs: profiles/r04_notes.md).  Exact: same bits.
     int ablate;                       // profiling library only (vatl_tune_set(17, bits), wrong results): 1 no output transform, 2 no LDS
                                       // reads / input transform, 4 no filter loads, 8 no staging DMA, 16 no barriers
     unsigned x_bytes, u_bytes, y_bytes;
@@ -263,6 +265,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
     const int ia = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
     const int ib = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
     const float sgn = xi == 1 ? 1.f : -1.f;
+    const f32x4 m1 = {p.neg_one, p.neg_one, p.neg_one, p.neg_one};
     const int roa = ia * ROWF, rob = ib * ROWF;
 
     // ---- U fragments: [n_tile][step][position][nh][lane][4]; the packing groups 32 p.nhp channels per filter tile ----------------------
@@ -326,7 +329,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
                 tc[j] = da + sgn * db;
             }
         }
-        v[0] = tc[0] - tc[2]; v[1] = tc[1] + tc[2]; v[2] = tc[2] - tc[1]; v[3] = tc[1] - tc[3];
+        v[0] = tc[0] + m1 * tc[2]; v[1] = tc[1] + tc[2]; v[2] = tc[2] + m1 * tc[1]; v[3] = tc[1] + m1 * tc[3];
     };
     auto mfma_group = [&](f32x16 (&ac)[4], const f32x4 (&v)[4], const f32x4 (&uu)[4]) {
 #pragma unroll
@@ -676,6 +679,7 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
     const int ia = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
     const int ib = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
     const float sgn = xi == 1 ? 1.f : -1.f;
+    const f32x4 m1 = {p.neg_one, p.neg_one, p.neg_one, p.neg_one};
     const int roa = ia * ROWF, rob = ib * ROWF;
     // ---- filter fragments ----
     const int steps = p.stages * 2;
@@ -775,7 +779,7 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
                 const f32x4 db = *reinterpret_cast<const f32x4*>(Rb + rob + (a ^ x8));
                 tc[j] = da + sgn * db;
             }
-            v[0] = tc[0] - tc[2]; v[1] = tc[1] + tc[2]; v[2] = tc[2] - tc[1]; v[3] = tc[1] - tc[3];
+            v[0] = tc[0] + m1 * tc[2]; v[1] = tc[1] + tc[2]; v[2] = tc[2] + m1 * tc[1]; v[3] = tc[1] + m1 * tc[3];
         };
         auto stage_dma = [&](int buf, int st) {            // (the staging offsets are read from the record at every use: 5 fewer registers live across the stage loop)
             int tid_p = tid_o;
@@ -1091,6 +1095,7 @@ static int winograd_impl(int MO, const float* x, const float* u, const float* sc
     if (!x || !u || !y || N <= 0 || H <= 0 || W <= 0) return fail(VATL_EINVAL, "winograd: null pointer or empty batch");
     if (Cin % 16 != 0 || (Cout & 3)) return fail(VATL_EINVAL, "winograd: Cin %d must be a multiple of 16 and Cout %d of 4", Cin, Cout);
     WinoParams p{};
+    p.neg_one = -1.0f;
     p.x = x; p.u = u; p.scale = scale; p.bias = bias; p.res = residual; p.y = y; p.stats = stats;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
     p.TH = (H + MO - 1) / MO; p.TW = (W + MO - 1) / MO; p.tpi = p.TH * p.TW;
