@@ -473,18 +473,40 @@ class ActiveLearning:
     def _records_json(self):
         """json.dumps of ``self.kpt_json``, ``self.kpt_json_ann`` and ``self._gt_dict()`` — the same text, character for character — with every
         record's shared fields (box, ids, score, the two key-point lists, OKS) encoded ONCE instead of once per file: the three files differ only
-        in which of the two lists a record's "keypoints" holds, and formatting ~110 floats per record is what writing them costs."""
+        in which of the two lists a record's "keypoints" holds, and formatting ~110 floats per record is what writing them costs.  A field is
+        encoded for ALL records by one encoder call (a column of the records as one nested list, cut at the inner brackets), and the fields that
+        come from the data set alone (box, ids, ground truth: the same in every round of a run) are kept from the previous call and reused when
+        their values are unchanged."""
         import json
         enc = json.dumps
+
+        def column(key, nested):
+            vals = [rec[key] for rec in self.kpt_json]
+            if not vals:
+                return vals, []
+            text = enc(vals)
+            return vals, (("[" + t + "]" for t in text[2:-2].split("], [")) if nested else text[1:-1].split(", "))
+        fixed_vals, fixed_text = [], []
+        cached = getattr(self, "_records_fixed", None)
+        for k, (key, nested) in enumerate((("bbox", True), ("image_id", False), ("id", False), ("category_id", False), ("GT_keypoints", True))):
+            vals = [rec[key] for rec in self.kpt_json]
+            if cached is not None and cached[0][k] == vals:          # (list comparison: a NaN in the ground truth re-encodes, which is only slower)
+                text = cached[1][k]
+            else:
+                text = list(column(key, nested)[1])
+            fixed_vals.append(vals); fixed_text.append(text)
+        self._records_fixed = (fixed_vals, fixed_text)
+        box_s, img_s, id_s, cat_s, gt_s = fixed_text
+        kp_s, score_s, oks_s = list(column("keypoints", True)[1]), column("score", False)[1], column("OKS", False)[1]
+        n = len(self.kpt_json)
+        assert all(len(t) == n for t in (box_s, img_s, id_s, cat_s, gt_s, kp_s, score_s, oks_s)), "a record field does not encode to one piece per record"
         pred, ann, gt = [], [], []
-        for rec, rec_ann in zip(self.kpt_json, self.kpt_json_ann):
-            kp_s, gt_s = enc(rec["keypoints"]), enc(rec["GT_keypoints"])
-            head = '{"bbox": %s, "image_id": %s, "id": %s, "score": %s, "category_id": %s, "keypoints": ' % (
-                enc(rec["bbox"]), enc(rec["image_id"]), enc(rec["id"]), enc(rec["score"]), enc(rec["category_id"]))
-            tail = ', "GT_keypoints": %s, "OKS": %s}' % (gt_s, enc(rec["OKS"]))
-            pred.append(head + kp_s + tail)
-            ann.append(head + (gt_s if rec_ann["keypoints"] is rec["GT_keypoints"] else kp_s) + tail)
-            gt.append(head + gt_s + tail)
+        for i, (rec, rec_ann) in enumerate(zip(self.kpt_json, self.kpt_json_ann)):
+            head = '{"bbox": %s, "image_id": %s, "id": %s, "score": %s, "category_id": %s, "keypoints": ' % (box_s[i], img_s[i], id_s[i], score_s[i], cat_s[i])
+            tail = ', "GT_keypoints": %s, "OKS": %s}' % (gt_s[i], oks_s[i])
+            pred.append(head + kp_s[i] + tail)
+            ann.append(head + (gt_s[i] if rec_ann["keypoints"] is rec["GT_keypoints"] else kp_s[i]) + tail)
+            gt.append(head + gt_s[i] + tail)
         g = self._gt_dict()
         assert list(g) == ["images", "categories", "annotations"]
         return ("[" + ", ".join(pred) + "]", "[" + ", ".join(ann) + "]",
