@@ -33,8 +33,7 @@ constexpr unsigned C32_OOB = 0xFFFFFFF0u;
 constexpr int C32_U_FLOATS = 8 * 2 * 64 * 16;     // 16384
 constexpr int C32_PATCH = 7 * 256;                // floats of a wave's patch buffer: 6 x 18 pixels x 16 channels = 432 16-byte chunks, 7 requests of 64
 constexpr int C32_WAVES = 8;
-constexpr int C32_TAB = 8 * 64 + 16 * 64;         // staging tables: [lane][8] relative byte offsets of the 7 requests, [16 border classes][lane] validity bits
-constexpr int C32_LDS_FLOATS = C32_U_FLOATS + C32_WAVES * C32_PATCH + 64 + C32_TAB;       // + scale, bias, staging tables
+constexpr int C32_LDS_FLOATS = C32_U_FLOATS + C32_WAVES * C32_PATCH + 64;       // + scale, bias
 
 __global__ __launch_bounds__(512, 1) void winograd_c32_kernel(C32Params p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -59,31 +58,27 @@ __global__ __launch_bounds__(512, 1) void winograd_c32_kernel(C32Params p) {
     // staging: request j writes LDS chunks 64 j .. 64 j + 63; chunk id = pixel * 4 + position, position = source quad ^ ((patch column >> 2) & 3): the 16 tiles
     // of a read fall on 8 different 4-word bank groups (two-way conflicts; a padded pixel pitch of five chunks makes them 16 — measured: no faster, two more
     // requests per stage).  What a request needs per unit is origin + a per-lane constant and a yes / no for "inside the image", which depends only on whether the
-    // unit touches the top / bottom / left / right border: both live in LDS tables (written once, by wave 0), so a stage costs ~4 vector instructions per request
+    // unit touches the top / bottom / left / right border: both are per-lane constants (below), so a stage costs ~4 vector instructions per request
     // instead of ~13 (vector instructions are paid in full next to the MFMAs on this hardware).
-    int* TabRel = reinterpret_cast<int*>(smem + C32_U_FLOATS + C32_WAVES * C32_PATCH + 64);   // [lane][8]
-    int* TabOk = TabRel + 8 * 64;                                                               // [class = top | bottom << 1 | left << 2 | right << 3][lane]: bit j
-    if (wave == 0) {
-        int okc[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) okc[c] = 0;
+    // (in REGISTERS: an LDS table read behind an LDS-DMA request makes the compiler wait for every memory operation in flight — it cannot tell the table from the
+    // DMA's destination — which drained the stores the counted wait at the top of a unit leaves in flight)
+    int rel[7];
+    int ok_all = 0, ok_top = 0, ok_bottom = 0, ok_left = 0, ok_right = 0;                      // bit j: the chunk exists / is inside the image when the unit touches that border
+    {
+        // rows / columns a unit may read: top: patch row 0 is image row -1; bottom: the last unit row starts at image row 4 (UH - 1) - 1; likewise left / right
+        const int ylast = p.H - (4 * (p.UH - 1) - 1), xlast = p.W - (16 * (p.UW - 1) - 1);      // patch rows / columns below these are inside the image
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             const int id = 64 * j + lane, px = id >> 2;
             const int pr = px / 18, pc = px - pr * 18;
             const int sq = (id & 3) ^ ((pc >> 2) & 3);
-            TabRel[lane * 8 + j] = ((pr * p.W + pc) * 32 + sq * 4) * 4;
-            // rows / columns a unit of the class may read: top: patch row 0 is image row -1; bottom: the last unit row starts at image row 4 (UH - 1) - 1; likewise left / right
-            const int ylast = p.H - (4 * (p.UH - 1) - 1), xlast = p.W - (16 * (p.UW - 1) - 1);      // patch rows / columns below these are inside the image
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const bool ok = px < 108 && (!(c & 1) || pr >= 1) && (!(c & 2) || pr < ylast) && (!(c & 4) || pc >= 1) && (!(c & 8) || pc < xlast);
-                okc[c] |= (ok ? 1 : 0) << j;
-            }
+            rel[j] = ((pr * p.W + pc) * 32 + sq * 4) * 4;
+            ok_all |= (px < 108 ? 1 : 0) << j;
+            ok_top |= (pr >= 1 ? 1 : 0) << j;
+            ok_bottom |= (pr < ylast ? 1 : 0) << j;
+            ok_left |= (pc >= 1 ? 1 : 0) << j;
+            ok_right |= (pc < xlast ? 1 : 0) << j;
         }
-        TabRel[lane * 8 + 7] = 0;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) TabOk[c * 64 + lane] = okc[c];
     }
     __syncthreads();
     // input transform: lane (tile t = lane % 16 at (t & 7, t >> 3) of the 8 x 2 patch, channel k4 = lane / 16 of the K-step's four).  LDS word of pixel
@@ -102,10 +97,7 @@ __global__ __launch_bounds__(512, 1) void winograd_c32_kernel(C32Params p) {
     auto stage = [&](int unit, int half) {                // the 16-channel half of the unit's patch -> this wave's buffer (zeros outside the image = the padding)
         const int img = fdiv(unit, p.d_upi), rem = unit - img * p.upi;
         const int uy = fdiv(rem, p.d_uw), ux = rem - uy * p.UW;
-        const int cls = (uy == 0 ? 1 : 0) | (uy == p.UH - 1 ? 2 : 0) | (ux == 0 ? 4 : 0) | (ux == p.UW - 1 ? 8 : 0);
-        const int okbits = TabOk[cls * 64 + lane];
-        const int4 r0 = *reinterpret_cast<const int4*>(TabRel + lane * 8), r1 = *reinterpret_cast<const int4*>(TabRel + lane * 8 + 4);
-        const int rel[7] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z};
+        const int okbits = ok_all & (uy == 0 ? ok_top : -1) & (uy == p.UH - 1 ? ok_bottom : -1) & (ux == 0 ? ok_left : -1) & (ux == p.UW - 1 ? ok_right : -1);
         const int origin = (((img * p.H + 4 * uy - 1) * p.W + 16 * ux - 1) * 32 + half * 16) * 4;        // byte offset of patch pixel (0, 0), this half (may be negative: never used then)
 #pragma unroll
         for (int j = 0; j < 7; ++j) {

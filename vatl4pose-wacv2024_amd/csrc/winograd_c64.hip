@@ -5,20 +5,18 @@
 //     transform serves four 16-column blocks and one output transform 16 K-steps: half the vector instructions per MFMA of the 32-channel kernel — and vector
 //     instructions are paid in full next to fp32 MFMAs on this hardware (tools/probes/mfma_valu_overlap.hip), while a second wave per SIMD buys little
 //     (winograd_c32 with one wave per SIMD: 318 - 332 us against 286);
-//   * the transformed filter (256 KB) does not fit the LDS: K-step S's slice (16 positions x 4 channels x 64 couts = 16 KB) streams through a ring of four
-//     LDS slots, requested by the block's four waves together (LDS-DMA, a KB per request) two K-steps before its fragments are read; ONE barrier per K-step;
-//   * everything else is private to the wave: its 10 x 10-pixel input patch (16 channels at a time, two buffers), the input transform B^T d B in registers
-//     (lane = (tile, channel of the K-step's four)), the output transform A^T M A and the write-out from the accumulators.
-// Waits are counted (`s_waitcnt vmcnt(N)`, the vector memory counter retires in order on gfx9): a K-step waits for the ring slot it reads fragments from next,
-// everything younger (later ring requests, the next patch, the skip-connection loads, the stores of the unit before) stays in flight.
+//   * the transformed filter (256 KB) does not fit the LDS, and a shared LDS ring costs a barrier per K-step (measured: 10 % of the kernel): every wave loads
+//     its filter fragments itself, global -> registers, one K-step ahead (16 KB per K-step; the four waves of a CU ask for the same lines within a K-step, the
+//     filter stays in L2) — no barrier anywhere after the prologue;
+//   * everything else is private to the wave too: its 10 x 10-pixel input patch (LDS-DMA, 16 channels at a time, two buffers), the input transform B^T d B in
+//     registers (lane = (tile, channel of the K-step's four)), the output transform A^T M A and the write-out from the accumulators.
+// The MFMAs take the FILTER as their A operand: a lane's accumulator tuple is then four consecutive output channels of one pixel, and the write-out (and the
+// skip-connection read) is 16 wide memory operations per unit instead of 64 narrow ones.
 #include "common.h"
 
 #include <atomic>
 #include <utility>
 
-#ifndef C64_ABL
-#define C64_ABL 0
-#endif
 namespace vatl {
 
 struct C64Params {
@@ -38,18 +36,8 @@ typedef __attribute__((address_space(3))) void c64_lds_void;
 typedef unsigned c64_u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned C64_OOB = 0xFFFFFFF0u;
 constexpr int C64_U_FLOATS = 16 * 4 * 4 * 64 * 4;   // 65536
-constexpr int C64_SLOT = 4 * 4 * 64 * 4;            // floats of a K-step's filter slice: 4096
 constexpr int C64_PATCH = 7 * 256;                  // floats of a patch buffer: 10 x 10 pixels x 16 channels = 400 16-byte chunks, 7 requests of 64
-constexpr int C64_LDS_FLOATS = 4 * C64_SLOT + 4 * 2 * C64_PATCH + 128;
-
-// requests a wave issues in K-step T after its four ring requests: the next patch quarter (7) at the first K-step of a quarter, the skip-connection loads
-// (16) in K-step 13, the unit's stores (16) behind K-step 15
-template <bool RES> constexpr int c64_after(int T) { return (T % 4 == 0 ? 7 : 0) + (RES && T == 13 ? 16 : 0) + (T == 15 ? 16 : 0); }
-// ... younger than the ring requests of K-step S - 2 (the slice whose fragments K-step S reads) at the top of K-step S
-template <bool RES> constexpr int c64_younger(int S) {
-    const int n = c64_after<RES>((S + 14) % 16) + 4 + c64_after<RES>((S + 15) % 16);
-    return n > 63 ? 63 : n;
-}
+constexpr int C64_LDS_FLOATS = 4 * 2 * C64_PATCH + 128;
 
 template <int N> __device__ __forceinline__ void c64_wait() {
     static_assert(N >= 0 && N <= 63, "vmcnt");
@@ -63,10 +51,9 @@ template <class F, int... I> __device__ __forceinline__ void c64_unroll(F&& f, s
 template <bool RES>
 __device__ __forceinline__ void winograd_c64_body(const C64Params& p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ring = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* Pw = smem + 4 * C64_SLOT + wave * 2 * C64_PATCH;
-    float* SBs = smem + 4 * C64_SLOT + 4 * 2 * C64_PATCH;         // scale[64], bias[64]
+    float* Pw = smem + wave * 2 * C64_PATCH;
+    float* SBs = smem + 4 * 2 * C64_PATCH;         // scale[64], bias[64]
     if (tid < 64) { SBs[tid] = p.scale ? p.scale[tid] : 1.f; SBs[64 + tid] = p.bias ? p.bias[tid] : 0.f; }
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.bytes, 0x00020000);
@@ -108,11 +95,6 @@ __device__ __forceinline__ void winograd_c64_body(const C64Params& p) {
     const float lo = p.relu ? 0.f : -INFINITY;
     const unsigned lane16 = (unsigned)lane * 16u;
 
-    auto request_u = [&](int S) {                          // this wave's four KB of K-step S's filter slice -> ring slot S & 3
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ur, (c64_lds_void*)(Ring + (S & 3) * C64_SLOT + (4 * wave + r) * 256), 16, lane16, (S * 16 + 4 * wave + r) * 1024, 0, 0);
-    };
     auto stage = [&](int unit, int quarter) {              // 16 channels of the unit's patch -> this wave's buffer quarter & 1 (zeros outside the image = the padding)
         const bool live = unit < p.units;
         const int img = fdiv(unit, p.d_upi), rem = unit - img * p.upi;
@@ -127,14 +109,11 @@ __device__ __forceinline__ void winograd_c64_body(const C64Params& p) {
         }
     };
 
-    const int ustride = gridDim.x * 4;
-    int unit = blockIdx.x * 4 + wave;
-    // ---- prologue: ring slots 0 .. 2, the first patch quarter ----
-    request_u(0); request_u(1); request_u(2);
-    stage(unit, 0);
-    c64_wait<0>();
-    __syncthreads();
-
+    f32x4 uf[4][4];                                        // filter fragments [column block][position row xi] of the K-step about to run
+    auto load_uf = [&](int S, int nb) {
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) uf[nb][xi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, lane16, ((S * 4 + nb) * 4 + xi) * 1024, 0));
+    };
     float d[16];
     auto load_d = [&](int S) {                             // the 16 pixels of this lane's (tile, channel) for K-step S (of the unit whose quarter S / 4 is in buffer (S / 4) & 1)
         const float* buf = Pw + ((S >> 2) & 1) * C64_PATCH + d_base;
@@ -145,12 +124,14 @@ __device__ __forceinline__ void winograd_c64_body(const C64Params& p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) d[i * 4 + j] = (i < 2 ? pa : pb)[(i * 10 + j) * 16];
     };
-    f32x4 uf[4][4];                                        // filter fragments [column block][position row xi] of the K-step about to run
-    auto load_uf = [&](int S, int nb) {
-        const f32x4* Ul = reinterpret_cast<const f32x4*>(Ring + (S & 3) * C64_SLOT) + lane;
+
+    const int ustride = gridDim.x * 4;
+    int unit = blockIdx.x * 4 + wave;
+    stage(unit, 0);
+    c64_wait<0>();
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi) uf[nb][xi] = Ul[(nb * 4 + xi) * 64];
-    };
+    for (int nb = 0; nb < 4; ++nb) load_uf(0, nb);
+
     for (int it = 0; it < p.iters; ++it, unit += ustride) {
         f32x4 acc[16][4];
         f32x4 yres[RES ? 16 : 1];
@@ -160,19 +141,12 @@ __device__ __forceinline__ void winograd_c64_body(const C64Params& p) {
         // byte offset of this lane's tile's first output pixel, couts 4 k4 .. of column block 0
         const unsigned base = (unit < p.units && ty < p.TH && tx < p.TW) ? (unsigned)((((img * p.H + 2 * ty) * p.W + 2 * tx) * 64 + 4 * k4) * 4) : C64_OOB;
         const unsigned rowb = (unsigned)(p.W * 64 * 4);
-        // K-step 0's pixels and fragments (both landed before K-step 15 of the unit before / in the prologue): read here, not behind K-step 15's MFMAs — 80
-        // registers less across the write-out, where the skip-connection values and the accumulator reads need them
+        // this unit's first patch quarter (requested in K-step 12 of the unit before): at least 64 younger memory operations have been issued since
+        c64_wait<63>();
         load_d(0);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) load_uf(0, nb);
         auto kstep = [&](auto Sc) {
             constexpr int S = decltype(Sc)::value;
-            // slice S + 1 (requested in K-step S - 2) has landed in every wave's share after this wait + barrier; slot (S + 3) & 3 = slice S - 1 has been read by all
-            // (first unit: the prologue has waited for slices 0 .. 2, and K-step 2's count lies inside the unit)
-            c64_wait<c64_younger<RES>(S)>();
-            if (C64_ABL != 1) __builtin_amdgcn_s_barrier();
-            if (C64_ABL != 2) request_u((S + 3) & 15);
-            if ((S & 3) == 0 && C64_ABL != 3) stage(S < 12 ? unit : unit + ustride, ((S >> 2) + 1) & 3);
+            if ((S & 3) == 0) stage(S < 12 ? unit : unit + ustride, ((S >> 2) + 1) & 3);
             if (RES && S == 13) {
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
@@ -195,7 +169,9 @@ __device__ __forceinline__ void winograd_c64_body(const C64Params& p) {
                 asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(v23) : "v"(tl[i]), "v"(th[i]));
                 v[i * 4 + 0] = v01.x; v[i * 4 + 1] = v01.y; v[i * 4 + 2] = v23.x; v[i * 4 + 3] = v23.y;
             }
-            if (S < 15 && C64_ABL != 8) load_d(S + 1);
+            // the next K-step's pixels; a new quarter's patch was requested at the top of K-step S - 3, before the 48 fragment loads of K-steps S - 3 .. S - 1
+            if (S < 15 && (S & 3) == 3) c64_wait<48>();
+            if (S < 15) load_d(S + 1);
             __builtin_amdgcn_sched_barrier(0);
             // MFMAs as inline assembly with the accumulator tied to an AGPR tuple: with the builtin the register allocator treats an MFMA's input and output
             // accumulator as two live ranges, fragments the (exactly full) AGPR half and shuffles tuples through VGPRs between the MFMAs.  What the compiler
@@ -205,11 +181,10 @@ __device__ __forceinline__ void winograd_c64_body(const C64Params& p) {
             for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    if (C64_ABL == 5 && S > 0 && q > 0) continue;
                     if (S == 0) asm("v_mfma_f32_16x16x4_f32 %0, %2, %1, 0" : "=a"(acc[q][nb]) : "v"(v[q]), "v"(uf[nb][q >> 2][q & 3]));
                     else asm("v_mfma_f32_16x16x4_f32 %0, %2, %1, %0" : "+a"(acc[q][nb]) : "v"(v[q]), "v"(uf[nb][q >> 2][q & 3]));
                 }
-                if (S < 15 && C64_ABL != 7) load_uf(S + 1, nb);            // the next K-step's fragments of this column block, behind the MFMAs of the others
+                if (S < 15) load_uf(S + 1, nb);            // the next K-step's fragments of this column block: a K-step of MFMAs ahead
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -217,8 +192,16 @@ __device__ __forceinline__ void winograd_c64_body(const C64Params& p) {
         // ---- output transform (registers only) + write-out: tile lane % 16, couts 16 nb + 4 k4 + 0 .. 3 ----
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (8 passes) before the first accumulator read
         __builtin_amdgcn_sched_barrier(0);
+        if (!RES) {                                        // the next unit's first fragments, behind the write-out (with a skip connection: once half its values are used)
 #pragma unroll
-        for (int nb = 0; nb < (C64_ABL == 6 ? 1 : 4); ++nb) {
+            for (int nb = 0; nb < 4; ++nb) load_uf(0, nb);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            if (RES && nb == 2) {
+#pragma unroll
+                for (int n2 = 0; n2 < 4; ++n2) load_uf(0, n2);
+            }
             const f32x4 scn = *reinterpret_cast<const f32x4*>(SBs + 16 * nb + 4 * k4), bin = *reinterpret_cast<const f32x4*>(SBs + 64 + 16 * nb + 4 * k4);
             f32x4 t0[4], t1[4], yq[4];
 #pragma unroll
@@ -234,13 +217,12 @@ __device__ __forceinline__ void winograd_c64_body(const C64Params& p) {
             for (int ab = 0; ab < 4; ++ab) {
                 f32x4 o = yq[ab];
                 if (RES) o += yres[nb * 4 + ab];
-                if (C64_ABL == 4 && o[0] != 12345.f) continue;
                 o = f32x4{fmaxf(o[0], lo), fmaxf(o[1], lo), fmaxf(o[2], lo), fmaxf(o[3], lo)};
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(c64_u32x4, o), yr, base != C64_OOB ? base + (ab >> 1) * rowb + (ab & 1) * 256u + nb * 64u : C64_OOB, 0, 0);
             }
         }
     }
-    c64_wait<0>();                                         // nothing of this block may land in the LDS of the next
+    c64_wait<0>();                                         // no request of this block may land in the LDS of the next
 }
 
 template <bool RES>
