@@ -145,7 +145,7 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
                    "stem_pool_fwd": 0,               # the fused stem: conv1 + bn1 + relu + maxpool in one launch — its pooling is inside the timed launch
                    "bottleneck_chain_fwd": 0,        # conv3 + skip of one bottleneck and conv1 of the next in one launch
                    "conv1x1_rows_fwd": 0,            # K = 128 1x1 layers as a row-streaming GEMM
-                   "conv3x3_winograd_c32_fwd": 9, "conv3x3_winograd_c64_fwd": 9}    # 32 -> 32 channel 3x3 layers (HRNet): wave-private Winograd
+                   "conv3x3_winograd_c32_fwd": 9}    # 32 -> 32 channel 3x3 layers (HRNet): wave-private Winograd
     originals = {n: getattr(vh, n) for n in timed_names}
 
     def wrap(fn, is_wino=0):

@@ -118,16 +118,6 @@ int vatl_conv3x3_winograd_c32_supported(int N, int H, int W, int Cin, int Cout);
 int vatl_conv3x3_winograd_c32_fwd(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, int N, int H, int W,
                                   int relu, void* stream);
 
-/* Winograd F(2x2,3x3) for 64 -> 64 channel 3x3 / stride 1 / pad 1 layers with wave-private tiles at one wave per SIMD (csrc/winograd_c64.hip: 256 accumulator
- * registers per wave, the transformed filter streamed through an LDS ring; BasicBlock convs of HRNet's second branch, hrnet.py:24-56, conv2 of ResNet's stage 1,
- * Resnet.py:104-128): x, residual, y NHWC (N,H,W,64), H and W even, N*H*W*64 < 2^29; u from vatl_pack_winograd_c64_weight ((64,64,3,3) filter ->
- * vatl_winograd_c64_weight_floats() floats); y = act(scale * conv(x) + bias + residual), scale / bias / residual may be NULL. */
-int64_t vatl_winograd_c64_weight_floats(void);
-int vatl_pack_winograd_c64_weight(const float* w, float* u, void* stream);
-int vatl_conv3x3_winograd_c64_supported(int N, int H, int W, int Cin, int Cout);
-int vatl_conv3x3_winograd_c64_fwd(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, int N, int H, int W,
-                                  int relu, void* stream);
-
 /* 1x1 convolution with K = 128 input channels as a row-streaming GEMM (csrc/conv1x1_rows.hip): y = act(scale * (A W^T) + bias + residual) for the short-K /
  * wide-N layers the tiled implicit GEMM runs far from both roofs (Bottleneck.conv3 of ResNet stage 2, Resnet.py:120-128; with x2: conv3 + projection
  * shortcut of stage 1's first block as vatl_conv1x1_dual_fwd computes it, Resnet.py:104-128, 185-189).  a (M, K1), x2 (M, K2) or NULL: the K columns

@@ -50,13 +50,10 @@ ROWS_GEMM = os.environ.get("VATL_ROWS_GEMM", "1") != "0"
 # 32 -> 32 channel 3x3 layers (HRNet's highest-resolution branch) through the wave-private Winograd kernel (csrc/winograd_c32.hip: a wave owns 16 tiles with all 16
 # transform positions, no cross-wave exchange).  VATL_WINO_C32=0 = the general Winograd kernel.
 WINO_C32 = os.environ.get("VATL_WINO_C32", "1") != "0"
-# 64 -> 64 channel 3x3 layers (HRNet's second branch, conv2 of ResNet's stage 1 and of HRNet's layer1) through the wave-private Winograd kernel at one wave per SIMD
-# (csrc/winograd_c64.hip: 256 accumulator registers per wave, filter fragments from L2 a K-step ahead).  VATL_WINO_C64=0 = the general Winograd kernel.
-WINO_C64 = os.environ.get("VATL_WINO_C64", "1") != "0"
 
 
 class _Conv:
-    __slots__ = ("w", "u", "u32", "u64", "scale", "bias", "cout", "r", "s", "stride", "pad")
+    __slots__ = ("w", "u", "u32", "scale", "bias", "cout", "r", "s", "stride", "pad")
 
     def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d | None):
         assert conv.groups == 1 and conv.dilation == (1, 1)
@@ -70,9 +67,6 @@ class _Conv:
         self.u32 = None
         if self.u is not None and WINO_C32 and conv.in_channels == 32 and self.cout == 32:
             self.u32 = vh.pack_winograd_c32_weight(conv.weight.detach())
-        self.u64 = None
-        if self.u is not None and WINO_C64 and conv.in_channels == 64 and self.cout == 64:
-            self.u64 = vh.pack_winograd_c64_weight(conv.weight.detach())
         cb = conv.bias.detach() if conv.bias is not None else None
         if bn is not None:
             self.scale, self.bias = vh.bn_fold(_d(bn.weight), _d(bn.bias), bn.running_mean, bn.running_var, bn.eps, cb)
@@ -85,8 +79,6 @@ class _Conv:
         if self.u is not None and not out_nchw and not vh.latency_mode():
             if self.u32 is not None and vh.conv3x3_winograd_c32_supported(x.shape[0], x.shape[1], x.shape[2], 32, 32):
                 return vh.conv3x3_winograd_c32_fwd(x, self.u32, self.scale, self.bias, relu, residual=residual, out=out)
-            if self.u64 is not None and vh.conv3x3_winograd_c64_supported(x.shape[0], x.shape[1], x.shape[2], 64, 64):
-                return vh.conv3x3_winograd_c64_fwd(x, self.u64, self.scale, self.bias, relu, residual=residual, out=out)
             return vh.conv3x3_winograd_fwd(x, self.u, self.scale, self.bias, self.cout, relu, residual=residual, out=out)
         if (ROWS_GEMM and self.r == 1 and self.stride == 1 and not out_nchw and not vh.latency_mode() and x.shape[-1] == 128
                 and vh.conv1x1_rows_supported(128, 0, self.cout, x.shape[0] * x.shape[1] * x.shape[2])):

@@ -38,10 +38,6 @@ SIGNATURES = {
     "vatl_pack_winograd_c32_weight": (_i, [_p, _p, _p]),
     "vatl_conv3x3_winograd_c32_supported": (_i, [_i, _i, _i, _i, _i]),
     "vatl_conv3x3_winograd_c32_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "vatl_winograd_c64_weight_floats": (_i64, []),
-    "vatl_pack_winograd_c64_weight": (_i, [_p, _p, _p]),
-    "vatl_conv3x3_winograd_c64_supported": (_i, [_i, _i, _i, _i, _i]),
-    "vatl_conv3x3_winograd_c64_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_conv1x1_rows_supported": (_i, [_i, _i, _i, _i64]),
     "vatl_conv1x1_rows_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p]),
     "vatl_bottleneck_chain_supported": (_i, [_i, _i, _i, _i64]),
@@ -516,28 +512,6 @@ def conv3x3_winograd_c32_fwd(x, u, scale, bias, relu: bool, residual=None, out=N
     return y
 
 
-
-def pack_winograd_c64_weight(w: torch.Tensor) -> torch.Tensor:
-    """(64,64,3,3) -> G g G^T in the ring order of csrc/winograd_c64.hip."""
-    if tuple(w.shape) != (64, 64, 3, 3):
-        raise VatlError("pack_winograd_c64_weight: a (64, 64, 3, 3) filter")
-    out = torch.empty(int(lib().vatl_winograd_c64_weight_floats()), device=w.device, dtype=torch.float32)
-    _check(lib().vatl_pack_winograd_c64_weight(_ptr(w.contiguous()), _ptr(out), _stream()), "vatl_pack_winograd_c64_weight")
-    return out
-
-
-def conv3x3_winograd_c64_supported(n: int, h: int, w: int, cin: int, cout: int) -> bool:
-    return bool(lib().vatl_conv3x3_winograd_c64_supported(n, h, w, cin, cout))
-
-
-def conv3x3_winograd_c64_fwd(x, u, scale, bias, relu: bool, residual=None, out=None):
-    """3x3 / stride 1 / pad 1, 64 -> 64 channels, NHWC, Winograd F(2x2,3x3) with wave-private tiles at one wave per SIMD (csrc/winograd_c64.hip)."""
-    n, h, w, c = x.shape
-    y = out if out is not None else torch.empty_like(x)
-    assert x.is_contiguous() and y.is_contiguous() and (residual is None or (residual.is_contiguous() and residual.shape == x.shape))
-    _check(lib().vatl_conv3x3_winograd_c64_fwd(_ptr(x), _ptr(u), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(y), n, h, w, int(relu), _stream()),
-           "vatl_conv3x3_winograd_c64_fwd")
-    return y
 
 def conv1x1_rows_supported(k1: int, k2: int, n: int, m: int) -> bool:
     return bool(lib().vatl_conv1x1_rows_supported(k1, k2, n, m))
