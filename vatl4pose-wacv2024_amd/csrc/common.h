@@ -45,6 +45,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // 64-lane butterfly reductions (wave = 64 on CDNA)
+// Barrier for LDS hand-offs: waits for this wave's LDS operations only.  `__syncthreads()` is a workgroup release fence + barrier: with global STORES or LDS-DMA
+// requests in flight hipcc emits `s_waitcnt vmcnt(0)` in front of it, and the vector memory counter retires in order — so a plain barrier in a write-out waits for
+// the acknowledgement of every store issued before it and for every load / DMA request issued after those (skip-connection values and staging requests issued early
+// on purpose).  Where the threads of a block exchange data through LDS only, this is the barrier to use; data that arrives by LDS-DMA needs its own counted
+// `s_waitcnt vmcnt(N)` in front, as everywhere in csrc/.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -511,7 +511,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();                                     // (LDS hand-off only: the stores of the half before and the skip-connection loads requested above stay in flight)
         if constexpr (!EARLY) request_consts();
 
         // xi sum (the same rows of A^T) per (tile, output column b, channel quad); 16-byte stores of NHWC channel runs
@@ -567,10 +567,10 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
         }
         if (p.stats) {
             // BatchNorm batch statistics of the pixels just stored: one (sum, sum^2) double pair per (row block, channel), fixed order
-            __syncthreads();
+            lds_barrier();
             f32x4* sh = reinterpret_cast<f32x4*>(smem);
             sh[tid] = ssum; sh[NT + tid] = ssq;
-            __syncthreads();
+            lds_barrier();
             if (tid < C4) {
                 double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
     #pragma unroll 2
@@ -590,7 +590,7 @@ __device__ __forceinline__ void winograd_body(const WinoParams& p, float* smem, 
                 }
             }
         }
-        if (NB > 1 && hh + 1 < NB) __syncthreads();       // the next half's tiles go where this one's were read
+        if (NB > 1 && hh + 1 < NB) lds_barrier();          // the next half's tiles go where this one's were read (this half's stores stay in flight)
     }
 }
 
@@ -808,8 +808,8 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
             for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) accs[hh][nu][e] = 0.f;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the period's first two stages have landed
+        lds_barrier();
 
         if constexpr (NB == 2) {
             for (int st = 0; st < p.stages; ++st) {
@@ -900,7 +900,7 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
                     Ps[((xi * MO + 1) * W_TB + row) * W_LDP + cl] = m1v - m2v - m3v;
                 }
             }
-            __syncthreads();
+            lds_barrier();                                 // (LDS hand-off only: skip-connection loads, the next period's requests and the stores of the half before stay in flight)
 #pragma unroll
             for (int u = 0; u < MO; ++u) {
                 const int rest = (tid_o + NT * u) / C4;
@@ -919,7 +919,7 @@ __device__ __forceinline__ void winograd_persist_body(const WinoParams& p, float
                     wbuf_store4(yr, (nvh[hh] && off[u][a] != WOOB) ? off[u][a] + hoff : WOOB, o);
                 }
             }
-            __syncthreads();                               // the next half's / the next period's stage goes where these tiles were read
+            lds_barrier();                                 // the next half's / the next period's stage goes where these tiles were read (the stores stay in flight)
         }
     }
 }
