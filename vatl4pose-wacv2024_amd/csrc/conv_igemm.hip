@@ -232,10 +232,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             // BatchNorm batch statistics of the tile just stored (training forward): per-thread fp32 sums over NP rows,
             // combined over the RPP row groups in double, one (sum, sum^2) pair per (row block, channel) — the layout
             // bn_train_finalize_kernel reduces in a fixed order (deterministic, no atomics).
-            __syncthreads();                               // every thread is done reading Cs
+            lds_barrier();                                 // every thread is done reading Cs (LDS hand-off only: __syncthreads() would wait for the tile's stores)
             f32x4* sh = reinterpret_cast<f32x4*>(smem);
             sh[tid] = ssum; sh[NT + tid] = ssq;
-            __syncthreads();
+            lds_barrier();
             if (tid < C4) {
                 double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
 #pragma unroll 2                                           // (full unrolling cost the 128x32 kernel 256 VGPRs and spills)
