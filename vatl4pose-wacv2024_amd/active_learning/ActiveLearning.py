@@ -30,7 +30,7 @@ from torch.utils.data import DataLoader, Subset
 import vatl_hip as vh
 from alphapose.models import builder
 from alphapose.utils.bbox import bbox_xyxy_to_xywh
-from alphapose.utils.metrics import DataLogger, calc_accuracy
+from alphapose.utils.metrics import DataLogger, calc_accuracy, calc_accuracy_begin
 from alphapose.utils.transforms import get_func_heatmap_to_coord
 
 from .al_metric import compute_OKS_batch
@@ -610,6 +610,9 @@ class ActiveLearning:
         self.model.train()
         trainer = hip_train.trainer_for(self.model)
         arena = hip_train.arena_for(self.model)
+        # the per-step loss / accuracy read-backs wait until the epoch's steps are enqueued: read inside the loop they drain the stream every step, and the host's
+        # preparation of the next mini-batch (crops, targets) then runs behind the step instead of beside it.  Same values, same order into the loggers.
+        pending = []
         for _ in range(self.retrain_epoch):
             for (idxs, inps, labels, label_masks, *_rest) in loader:
                 nb = len(idxs)
@@ -619,8 +622,8 @@ class ActiveLearning:
                 if not mine:                                                           # fewer chunks than ranks: contribute zeros
                     arena.flat.zero_()
                 for k, (lo, hi) in enumerate(mine):
-                    x = inps[lo:hi, 0].to(self.device).float().contiguous()
-                    lab, msk = labels[lo:hi].to(self.device).float().contiguous(), label_masks[lo:hi].to(self.device).float()
+                    x = vh.upload(inps[lo:hi, 0], self.device, torch.float32).contiguous()
+                    lab, msk = vh.upload(labels[lo:hi], self.device, torch.float32).contiguous(), vh.upload(label_masks[lo:hi], self.device, torch.float32)
                     with torch.no_grad():
                         out = trainer.forward(x)
                         loss, dout = vh.masked_mse_fwd_bwd(out, lab, msk)              # 0.5 * MSE(out*m, label*m) and its gradient
@@ -631,9 +634,8 @@ class ActiveLearning:
                         trainer.backward(dout, arena=arena, overlap=len(mine) == 1)
                         if len(mine) > 1:                                              # several replicas walked on one GPU: accumulate
                             acc = arena.flat.clone() if acc is None else acc.add_(arena.flat)
-                    loss_logger.update(float(loss), hi - lo)
                     m = msk.reshape(msk.shape[0], -1, 1, 1)
-                    acc_logger.update(calc_accuracy(out * m, lab * m), hi - lo)
+                    pending.append((loss, calc_accuracy_begin(out * m, lab * m), hi - lo))
                 if acc is not None:
                     arena.flat.copy_(acc)
                     with torch.no_grad():
@@ -643,6 +645,9 @@ class ActiveLearning:
                 arena.attach()
                 self.optimizer.step()
             self.scheduler.step()
+        for loss, acc_finish, cnt in pending:
+            loss_logger.update(float(loss), cnt)
+            acc_logger.update(acc_finish(), cnt)
         D.broadcast_buffers_(self.model)           # BN statistics are per rank; rank 0's survive (DataParallel semantics)
         self.last_train_loss, self.last_train_acc = self._global_avg(loss_logger), self._global_avg(acc_logger)
         if "WPU" in self.uncertainty:              # ActiveLearning.py:680-684: a fresh AE is fine-tuned on the labeled poses

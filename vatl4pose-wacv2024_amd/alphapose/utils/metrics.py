@@ -39,20 +39,32 @@ def calc_accuracy(preds, labels, thr=0.5):
     """Fraction of joints whose heat-map arg-max lies within ``thr`` of the label's
     arg-max, distances normalised by (W,H)/10, averaged over joints that have at
     least one labelled item (label arg-max > 1 in both axes)."""
+    return calc_accuracy_begin(preds, labels, thr)()
+
+
+def calc_accuracy_begin(preds, labels, thr=0.5):
+    """``calc_accuracy`` in two halves: the arg-max decodes are enqueued now (device work), the returned callable reads them back and does the
+    host arithmetic — so a training loop can log the accuracy of a step without waiting for the step (the read-back of a (B, J, 2) tensor
+    drains the stream; the reference's per-iteration ``loss.item()`` does the same, but there the loader runs in worker processes)."""
+    from .transforms import get_max_pred_batch_begin
     hm_h, hm_w = preds.shape[2], preds.shape[3]
-    p, _ = get_max_pred_batch(preds)
-    t, _ = get_max_pred_batch(labels)
-    norm = np.array([hm_w, hm_h], np.float64) / 10
-    valid = (t[..., 0] > 1) & (t[..., 1] > 1)                       # (B,J)
-    d = np.linalg.norm(p.astype(np.float32) / norm - t.astype(np.float32) / norm, axis=2)
-    d = np.where(valid, d, 0.0).T                                   # (J,B); 0 marks "not counted" like the reference
-    total, cnt = 0.0, 0
-    for row in d:
-        used = row != 0
-        if used.sum() > 0:
-            total += float((row[used] < thr).sum()) / used.sum()
-            cnt += 1
-    return total / cnt if cnt > 0 else 0
+    p_fin, t_fin = get_max_pred_batch_begin(preds), get_max_pred_batch_begin(labels)
+
+    def finish():
+        p, _ = p_fin()
+        t, _ = t_fin()
+        norm = np.array([hm_w, hm_h], np.float64) / 10
+        valid = (t[..., 0] > 1) & (t[..., 1] > 1)                       # (B,J)
+        d = np.linalg.norm(p.astype(np.float32) / norm - t.astype(np.float32) / norm, axis=2)
+        d = np.where(valid, d, 0.0).T                                   # (J,B); 0 marks "not counted" like the reference
+        total, cnt = 0.0, 0
+        for row in d:
+            used = row != 0
+            if used.sum() > 0:
+                total += float((row[used] < thr).sum()) / used.sum()
+                cnt += 1
+        return total / cnt if cnt > 0 else 0
+    return finish
 
 
 def evaluate_mAP(res_file, ann_type="bbox", ann_file="./data/coco/annotations/person_keypoints_val2017.json", silence=False):

@@ -65,11 +65,16 @@ def heatmap_to_coord_simple_regress(preds, bbox, hm_shape, norm_type, hms_flip=N
 
 def get_max_pred_batch(batch_heatmaps):
     """(B,J,H,W) -> preds (B,J,2) f32 heat-map pixel coords (zeroed where max <= 0), maxvals (B,J,1)."""
+    return get_max_pred_batch_begin(batch_heatmaps)()
+
+
+def get_max_pred_batch_begin(batch_heatmaps):
+    """``get_max_pred_batch`` with the read-back deferred: the decode is enqueued now, the returned callable copies the results to the host."""
     h = _dev_f32(batch_heatmaps)
     _, maxv, idx = vh.decode(h, torch.zeros((h.shape[0], 4), device=h.device))
     w = h.shape[3]
     preds = torch.stack([(idx % w).float(), (idx // w).float()], dim=2) * (maxv > 0).unsqueeze(-1).float()
-    return preds.cpu().numpy(), maxv.unsqueeze(-1).cpu().numpy()
+    return lambda: (preds.cpu().numpy(), maxv.unsqueeze(-1).cpu().numpy())
 
 
 def get_max_pred(heatmaps):

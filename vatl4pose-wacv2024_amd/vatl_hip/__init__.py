@@ -188,9 +188,11 @@ def upload(host, device, dtype=None):
     non-blocking.  (A plain `.to(device)` from pageable memory blocks the host until every launch queued before it has finished — a few
     of those per loader batch serialise the host's batch preparation with the device's forward pass.)"""
     t = torch.as_tensor(host)
+    device = torch.device(device)
+    if t.is_cuda:                                           # already on a device: nothing to stage
+        return t.to(device=device, dtype=dtype if dtype is not None else t.dtype)
     if dtype is not None and t.dtype != dtype:
         t = t.to(dtype)
-    device = torch.device(device)
     if device.type != "cuda" or t.numel() == 0:
         return t.to(device)
     return t.contiguous().pin_memory().to(device, non_blocking=True)
