@@ -41,6 +41,14 @@ const char* vatl_last_error(void);
  * cuDNN calls behind nn.Conv2d, Resnet.py:63-100).  Any of the four outputs may be NULL. */
 int vatl_flop_meter_begin(void);
 int vatl_flop_meter_end(double* direct_flops, double* winograd_flops, int64_t* direct_launches, int64_t* winograd_launches);
+/* Launch counts per kernel family since the calling thread's last _begin (read BEFORE _end): counts[k] for route k of
+ * VATL_ROUTE_NAMES below, k < n; returns the number of routes the library knows.  Diagnostic: lets a test assert that the
+ * configuration it pins really took the route it names (two-half Winograd blocks, staging-address tables, the
+ * BatchNorm-backward epilogue, ...) instead of trusting the dispatch rules. */
+#define VATL_ROUTE_NAMES "igemm,igemm_bnbwd,igemm_dma,persistent_1x1,streamk,rows_1x1,bottleneck_chain,stem_pool,halo_3x3," \
+                         "winograd,winograd_2h,winograd_bnbwd,winograd_persist,winograd_c32,wgrad,winograd_wgrad,winograd_wgrad_2h," \
+                         "winograd_wgrad_table"
+int vatl_flop_meter_routes(int64_t* counts, int n);
 
 /* ------------------------------------------------------------------------ *
  * Layout and parameter preparation (done once per weight version)

@@ -71,6 +71,16 @@ def test_ctypes_table_mirrors_header(built_lib):
             assert res is _ctype_of(ret), name
 
 
+def test_route_names_of_the_meter_match_the_header(built_lib):
+    """vatl_flop_meter_routes: the header's VATL_ROUTE_NAMES, the Python tuple and the library's route count agree (host-only call)."""
+    src = open(HEADER).read()
+    m = re.search(r"#define VATL_ROUTE_NAMES((?:\s*\\?\s*\"[a-z0-9_,]+\")+)", src)
+    names = tuple("".join(re.findall(r'"([a-z0-9_,]+)"', m.group(1))).split(","))
+    assert names == built_lib.ROUTE_NAMES
+    counts = (ctypes.c_int64 * 32)()
+    assert built_lib.lib().vatl_flop_meter_routes(counts, 32) == len(names) and not any(counts)
+
+
 def test_conv_cout_pad_is_host_only(built_lib):
     assert [built_lib.conv_cout_pad(c) for c in (17, 32, 40, 64, 96, 256, 2048)] == [32, 32, 64, 64, 128, 256, 2048]
 

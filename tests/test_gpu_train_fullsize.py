@@ -1,0 +1,180 @@
+"""The two fine-tune configurations bench.py TIMES (BASELINE.json configs 3 / 5), asserted at the size the bench runs them:
+SimpleBaseline-R50 256x192 at B = 120 and FastPose-R152 384x288 at B = 32 through bench.finetune_step_fn's exact sequence
+(arena.begin -> Trainer.backward(arena, overlap=True) -> finish -> attach -> AdamW; reference: ActiveLearning.py:657-673).
+
+The small-batch tests (tests/test_gpu_train.py) pin every kernel instantiation on its own; at these sizes the dispatch rules pick
+routes no small batch reaches — Winograd weight gradients with two gradient halves per block (>= 256 channels), their
+staging-address tables, two-half forward blocks (launches of >= 400 blocks), the two-stream weight gradients — and this file
+asserts the COMPOSITION: values against the float64 oracle graph on the same batch, bit-reproducibility, stream-order
+independence, and (through the library's route counters) that those routes really ran.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets
+from tests.gpu_util import dev, record
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "cfg3": dict(cfg="SIMPLE_R50", hw=(256, 192), batch=120, groups=(("final_layer", 10), ("preact", 1), ("deconv_layers", 5)),
+                 ref=lambda: nets.SimplePoseRef(50), head="final_layer", tail="deconv_layers.6.weight"),
+    "cfg5": dict(cfg="FAST_R152", hw=(384, 288), batch=32, groups=(("conv_out", 10), ("preact", 1), ("duc1", 5), ("duc2", 5)),
+                 ref=lambda: nets.FastPoseRef(152), head="conv_out", tail="duc2.conv.weight"),
+}
+
+
+def _inputs(case, device):
+    """The batch bench.extra_finetune draws (same generator, same seed, rank 0)."""
+    hw, b = case["hw"], case["batch"]
+    g = torch.Generator(device=device)
+    g.manual_seed(166)
+    x = torch.rand((b, 3, hw[0], hw[1]), device=device, generator=g) - 0.45
+    labels = torch.rand((b, 17, hw[0] // 4, hw[1] // 4), device=device, generator=g) * 0.1
+    masks = (torch.rand((b, 17, 1, 1), device=device, generator=g) > 0.2).float()
+    return x, labels, masks
+
+
+def _oracle_step(case, sd, x, labels, masks, dtype):
+    """The reference's step (ActiveLearning.py:667-671: loss = 0.5 * MSE(out * mask, label * mask); backward) on the oracle graph, CPU."""
+    ref = case["ref"]()
+    ref.load_state_dict(sd, strict=True)
+    ref = ref.to(dtype).train()
+    out = ref(x.to(dtype))
+    m = masks.to(dtype)
+    loss = 0.5 * torch.nn.functional.mse_loss(out * m, labels.to(dtype) * m)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+    bufs = {k: v.detach().clone() for k, v in ref.named_buffers() if "running" in k}
+    return float(loss), grads, bufs
+
+
+def _sample_keys(named, case):
+    """Head weight + bias, the last up-sampling layer's weight, and ten conv weights spread over the trunk."""
+    convs = [k for k, p in named.items() if k.startswith("preact.") and p.dim() == 4]
+    step = max(1, len(convs) // 10)
+    trunk = convs[step // 2::step][:10]
+    return [case["head"] + ".weight", case["head"] + ".bias", case["tail"]] + trunk
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg5"])
+def test_bench_size_step_values_bits_and_routes(name):
+    import bench
+    import vatl_hip as vh
+    from alphapose.models import hip_train
+    case = CASES[name]
+    d = dev()
+    m = bench.build_net(getattr(bench, case["cfg"]), case["hw"], d).train()
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x, labels, masks = _inputs(case, d)
+    tr, arena = hip_train.trainer_for(m), hip_train.arena_for(m)
+    stats = [b_ for n_, b_ in m.named_buffers() if "running" in n_ or "num_batches" in n_]
+    stats0 = [b_.clone() for b_ in stats]
+
+    def restore_stats():
+        with torch.no_grad():
+            for b_, s_ in zip(stats, stats0):
+                b_.copy_(s_)
+
+    def fwd_bwd(use_arena=True, overlap=True):
+        """forward + loss + backward exactly as bench.finetune_step_fn's step() runs them (no optimizer: the weights stay put)"""
+        restore_stats()
+        with torch.no_grad():
+            out = tr.forward(x)
+            loss, dout = vh.masked_mse_fwd_bwd(out, labels, masks)
+            if use_arena:
+                arena.begin()
+                tr.backward(dout, arena=arena, overlap=overlap)
+                arena.finish()
+                arena.attach()
+                flat = arena.flat.clone()
+            else:
+                grads = tr.backward(dout)
+                flat = torch.cat([grads[p].reshape(-1) for p in arena.params])
+        torch.cuda.synchronize()
+        return out.clone(), float(loss), flat, [b_.clone() for b_ in stats]
+
+    fwd_bwd()                                               # first step: records the weight re-pack plan (the bench's warm-up)
+    with vh.flop_meter() as fm:
+        out_a, loss_a, flat_a, stats_a = fwd_bwd()
+    routes = {k: v for k, v in fm.routes.items() if v}
+    record("fullsize_routes", config=name, **routes)
+    # ---- the routes only these sizes reach really ran
+    assert routes.get("winograd_wgrad_2h", 0) >= 1 and routes.get("winograd_wgrad_table", 0) == routes.get("winograd_wgrad", 0) + routes["winograd_wgrad_2h"]
+    assert routes.get("winograd_2h", 0) >= 1 and routes.get("winograd_bnbwd", 0) >= 1 and routes.get("igemm_bnbwd", 0) >= 1 and routes.get("wgrad", 0) >= 1
+    if name == "cfg3":                                      # R50: 10 stride-1 3x3 layers with >= 128 channels (7 of them >= 256) + 3 transposed convs
+        assert routes["winograd_wgrad_2h"] == 7 and routes["winograd_wgrad"] == 6, routes
+    assert hip_train._side.enabled                          # the weight gradients of this step ran on the side stream
+
+    # ---- bit-reproducible, and independent of the arena / overlap / stream order
+    out_b, loss_b, flat_b, stats_b = fwd_bwd()
+    assert torch.equal(out_a, out_b) and loss_a == loss_b and torch.equal(flat_a, flat_b)
+    assert all(torch.equal(p_, q_) for p_, q_ in zip(stats_a, stats_b))
+    _, loss_c, flat_c, _ = fwd_bwd(overlap=False)
+    assert loss_c == loss_a and torch.equal(flat_a, flat_c), "overlap=True and overlap=False must give the same bits"
+    hip_train._side.enabled = False
+    try:
+        _, loss_d, flat_d, _ = fwd_bwd(use_arena=False)     # fresh gradient tensors, one stream
+    finally:
+        hip_train._side.enabled = True
+    assert loss_d == loss_a and torch.equal(flat_a, flat_d), "side-stream weight gradients must give the single-stream bits"
+    del out_b, flat_b, flat_c, flat_d
+
+    # ---- values: float64 oracle graph on the same batch; torch fp32 on the same graph is the yardstick for the gradients
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    xc, lc, mc = x.cpu(), labels.cpu(), masks.cpu()
+    loss64, g64, buf64 = _oracle_step(case, sd0, xc, lc, mc, torch.float64)
+    loss32, g32, _ = _oracle_step(case, sd0, xc, lc, mc, torch.float32)
+    np.testing.assert_allclose(loss_a, loss64, rtol=1e-5)
+    named = dict(m.named_parameters())
+    got_stats = {n_: b_ for n_, b_ in zip([n_ for n_, _ in m.named_buffers() if "running" in n_ or "num_batches" in n_], stats_a) if "running" in n_}
+    worst = 0.0
+    for k, want in buf64.items():
+        got = got_stats[k].double().cpu()
+        err = float((got - want).abs().max() / want.abs().max().clamp_min(1e-3))
+        worst = max(worst, err)
+        assert err < 1e-4, (k, err)
+    record("fullsize_values", config=name, loss=loss_a, loss_f64=loss64, loss_torch_f32=loss32, running_stats_worst_rel=worst)
+    off = arena.offset
+    bad, tight = [], 0
+    for key in _sample_keys(named, case):
+        p = named[key]
+        got = flat_a[off[p]:off[p] + p.numel()].double().cpu()
+        exact, ref = g64[key].reshape(-1), g32[key].reshape(-1).double()
+        n = max(float(exact.norm()), 1e-30)
+        ours, theirs = float((got - exact).norm() / n), float((ref - exact).norm() / n)
+        ratio = float(got.norm()) / n
+        record("fullsize_grad", config=name, key=key, ours_vs_f64=ours, torch_f32_vs_f64=theirs, norm_ratio=ratio)
+        tight += theirs < 1e-4
+        if not (ours <= 1.5 * theirs + 1e-4 and abs(ratio - 1) < 5e-3 + 0.5 * theirs):
+            bad.append((key, ours, theirs, ratio))
+    assert not bad, bad
+    assert tight >= 2                                       # the head tensors are pinned at the 1e-4 level
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg5"])
+def test_bench_step_function_two_runs_same_weights(name):
+    """bench.finetune_step_fn itself (forward, loss, arena backward with overlap, AdamW with the bench's parameter groups), three
+    steps from the same seed on two separately built models: the losses, every parameter and every BatchNorm buffer bit-identical."""
+    import bench
+    from active_learning.optim import AdamW
+    case = CASES[name]
+    d = dev()
+    finals = []
+    for _ in range(2):
+        m = bench.build_net(getattr(bench, case["cfg"]), case["hw"], d).train()
+        opt = AdamW(params=[{"params": getattr(m, a).parameters(), "lr": 2.5e-4 * f} for a, f in case["groups"]], weight_decay=0.7)
+        x, labels, masks = _inputs(case, d)
+        step, arena = bench.finetune_step_fn(m, opt, x, labels, masks, 1)
+        losses = [float(step()) for _ in range(3)]
+        torch.cuda.synchronize()
+        finals.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+        del m, opt, step, arena
+        torch.cuda.empty_cache()
+    (la, sa), (lb, sb) = finals
+    assert la == lb and la[0] != la[2]                      # the weights moved, identically
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k

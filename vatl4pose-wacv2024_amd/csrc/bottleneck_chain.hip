@@ -216,12 +216,14 @@ extern "C" int vatl_bottleneck_chain_fwd(const float* a, const float* w3, const 
         const int grid = p.m_tiles < 512 ? p.m_tiles : 512;                   // 237 registers: two blocks per CU
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
         meter_add(0, 2.0 * padded * 256.0 * 64.0 * 2.0);
+        meter_route(kRouteChain);
     } else {
         auto kern = bottleneck_chain_kernel<false>;
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, c0, "bottleneck_chain")) return rc;
         const int grid = p.m_tiles < 512 ? p.m_tiles : 512;                   // (163 registers: a third block per CU fits and was measured: no gain)
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
         meter_add(0, 2.0 * padded * 256.0 * 64.0);
+        meter_route(kRouteChain);
     }
     return check_launch("bottleneck_chain");
 }

@@ -19,6 +19,14 @@ int fail(int code, const char* fmt, ...);
 // kind 0 (direct sums: implicit GEMM, weight gradients) or kind 1 (Winograd transform-domain GEMMs).  Thread-local like the
 // split-K scope: nothing global, off unless the thread asked for it.
 void meter_add(int kind, double flops);
+// ... and WHICH kernel family a launch took (vatl_flop_meter_routes): the tests assert that the configuration they pin really ran the
+// route they name (two-half Winograd blocks, staging-address tables, the BatchNorm-backward epilogue, ...).  Same thread-local switch.
+enum MeterRoute {
+    kRouteIgemm = 0, kRouteIgemmBnBwd, kRouteIgemmDma, kRoutePersistent1x1, kRouteStreamK, kRouteRows, kRouteChain, kRouteStemPool, kRouteHalo,
+    kRouteWino, kRouteWino2H, kRouteWinoBnBwd, kRouteWinoPersist, kRouteWinoC32, kRouteWgrad, kRouteWinoWgrad, kRouteWinoWgrad2H,
+    kRouteWinoWgradTable, kRouteCount
+};
+void meter_route(int route);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

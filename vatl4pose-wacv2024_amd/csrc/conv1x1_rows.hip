@@ -161,5 +161,6 @@ extern "C" int vatl_conv1x1_rows_fwd(const float* a, const float* x2, const floa
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, (hipStream_t)stream, p);
     }
     meter_add(0, 2.0 * ((double)p.m_tiles * 32.0) * (double)N * 128.0);
+    meter_route(kRouteRows);
     return check_launch("conv1x1_rows");
 }

@@ -182,6 +182,7 @@ static int launch_halo(HaloParams p, hipStream_t st) {
     const int grid = p.total < 512 ? p.total : 512;        // two resident blocks per CU, each walks total / 512 patches
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, st, p);
     meter_add(0, 2.0 * (double)p.total * TH * TW * 32.0 * 32.0 * 9.0);
+    meter_route(kRouteHalo);
     return check_launch("conv3x3_halo");
 }
 

@@ -1379,6 +1379,7 @@ static int launch(const ConvParams& p, int phases, hipStream_t st) {
     dim3 grid((unsigned)(m_tiles * q.n_tiles), (unsigned)phases, (unsigned)q.splits);
     hipLaunchKernelGGL(kern, grid, dim3(NT), smem, st, q);
     meter_add(0, 2.0 * ((double)m_tiles * BM) * ((double)q.n_tiles * BN) * ((double)q.ktiles * BK) * phases);
+    meter_route(BNB ? kRouteIgemmBnBwd : kRouteIgemm);
     if (q.splits > 1) {
         const long long total = q.part_slice;
         long long gsz = (total + 255) / 256; if (gsz > 8192) gsz = 8192;
@@ -1403,6 +1404,7 @@ static int launch_dma(const ConvParams& p, int phases, hipStream_t st) {
     dim3 grid((unsigned)(q.m_tiles * q.n_tiles), (unsigned)phases, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, q);
     meter_add(0, 2.0 * ((double)q.m_tiles * BM) * ((double)q.n_tiles * BN) * ((double)q.ktiles * BK) * phases);
+    meter_route(kRouteIgemmDma);
     return check_launch("conv_igemm_dma");
 }
 
@@ -1430,6 +1432,7 @@ static int launch_persistent_impl(const ConvParams& p, hipStream_t st) {
     if (D2) hipLaunchKernelGGL(kern2, dim3((unsigned)grid), dim3(256), smem, st, q);
     else    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, st, q);
     meter_add(0, 2.0 * ((double)q.m_tiles * BM) * ((double)q.n_tiles * BN) * ((double)q.ktiles * BK));
+    meter_route(kRoutePersistent1x1);
     return check_launch("gemm1x1_persistent");
 }
 
@@ -1468,6 +1471,7 @@ static int launch_streamk(const ConvParams& p, hipStream_t st) {
     sk.tiles = q.m_tiles * q.n_tiles;
     hipLaunchKernelGGL(kern, dim3(kStreamKGrid), dim3(256), smem, st, q, sk);
     meter_add(0, 2.0 * ((double)q.m_tiles * 64) * ((double)q.n_tiles * 128) * ((double)q.ktiles * BK));
+    meter_route(kRouteStreamK);
     return check_launch("conv_streamk");
 }
 

@@ -284,6 +284,7 @@ static int launch_wgrad_t(WgradParams p, const WgradPlan& plan, hipStream_t st) 
     p.kt_per_split = plan.kt_per_split;
     hipLaunchKernelGGL((conv_wgrad_kernel<BN, BJ, WN, WJ, STEM>), dim3((unsigned)(plan.tiles * plan.splits)), dim3(256), 0, st, p);
     meter_add(0, 2.0 * (double)plan.tiles * BN * BJ * (double)cdiv(p.M, 32) * 32.0);
+    meter_route(kRouteWgrad);
     return check_launch("conv_wgrad");
 }
 

@@ -985,6 +985,7 @@ static int launch_wino(const WinoParams& p, int phases, hipStream_t st) {
     if (smem > kWinoMaxLds) return fail(VATL_EINVAL, "winograd: %d bytes of LDS per block", smem);
     hipLaunchKernelGGL(kern, dim3(p.m_tiles * p.n_tiles * phases), dim3(256), smem, st, p);
     meter_add(1, 2.0 * ((double)p.m_tiles * W_TB) * ((double)p.n_tiles * 32 * NB) * 16.0 * ((double)p.stages * W_CK) * phases);
+    meter_route(BNB ? kRouteWinoBnBwd : (NB == 2 ? kRouteWino2H : kRouteWino));
     return check_launch("winograd");
 }
 
@@ -1045,6 +1046,7 @@ static int launch_wino_persist(const WinoParams& base, int N, bool two, hipStrea
     if (int rc = two ? (pf ? go(winograd_persist_kernel<2, true>, 3) : go(winograd_persist_kernel<2, false>, 1))
                      : (pf ? go(winograd_persist_kernel<1, true>, 2) : go(winograd_persist_kernel<1, false>, 0))) return rc;
     meter_add(1, 2.0 * ((double)periods * Lt) * ((double)n_tiles * 32 * NBh) * 16.0 * ((double)base.stages * W_CK));
+    meter_route(kRouteWinoPersist);
     *covered = periods * Pi;
     return check_launch("winograd_persist");
 }

@@ -25,7 +25,18 @@ void meter_add(int kind, double flops) {
     tl_meter_flops[kind & 1] += flops;
     tl_meter_launches[kind & 1] += 1;
 }
-void meter_begin() { tl_meter_on = true; tl_meter_flops[0] = tl_meter_flops[1] = 0.0; tl_meter_launches[0] = tl_meter_launches[1] = 0; }
+static thread_local long long tl_meter_routes[kRouteCount] = {};
+void meter_route(int route) {
+    if (tl_meter_on && route >= 0 && route < kRouteCount) tl_meter_routes[route] += 1;
+}
+void meter_begin() {
+    tl_meter_on = true; tl_meter_flops[0] = tl_meter_flops[1] = 0.0; tl_meter_launches[0] = tl_meter_launches[1] = 0;
+    for (int k = 0; k < kRouteCount; ++k) tl_meter_routes[k] = 0;
+}
+int meter_routes(long long* out, int n) {
+    for (int k = 0; k < n && k < kRouteCount; ++k) out[k] = tl_meter_routes[k];
+    return kRouteCount;
+}
 void meter_end(double* flops, long long* launches) {
     for (int k = 0; k < 2; ++k) { flops[k] = tl_meter_flops[k]; launches[k] = tl_meter_launches[k]; }
     tl_meter_on = false;
@@ -525,7 +536,7 @@ using namespace vatl;
 extern "C" int vatl_version(void) { return VATL_VERSION; }
 extern "C" const char* vatl_last_error(void) { return err_buf(); }
 
-namespace vatl { void meter_begin(); void meter_end(double*, long long*); }
+namespace vatl { void meter_begin(); void meter_end(double*, long long*); int meter_routes(long long*, int); }
 extern "C" int vatl_flop_meter_begin(void) { vatl::meter_begin(); return 0; }
 extern "C" int vatl_flop_meter_end(double* direct_flops, double* winograd_flops, int64_t* direct_launches, int64_t* winograd_launches) {
     double f[2]; long long n[2];
@@ -535,6 +546,13 @@ extern "C" int vatl_flop_meter_end(double* direct_flops, double* winograd_flops,
     if (direct_launches) *direct_launches = n[0];
     if (winograd_launches) *winograd_launches = n[1];
     return 0;
+}
+extern "C" int vatl_flop_meter_routes(int64_t* counts, int n) {
+    if (!counts || n < 0) return vatl::fail(VATL_EINVAL, "flop_meter_routes: null pointer");
+    long long tmp[64] = {};
+    const int have = vatl::meter_routes(tmp, n < 64 ? n : 64);
+    for (int k = 0; k < n; ++k) counts[k] = k < have && k < 64 ? (int64_t)tmp[k] : 0;
+    return have;
 }
 
 extern "C" int vatl_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int Cpad, void* stream) {

@@ -271,6 +271,7 @@ static int launch_stem_pool(const StemPoolParams& p, hipStream_t st) {
     // executed MFMA FLOPs: every step multiplies 2 stem rows x (W / 2) pixels x 64 channels x K = 3 KS (KS + 1) (+ one recomputed step per pooling band below the first)
     const double steps = (double)p.N * ((p.H >> 2) + (KS == 7 ? p.bands - 1 : 0));
     meter_add(0, 2.0 * steps * 2.0 * (p.W / 2) * 64.0 * (3.0 * KS * (KS + 1)));
+    meter_route(kRouteStemPool);
     return check_launch("stem_pool");
 }
 

@@ -271,5 +271,6 @@ extern "C" int vatl_conv3x3_winograd_c32_fwd(const float* x, const float* u, con
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, (hipStream_t)stream, p);
     // executed MFMA FLOPs: units x 16 tiles x 32 cout x 32 cin x 16 positions
     meter_add(1, 2.0 * (double)p.units * 16.0 * 32.0 * 32.0 * 16.0);
+    meter_route(kRouteWinoC32);
     return check_launch("winograd_c32");
 }

@@ -449,6 +449,7 @@ static int winograd_wgrad_impl(const float* x, const float* g, float* dw, float*
         if (nbn == 2) hipLaunchKernelGGL((winograd_wgrad_table_kernel<MO, kWWTK, 2>), tgrid, dim3(256), 0, st, p, tx, tg);
         else          hipLaunchKernelGGL((winograd_wgrad_table_kernel<MO, kWWTK, 1>), tgrid, dim3(256), 0, st, p, tx, tg);
         p.tab_x = tx; p.tab_g = tg;
+        meter_route(kRouteWinoWgradTable);
     }
     if (nbn == 2) {
         auto kern = winograd_wgrad_kernel<MO, kWWTK, 2>;
@@ -460,6 +461,7 @@ static int winograd_wgrad_impl(const float* x, const float* g, float* dw, float*
         hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
     }
     meter_add(1, 2.0 * (double)p.CnPad * p.CxPad * 16.0 * q.phases * (double)((mt + kWWTK - 1) / kWWTK * kWWTK));
+    meter_route(nbn == 2 ? kRouteWinoWgrad2H : kRouteWinoWgrad);
     if (int rc = check_launch("winograd_wgrad")) return rc;
     hipLaunchKernelGGL(winograd_wgrad_finish_kernel<MO>, dim3((unsigned)((long long)q.phases * Cn * ((Cx + 63) / 64))), dim3(256), 0, st, workspace, dw, Cn, Cx,
                        p.CnPad, p.CxPad, q.splits);

@@ -28,6 +28,7 @@ SIGNATURES = {
     "vatl_last_error": (C.c_char_p, []),
     "vatl_flop_meter_begin": (_i, []),
     "vatl_flop_meter_end": (_i, [_p, _p, _p, _p]),
+    "vatl_flop_meter_routes": (_i, [_p, _i]),
     "vatl_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "vatl_nhwc_to_nchw": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "vatl_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -233,6 +234,10 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+ROUTE_NAMES = ("igemm", "igemm_bnbwd", "igemm_dma", "persistent_1x1", "streamk", "rows_1x1", "bottleneck_chain", "stem_pool", "halo_3x3", "winograd",
+               "winograd_2h", "winograd_bnbwd", "winograd_persist", "winograd_c32", "wgrad", "winograd_wgrad", "winograd_wgrad_2h", "winograd_wgrad_table")
+
+
 class flop_meter:
     """`with vh.flop_meter() as fm: ...` — executed MFMA FLOPs (tile padding included) of the matrix-core launches the calling host
     thread makes inside the block: fm.direct (implicit GEMM / weight gradients), fm.winograd (transform-domain GEMMs), fm.total, and the
@@ -245,6 +250,9 @@ class flop_meter:
         return self
 
     def __exit__(self, *exc):
+        counts = (C.c_int64 * len(ROUTE_NAMES))()
+        _check(min(0, lib().vatl_flop_meter_routes(counts, len(ROUTE_NAMES))), "flop_meter_routes")
+        self.routes = {n: int(c) for n, c in zip(ROUTE_NAMES, counts)}          # launches per kernel family (include/vatl_hip.h VATL_ROUTE_NAMES)
         d, w, nd, nw = C.c_double(0), C.c_double(0), C.c_int64(0), C.c_int64(0)
         _check(lib().vatl_flop_meter_end(C.byref(d), C.byref(w), C.byref(nd), C.byref(nw)), "flop_meter_end")
         self.direct, self.winograd, self.total = d.value, w.value, d.value + w.value
