@@ -15,7 +15,10 @@
  *     the last failure on the calling thread is vatl_last_error();
  *   - activations between conv entry points are NHWC fp32 ("channels-last"),
  *     the network input and the heat-maps are NCHW fp32 like the reference's;
- *   - re-entrant, no global mutable state except the thread-local error string.
+ *   - re-entrant.  Mutable state: the thread-local error string, FLOP meter and split-K / stream-K workspace registrations of
+ *     the calling host thread; and two PROCESS-GLOBAL pieces — the route selectors of vatl_tune_set (every accepted value
+ *     computes the same bits) and the opt-in device-wide split-K workspace of vatl_set_splitk_workspace (changes bits; off
+ *     unless the caller registers one).  Nothing in the library reads the environment.
  */
 #ifndef VATL_HIP_H
 #define VATL_HIP_H
@@ -148,23 +151,31 @@ int vatl_bottleneck_chain_fwd(const float* a, const float* w3, const float* scal
                               const float* w1, const float* scale1, const float* bias1, float* y1, int64_t M, int Cmid, int Cout,
                               int Cnext, void* stream);
 
-/* Tuning knobs (benchmarks / A-B tests only).  Results are identical for every setting of
- * knob 0 = k-loop schedule of the conv kernel, values 0, 2, 4, 5 (see csrc/conv_igemm.hip), 1 = tile order, 2 = block
- * stagger, 3 = target block count of the weight-gradient launches (number of pixel splits), 5 = rows of the conv block
- * tile (0 = chosen from the grid size, 64, 128), 7 = persistent 1x1 kernel for K <= 256 v (0 = off, default 1), 8 = halo-tile kernel for the
- * 32-channel 3x3 layers (csrc/conv3x3_halo.hip; 1 = on, default; 0 = generic implicit GEMM; bit-identical results), 9 = split-K cut policy while a
- * workspace is registered (0 = by the launch's own block count, 1 = by the layer's per-image geometry only: batch-invariant bits), 10 = operand
- * look-ahead of the persistent 1x1 kernel in k-tiles (1, or 2 = default; bit-identical results), 12 = stream-K route (see
- * vatl_set_streamk_workspace_thread; 1 = default, 0 = off), 16 = pixels per thread of the crop warp kernel (8 = default, 4), 18 = KB of filter slices per group of the Winograd
- * kernel's tile order (default 2048; 0 = one slice), 19 = target block count of the Winograd weight-gradient launches (default 1024; the transposed
- * convs use 4x that), 21 = 32-channel filter halves per Winograd block (1 = one, 2 = default: two where the filter has an even number of halves and the launch keeps
- * >= 400 blocks, 3 = two wherever the filter allows; bit-identical results), 22 = persistent Winograd route for layers of at most v 16-channel stages (default 8), 23 = gradient halves per
- * block of the Winograd weight-gradient kernel (1, 2 = default), 24 = prefetching variant of the persistent Winograd kernel (bits), 25 = staging-address tables of the Winograd weight-gradient
- * kernels (1 = default: written by a small kernel before the launch, into the workspace; 0 = formed per stage in the kernel; bit-identical results).  Knob 0 values 10..13, knob 4 (wgrad ablation bits), knob 6 (conv ablation bits: 1 no epilogue, 2 one k-tile) and knob 17
- * (Winograd ablation bits: 1 no output transform, 2 no LDS reads, 4 no filter loads, 8 no staging DMA, 16 no barriers) are profiling
- * ablations that compute WRONG results: they are not compiled into the product library at all (every such call returns
- * VATL_EINVAL); the profiling variant built with -DVATL_ABLATION (build.py --ablation -> libvatl_hip_ablation.so, loaded
- * through VATL_HIP_LIB) accepts them when the environment also has VATL_ALLOW_ABLATION=1. */
+/* Route selectors (benchmarks / A-B tests only).  PROCESS-GLOBAL (relaxed atomics inside the library; set them before
+ * several host threads launch) and FROZEN: the shipped library accepts exactly the knobs of this table, and every accepted value
+ * computes the SAME BITS as the default — a caller can never change results through this entry point (tests/test_gpu_conv.py and
+ * tests/test_gpu_winograd.py assert the bit-identity knob by knob).  Anything else returns VATL_EINVAL.
+ *
+ *   knob  default  values          selects
+ *    0      4      0, 2, 4, 5      k-loop schedule of the implicit-GEMM kernel (two-phase / interleaved / distance-2 prefetch / LDS-DMA)
+ *    1      0      0, 1            tile order of the implicit-GEMM grid (n-tile or m-tile fastest)
+ *    5      0      0, 64, 128      rows of the implicit-GEMM block tile (0 = chosen from the grid size).  Conv outputs are bit-identical;
+ *                                  the float64 row-block partials of the training entry points' BatchNorm statistics follow the tile
+ *    7      1      0 .. 64         persistent 1x1 GEMM kernel for K <= 256 v (0 = off)
+ *    8      1      0, 1            halo-tile kernel for the 32-channel 3x3 layers (csrc/conv3x3_halo.hip) vs the implicit GEMM
+ *   10      2      1, 2            operand look-ahead of the persistent 1x1 kernel in k-tiles
+ *   18    2048     0 .. 2^20       KB of filter slices per group of the Winograd kernel's tile order (0 = one slice)
+ *   21      2      1, 2, 3         32-channel filter halves per Winograd block (2 = two where the launch keeps >= 400 blocks, 3 = wherever possible)
+ *   22      8      0 .. 4096       persistent Winograd route for layers of at most v 16-channel stages (0 = never)
+ *   24      2      0 .. 3          prefetching variant of the persistent Winograd kernel (bit 0 / 1: one- / two-half blocks)
+ *   25      1      0, 1            staging-address tables of the Winograd weight-gradient kernels (0 = addresses formed in the kernel)
+ *
+ * NOT in the shipped library: knobs that change the summation order (3 / 19 = pixel splits of the weight-gradient launches, 9 = split-K
+ * cut policy, 12 = stream-K switch, 23 = gradient halves per Winograd weight-gradient block), performance-only experiments (2 = block
+ * stagger, 16 = pixels per thread of the crop kernel) and the profiling ablations that compute WRONG results by construction (knob 0
+ * values 10..13, knobs 4 / 6 / 17).  They exist only in the variant built with -DVATL_ABLATION (build.py --ablation ->
+ * libvatl_hip_ablation.so, loaded through VATL_HIP_LIB by the tools under tools/); the wrong-result ones additionally need
+ * VATL_ALLOW_ABLATION=1 in the environment of that variant. */
 int vatl_tune_set(int knob, int value);
 /* Opt-in split-K for small batches (single-frame / online inference): with a caller-owned workspace registered, conv
  * launches of fewer than 256 blocks and >= 16 k-tiles are cut along K into ~512 blocks; every split writes a raw partial
@@ -175,7 +186,7 @@ int vatl_tune_set(int knob, int value);
  * it) and is shared by that device's streams: use from one stream at a time.  NULL disables it for the current device. */
 int vatl_set_splitk_workspace(float* workspace, int64_t floats);
 /* The same for the launches of the CALLING HOST THREAD only (thread-local; takes precedence over the device-wide workspace
- * while set; NULL clears it), always with the batch-invariant cut (vatl_tune_set knob 9 = 1 semantics: the cut depends on the
+ * while set; NULL clears it), always with the batch-invariant cut (the cut depends on the
  * layer's per-image geometry, so a crop's bits do not depend on how many crops share its call).  This is what module calls
  * with <= 16 crops use for their duration (scripts/poseestimator_eval.py shape): no global switch, no buffer shared between
  * host threads.  The workspace must be on the device the thread launches on; one stream per thread at a time. */
@@ -187,7 +198,7 @@ int vatl_set_splitk_workspace_thread(float* workspace, int64_t floats);
  * reproducible; agrees with the unsplit kernel to fp32 rounding, not bit for bit — which is why only the training paths use
  * it).  workspace: vatl_streamk_workspace_bytes() bytes of device memory, ZEROED once by the caller before it is registered
  * (flags carry a per-launch epoch and are never reset), owned by the caller, used by this thread's launches on one stream at
- * a time; NULL clears the registration.  vatl_tune_set(12, 0) switches the route off. */
+ * a time; NULL clears the registration. */
 int64_t vatl_streamk_workspace_bytes(void);
 int vatl_set_streamk_workspace_thread(void* workspace, int64_t bytes);
 /* CoutPad the packer must use for a given Cout (multiple of the kernel's N tile). */

@@ -98,7 +98,68 @@ def test_product_library_has_no_wrong_result_ablations(monkeypatch):
     import vatl_hip as vh
     monkeypatch.setenv("VATL_ALLOW_ABLATION", "1")
     lib = vh.lib()
-    for knob, value in ((0, 10), (0, 11), (0, 12), (0, 13), (4, 1), (6, 1), (6, 2)):
+    for knob, value in ((0, 10), (0, 11), (0, 12), (0, 13), (4, 1), (6, 1), (6, 2), (17, 1)):
         assert lib.vatl_tune_set(knob, value) != 0
         assert b"VATL_ABLATION" in lib.vatl_last_error()
-    assert lib.vatl_tune_set(0, 4) == 0 and lib.vatl_tune_set(6, 0) == 0 and lib.vatl_tune_set(4, 0) == 0
+    assert lib.vatl_tune_set(0, 4) == 0
+
+
+# include/vatl_hip.h's knob table: (knob, default, another accepted value)
+PRODUCT_KNOBS = ((0, 4, 2), (1, 0, 1), (5, 0, 128), (7, 1, 4), (8, 1, 0), (10, 2, 1), (18, 2048, 0), (21, 2, 1), (22, 8, 0), (24, 2, 0), (25, 1, 0))
+
+
+def test_knob_surface_is_frozen():
+    """vatl_tune_set of the shipped library accepts exactly the bit-identical route selectors the header tabulates; the knobs that change
+    the summation order (3, 9, 12, 19, 23) and the performance experiments (2, 16) are not in it (host-only calls: no GPU needed)."""
+    import vatl_hip as vh
+    lib = vh.lib()
+    src = open(HEADER).read()
+    table = {int(m.group(1)): int(m.group(2)) for m in re.finditer(r"^ \*\s+(\d+)\s+(\d+)\s+[0-9]", src, flags=re.M)}
+    assert table == {k: d for k, d, _ in PRODUCT_KNOBS}, table
+    try:
+        for knob, default, other in PRODUCT_KNOBS:
+            assert lib.vatl_tune_set(knob, other) == 0, knob
+    finally:
+        for knob, default, _ in PRODUCT_KNOBS:
+            assert lib.vatl_tune_set(knob, default) == 0, knob
+    for knob, value in ((2, 50), (3, 512), (4, 0), (6, 0), (9, 1), (12, 0), (16, 4), (19, 2048), (23, 1), (11, 0), (26, 0), (0, 1), (0, 3)):
+        assert lib.vatl_tune_set(knob, value) != 0, (knob, value)
+        assert b"not a product knob" in lib.vatl_last_error()
+
+
+# the environment variables the package may read, each documented in INTEGRATION.md ("Process-global state and switches")
+ALLOWED_ENV = {"VATL_HIP_LIB", "VATL_DIST_BACKEND", "VATL_SPAWN", "VATL_WORKER_PARENT", "VATL_WORKER_CLASS",
+               "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PYTHONPATH", "HIPCC"}
+
+
+def test_no_undocumented_environment_switch():
+    """Every os.environ / getenv read under the package names a variable of ALLOWED_ENV, and INTEGRATION.md documents each of them:
+    no route, kernel or precision choice hides behind an environment variable (round-4 verdict: 29 such reads)."""
+    pkg = os.path.join(ROOT, "vatl4pose-wacv2024_amd")
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    literal = r"environ(?:\.get\(|\.setdefault\(|\[)\s*[\"']([A-Za-z0-9_]+)[\"']"
+    seen = set()
+    for base, dirs, files in os.walk(pkg):
+        dirs[:] = [d for d in dirs if d not in ("build", "build_ablation", "__pycache__")]
+        for f in files:
+            path = os.path.join(base, f)
+            if f.endswith(".py"):
+                src = open(path).read()
+                reads = re.findall(literal, src)
+                # every other mention of the environment must be a whole-environment hand-over to a child process, never a computed name
+                rest = re.sub(literal, "", src)
+                rest = rest.replace("dict(os.environ,", "").replace("os.environ.update(", "")
+                assert not re.search(r"\bos\.environ\b|\bgetenv\b|\bputenv\b", rest), f"{path}: environment access that is not a literal, documented name"
+            elif f.endswith((".hip", ".h")):
+                src = re.sub(r"#ifdef VATL_ABLATION.*?#(?:else|endif)", "", open(path).read(), flags=re.S)   # the profiling variant reads VATL_ALLOW_ABLATION
+                reads = re.findall(r"getenv\(\s*\"([A-Za-z0-9_]+)\"", src)
+                assert src.count("getenv") == len(reads), path
+            else:
+                continue
+            for name in reads:
+                assert name in ALLOWED_ENV, f"{path} reads ${name}: not a documented switch"
+                seen.add(name)
+    for name in sorted(seen):
+        if name.startswith("VATL_"):
+            assert f"`{name}`" in doc, f"{name} is read by the package but INTEGRATION.md does not document it"
+    assert "VATL_HIP_LIB" in seen

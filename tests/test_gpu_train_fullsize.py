@@ -7,6 +7,11 @@ routes no small batch reaches — Winograd weight gradients with two gradient ha
 staging-address tables, two-half forward blocks (launches of >= 400 blocks), the two-stream weight gradients — and this file
 asserts the COMPOSITION: values against the float64 oracle graph on the same batch, bit-reproducibility, stream-order
 independence, and (through the library's route counters) that those routes really ran.
+
+Gradient yardstick: with the bench's default initialisation the trunk gradients are ill-conditioned — torch's own fp32 run of the
+same graph is 2e-2 (R50) / 1.2e-1 (R152) away from the float64 gradients in the trunk, 6e-7 in the head (measured on MI355X's host,
+profiles/r05_notes.md) — so, like tests/test_gpu_train.py::test_b16_default_init_step_vs_reference_and_float64, every sampled tensor
+must be as close to float64 as torch fp32 is (ours <= 1.5 x torch + 1e-4); loss 1e-5, BatchNorm running statistics 1e-4.
 """
 import os
 
@@ -106,7 +111,9 @@ def test_bench_size_step_values_bits_and_routes(name):
     assert routes.get("winograd_wgrad_2h", 0) >= 1 and routes.get("winograd_wgrad_table", 0) == routes.get("winograd_wgrad", 0) + routes["winograd_wgrad_2h"]
     assert routes.get("winograd_2h", 0) >= 1 and routes.get("winograd_bnbwd", 0) >= 1 and routes.get("igemm_bnbwd", 0) >= 1 and routes.get("wgrad", 0) >= 1
     if name == "cfg3":                                      # R50: 10 stride-1 3x3 layers with >= 128 channels (7 of them >= 256) + 3 transposed convs
-        assert routes["winograd_wgrad_2h"] == 7 and routes["winograd_wgrad"] == 6, routes
+        assert routes["winograd_wgrad_2h"] == 7 and routes["winograd_wgrad"] == 6 and routes["winograd_bnbwd"] == 13 and routes["igemm_bnbwd"] == 41, routes
+    else:                                                   # R152: 46 such layers (39 of them >= 256 channels: 7 in stage 2 at 128, DUC convs included)
+        assert routes["winograd_wgrad_2h"] == 39 and routes["winograd_wgrad"] == 7 and routes["winograd_bnbwd"] == 44, routes
     assert hip_train._side.enabled                          # the weight gradients of this step ran on the side stream
 
     # ---- bit-reproducible, and independent of the arena / overlap / stream order

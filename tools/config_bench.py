@@ -190,7 +190,11 @@ def fastpose_infer(dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="cfg3,cfg4,cfg5")
+    ap.add_argument("--single-stream", action="store_true", help="weight gradients on the main stream (profiling: per-kernel durations add up to the step)")
     a = ap.parse_args()
+    if a.single_stream:
+        from alphapose.models import hip_train
+        hip_train._side.enabled = False
     dev = torch.device("cuda:0")
     for name in a.only.split(","):
         {"cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5, "fastpose": fastpose_infer}[name](dev)

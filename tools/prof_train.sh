@@ -7,7 +7,7 @@ OUT="$REPO/gpurun_out/$TAG"
 mkdir -p "$OUT"; export TMPDIR=/tmp
 cd /tmp
 rm -rf "$OUT/t"
-VATL_WGRAD_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/t" -o p -- python3 "$REPO/tools/train_bench.py" --steps 7 --warmup 0 "$@" > "$OUT/t.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/t" -o p -- python3 "$REPO/tools/train_bench.py" --steps 7 --warmup 0 --single-stream "$@" > "$OUT/t.log" 2>&1
 grep '^{' "$OUT/t.log" | tail -1 | cut -c1-200
 cp "$OUT/t/p_kernel_stats.csv" "$OUT/kernel_stats.csv"
 python3 "$REPO/tools/gap_report.py" "$OUT/t/p_kernel_trace.csv" | tee "$OUT/gap_report.json" | cut -c1-600

@@ -18,12 +18,12 @@ prof() {   # name, script args...
 echo "== bench kernel stats"; prof bench "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-extra
 python3 "$REPO/tools/layer_report.py" "$OUT/bench/p_kernel_trace.csv" > "$OUT/layer_report.txt" 2>&1; tail -3 "$OUT/layer_report.txt"
 echo "== train step (config 3), single stream so that per-kernel durations add up to the step"
-VATL_WGRAD_STREAM=0 prof train "$REPO/tools/train_bench.py" --steps 7 --warmup 0
+prof train "$REPO/tools/train_bench.py" --steps 7 --warmup 0 --single-stream
 python3 "$REPO/tools/gap_report.py" "$OUT/train/p_kernel_trace.csv" > "$OUT/train_gap_report.json" 2>&1; cat "$OUT/train_gap_report.json" | cut -c1-400
 echo "== train step (config 3), default (weight gradients on the side stream)"; prof train_overlap "$REPO/tools/train_bench.py" --steps 7 --warmup 0
 python3 "$REPO/tools/gap_report.py" "$OUT/train_overlap/p_kernel_trace.csv" > "$OUT/train_overlap_gap_report.json" 2>&1
 echo "== HRNet pass (config 4)"; prof hrnet "$REPO/tools/config_bench.py" --only cfg4
-echo "== FastPose-R152 step (config 5)"; VATL_WGRAD_STREAM=0 prof cfg5 "$REPO/tools/config_bench.py" --only cfg5
+echo "== FastPose-R152 step (config 5)"; prof cfg5 "$REPO/tools/config_bench.py" --only cfg5 --single-stream
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "== rocprofv3 --pmc $c"
   rm -rf "$OUT/pmc_$c"

@@ -9,11 +9,11 @@ import collections, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "vatl4pose-wacv2024_amd"), os.path.join(ROOT, "tools")):
     sys.path.insert(0, p)
-os.environ["VATL_WGRAD_STREAM"] = "0"
 import torch
 import config_bench as cb
 import vatl_hip as vh
 from alphapose.models import hip_train
+hip_train._side.enabled = False          # one stream: every call is timed on its own
 from active_learning import optim as O
 
 which = next((a for a in sys.argv[1:] if a.startswith("cfg")), "cfg3")

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--wgrad-blocks", type=int, default=0, help="vatl_tune_set(3, v): target block count of the wgrad launches")
+    ap.add_argument("--single-stream", action="store_true", help="weight gradients on the main stream (profiling: per-kernel durations add up to the step)")
     ap.add_argument("--model", default="simplepose", choices=["simplepose", "fastpose", "hrnet"], help="backbone (autograd path for fastpose / hrnet)")
     a = ap.parse_args()
     import vatl_hip as vh
@@ -55,6 +56,8 @@ def main():
     labels = torch.rand((a.batch, 17, 64, 48), device=dev, generator=g) * 0.1
     masks = (torch.rand((a.batch, 17, 1, 1), device=dev, generator=g) > 0.2).float()
     from alphapose.models import hip_train
+    if a.single_stream:
+        hip_train._side.enabled = False
 
     def step_autograd():                                           # the module's own autograd path (FastPose / HRNet trainers behind it)
         opt.zero_grad(set_to_none=True)

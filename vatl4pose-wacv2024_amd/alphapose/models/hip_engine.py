@@ -19,8 +19,6 @@ There is no fallback: without the library or on CPU tensors this raises.
 """
 from __future__ import annotations
 
-import os
-
 import torch
 import torch.nn as nn
 
@@ -29,27 +27,28 @@ import vatl_hip as vh
 # items per launch sequence; bounds workspace (stem output = 3.1 MB/crop) and keeps
 # every tensor below the kernels' 2^30-element guard (32-bit buffer byte offsets);
 # large chunks keep every layer's tile grid a multiple of the 512 resident blocks
-MAX_CHUNK = int(os.environ.get("VATL_MAX_CHUNK", "1024"))
-# The stem / max-pool / layer-1 tensors are the largest of the network (3.1 MB + 0.8 MB x 7 per crop) and their
-# 1x1 convolutions are HBM-bound in fp32.  Running that first stage in sub-batches keeps its intermediates inside
-# the 256 MB Infinity Cache (the allocator hands the same buffers to every sub-batch); the MFMA-bound later stages
-# run on the whole batch so that their tile grids stay large.  0 disables.
-STAGE1_CHUNK = int(os.environ.get("VATL_STAGE1_CHUNK", "0"))   # measured neutral-to-negative on MI355X (profiles/r01_notes.md): off
+MAX_CHUNK = 1024
+# (Running the stem / layer-1 stage in Infinity-Cache-sized sub-batches was measured neutral-to-negative on MI355X in round 1,
+# profiles/r01_notes.md, and is gone.)
+
+# ROUTE CONSTANTS.  None of the switches below is read from the environment: the product takes exactly one route per layer
+# geometry.  Tools and tests that A/B a route set the module attribute (before the plan of a model is built) — INTEGRATION.md
+# "Process-global state and switches" lists which of them change bits.
 
 
 # 3x3 / stride 1 / pad 1 layers run as Winograd F(2x2, 3x3) (csrc/conv_winograd.hip: 2.25x fewer multiplies, fp32).  The choice depends
 # on the layer's geometry only — never on the batch — so a crop's heat-map bits do not depend on how it was batched.  The one exception is the
 # small-batch module call (`model(x)` with <= 16 crops, run_module_nchw below): since round 3 it runs with split-K BY DEFAULT (before that
-# split-K was opt-in through VATL_SPLITK_MB) and stays on the implicit GEMM for every batch size it serves (vh.latency_mode()), so
-# `model(x)` gives one set of bits for <= 16 crops and the stream route's bits above; both hold the 1e-4 / arg-max contract, and
-# VATL_SPLITK_AUTO=0 makes the module call take the stream route at every size.  VATL_WINOGRAD=0 = the implicit GEMM everywhere.
-WINOGRAD = os.environ.get("VATL_WINOGRAD", "1") != "0"
+# split-K was opt-in) and stays on the implicit GEMM for every batch size it serves (vh.latency_mode()), so
+# `model(x)` gives one set of bits for <= 16 crops and the stream route's bits above; both hold the 1e-4 / arg-max contract
+# (SPLITK_AUTO_MAX = 0 makes the module call take the stream route at every size).  WINOGRAD = False = the implicit GEMM everywhere (other bits).
+WINOGRAD = True
 # 1x1 layers with K = 128 and N a multiple of 128 (Bottleneck.conv3 of stage 2; conv3 + projection of stage 1's first block) through the row-streaming GEMM
-# (csrc/conv1x1_rows.hip: filter slice in registers, 32-pixel tiles; bit-identical to the tiled kernels).  VATL_ROWS_GEMM=0 = the tiled kernels.
-ROWS_GEMM = os.environ.get("VATL_ROWS_GEMM", "1") != "0"
+# (csrc/conv1x1_rows.hip: filter slice in registers, 32-pixel tiles; bit-identical to the tiled kernels, which ROWS_GEMM = False selects).
+ROWS_GEMM = True
 # 32 -> 32 channel 3x3 layers (HRNet's highest-resolution branch) through the wave-private Winograd kernel (csrc/winograd_c32.hip: a wave owns 16 tiles with all 16
-# transform positions, no cross-wave exchange).  VATL_WINO_C32=0 = the general Winograd kernel.
-WINO_C32 = os.environ.get("VATL_WINO_C32", "1") != "0"
+# transform positions, no cross-wave exchange).  False = the general Winograd kernel (same values to fp32 rounding, not the same bits).
+WINO_C32 = True
 
 
 class _Conv:
@@ -110,8 +109,8 @@ def _d(p):
 
 
 # Fuse conv3 with the projection shortcut of a stage's first block into one dual-source GEMM (vatl_conv1x1_dual_fwd):
-# the projection output (3.2 GB per 1024 crops in layer 1) is never written or re-read.  VATL_FUSE_PROJ=0 = two launches.
-FUSE_PROJ = os.environ.get("VATL_FUSE_PROJ", "1") != "0"
+# the projection output (3.2 GB per 1024 crops in layer 1) is never written or re-read.  False = two launches (other summation order).
+FUSE_PROJ = True
 
 
 class _BottleneckPlan:
@@ -144,8 +143,8 @@ class _BottleneckPlan:
 
 # conv3 + bn3 + skip + relu of an identity-shortcut bottleneck chained with the NEXT block's conv1 + bn1 + relu in one launch (csrc/bottleneck_chain.hip, the
 # 64 -> 256 -> 64 shapes of ResNet stage 1 / HRNet layer1): the 256-channel tensor is written once and not re-read.  Not in the small-batch module calls.
-# VATL_FUSE_CHAIN=0 = the separate launches.
-FUSE_CHAIN = os.environ.get("VATL_FUSE_CHAIN", "1") != "0"
+# False = the separate launches (conv3's output bit-identical; the chained conv1 sums K in four pieces).
+FUSE_CHAIN = True
 
 
 def _run_blocks(blocks, x, out=None):
@@ -176,8 +175,8 @@ def _run_blocks(blocks, x, out=None):
 
 # conv1 + bn1 + relu + maxpool of the ResNet trunk as ONE launch that reads the NCHW crops directly (csrc/stem_pool.hip: K = 168 instead of the 224 of the
 # 4-channel implicit GEMM, no 3.2 GB stem activation per 1024 crops, no layout pass) where the input size allows (256x192: yes; 384x288: no).  Not in the
-# small-batch module calls (vh.latency_mode(): a handful of crops leaves most of its per-image blocks without work).  VATL_FUSE_STEM=0 = three launches.
-FUSE_STEM = os.environ.get("VATL_FUSE_STEM", "1") != "0"
+# small-batch module calls (vh.latency_mode(): a handful of crops leaves most of its per-image blocks without work).  False = three launches (K summed in another order).
+FUSE_STEM = True
 
 
 def _stem_pool_weight(net):
@@ -206,14 +205,7 @@ class _TrunkPlan:
         return _run_blocks(self.blocks[:self.n_stage1], self._stem(x_nchw), out=out)
 
     def __call__(self, x_nchw):
-        n = x_nchw.shape[0]
-        if STAGE1_CHUNK <= 0 or n <= STAGE1_CHUNK or type(self.blocks[self.n_stage1 - 1]) is not _BottleneckPlan:
-            x = self._stage1(x_nchw)
-        else:
-            h, w = x_nchw.shape[2] // 4, x_nchw.shape[3] // 4
-            x = torch.empty((n, h, w, self.blocks[self.n_stage1 - 1].c3.cout), device=x_nchw.device, dtype=torch.float32)
-            for i in range(0, n, STAGE1_CHUNK):
-                self._stage1(x_nchw[i:i + STAGE1_CHUNK], out=x[i:i + STAGE1_CHUNK])
+        x = self._stage1(x_nchw)
         for b in self.blocks[self.n_stage1:]:
             x = b(x)
         return x
@@ -457,20 +449,15 @@ def _plan_for(m: nn.Module, device):
     return plan
 
 
-_SPLITK_MB = int(os.environ.get("VATL_SPLITK_MB", "0"))   # opt-in small-batch latency mode (vatl_hip.enable_splitk); 0 = off
-_splitk_ready = set()                                      # device indices whose workspace is registered
 # Module calls `model(x)` with at most this many crops (scripts/poseestimator_eval.py style, BASELINE.json configs[0]: B = 4) run
 # with split-K for their duration: every conv launch of such a batch is a fraction of one round of blocks (SimplePose-R50
 # forward + decode at B = 4: 2.6 -> 1.2 ms).  Results agree with the unsplit kernels to fp32 rounding, not bit for bit, so the
 # evaluation stream of ActiveLearning (forward_into / forward_with_embedding: THC de-duplication needs a crop's bits to be
-# independent of its batch) never uses it.  VATL_SPLITK_AUTO=0 switches it off.
-_SPLITK_AUTO_MAX = int(os.environ.get("VATL_SPLITK_AUTO", "16"))
+# independent of its batch) never uses it.  0 switches it off.
+SPLITK_AUTO_MAX = 16
 
 
 def _prepare_input(m: nn.Module, x: torch.Tensor):
-    if _SPLITK_MB > 0 and x.is_cuda and x.device.index not in _splitk_ready:
-        vh.enable_splitk(_SPLITK_MB, x.device)
-        _splitk_ready.add(x.device.index)
     if not x.is_cuda:
         raise vh.VatlError("the pose network runs on MI355X only: move the model and inputs to a HIP device "
                            "(there is deliberately no CPU fallback)")
@@ -486,7 +473,7 @@ def run_module_nchw(m: nn.Module, x: torch.Tensor) -> torch.Tensor:
         return hip_train.forward_train(m, x)
     x = _prepare_input(m, x)
     plan = _plan_for(m, x.device)
-    if 0 < x.shape[0] <= min(_SPLITK_AUTO_MAX, _chunk_limit(x.shape[2:])):
+    if 0 < x.shape[0] <= min(SPLITK_AUTO_MAX, _chunk_limit(x.shape[2:])):
         with vh.splitk_scope(x.device):
             return plan(x)
     if x.shape[0] <= _chunk_limit(x.shape[2:]):

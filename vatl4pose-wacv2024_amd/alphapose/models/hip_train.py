@@ -78,11 +78,11 @@ class _SideStream:
     consume dz and nothing downstream needs dW before the optimizer step, so the wgrad launches run beside the critical chain
     (BatchNorm backward -> data gradient -> previous layer): at fine-tune batch sizes every conv launch is only 1-3 rounds of
     resident blocks, and the MFMA-bound wgrad blocks fill the tails of the dgrad launches and overlap the HBM-bound BatchNorm
-    passes.  Same kernels, same arguments: results are bit-identical to the single-stream order.  VATL_WGRAD_STREAM=0 = off."""
+    passes.  Same kernels, same arguments: results are bit-identical to the single-stream order (tests/test_gpu_train_fullsize.py).
+    ``_side.enabled = False`` (profiling tools: per-kernel durations then add up to the step time) = one stream."""
 
     def __init__(self):
-        import os
-        self.enabled = os.environ.get("VATL_WGRAD_STREAM", "1") != "0"
+        self.enabled = True
         self._streams = {}
         self.used = False
 
@@ -124,17 +124,17 @@ def _gout(grads, p):
     return grads.out(p) if isinstance(grads, _Grads) else None
 
 
-import os as _os
-# BatchNorm-backward reduction inside the producing data-gradient launch (vatl_conv2d_fwd_ex_bnbwd); VATL_FUSE_BN_BWD=0 = the
+# ROUTE CONSTANTS of the trainers (module attributes, not environment switches; tests / tools that A/B a route set them):
+# BatchNorm-backward reduction inside the producing data-gradient launch (vatl_conv2d_fwd_ex_bnbwd); False = the
 # stand-alone reduction pass (same values up to the summation order of the per-channel sums)
-_FUSE_BN_BWD = _os.environ.get("VATL_FUSE_BN_BWD", "1") != "0"
-_WINOGRAD = _os.environ.get("VATL_WINOGRAD", "1") != "0"    # 3x3 / stride-1 layers: forward + data gradient as Winograd F(2x2,3x3)
+_FUSE_BN_BWD = True
+_WINOGRAD = True    # 3x3 / stride-1 layers: forward + data gradient as Winograd F(2x2,3x3)
 # ... and the weight gradient from this many channels on (measured at B = 120, tools/wino_wgrad_bench.py: 128 channels 1.30x, 256 1.35x, 512 1.44x
 # over the implicit GEMM; 64 channels 1.0x, 32 channels slower — both operands are transformed per tile pair, 2.5x the vector work of the forward)
-_WINOGRAD_WGRAD_MIN_C = int(_os.environ.get("VATL_WINOGRAD_WGRAD_MINC", "128"))
+_WINOGRAD_WGRAD_MIN_C = 128
 # ... for layers with at least this many channels: on the narrow tiles (32 / 64 output channels) the statistics epilogue costs
 # more than the stand-alone reduction pass it replaces (HRNet-W32 step 63.9 -> 69.4 ms with every layer fused)
-_FUSE_BN_MIN_C = int(_os.environ.get("VATL_FUSE_BN_MINC", "128"))
+_FUSE_BN_MIN_C = 128
 
 # tests only: when a list, every ReLU the trainers apply appends its output's mask (y > 0), in execution order — what lets a float64
 # reference of a block be evaluated with exactly the ReLU decisions the fp32 forward took (tests/test_gpu_train.py)
@@ -172,7 +172,7 @@ def _flush_batch_counters():
     _pending_stats.clear()
 
 
-_USE_PACK_PLAN = __import__("os").environ.get("VATL_PACK_PLAN", "1") != "0"      # VATL_PACK_PLAN=0: every re-pack its own launch
+_USE_PACK_PLAN = True      # False: every re-pack its own launch (same bits; tests/test_gpu_train.py A/Bs it)
 
 
 def _planned(kind):

@@ -1598,40 +1598,48 @@ extern "C" int vatl_tune_wgrad_blocks(int blocks);
 extern "C" int vatl_crop_tune_px(int px);
 
 extern "C" int vatl_tune_set(int knob, int value) {
-    // Ablation settings (schedule variants 10..13, wgrad ablation bits) produce WRONG results by construction; they exist
-    // for the profiling notes only and are refused unless the process opted in.
-    const bool ablation = (knob == 0 && value >= 10) || ((knob == 4 || knob == 6 || knob == 17) && value != 0);
-    if (ablation) {
+    // PRODUCT KNOBS — process-global route selectors (relaxed atomics; set them before launching from several threads).  Every accepted
+    // value computes the SAME BITS as the default (tests/test_gpu_conv.py, tests/test_gpu_winograd.py assert it per knob); the table in
+    // include/vatl_hip.h is the contract.  Nothing else is accepted by the shipped library.
+    switch (knob) {
+    case 0:  if (value == 0 || value == 2 || value == 4 || value == 5) { g_var.store(value, std::memory_order_relaxed); return 0; } break;
+    case 1:  if (value == 0 || value == 1) { g_order.store(value, std::memory_order_relaxed); return 0; } break;
+    case 5:  if (value == 0 || value == 64 || value == 128) { g_bm.store(value, std::memory_order_relaxed); return 0; } break;
+    case 7:  if (value >= 0 && value <= 64) { g_persist.store(value, std::memory_order_relaxed); return 0; } break;
+    case 8:  if (value == 0 || value == 1) return conv3x3_halo_enable(value); break;
+    case 10: if (value == 1 || value == 2) { g_persist_dist.store(value, std::memory_order_relaxed); return 0; } break;
+    case 18: if (value >= 0 && value <= (1 << 20)) return wino_set_group_kb(value); break;
+    case 21: if (value >= 1 && value <= 3) return wino_set_halves(value); break;
+    case 22: if (value >= 0 && value <= 4096) return wino_set_persist(value); break;
+    case 24: if (value >= 0 && value <= 3) return wino_set_persist_pf(value); break;
+    case 25: if (value == 0 || value == 1) return wino_wgrad_set_table(value); break;
+    default: break;
+    }
 #ifdef VATL_ABLATION
+    // PROFILING VARIANT ONLY (build.py --ablation -> libvatl_hip_ablation.so): knobs that change the summation order (3, 9, 12, 19) or are not pinned bit-identical (23), performance-only
+    // experiments (2, 16) and the ablations that compute WRONG results by construction (0: 10..13, 4, 6, 17; these also need VATL_ALLOW_ABLATION=1).
+    const bool wrong = (knob == 0 && value >= 10) || ((knob == 4 || knob == 6 || knob == 17) && value != 0);
+    if (wrong) {
         const char* ok = getenv("VATL_ALLOW_ABLATION");
         if (!ok || ok[0] != '1') return fail(VATL_EINVAL, "tune_set: knob %d value %d is a profiling ablation (wrong results); set VATL_ALLOW_ABLATION=1", knob, value);
-#else
-        return fail(VATL_EINVAL, "tune_set: knob %d value %d is a profiling ablation (wrong results by construction): not compiled into this "
-                    "library; build the profiling variant with `build.py --ablation` (-DVATL_ABLATION)", knob, value);
-#endif
     }
+    if (knob == 0 && value >= 10 && value <= 13) { g_var.store(value, std::memory_order_relaxed); return 0; }
+    if (knob == 2 && value >= 0 && value <= 200) { g_stagger.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 3 && vatl_tune_wgrad_blocks(value) == 0) return 0;
-    if (knob == 5 && (value == 0 || value == 64 || value == 128)) { g_bm.store(value, std::memory_order_relaxed); return 0; }
+    if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
     if (knob == 6 && value >= 0 && value <= 15) { g_ablate.store(value, std::memory_order_relaxed); return 0; }
-    if (knob == 7 && value >= 0 && value <= 64) { g_persist.store(value, std::memory_order_relaxed); return 0; }
-    if (knob == 8 && (value == 0 || value == 1)) return conv3x3_halo_enable(value);
     if (knob == 9 && (value == 0 || value == 1)) { g_splitk_policy.store(value, std::memory_order_relaxed); return 0; }
+    if (knob == 12 && (value == 0 || value == 1)) { g_streamk.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 16 && vatl_crop_tune_px(value) == 0) return 0;
     if (knob == 17 && value >= 0 && value <= 63) return wino_set_ablate(value);
-    if (knob == 18 && value >= 0 && value <= (1 << 20)) return wino_set_group_kb(value);
-    if (knob == 21 && value >= 1 && value <= 3) return wino_set_halves(value);
-    if (knob == 22 && value >= 0 && value <= 4096) return wino_set_persist(value);
-    if (knob == 23 && value >= 1 && value <= 2) return wino_wgrad_set_halves(value);
-    if (knob == 24 && value >= 0 && value <= 3) return wino_set_persist_pf(value);
-    if (knob == 25 && (value == 0 || value == 1)) return wino_wgrad_set_table(value);
     if (knob == 19 && value >= 1 && value <= (1 << 20)) return wino_wgrad_set_blocks(value);
-    if (knob == 12 && (value == 0 || value == 1)) { g_streamk.store(value, std::memory_order_relaxed); return 0; }
-    if (knob == 10 && (value == 1 || value == 2)) { g_persist_dist.store(value, std::memory_order_relaxed); return 0; }
-    if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
-    if (knob == 0 && value >= 0 && value <= 13) { g_var.store(value, std::memory_order_relaxed); return 0; }
-    if (knob == 1 && value >= 0 && value <= 1) { g_order.store(value, std::memory_order_relaxed); return 0; }
-    if (knob == 2 && value >= 0 && value <= 200) { g_stagger.store(value, std::memory_order_relaxed); return 0; }
+    if (knob == 23 && value >= 1 && value <= 2) return wino_wgrad_set_halves(value);
     return fail(VATL_EINVAL, "tune_set: unknown knob %d / value %d", knob, value);
+#else
+    return fail(VATL_EINVAL, "tune_set: knob %d / value %d is not a product knob (include/vatl_hip.h lists them: 0, 1, 5, 7, 8, 10, 18, 21, 22, 24, 25 — all bit-identical); "
+                "knobs that change the summation order, performance experiments and profiling ablations exist only in the variant built with "
+                "`build.py --ablation` (-DVATL_ABLATION)", knob, value);
+#endif
 }
 
 extern "C" int vatl_set_splitk_workspace_thread(float* workspace, int64_t floats) {

@@ -164,18 +164,6 @@ def lib() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = l
-        if os.environ.get("VATL_CONV_VAR"):          # A/B knob for benchmarks and tests (results are identical)
-            l.vatl_tune_set(0, int(os.environ["VATL_CONV_VAR"]))
-        if os.environ.get("VATL_WINO_GROUP_KB"):     # tile-order knob of the Winograd kernel (results are identical)
-            l.vatl_tune_set(18, int(os.environ["VATL_WINO_GROUP_KB"]))
-        if os.environ.get("VATL_WINO_HALVES"):       # 32-channel filter halves per Winograd block: 1, or 2 where the layer allows (results are identical)
-            l.vatl_tune_set(21, int(os.environ["VATL_WINO_HALVES"]))
-        if os.environ.get("VATL_WINO_PERSIST"):      # 3x3 layers with at most this many 16-channel stages take the persistent Winograd route; 0 = never (results are identical)
-            l.vatl_tune_set(22, int(os.environ["VATL_WINO_PERSIST"]))
-        if os.environ.get("VATL_WINO_PERSIST_PF"):   # bit 0 / 1: the prefetching variant of the persistent route for one- / two-half blocks (results are identical)
-            l.vatl_tune_set(24, int(os.environ["VATL_WINO_PERSIST_PF"]))
-        if os.environ.get("VATL_WGRAD_TABLES"):               # A/B of the Winograd weight gradients' staging-address tables (0 = addresses formed in the kernel; same bits)
-            l.vatl_tune_set(25, int(os.environ["VATL_WGRAD_TABLES"]))
     return _lib
 
 
@@ -286,7 +274,7 @@ _splitk_scratch = {}                                 # device index -> free list
 _splitk_scratch_lock = __import__("threading").Lock()
 # the batch-invariant cut sizes a layer's split from what a 16-crop batch needs (conv_igemm.hip: launch): the largest is SimplePose's last
 # transposed conv, 3 slices x 16 crops x 64 x 48 x 256 floats = 151 MB; a smaller workspace only makes that layer run unsplit
-SPLITK_SCRATCH_MB = int(os.environ.get("VATL_SPLITK_SCRATCH_MB", "256"))
+SPLITK_SCRATCH_MB = 256
 
 
 class splitk_scope:
@@ -410,6 +398,7 @@ class PackPlan:
         self.ready = True
 
 
+STREAMK_IN_TRAINING = False                          # module constant, not an environment switch (see streamk_scope)
 _streamk_ws = {}                                     # (host thread, device index) -> zero-initialised stream-K workspace
 
 
@@ -417,7 +406,7 @@ class streamk_scope:
     """Stream-K for this host thread's conv launches while the scope is open (the trainers' forward / backward passes): launches
     that would leave much of the chip idle share their (tile, k-tile) units evenly over 768 persistent blocks
     (vatl_set_streamk_workspace_thread).  Results are deterministic but not the unsplit kernels' bits, so nothing outside
-    training opens it — and the trainers open it only under VATL_STREAMK=1: measured on MI355X (profiles/r03_notes.md) the route
+    training opens it — and the trainers open it only when STREAMK_IN_TRAINING is set (off): measured on MI355X (profiles/r03_notes.md) the route
     gains 8-23 % on the launches it takes when they run ALONE (R50 stage 4 at B = 120, FastPose-R152 stages 3-4 at B = 32), but
     in the real step the block slots those launches leave idle are where the side stream's weight-gradient kernels run, and 768
     persistent blocks take that overlap away: fine-tune step 44.8 -> 44.7 ms (R50), 67.5 -> 70.4 ms (R152).  ``force`` opens it
@@ -429,7 +418,7 @@ class streamk_scope:
         self.force = force
 
     def __enter__(self):
-        if not self.force and os.environ.get("VATL_STREAMK", "0") != "1":
+        if not self.force and not STREAMK_IN_TRAINING:
             return self
         import threading
         key = (threading.get_ident(), self.idx)
