@@ -64,3 +64,47 @@ def test_record_files_reuse_the_data_set_fields_between_rounds():
     check([5], side2)
     check([0], side[:1])
     check([], side[:0])
+
+
+def test_records_are_written_by_a_gated_host_thread(tmp_path):
+    """`_write_records` hands the round's records to a host thread; while the main thread is host-critical (gate closed) the thread only
+    advances at its 0.25 s check-point time-outs, `flush_records()` opens the gate and waits; the files are `json.dumps` of the lists,
+    the next round's call waits for the previous one (files in round order), and an error in the thread is raised by the flush."""
+    import os
+    import time
+    from active_learning.ActiveLearning import ActiveLearning
+    from alphapose.utils.config import edict
+    al = ActiveLearning.__new__(ActiveLearning)
+    r = np.random.RandomState(3)
+    n = 300
+    al.labeled_id = [1, 5, 9]
+    al.opt = types.SimpleNamespace(work_dir=str(tmp_path))
+    al.cfg = edict({"DATASET": {"EVAL": {"TYPE": "x"}}})
+    side = np.concatenate([np.arange(n)[:, None] * 1.0, np.arange(n)[:, None] + 7.0, r.uniform(0, 500, (n, 4)), r.uniform(0, 500, (n, 51))], 1)
+    kp1, kp2 = (r.standard_normal((n, 51)) * 50).astype(np.float32), (r.standard_normal((n, 51)) * 50).astype(np.float32)
+    al._host_critical(True)
+    t0 = time.perf_counter()
+    al._write_records(kp1, r.uniform(0, 1, n), side)
+    assert time.perf_counter() - t0 < 0.2                        # the call itself only snapshots its arguments
+    kp1[:] = 0                                                   # ... so the caller may reuse its buffers
+    al.flush_records()
+    assert al._records_job is None
+    pred = open(os.path.join(tmp_path, "predicted_kpt.json")).read()
+    assert pred == json.dumps(al.kpt_json) and al.kpt_json[3]["keypoints"][0] != 0.0
+    assert open(os.path.join(tmp_path, "predicted_kpt_ann.json")).read() == json.dumps(al.kpt_json_ann)
+    assert open(os.path.join(tmp_path, "GT_kpt.json")).read() == json.dumps(al._gt_dict())
+    al._host_critical(False)
+    al._write_records(kp2, r.uniform(0, 1, n), side)             # round 2 ...
+    al._host_critical(True)                                      # (round 3's thread pauses at its first check-point: 0.25 s to look at the files)
+    al._write_records(kp1, r.uniform(0, 1, n), side)             # ... is complete before round 3 starts
+    assert json.loads(open(os.path.join(tmp_path, "predicted_kpt.json")).read())[0]["keypoints"] == kp2[0].astype(np.float64).tolist()
+    al.flush_records()
+    assert json.loads(open(os.path.join(tmp_path, "predicted_kpt.json")).read())[0]["keypoints"] == [0.0] * 51
+    al.opt.work_dir = os.path.join(str(tmp_path), "predicted_kpt.json", "not-a-directory")
+    al._write_records(kp2, r.uniform(0, 1, n), side)
+    try:
+        al.flush_records()
+        raise AssertionError("the thread's error must surface")
+    except (NotADirectoryError, FileExistsError, OSError):
+        pass
+    al.flush_records()                                           # raised once

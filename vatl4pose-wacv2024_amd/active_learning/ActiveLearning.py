@@ -310,10 +310,17 @@ class ActiveLearning:
 
     @_collective
     def eval_and_query(self):
-        from . import distributed as D
-        from . import query as Q
         self.model.eval()
         n = self.eval_len
+        self._host_critical(True)                      # the record thread of the previous round pauses while this one prepares / enqueues device work
+        try:
+            return self._eval_and_query(n)
+        finally:
+            self._host_critical(False)
+
+    def _eval_and_query(self, n):
+        from . import distributed as D
+        from . import query as Q
         if self.need_embedding and not hasattr(self.model, "get_embedding"):
             raise ValueError("this pose network has no get_embedding: representativeness / filters need it (SURVEY.md §9 item 3)")
         self.emb_dim = 2048
@@ -326,9 +333,12 @@ class ActiveLearning:
         def side_rows(lo, hi):                     # the rows _score_range stashed for exactly this range
             assert self._side[0] == lo and self._side[1] == hi
             return self._side[2]
-        side = D.sharded_rows(n, side_rows, 2 + 4 + 3 * self.cfg.DATA_PRESET.NUM_JOINTS, self.device, halo=1 if self.dedup else 0).cpu().numpy()
+        side = D.sharded_rows(n, side_rows, 2 + 4 + 3 * self.cfg.DATA_PRESET.NUM_JOINTS, self.device, halo=1 if self.dedup else 0)
+        self._host_critical(False)                     # everything is enqueued: while the main thread waits for the device, the record thread runs
+        side = side.cpu().numpy()
         self._side = None
         rows = rows_dev[:, :55].cpu().numpy()
+        self._host_critical(True)
         kp_all = rows[:, :51].copy()
         unc = rows[:, 51:53].astype(np.float64)
         lp = rows[:, 53].astype(np.float64)
@@ -442,54 +452,113 @@ class ActiveLearning:
         if self.actual_finish < 100:
             self.is_early_stop = True
 
+    # ------------------------------------------------------------------ result records (ActiveLearning.py:310-327, 438-447, 693-705)
+    # Formatting ~110 floats per item and writing three files costs the host ~20 ms per 1024 items — as much as a quarter of the device's
+    # evaluation pass — and nothing in eval_and_query needs the result.  The records of a round are therefore built, encoded and written
+    # by a host thread (`_RecordsJob`); the main thread CLOSES the thread's gate while it is preparing / enqueueing device work (the two
+    # would only take the interpreter lock from each other) and opens it while it waits for the device, so in an evaluate -> retrain ->
+    # evaluate loop the files of round r are produced inside the waits of what follows.  `flush_records()` (called by the next
+    # `_write_records`, `_third_party_scores`, `outcome`, and by every reader of `kpt_json` / `kpt_json_ann` / `GT_json`) waits for them.
+    def _gate(self):
+        g = self.__dict__.get("_records_gate")
+        if g is None:
+            import threading
+            g = self.__dict__["_records_gate"] = threading.Event()
+            g.set()
+        return g
+
+    def _host_critical(self, on: bool):
+        """on: the main thread is about to prepare / enqueue device work (the record thread pauses at its next check-point); off: it waits."""
+        (self._gate().clear if on else self._gate().set)()
+
+    def flush_records(self):
+        """Wait until the record lists of the last evaluated round exist and its files are on disk (re-raises what the thread raised)."""
+        job = self.__dict__.get("_records_job")
+        if job is not None:
+            self._gate().set()
+            job.join()
+            self.__dict__["_records_job"] = None
+            if job.error is not None:
+                raise job.error
+
+    kpt_json = property(lambda self: (self.flush_records(), self.__dict__.get("_kpt_json", []))[1])
+    kpt_json_ann = property(lambda self: (self.flush_records(), self.__dict__.get("_kpt_json_ann", []))[1])
+    GT_json = property(lambda self: (self.flush_records(), self.__dict__.get("_GT_json", []))[1])
+
     def _write_records(self, kp_all, oks, side):
         """The reference's result records (ActiveLearning.py:310-327, 438-447): one COCO-style dict per item in
         ``self.kpt_json`` (predictions), ``self.kpt_json_ann`` (labeled items carry their ground truth) and ``self.GT_json``;
         written as predicted_kpt.json / predicted_kpt_ann.json / GT_kpt.json when ``opt.work_dir`` is set, so the
-        third-party evaluate_mAP / ospa_for_loc tools can be run on them (they stay outside this package)."""
-        labeled = set(self.labeled_id)
-        self.kpt_json, self.kpt_json_ann, self.GT_json = [], [], []
-        kp32 = np.asarray(kp_all, np.float32)
+        third-party evaluate_mAP / ospa_for_loc tools can be run on them (they stay outside this package).  Asynchronous: see above."""
+        import threading
+        from . import distributed as D
+        self.flush_records()                                       # one round at a time, files in round order
+        work_dir = getattr(self.opt, "work_dir", None)
+        al, gate = self, self._gate()
+        args = (np.array(kp_all, np.float32), np.array(oks, np.float64), np.array(side, np.float64), set(self.labeled_id),
+                work_dir if (work_dir and D.is_main()) else None)
+
+        class _RecordsJob(threading.Thread):
+            error = None
+
+            def run(self):
+                try:
+                    al._build_records(*args, pause=lambda: gate.wait(0.25))
+                except BaseException as e:                         # surfaced by flush_records() on the main thread
+                    self.error = e
+        job = self.__dict__["_records_job"] = _RecordsJob(name="vatl-records", daemon=False)
+        job.start()
+
+    def _build_records(self, kp32, oks, side, labeled, work_dir, pause=lambda: None):
+        pause()
         conf = kp32[:, 2::3]
         # whole columns converted once (a numpy call per item costs more than the record itself); float32 arithmetic like the per-item form
-        score = (conf.mean(1) + np.float32(1.25) * conf.max(1)).astype(np.float64).tolist()
+        score = (conf.mean(1) + np.float32(1.25) * conf.max(1)).astype(np.float64).tolist() if len(kp32) else []
         kps, gts, boxes = kp32.astype(np.float64).tolist(), side[:, 6:].tolist(), side[:, 2:6].tolist()
-        img_ids, ann_ids, oks_l = side[:, 0].astype(np.int64).tolist(), side[:, 1].astype(np.int64).tolist(), np.asarray(oks, np.float64).tolist()
+        img_ids, ann_ids, oks_l = side[:, 0].astype(np.int64).tolist(), side[:, 1].astype(np.int64).tolist(), oks.tolist()
+        pause()
+        kpt_json, kpt_json_ann, GT_json = [], [], []
         for i in range(len(kp32)):
             rec = {"bbox": boxes[i], "image_id": img_ids[i], "id": ann_ids[i], "score": score[i], "category_id": 1, "keypoints": kps[i],
                    "GT_keypoints": gts[i], "OKS": oks_l[i]}
-            self.kpt_json.append(rec)
-            self.kpt_json_ann.append(dict(rec, keypoints=gts[i]) if i in labeled else dict(rec))
-            self.GT_json.append(dict(rec, keypoints=gts[i]))
-        work_dir = getattr(self.opt, "work_dir", None)
-        from . import distributed as D
-        if work_dir and D.is_main():
+            kpt_json.append(rec)
+            kpt_json_ann.append(dict(rec, keypoints=gts[i]) if i in labeled else dict(rec))
+            GT_json.append(dict(rec, keypoints=gts[i]))
+        self.__dict__["_kpt_json"], self.__dict__["_kpt_json_ann"], self.__dict__["_GT_json"] = kpt_json, kpt_json_ann, GT_json
+        if work_dir:
             import os
             os.makedirs(work_dir, exist_ok=True)
-            for name, text in zip(("predicted_kpt.json", "predicted_kpt_ann.json", "GT_kpt.json"), self._records_json()):
+            texts = self._records_json_of(kpt_json, kpt_json_ann, GT_json, pause)
+            pause()
+            for name, text in zip(("predicted_kpt.json", "predicted_kpt_ann.json", "GT_kpt.json"), texts):
                 with open(os.path.join(work_dir, name), "w") as f:
                     f.write(text)
 
     def _records_json(self):
-        """json.dumps of ``self.kpt_json``, ``self.kpt_json_ann`` and ``self._gt_dict()`` — the same text, character for character — with every
+        """The three files' text of the last evaluated round (waits for the record thread)."""
+        return self._records_json_of(self.kpt_json, self.kpt_json_ann, self.GT_json)
+
+    def _records_json_of(self, kpt_json, kpt_json_ann, GT_json, pause=lambda: None):
+        """json.dumps of ``kpt_json``, ``kpt_json_ann`` and ``_gt_dict()`` — the same text, character for character — with every
         record's shared fields (box, ids, score, the two key-point lists, OKS) encoded ONCE instead of once per file: the three files differ only
         in which of the two lists a record's "keypoints" holds, and formatting ~110 floats per record is what writing them costs.  A field is
         encoded for ALL records by one encoder call (a column of the records as one nested list, cut at the inner brackets), and the fields that
         come from the data set alone (box, ids, ground truth: the same in every round of a run) are kept from the previous call and reused when
-        their values are unchanged."""
+        their values are unchanged.  ``pause`` is called between the encoder calls (the record thread's check-point)."""
         import json
         enc = json.dumps
 
         def column(key, nested):
-            vals = [rec[key] for rec in self.kpt_json]
+            pause()
+            vals = [rec[key] for rec in kpt_json]
             if not vals:
                 return vals, []
             text = enc(vals)
             return vals, (("[" + t + "]" for t in text[2:-2].split("], [")) if nested else text[1:-1].split(", "))
         fixed_vals, fixed_text = [], []
-        cached = getattr(self, "_records_fixed", None)
+        cached = self.__dict__.get("_records_fixed")
         for k, (key, nested) in enumerate((("bbox", True), ("image_id", False), ("id", False), ("category_id", False), ("GT_keypoints", True))):
-            vals = [rec[key] for rec in self.kpt_json]
+            vals = [rec[key] for rec in kpt_json]
             if cached is not None and cached[0][k] == vals:          # (list comparison: a NaN in the ground truth re-encodes, which is only slower)
                 text = cached[1][k]
             else:
@@ -498,25 +567,27 @@ class ActiveLearning:
         self._records_fixed = (fixed_vals, fixed_text)
         box_s, img_s, id_s, cat_s, gt_s = fixed_text
         kp_s, score_s, oks_s = list(column("keypoints", True)[1]), column("score", False)[1], column("OKS", False)[1]
-        n = len(self.kpt_json)
+        n = len(kpt_json)
         assert all(len(t) == n for t in (box_s, img_s, id_s, cat_s, gt_s, kp_s, score_s, oks_s)), "a record field does not encode to one piece per record"
+        pause()
         pred, ann, gt = [], [], []
-        for i, (rec, rec_ann) in enumerate(zip(self.kpt_json, self.kpt_json_ann)):
+        for i, (rec, rec_ann) in enumerate(zip(kpt_json, kpt_json_ann)):
             head = '{"bbox": %s, "image_id": %s, "id": %s, "score": %s, "category_id": %s, "keypoints": ' % (box_s[i], img_s[i], id_s[i], score_s[i], cat_s[i])
             tail = ', "GT_keypoints": %s, "OKS": %s}' % (gt_s[i], oks_s[i])
             pred.append(head + kp_s[i] + tail)
             ann.append(head + (gt_s[i] if rec_ann["keypoints"] is rec["GT_keypoints"] else kp_s[i]) + tail)
             gt.append(head + gt_s[i] + tail)
-        g = self._gt_dict()
+        g = self._gt_dict(GT_json)
         assert list(g) == ["images", "categories", "annotations"]
         return ("[" + ", ".join(pred) + "]", "[" + ", ".join(ann) + "]",
                 '{"images": %s, "categories": %s, "annotations": [%s]}' % (enc(g["images"]), enc(g["categories"]), ", ".join(gt)))
 
-    def _gt_dict(self):
+    def _gt_dict(self, GT_json=None):
         """``save_GT_dict`` (ActiveLearning.py:693-705): the ground truth in COCO layout — ``images`` / ``categories`` copied from the
         evaluation set's annotation file when there is one, the records of this round as ``annotations``."""
         import json
         import os
+        GT_json = self.GT_json if GT_json is None else GT_json
         ev = self.cfg.DATASET.EVAL
         path = os.path.join(str(ev.get("ROOT", "")), str(ev.get("ANN", ""))) if ev.get("ANN") else ""
         if path and os.path.isfile(path):
@@ -524,16 +595,23 @@ class ActiveLearning:
                 src = json.load(f)
             images, cats = src.get("images", []), src.get("categories", [])
         else:                                                      # datasets without an annotation file (synthetic / in-memory videos)
-            images = [{"id": i, "image_id": i} for i in sorted({r["image_id"] for r in self.GT_json})]
+            images = [{"id": i, "image_id": i} for i in sorted({r["image_id"] for r in GT_json})]
             cats = [{"id": 1, "name": "person"}]
-        return {"images": images, "categories": cats, "annotations": self.GT_json}
+        return {"images": images, "categories": cats, "annotations": GT_json}
 
     def _third_party_scores(self, work_dir):
         """mAP / OSPA of the written records through the reference's third-party tools (ActiveLearning.py:442-447) when they are
         installed (pycocotools / halpecocotools, JRDB_toolkit); None for whatever is missing."""
         import os
-        from alphapose.utils.metrics import evaluate_mAP
+        from alphapose.utils.metrics import evaluate_mAP, have_coco_tools
         gt, out = os.path.join(work_dir, "GT_kpt.json"), {}
+        have_ospa = True
+        try:
+            import JRDB_toolkit.pose_eval  # noqa: F401
+        except ImportError:
+            have_ospa = False
+        if have_coco_tools() or have_ospa:                        # somebody is about to read the files: they must be complete
+            self.flush_records()
         for key, name in (("res", "predicted_kpt.json"), ("res_ann", "predicted_kpt_ann.json")):
             try:
                 out[key] = evaluate_mAP(os.path.join(work_dir, name), ann_type="keypoints", ann_file=gt, silence=True)
@@ -610,9 +688,20 @@ class ActiveLearning:
         self.model.train()
         trainer = hip_train.trainer_for(self.model)
         arena = hip_train.arena_for(self.model)
-        # the per-step loss / accuracy read-backs wait until the epoch's steps are enqueued: read inside the loop they drain the stream every step, and the host's
-        # preparation of the next mini-batch (crops, targets) then runs behind the step instead of beside it.  Same values, same order into the loggers.
+        # the per-step loss / accuracy read-backs wait until the EPOCH's steps are enqueued: read inside the loop they drain the stream every step, and the host's
+        # preparation of the next mini-batch (crops, targets) then runs behind the step instead of beside it.  Flushed once per epoch (one synchronisation, before
+        # the scheduler step): the host never runs more than an epoch ahead of the device, a kernel error surfaces in the epoch that produced it (a NaN loss reaches the logger of that epoch), and the
+        # loggers hold every finished epoch if a later one raises.  Same values, same order into the loggers.
         pending = []
+        self._host_critical(True)
+
+        def flush():
+            self._host_critical(False)                                                     # a wait for the device: the record thread's turn
+            for loss, acc_finish, cnt in pending:
+                loss_logger.update(float(loss), cnt)                                   # (a NaN is logged, not raised: the reference's behaviour)
+                acc_logger.update(acc_finish(), cnt)
+            pending.clear()
+            self._host_critical(True)
         for _ in range(self.retrain_epoch):
             for (idxs, inps, labels, label_masks, *_rest) in loader:
                 nb = len(idxs)
@@ -644,10 +733,9 @@ class ActiveLearning:
                 arena.finish()
                 arena.attach()
                 self.optimizer.step()
+            flush()
             self.scheduler.step()
-        for loss, acc_finish, cnt in pending:
-            loss_logger.update(float(loss), cnt)
-            acc_logger.update(acc_finish(), cnt)
+        self._host_critical(False)
         D.broadcast_buffers_(self.model)           # BN statistics are per rank; rank 0's survive (DataParallel semantics)
         self.last_train_loss, self.last_train_acc = self._global_avg(loss_logger), self._global_avg(acc_logger)
         if "WPU" in self.uncertainty:              # ActiveLearning.py:680-684: a fresh AE is fine-tuned on the labeled poses
@@ -725,6 +813,7 @@ class ActiveLearning:
                 self.query_size = self.query_sizes[self.round_cnt] - len(self.labeled_id)
         if not finish:
             return None
+        self.flush_records()                           # the last round's files are complete when the run hands its results back
         return (self.percentage, self.performance, self.performance_ann, self.query_list_list, self.uncertainty_dict, self.uncertainty_mean,
                 self.influence_dict, self.combine_weight, self.spearmanr_list, self.corr_list, self.true_labeled_dict, self.true_unlabeled_dict,
                 self.false_labeled_dict, self.false_unlabeled_dict, self.actual_finish, self.finished_minerror, self.finished_oursc,

@@ -67,6 +67,12 @@ def calc_accuracy_begin(preds, labels, thr=0.5):
     return finish
 
 
+def have_coco_tools() -> bool:
+    """Whether evaluate_mAP can run here (the COCO API is importable)."""
+    import importlib.util
+    return importlib.util.find_spec("pycocotools") is not None
+
+
 def evaluate_mAP(res_file, ann_type="bbox", ann_file="./data/coco/annotations/person_keypoints_val2017.json", silence=False):
     """COCO evaluation of a result json against a ground-truth json (metrics.py:65-115) -> {'AP', 'AP .5', ..., 'AR'}.
 

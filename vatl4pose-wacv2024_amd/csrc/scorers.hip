@@ -156,8 +156,10 @@ __global__ void pose_scores_kernel(const float* __restrict__ kpts, float* __rest
         if (v > mx || v != v) mx = (mx != mx) ? mx : v;
     }
     if (hp) hp[i] = -sum;
-    // float(np.mean(s) + 1.25 * np.max(s)): float32 mean (pairwise sum / J), the rest in double, stored as float32
-    if (pose_score) pose_score[i] = (float)((double)(sum / (float)J) + 1.25 * (double)mx);
+    // float(np.mean(s) + 1.25 * np.max(s)) on float32 scores: float32 mean (pairwise sum / J, correctly rounded), float32 product, float32 sum —
+    // three roundings, no fused multiply-add: what NumPy >= 2 computes (python float x np.float32 stays float32; the oracle, the golden vectors
+    // and ActiveLearning._write_records run on that).  NumPy 1.x's value-based promotion made the product float64: <= 1 ulp of float32 away.
+    if (pose_score) pose_score[i] = __fadd_rn(__fdiv_rn(sum, (float)J), __fmul_rn(1.25f, mx));
 }
 
 // --------------------------------------------------------------------------

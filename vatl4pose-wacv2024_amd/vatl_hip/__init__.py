@@ -172,10 +172,14 @@ def _check(rc: int, what: str):
         raise VatlError(f"{what} failed ({rc}): {lib().vatl_last_error().decode()}")
 
 
-def upload(host, device, dtype=None):
+def upload(host, device, dtype=None, owned: bool = False):
     """Host array / CPU tensor -> device tensor WITHOUT draining the stream: staged through PyTorch's pinned-memory cache and copied
     non-blocking.  (A plain `.to(device)` from pageable memory blocks the host until every launch queued before it has finished — a few
-    of those per loader batch serialise the host's batch preparation with the device's forward pass.)"""
+    of those per loader batch serialise the host's batch preparation with the device's forward pass.)
+
+    The source is gathered ONCE, straight into a pinned staging buffer of this call (strided views of a loader batch included: no
+    pageable intermediate), so the caller may overwrite ``host`` as soon as the call returns — also when ``host`` itself is pinned,
+    unless it passes ``owned=True`` ("the buffer is mine and stays untouched until the copy has run": then it is read in place)."""
     t = torch.as_tensor(host)
     device = torch.device(device)
     if t.is_cuda:                                           # already on a device: nothing to stage
@@ -184,7 +188,11 @@ def upload(host, device, dtype=None):
         t = t.to(dtype)
     if device.type != "cuda" or t.numel() == 0:
         return t.to(device)
-    return t.contiguous().pin_memory().to(device, non_blocking=True)
+    if owned and t.is_pinned() and t.is_contiguous():
+        return t.to(device, non_blocking=True)
+    stage = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)         # caching host allocator: reused once the copy below has completed
+    stage.copy_(t)
+    return stage.to(device, non_blocking=True)
 
 
 def _ptr(t, dtype=torch.float32):
@@ -236,6 +244,13 @@ class flop_meter:
         self.direct = self.winograd = self.total = 0.0
         self.direct_launches = self.winograd_launches = 0
         return self
+
+    @staticmethod
+    def launches_now() -> int:
+        """Matrix-core launches metered since __enter__ (every metered launch also bumps exactly one route counter)."""
+        counts = (C.c_int64 * len(ROUTE_NAMES))()
+        _check(min(0, lib().vatl_flop_meter_routes(counts, len(ROUTE_NAMES))), "flop_meter_routes")
+        return int(sum(counts))
 
     def __exit__(self, *exc):
         counts = (C.c_int64 * len(ROUTE_NAMES))()
