@@ -45,6 +45,7 @@ def test_active_learning_rounds(unc, tmp_path):
     assert len(al.labeled_id) == 6 and len(al.unlabeled_id) == 18
     # result records (ActiveLearning.py:310-327): COCO-style dicts, written where the driver expects them
     import json, os
+    al.flush_records()                           # written by a host thread: complete at the next entry point / outcome() / flush_records()
     recs = json.load(open(os.path.join(opt.work_dir, "predicted_kpt.json")))
     assert len(recs) == 24 and set(recs[0]) == {"bbox", "image_id", "id", "score", "category_id", "keypoints", "GT_keypoints", "OKS"}
     np.testing.assert_allclose(recs[3]["keypoints"], al.keypoints[3], rtol=1e-6)

@@ -303,6 +303,7 @@ def test_posetrack_json_dataset_items_and_evaluation(tmp_path):
     al.eval_and_query()
     assert len(al.labeled_id) == 2 and len(al.unlabeled_id) == 6
     import json
+    al.flush_records()                                                                          # the record files are written by a host thread (complete at the next entry point / outcome / flush)
     gt = json.load(open(os_mod.path.join(opt.work_dir, "GT_kpt.json")))                        # images / categories come from the annotation file
     assert len(gt["images"]) == 4 and gt["images"][0]["file_name"].endswith("000000.png") and len(gt["annotations"]) == 8
     assert al.outcome() is None and np.isfinite(al.last_train_loss)

@@ -243,6 +243,8 @@ class ActiveLearning:
         # memory inside the loop would block the host until the batch's forward pass has finished, and the next batch's crops are prepared
         # by the host — the loop must only enqueue
         bb_h = np.zeros((n, 4), np.float32)
+        bb_dev = None                                                     # crop boxes that arrive as DEVICE tensors (FrameVideo crops on the GPU) stay there: a `.cpu()` here
+                                                                          # would wait for the batch's forward pass and serialise the host's next batch with the device
         ip_h, in_h = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
         gt_all = np.zeros((n, 3 * J), np.float64)
         ann_all = np.zeros((n, 4), np.float64)
@@ -264,7 +266,12 @@ class ActiveLearning:
                 hm_all[idx] = cur
                 if emb_all is not None:                                   # ActiveLearning.py:284-286, without the second trunk pass
                     emb_all[idx] = emb_b
-            bb_h[loc] = bboxes_crop.cpu().numpy()
+            if bboxes_crop.is_cuda:
+                if bb_dev is None:
+                    bb_dev = torch.zeros((n, 4), device=self.device)
+                bb_dev[idx] = bboxes_crop.to(self.device, torch.float32)
+            else:
+                bb_h[loc] = bboxes_crop.numpy()
             ip_h[loc], in_h[loc] = np.asarray(isPrev, np.uint8), np.asarray(isNext, np.uint8)
             if thc_norm is not None and not self.dedup:                   # reference-faithful: explicit prev/next forwards
                 ip, inx = vh.upload(ip_h[loc], self.device), vh.upload(in_h[loc], self.device)
@@ -274,7 +281,7 @@ class ActiveLearning:
             gt_all[loc] = GTkpts.reshape(len(idxs), -1).numpy()
             ids_all[loc, 0], ids_all[loc, 1] = np.asarray(img_ids, np.float64), np.asarray(ann_ids, np.float64)
             ann_all[loc] = bbox_xyxy_to_xywh(bboxes_ann.numpy().astype(np.float64))
-        bb_all, ip_all, in_all = vh.upload(bb_h, self.device), vh.upload(ip_h, self.device), vh.upload(in_h, self.device)
+        bb_all, ip_all, in_all = (bb_dev if bb_dev is not None else vh.upload(bb_h, self.device)), vh.upload(ip_h, self.device), vh.upload(in_h, self.device)
         ae_flat = self.AE.packed() if self.AE is not None else None
         s = score_batch(hm_all, bb_all, ip_all, in_all, thc_norm=thc_norm if self.dedup else None, ae_flat=ae_flat,
                         ae_dims=(self.AE.input_dim, self.AE.z_dim) if self.AE is not None else (42, 4),
