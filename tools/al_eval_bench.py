@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--retrain", action="store_true", help="also time one fine-tune epoch over all items")
     ap.add_argument("--representativeness", default="None")
     ap.add_argument("--filter", default="None")
+    ap.add_argument("--trace", action="store_true", help="print the wall-clock check-points of every eval_and_query round (ms since its start)")
     ap.add_argument("--cprofile", action="store_true", help="cProfile the rounds after the first and print the 30 most expensive functions (own time)")
     a = ap.parse_args()
     from active_learning import ActiveLearning
@@ -61,10 +62,14 @@ def main():
                 import cProfile
                 prof = cProfile.Profile(); prof.enable()
             torch.cuda.synchronize(); t0 = time.perf_counter()
+            if a.trace:
+                al._trace = []
             al.eval_and_query()
             if r == a.rounds - 1:
                 al.flush_records()                               # the last round's record files inside its time; earlier rounds' were written during the next round's device waits
             torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+            if a.trace:
+                print(f"round {r}: " + " | ".join(f"{lb} {1e3 * (t - t0):.1f}" for lb, t in list(al._trace)) + f" | end {1e3 * times[-1]:.1f}", flush=True)
         if prof is not None:
             import pstats
             prof.disable()

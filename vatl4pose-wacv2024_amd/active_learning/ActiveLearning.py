@@ -319,11 +319,8 @@ class ActiveLearning:
     def eval_and_query(self):
         self.model.eval()
         n = self.eval_len
-        self._host_critical(True)                      # the record thread of the previous round pauses while this one prepares / enqueues device work
-        try:
-            return self._eval_and_query(n)
-        finally:
-            self._host_critical(False)
+        self._host_critical(True)                      # the record thread works only while this one waits for the device (see _write_records)
+        return self._eval_and_query(n)
 
     def _eval_and_query(self, n):
         from . import distributed as D
@@ -334,7 +331,9 @@ class ActiveLearning:
         width = 55 + (self.emb_dim if self.need_embedding else 0)
         # one process per GPU: every rank scores a contiguous shard (+ a one-item halo for the temporal scores)
         # and the result rows are all-gathered (active_learning/distributed.py); world size 1 = whole stream
+        self._mark("eval: start")
         rows_dev = D.sharded_rows(n, self._score_range, width, self.device, halo=1 if self.dedup else 0)
+        self._mark("eval: every batch enqueued")
         fvecs = rows_dev[:, 55:].contiguous() if self.need_embedding else None          # (n, 2048) stays on the device
 
         def side_rows(lo, hi):                     # the rows _score_range stashed for exactly this range
@@ -346,12 +345,14 @@ class ActiveLearning:
         self._side = None
         rows = rows_dev[:, :55].cpu().numpy()
         self._host_critical(True)
+        self._mark("eval: rows on the host")
         kp_all = rows[:, :51].copy()
         unc = rows[:, 51:53].astype(np.float64)
         lp = rows[:, 53].astype(np.float64)
         oks = rows[:, 54].astype(np.float64)
         self.keypoints, self.oks = kp_all, oks
         self._write_records(kp_all, oks, side)
+        self._mark("eval: records handed over")
         evaluate = getattr(self.opt, "evaluate_fn", None)
         work_dir = getattr(self.opt, "work_dir", None)
         tp = self._third_party_scores(work_dir) if (work_dir and not evaluate and D.is_main()) else {}
@@ -462,10 +463,13 @@ class ActiveLearning:
     # ------------------------------------------------------------------ result records (ActiveLearning.py:310-327, 438-447, 693-705)
     # Formatting ~110 floats per item and writing three files costs the host ~20 ms per 1024 items — as much as a quarter of the device's
     # evaluation pass — and nothing in eval_and_query needs the result.  The records of a round are therefore built, encoded and written
-    # by a host thread (`_RecordsJob`); the main thread CLOSES the thread's gate while it is preparing / enqueueing device work (the two
-    # would only take the interpreter lock from each other) and opens it while it waits for the device, so in an evaluate -> retrain ->
-    # evaluate loop the files of round r are produced inside the waits of what follows.  `flush_records()` (called by the next
-    # `_write_records`, `_third_party_scores`, `outcome`, and by every reader of `kpt_json` / `kpt_json_ann` / `GT_json`) waits for them.
+    # by a host thread (`_RecordsJob`).  The two threads share the interpreter lock, so the thread works only inside WINDOWS: the main thread
+    # opens the thread's gate where it waits for the device (the read-backs at the end of eval_and_query, the per-epoch read-backs of
+    # retrain_model) and closes it again afterwards; the thread checks the gate (and yields the lock) every ~100 records, so it stops within a
+    # fraction of a millisecond.  In an evaluate -> retrain -> evaluate loop the files of round r are produced inside the waits of what
+    # follows.  A job that finds no window for 0.25 s stops waiting for one (an idle or foreign main thread must not starve it).
+    # `flush_records()` (called by the next `_write_records`, `_third_party_scores`, `outcome`, and by every reader of `kpt_json` /
+    # `kpt_json_ann` / `GT_json`) opens the gate and waits for the job.
     def _gate(self):
         g = self.__dict__.get("_records_gate")
         if g is None:
@@ -473,6 +477,13 @@ class ActiveLearning:
             g = self.__dict__["_records_gate"] = threading.Event()
             g.set()
         return g
+
+    def _mark(self, label):
+        """Wall-clock check-points of the entry points for tools/al_eval_bench.py --trace (``self._trace`` = a list, or absent: nothing recorded)."""
+        t = self.__dict__.get("_trace")
+        if t is not None:
+            import time
+            t.append((label, time.perf_counter()))
 
     def _host_critical(self, on: bool):
         """on: the main thread is about to prepare / enqueue device work (the record thread pauses at its next check-point); off: it waits."""
@@ -482,8 +493,12 @@ class ActiveLearning:
         """Wait until the record lists of the last evaluated round exist and its files are on disk (re-raises what the thread raised)."""
         job = self.__dict__.get("_records_job")
         if job is not None:
-            self._gate().set()
+            gate = self._gate()
+            was_open = gate.is_set()
+            gate.set()
             job.join()
+            if not was_open:
+                gate.clear()
             self.__dict__["_records_job"] = None
             if job.error is not None:
                 raise job.error
@@ -505,12 +520,22 @@ class ActiveLearning:
         args = (np.array(kp_all, np.float32), np.array(oks, np.float64), np.array(side, np.float64), set(self.labeled_id),
                 work_dir if (work_dir and D.is_main()) else None)
 
+        import time
+
         class _RecordsJob(threading.Thread):
             error = None
+            gated = True
+
+            def pause(self):
+                if self.gated and not gate.wait(0.25):
+                    self.gated = False                             # no window in sight: run to completion beside whatever the main thread does
+                time.sleep(0)                                      # hand the interpreter lock to a main thread that is waiting for it
 
             def run(self):
                 try:
-                    al._build_records(*args, pause=lambda: gate.wait(0.25))
+                    al._mark("records: job starts")
+                    al._build_records(*args, pause=self.pause)
+                    al._mark("records: job done")
                 except BaseException as e:                         # surfaced by flush_records() on the main thread
                     self.error = e
         job = self.__dict__["_records_job"] = _RecordsJob(name="vatl-records", daemon=False)
@@ -526,6 +551,8 @@ class ActiveLearning:
         pause()
         kpt_json, kpt_json_ann, GT_json = [], [], []
         for i in range(len(kp32)):
+            if i % 64 == 63:
+                pause()
             rec = {"bbox": boxes[i], "image_id": img_ids[i], "id": ann_ids[i], "score": score[i], "category_id": 1, "keypoints": kps[i],
                    "GT_keypoints": gts[i], "OKS": oks_l[i]}
             kpt_json.append(rec)
@@ -556,12 +583,13 @@ class ActiveLearning:
         enc = json.dumps
 
         def column(key, nested):
-            pause()
             vals = [rec[key] for rec in kpt_json]
-            if not vals:
-                return vals, []
-            text = enc(vals)
-            return vals, (("[" + t + "]" for t in text[2:-2].split("], [")) if nested else text[1:-1].split(", "))
+            pieces = []
+            for a in range(0, len(vals), 128):                    # one encoder call per 128 records (a call holds the interpreter lock: ~0.4 ms)
+                pause()
+                text = enc(vals[a:a + 128])
+                pieces.extend(("[" + t + "]" for t in text[2:-2].split("], [")) if nested else text[1:-1].split(", "))
+            return vals, pieces
         fixed_vals, fixed_text = [], []
         cached = self.__dict__.get("_records_fixed")
         for k, (key, nested) in enumerate((("bbox", True), ("image_id", False), ("id", False), ("category_id", False), ("GT_keypoints", True))):
@@ -579,6 +607,8 @@ class ActiveLearning:
         pause()
         pred, ann, gt = [], [], []
         for i, (rec, rec_ann) in enumerate(zip(kpt_json, kpt_json_ann)):
+            if i % 128 == 127:
+                pause()
             head = '{"bbox": %s, "image_id": %s, "id": %s, "score": %s, "category_id": %s, "keypoints": ' % (box_s[i], img_s[i], id_s[i], score_s[i], cat_s[i])
             tail = ', "GT_keypoints": %s, "OKS": %s}' % (gt_s[i], oks_s[i])
             pred.append(head + kp_s[i] + tail)
@@ -742,7 +772,6 @@ class ActiveLearning:
                 self.optimizer.step()
             flush()
             self.scheduler.step()
-        self._host_critical(False)
         D.broadcast_buffers_(self.model)           # BN statistics are per rank; rank 0's survive (DataParallel semantics)
         self.last_train_loss, self.last_train_acc = self._global_avg(loss_logger), self._global_avg(acc_logger)
         if "WPU" in self.uncertainty:              # ActiveLearning.py:680-684: a fresh AE is fine-tuned on the labeled poses
