@@ -298,10 +298,10 @@ class ActiveLearning:
         elif thc_norm is not None:
             unc[:, 0] = s.thc
             if self.unc_kind == "THC+WPU":
-                self._check_wpu(s.wpu_status)
+                self._wpu_status = s.wpu_status           # checked once the rows are on the host (a read-back here would drain the stream inside the loop)
                 unc[:, 1] = s.wpu
         elif self.unc_kind == "WPU":
-            self._check_wpu(s.wpu_status)
+            self._wpu_status = s.wpu_status
             unc[:, 0] = s.wpu
         elif self.unc_kind in ("MPE", "Margin", "Entropy"):
             unc[:, 0] = multi_peak_scores(hm_all, self.unc_kind).float()
@@ -344,6 +344,7 @@ class ActiveLearning:
         side = side.cpu().numpy()
         self._side = None
         rows = rows_dev[:, :55].cpu().numpy()
+        self._check_wpu(self.__dict__.pop("_wpu_status", None))      # compute_hybrid's two asserts (hybrid_feature.py:25,31), for this rank's shard
         self._host_critical(True)
         self._mark("eval: rows on the host")
         kp_all = rows[:, :51].copy()
@@ -684,6 +685,8 @@ class ActiveLearning:
 
     @staticmethod
     def _check_wpu(status):
+        if status is None:
+            return
         st = status.cpu().numpy()
         assert not (st == 1).any(), "height of human body must be positive!"
         assert not (st == 2).any(), "at least one visible keypoint is required!"

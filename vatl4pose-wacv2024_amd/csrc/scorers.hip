@@ -159,7 +159,14 @@ __global__ void pose_scores_kernel(const float* __restrict__ kpts, float* __rest
     // float(np.mean(s) + 1.25 * np.max(s)) on float32 scores: float32 mean (pairwise sum / J, correctly rounded), float32 product, float32 sum —
     // three roundings, no fused multiply-add: what NumPy >= 2 computes (python float x np.float32 stays float32; the oracle, the golden vectors
     // and ActiveLearning._write_records run on that).  NumPy 1.x's value-based promotion made the product float64: <= 1 ulp of float32 away.
-    if (pose_score) pose_score[i] = __fadd_rn(__fdiv_rn(sum, (float)J), __fmul_rn(1.25f, mx));
+    // (HIP's __fmul_rn / __fadd_rn are plain operators: without the pragma hipcc's default -ffp-contract=fast fuses them into one v_fma_f32 — one rounding
+    //  fewer than NumPy, 1 ulp off on one item in three)
+    if (pose_score) {
+#pragma clang fp contract(off)
+        const float mean = sum / (float)J;
+        const float scaled = 1.25f * mx;
+        pose_score[i] = mean + scaled;
+    }
 }
 
 // --------------------------------------------------------------------------
