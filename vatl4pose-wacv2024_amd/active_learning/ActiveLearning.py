@@ -164,6 +164,14 @@ class ActiveLearning:
         if D.mirrored():                           # every worker has built its replica: the pickled datasets can go
             D.barrier()
             D.release_payloads()
+        if getattr(opt, "gc_freeze", True):
+            # The model, the data sets (one annotation dict per item) and the loaders built above live as long as this object.  A full pass of the
+            # cyclic collector over them costs 50 - 100 ms and — triggered by the allocation count, i.e. every few evaluation rounds — lands inside
+            # one (tools/al_eval_bench.py --trace: single rounds of 120 - 200 ms among rounds of 79).  gc.freeze() moves what exists NOW to the
+            # permanent generation: later passes only look at what the rounds allocate.  Reference counting is unaffected; opt.gc_freeze = False skips it.
+            import gc
+            gc.collect()
+            gc.freeze()
 
     # ------------------------------------------------------------------ estimator
     def initialize_estimator(self):
@@ -281,6 +289,7 @@ class ActiveLearning:
             gt_all[loc] = GTkpts.reshape(len(idxs), -1).numpy()
             ids_all[loc, 0], ids_all[loc, 1] = np.asarray(img_ids, np.float64), np.asarray(ann_ids, np.float64)
             ann_all[loc] = bbox_xyxy_to_xywh(bboxes_ann.numpy().astype(np.float64))
+            self._mark(f"batch@{a0}")
         bb_all, ip_all, in_all = (bb_dev if bb_dev is not None else vh.upload(bb_h, self.device)), vh.upload(ip_h, self.device), vh.upload(in_h, self.device)
         ae_flat = self.AE.packed() if self.AE is not None else None
         s = score_batch(hm_all, bb_all, ip_all, in_all, thc_norm=thc_norm if self.dedup else None, ae_flat=ae_flat,
@@ -310,6 +319,7 @@ class ActiveLearning:
         oks = vh.oks(s.keypoints.contiguous(), vh.upload(gt_all, self.device), vh.upload(ann_all, self.device))
         # float64 side rows for the result records (ActiveLearning.py:310-327): ids, annotation box (xywh), ground truth
         self._side = (lo, hi, vh.upload(np.concatenate([ids_all, ann_all, gt_all], 1), self.device))
+        self._mark("scored")
         cols = [kp, unc, s.localpeak[:, None], oks.float()[:, None]]
         if emb_all is not None:
             cols.append(emb_all)
@@ -504,9 +514,9 @@ class ActiveLearning:
             if job.error is not None:
                 raise job.error
 
-    kpt_json = property(lambda self: (self.flush_records(), self.__dict__.get("_kpt_json", []))[1])
-    kpt_json_ann = property(lambda self: (self.flush_records(), self.__dict__.get("_kpt_json_ann", []))[1])
-    GT_json = property(lambda self: (self.flush_records(), self.__dict__.get("_GT_json", []))[1])
+    kpt_json = property(lambda self: self._record_lists()[0])
+    kpt_json_ann = property(lambda self: self._record_lists()[1])
+    GT_json = property(lambda self: self._record_lists()[2])
 
     def _write_records(self, kp_all, oks, side):
         """The reference's result records (ActiveLearning.py:310-327, 438-447): one COCO-style dict per item in
@@ -543,89 +553,106 @@ class ActiveLearning:
         job.start()
 
     def _build_records(self, kp32, oks, side, labeled, work_dir, pause=lambda: None):
+        """The record thread's work: the record COLUMNS of the round (python lists straight from the arrays), and — when there is a work
+        directory — the three files' text from those columns.  The per-item dicts of ``kpt_json`` / ``kpt_json_ann`` / ``GT_json`` are only built when
+        somebody reads them (``_record_lists``): 3 x 1024 dicts per round are ~10 k collector-tracked objects, and the full collections they
+        trigger every few rounds (50 - 100 ms each over a process that holds a model and a data set) landed inside evaluation rounds."""
         pause()
         conf = kp32[:, 2::3]
         # whole columns converted once (a numpy call per item costs more than the record itself); float32 arithmetic like the per-item form
-        score = (conf.mean(1) + np.float32(1.25) * conf.max(1)).astype(np.float64).tolist() if len(kp32) else []
-        kps, gts, boxes = kp32.astype(np.float64).tolist(), side[:, 6:].tolist(), side[:, 2:6].tolist()
-        img_ids, ann_ids, oks_l = side[:, 0].astype(np.int64).tolist(), side[:, 1].astype(np.int64).tolist(), oks.tolist()
-        pause()
-        kpt_json, kpt_json_ann, GT_json = [], [], []
-        for i in range(len(kp32)):
-            if i % 64 == 63:
-                pause()
-            rec = {"bbox": boxes[i], "image_id": img_ids[i], "id": ann_ids[i], "score": score[i], "category_id": 1, "keypoints": kps[i],
-                   "GT_keypoints": gts[i], "OKS": oks_l[i]}
-            kpt_json.append(rec)
-            kpt_json_ann.append(dict(rec, keypoints=gts[i]) if i in labeled else dict(rec))
-            GT_json.append(dict(rec, keypoints=gts[i]))
-        self.__dict__["_kpt_json"], self.__dict__["_kpt_json_ann"], self.__dict__["_GT_json"] = kpt_json, kpt_json_ann, GT_json
+        cols = {"score": (conf.mean(1) + np.float32(1.25) * conf.max(1)).astype(np.float64).tolist() if len(kp32) else [],
+                "keypoints": kp32.astype(np.float64).tolist(), "GT_keypoints": side[:, 6:].tolist(), "bbox": side[:, 2:6].tolist(),
+                "image_id": side[:, 0].astype(np.int64).tolist(), "id": side[:, 1].astype(np.int64).tolist(), "OKS": oks.tolist(),
+                "category_id": [1] * len(kp32)}
+        self.__dict__["_records_cols"], self.__dict__["_records_labeled"] = cols, labeled
+        self.__dict__["_records_lists"] = None
         if work_dir:
             import os
             os.makedirs(work_dir, exist_ok=True)
-            texts = self._records_json_of(kpt_json, kpt_json_ann, GT_json, pause)
+            texts = self._records_text(cols, labeled, pause)
             pause()
             for name, text in zip(("predicted_kpt.json", "predicted_kpt_ann.json", "GT_kpt.json"), texts):
                 with open(os.path.join(work_dir, name), "w") as f:
                     f.write(text)
 
+    def _record_lists(self):
+        """(kpt_json, kpt_json_ann, GT_json) of the last evaluated round: one dict per item (ActiveLearning.py:310-327), built on first use."""
+        self.flush_records()
+        lists = self.__dict__.get("_records_lists")
+        if lists is None:
+            cols, labeled = self.__dict__.get("_records_cols"), self.__dict__.get("_records_labeled", ())
+            kpt_json, kpt_json_ann, GT_json = [], [], []
+            if cols is not None:
+                keys = ("bbox", "image_id", "id", "score", "category_id", "keypoints", "GT_keypoints", "OKS")
+                for i in range(len(cols["id"])):
+                    rec = {k: cols[k][i] for k in keys}
+                    kpt_json.append(rec)
+                    kpt_json_ann.append(dict(rec, keypoints=rec["GT_keypoints"]) if i in labeled else dict(rec))
+                    GT_json.append(dict(rec, keypoints=rec["GT_keypoints"]))
+            lists = self.__dict__["_records_lists"] = (kpt_json, kpt_json_ann, GT_json)
+        return lists
+
     def _records_json(self):
         """The three files' text of the last evaluated round (waits for the record thread)."""
-        return self._records_json_of(self.kpt_json, self.kpt_json_ann, self.GT_json)
+        self.flush_records()
+        cols = self.__dict__.get("_records_cols")
+        if cols is None:
+            cols = {k: [] for k in ("bbox", "image_id", "id", "score", "category_id", "keypoints", "GT_keypoints", "OKS")}
+        return self._records_text(cols, self.__dict__.get("_records_labeled", ()))
 
-    def _records_json_of(self, kpt_json, kpt_json_ann, GT_json, pause=lambda: None):
+    def _records_text(self, cols, labeled, pause=lambda: None):
         """json.dumps of ``kpt_json``, ``kpt_json_ann`` and ``_gt_dict()`` — the same text, character for character — with every
         record's shared fields (box, ids, score, the two key-point lists, OKS) encoded ONCE instead of once per file: the three files differ only
         in which of the two lists a record's "keypoints" holds, and formatting ~110 floats per record is what writing them costs.  A field is
-        encoded for ALL records by one encoder call (a column of the records as one nested list, cut at the inner brackets), and the fields that
+        encoded for 128 records per encoder call (a column of the records as one nested list, cut at the inner brackets), and the fields that
         come from the data set alone (box, ids, ground truth: the same in every round of a run) are kept from the previous call and reused when
         their values are unchanged.  ``pause`` is called between the encoder calls (the record thread's check-point)."""
         import json
         enc = json.dumps
 
         def column(key, nested):
-            vals = [rec[key] for rec in kpt_json]
+            vals = cols[key]
             pieces = []
-            for a in range(0, len(vals), 128):                    # one encoder call per 128 records (a call holds the interpreter lock: ~0.4 ms)
+            for a in range(0, len(vals), 128):                    # (a call holds the interpreter lock: ~0.4 ms for 128 records)
                 pause()
                 text = enc(vals[a:a + 128])
                 pieces.extend(("[" + t + "]" for t in text[2:-2].split("], [")) if nested else text[1:-1].split(", "))
-            return vals, pieces
+            return pieces
         fixed_vals, fixed_text = [], []
         cached = self.__dict__.get("_records_fixed")
         for k, (key, nested) in enumerate((("bbox", True), ("image_id", False), ("id", False), ("category_id", False), ("GT_keypoints", True))):
-            vals = [rec[key] for rec in kpt_json]
+            vals = cols[key]
             if cached is not None and cached[0][k] == vals:          # (list comparison: a NaN in the ground truth re-encodes, which is only slower)
                 text = cached[1][k]
             else:
-                text = list(column(key, nested)[1])
+                text = column(key, nested)
             fixed_vals.append(vals); fixed_text.append(text)
         self._records_fixed = (fixed_vals, fixed_text)
         box_s, img_s, id_s, cat_s, gt_s = fixed_text
-        kp_s, score_s, oks_s = list(column("keypoints", True)[1]), column("score", False)[1], column("OKS", False)[1]
-        n = len(kpt_json)
+        kp_s, score_s, oks_s = column("keypoints", True), column("score", False), column("OKS", False)
+        n = len(cols["id"])
         assert all(len(t) == n for t in (box_s, img_s, id_s, cat_s, gt_s, kp_s, score_s, oks_s)), "a record field does not encode to one piece per record"
         pause()
         pred, ann, gt = [], [], []
-        for i, (rec, rec_ann) in enumerate(zip(kpt_json, kpt_json_ann)):
+        for i in range(n):
             if i % 128 == 127:
                 pause()
             head = '{"bbox": %s, "image_id": %s, "id": %s, "score": %s, "category_id": %s, "keypoints": ' % (box_s[i], img_s[i], id_s[i], score_s[i], cat_s[i])
             tail = ', "GT_keypoints": %s, "OKS": %s}' % (gt_s[i], oks_s[i])
             pred.append(head + kp_s[i] + tail)
-            ann.append(head + (gt_s[i] if rec_ann["keypoints"] is rec["GT_keypoints"] else kp_s[i]) + tail)
+            ann.append(head + (gt_s[i] if i in labeled else kp_s[i]) + tail)
             gt.append(head + gt_s[i] + tail)
-        g = self._gt_dict(GT_json)
+        g = self._gt_dict(image_ids=cols["image_id"])
         assert list(g) == ["images", "categories", "annotations"]
         return ("[" + ", ".join(pred) + "]", "[" + ", ".join(ann) + "]",
                 '{"images": %s, "categories": %s, "annotations": [%s]}' % (enc(g["images"]), enc(g["categories"]), ", ".join(gt)))
 
-    def _gt_dict(self, GT_json=None):
+    def _gt_dict(self, image_ids=None):
         """``save_GT_dict`` (ActiveLearning.py:693-705): the ground truth in COCO layout — ``images`` / ``categories`` copied from the
-        evaluation set's annotation file when there is one, the records of this round as ``annotations``."""
+        evaluation set's annotation file when there is one, the records of this round as ``annotations`` (``image_ids`` given: header only,
+        ``annotations`` left empty — the record thread assembles that part from its column text)."""
         import json
         import os
-        GT_json = self.GT_json if GT_json is None else GT_json
         ev = self.cfg.DATASET.EVAL
         path = os.path.join(str(ev.get("ROOT", "")), str(ev.get("ANN", ""))) if ev.get("ANN") else ""
         if path and os.path.isfile(path):
@@ -633,9 +660,10 @@ class ActiveLearning:
                 src = json.load(f)
             images, cats = src.get("images", []), src.get("categories", [])
         else:                                                      # datasets without an annotation file (synthetic / in-memory videos)
-            images = [{"id": i, "image_id": i} for i in sorted({r["image_id"] for r in GT_json})]
+            ids = image_ids if image_ids is not None else [r["image_id"] for r in self.GT_json]
+            images = [{"id": i, "image_id": i} for i in sorted(set(ids))]
             cats = [{"id": 1, "name": "person"}]
-        return {"images": images, "categories": cats, "annotations": GT_json}
+        return {"images": images, "categories": cats, "annotations": [] if image_ids is not None else self.GT_json}
 
     def _third_party_scores(self, work_dir):
         """mAP / OSPA of the written records through the reference's third-party tools (ActiveLearning.py:442-447) when they are
