@@ -50,7 +50,7 @@ int vatl_flop_meter_end(double* direct_flops, double* winograd_flops, int64_t* d
  * BatchNorm-backward epilogue, ...) instead of trusting the dispatch rules. */
 #define VATL_ROUTE_NAMES "igemm,igemm_bnbwd,igemm_dma,persistent_1x1,streamk,rows_1x1,bottleneck_chain,stem_pool,halo_3x3," \
                          "winograd,winograd_2h,winograd_bnbwd,winograd_persist,winograd_c32,wgrad,winograd_wgrad,winograd_wgrad_2h," \
-                         "winograd_wgrad_table"
+                         "winograd_wgrad_table,winograd_f4"
 int vatl_flop_meter_routes(int64_t* counts, int n);
 
 /* ------------------------------------------------------------------------ *
@@ -128,6 +128,18 @@ int vatl_pack_winograd_c32_weight(const float* w, float* u, void* stream);
 int vatl_conv3x3_winograd_c32_supported(int N, int H, int W, int Cin, int Cout);
 int vatl_conv3x3_winograd_c32_fwd(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, int N, int H, int W,
                                   int relu, void* stream);
+
+/* Winograd F(4x4,3x3) for 3x3 / stride 1 / pad 1 layers on grids of whole 4x4 tiles (csrc/winograd_f4.hip; Bottleneck.conv2 of ResNet stages 2 / 3, Resnet.py:104-128;
+ * BasicBlock convs of HRNet's 128-channel branch, hrnet.py:24-56): 36 multiplies per (tile, input channel, output channel) for 16 outputs, 0.5625x the matrix work of
+ * vatl_conv3x3_winograd_fwd.  x (N,H,W,Cin), residual / y (N,H,W,Cout) NHWC; u from vatl_pack_winograd_f4_weight ((Cout,Cin,3,3) filter -> vatl_winograd_f4_weight_floats
+ * floats, U = G g G^T formed in float64); y = act(scale * conv(x) + bias + residual), scale / bias / residual may be NULL.  Served (vatl_conv3x3_winograd_f4_supported): H and W
+ * multiples of 4, Cin >= 64 a multiple of 16, Cout a multiple of 64.  Exact fp32 products and sums like the F(2x2) route; the rounding differs in the last bits (tests hold both
+ * routes to the same float64 bound), and a crop's bits do not depend on its batch position. */
+int64_t vatl_winograd_f4_weight_floats(int Cout, int Cin);
+int vatl_pack_winograd_f4_weight(const float* w, float* u, int Cout, int Cin, void* stream);
+int vatl_conv3x3_winograd_f4_supported(int N, int H, int W, int Cin, int Cout);
+int vatl_conv3x3_winograd_f4_fwd(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, int N, int H, int W,
+                                 int Cin, int Cout, int relu, void* stream);
 
 /* 1x1 convolution with K = 128 input channels as a row-streaming GEMM (csrc/conv1x1_rows.hip): y = act(scale * (A W^T) + bias + residual) for the short-K /
  * wide-N layers the tiled implicit GEMM runs far from both roofs (Bottleneck.conv3 of ResNet stage 2, Resnet.py:120-128; with x2: conv3 + projection

@@ -525,3 +525,39 @@ def test_wgrad_address_tables_give_the_bits_of_the_in_kernel_arithmetic(vh):
             assert torch.equal(a, c), (kind, b, h, w, cin, cout)
     finally:
         vh.tune_set(25, 1)
+
+
+def test_winograd_f4_vs_float64_and_the_f2_route(vh):
+    """vatl_conv3x3_winograd_f4_fwd (csrc/winograd_f4.hip): F(4x4,3x3) on 16x16x4 MFMAs for the layers whose grid is whole 4x4 tiles.  Against float64 convolutions on
+    shapes with whole and partial 16-tile blocks, one to eight 64-channel slices, short and long reductions, with / without folded BN, skip connection and ReLU; held to
+    the bound every Winograd test of this file uses (2e-5 of the largest output; measured 5e-6 .. 1.1e-5 on unit-variance data, the F(2x2) route 2e-7 .. 7e-7: the larger
+    transform constants cost ~4 bits per layer — on the reference's golden crops the heat-maps do not move, tests/test_gpu_conv.py); a crop's bits independent of its
+    batch position; unsupported shapes refused."""
+    r = np.random.RandomState(63)
+    assert vh.conv3x3_winograd_f4_supported(1024, 16, 12, 256, 256) and vh.conv3x3_winograd_f4_supported(1024, 32, 24, 128, 128)
+    assert not vh.conv3x3_winograd_f4_supported(4, 8, 6, 512, 512) and not vh.conv3x3_winograd_f4_supported(4, 16, 12, 32, 32)
+    assert not vh.conv3x3_winograd_f4_supported(4, 16, 12, 256, 96)
+    for n, h, wd, cin, cout in ((3, 16, 12, 256, 256), (2, 32, 24, 128, 128), (5, 8, 8, 64, 64), (1, 4, 4, 64, 128), (7, 12, 20, 80, 192), (2, 16, 12, 128, 512), (33, 4, 8, 64, 64)):
+        w = (r.standard_normal((cout, cin, 3, 3)) * (2.0 / (9 * cin)) ** 0.5).astype(np.float32)
+        sc, bi = r.uniform(0.5, 1.5, cout).astype(np.float32), r.standard_normal(cout).astype(np.float32)
+        u4, u2 = vh.pack_winograd_f4_weight(to_dev(w)), vh.pack_winograd_weight(to_dev(w))
+        x = r.standard_normal((n, h, wd, cin)).astype(np.float32)
+        res = r.standard_normal((n, h, wd, cout)).astype(np.float32)
+        conv = torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(w).double(), padding=1).permute(0, 2, 3, 1).numpy()
+        xd, rd = to_dev(x), to_dev(res)
+        for relu, use_res, use_sb in ((True, True, True), (False, False, False), (True, False, True)):
+            want = conv * (sc if use_sb else 1.0) + (bi if use_sb else 0.0) + (res if use_res else 0.0)
+            want = np.maximum(want, 0) if relu else want
+            s_, b_ = (to_dev(sc), to_dev(bi)) if use_sb else (None, None)
+            got = vh.conv3x3_winograd_f4_fwd(xd, u4, s_, b_, cout, relu, residual=rd if use_res else None)
+            f2 = vh.conv3x3_winograd_fwd(xd, u2, s_, b_, cout, relu, residual=rd if use_res else None)
+            e4, e2 = rel_err(got.cpu().numpy(), want), rel_err(f2.cpu().numpy(), want)
+            assert e4 < 2e-5 and e2 < 2e-5, (n, h, wd, cin, cout, relu, use_res, use_sb, e4, e2)
+        record(f"winograd_f4_{n}x{h}x{wd}x{cin}x{cout}", vs_fp64=e4, f2_route_vs_fp64=e2)
+        if n > 1:
+            full = vh.conv3x3_winograd_f4_fwd(xd, u4, to_dev(sc), to_dev(bi), cout, True, residual=rd)
+            solo = vh.conv3x3_winograd_f4_fwd(xd[1:2].contiguous(), u4, to_dev(sc), to_dev(bi), cout, True, residual=rd[1:2].contiguous())
+            assert torch.equal(solo, full[1:2])
+            assert torch.equal(vh.conv3x3_winograd_f4_fwd(xd, u4, to_dev(sc), to_dev(bi), cout, True, residual=rd), full)      # same bits again
+    with pytest.raises(vh.VatlError):
+        vh.conv3x3_winograd_f4_fwd(to_dev(r.standard_normal((1, 6, 8, 64)).astype(np.float32)), u4, None, None, 64, False)

@@ -1,0 +1,399 @@
+// Winograd F(4x4, 3x3) for the 3x3 / stride 1 / pad 1 layers whose output grid is a whole number of 4x4 tiles and whose reduction is long enough
+// to amortise the larger transforms (ResNet stages 2 / 3: 128 / 256 channels at 32x24 / 16x12; HRNet's 128-channel branch): a 4x4 output tile from
+// its 6x6 input tile with 36 multiplies per (input channel, output channel) where F(2x2, 3x3) needs 64 and the direct sum 144 — 0.5625x the MFMAs
+// of csrc/conv_winograd.hip.  Interpolation points (0, 1, -1, 2, -2, inf):
+//
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A        B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//                                                 A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+//                                                 G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//
+// still exact fp32 products with fp32 accumulation; U = G g G^T is formed in float64 by the packer.  Accuracy: on the reference's golden crops the
+// heat-maps of SimplePose-R50 with these eight layers on F(4x4) are 1.35e-6 (relative, max) from the float64 network where torch's fp32 network is
+// 1.29e-6 (tools/probes/f4_accuracy.py, CPU); the tests hold the kernel to the F(2x2) route's tolerance and the stream route to the golden arg-max.
+//
+// Block = 16 tiles (flat index over image, tile row, tile column) x 64 output channels x all 36 positions, four waves, v_mfma_f32_16x16x4_f32:
+//   * wave w owns the nine positions 9 w .. 9 w + 8 of the row-major 6 x 6 domain = one and a half rows, so it forms two row combinations
+//     (B^T along the rows: 3 instructions per column and channel) and nine column combinations per (tile, channel): 2.3 vector instructions per
+//     MFMA (vector instructions and fp32 MFMAs add up on a SIMD: profiles/r04_notes.md).  144 accumulator registers, two blocks per CU.
+//   * A operand: lane (tile = lane % 16, quad = lane / 16) reads ITS tile's pixels, four consecutive channels per 16-byte read = the four MFMA k-steps
+//     (k-step s multiplies channels {4 quad + s}: the same permutation on both operands).  The raw pixels of the block's 16 tiles x 36 pixels x 16
+//     channels are staged by LDS-DMA (double buffer, one stage ahead; out-of-image pieces are requested out of range = the zero padding), one 1 KB
+//     request per patch pixel: lane = (tile, channel quad), the quad rotated by tile / 4 so that the 16 tiles of a fragment read fall on 16 different
+//     bank groups.  A lane's requests differ by wave-uniform pixel offsets only: one base register + a 12-bit inside-the-image mask.
+//   * B operand (U): packed in fragment order [stage][position][16-channel column block][lane][k-step]: a wave's read is 1 KB contiguous, the four column
+//     blocks of a position 4 KB; straight from L2 into registers one position ahead.  A block needs the 64-channel slice of U (36 x Cin x 256 bytes:
+//     2.4 MB at 256 channels); the block -> (tile group, slice) map gives every XCD ONE slice, so that it stays in that XCD's L2.
+//   * Output transform: the nu sums in registers per owned row part, the xi sums through LDS (the staging buffers, two 32-channel halves): eight partial
+//     row tiles per block, every thread then combines them for whole 16-byte channel groups and stores NHWC channel runs with scale / bias / residual / ReLU.
+// The per-output arithmetic depends only on the tile's own pixels: results do not depend on the batch position.
+#include "common.h"
+
+#include <atomic>
+
+namespace vatl {
+
+struct F4Params {
+    const float* x;
+    const float* u;
+    const float* scale;
+    const float* bias;
+    const float* res;
+    float* y;
+    int N, H, W, Cin, Cout;
+    int TH, TW, tpi, Mtiles, m_tiles, n_tiles, stages, relu;
+    int xper;                          // XCDs per 64-channel slice (8 / n_tiles), 0: plain order
+    unsigned x_bytes, y_bytes, u_bytes;
+    FastDivU d_tpi, d_TW;
+};
+
+typedef __attribute__((address_space(3))) void f4_lds_void;
+constexpr int F4_TB = 16;                                  // tiles per block
+constexpr int F4_NDMA = 36;                                // wave-wide DMA instructions per stage (1 KB each): one per patch pixel, lane = (tile, channel quad)
+constexpr int F4_STAGE = F4_NDMA * 256;                    // floats per stage buffer: 9216 (36 864 bytes)
+constexpr int F4_KDMA = F4_NDMA / 4;                       // per wave: 9
+constexpr unsigned F4_OOB = 0xFFFF0000u;                   // stays out of range with stage * 64 bytes added (tensors <= 0xFFFF0000 bytes: checked on the host)
+constexpr int F4_ZT = 148;                                 // floats per (slot, tile) of the output exchange: 4 rows of 36 (32 channels + 4) + 4: four tiles apart = 16 banks apart
+constexpr int F4_LDS_FLOATS = 8 * 16 * F4_ZT;              // the output exchange (18 944 floats) is a little larger than the two stage buffers (18 432)
+
+// B^T (and, for the columns, B) along one axis: combination XI of six values
+template <int XI, typename T>
+__device__ __forceinline__ T f4_comb(const T& d0, const T& d1, const T& d2, const T& d3, const T& d4, const T& d5) {
+    if constexpr (XI == 0) return 4.f * d0 - 5.f * d2 + d4;
+    else if constexpr (XI == 1) return (d3 + d4) - 4.f * (d1 + d2);
+    else if constexpr (XI == 2) return (d4 - d3) + 4.f * (d1 - d2);
+    else if constexpr (XI == 3) return (d4 - d2) + 2.f * (d3 - d1);
+    else if constexpr (XI == 4) return (d4 - d2) - 2.f * (d3 - d1);
+    else return 4.f * d1 - 5.f * d3 + d5;
+}
+
+// rows of the 6 x 6 patch that combination XI reads (the others have a zero coefficient)
+template <int XI> __device__ __forceinline__ constexpr bool f4_uses(int i) {
+    return XI == 0 ? (i == 0 || i == 2 || i == 4) : (XI == 5 ? (i == 1 || i == 3 || i == 5) : (i >= 1 && i <= 4));
+}
+
+__device__ __forceinline__ f32x4 f4_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+// One row part of a wave: row XI of the transform domain, columns NU0 .. NU0 + NUN - 1, accumulators PL0 .. PL0 + NUN - 1.
+// Pl: this lane's slot in the current stage buffer (+ 256 floats per patch pixel); ub: byte offset of (stage, position 0, this block's first column block, this lane).
+template <int XI, int NU0, int NUN, int PL0, typename AFTER>
+__device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][4], __amdgpu_buffer_rsrc_t ur, unsigned ub, unsigned pos_bytes, f32x4 (&bcur)[4], AFTER after_reads,
+                                        bool more, unsigned next_ub) {
+    // row combination XI of the six patch columns as a chain of multiply-adds over the rows it uses, the read of the next term issued one ahead: two 16-byte
+    // temporaries instead of the 3 - 4 a column needs at once (the compiler otherwise issues all 18 - 24 reads of the part first: ~100 registers, spilled next
+    // to the 144 accumulators).  One instruction more per column than the shared-subexpression form for rows 1 - 4.
+    constexpr float CF[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0}, {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+    constexpr int NR = (XI == 0 || XI == 5) ? 3 : 4, R0 = XI == 0 ? 0 : 1, RS = (XI == 0 || XI == 5) ? 2 : 1;      // rows R0, R0 + RS, ...
+    f32x4 R[6];
+    f32x4 t = *reinterpret_cast<const f32x4*>(Pl + (R0 * 6 + 0) * 256);
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int i = R0 + k * RS;
+            const f32x4 cur = t;
+            if (k + 1 < NR) t = *reinterpret_cast<const f32x4*>(Pl + ((R0 + (k + 1) * RS) * 6 + jj) * 256);
+            else if (jj < 5) t = *reinterpret_cast<const f32x4*>(Pl + (R0 * 6 + jj + 1) * 256);
+            const float c = CF[XI][i];
+            if (k == 0) R[jj] = c == 1.f ? cur : c * cur;
+            else if (c == 1.f) R[jj] += cur;
+            else if (c == -1.f) R[jj] -= cur;
+            else R[jj] += c * cur;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    after_reads();                                         // (the second part of a stage: the next stage's DMA requests go out here, behind the stage's last LDS reads)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NUN; ++q) {
+        f32x4 V;
+        const int nu = NU0 + q;
+        // column combination nu of the row values (compile-time nu: the loop is unrolled)
+        switch (nu) {
+            case 0: V = f4_comb<0>(R[0], R[1], R[2], R[3], R[4], R[5]); break;
+            case 1: V = f4_comb<1>(R[0], R[1], R[2], R[3], R[4], R[5]); break;
+            case 2: V = f4_comb<2>(R[0], R[1], R[2], R[3], R[4], R[5]); break;
+            case 3: V = f4_comb<3>(R[0], R[1], R[2], R[3], R[4], R[5]); break;
+            case 4: V = f4_comb<4>(R[0], R[1], R[2], R[3], R[4], R[5]); break;
+            default: V = f4_comb<5>(R[0], R[1], R[2], R[3], R[4], R[5]); break;
+        }
+        // the filter fragments of the NEXT position (of this part, or the first one of what follows) are requested before this position's MFMAs
+        f32x4 bnext[4];
+        const bool last = q == NUN - 1;
+        if (!last || more) {
+            const unsigned nb = last ? next_ub : ub + (unsigned)(XI * 6 + nu + 1) * pos_bytes;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bnext[n] = f4_buf_load4(ur, nb + n * 1024u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[PL0 + q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[s], bcur[n][s], acc[PL0 + q][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!last || more) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) bcur[n] = bnext[n];
+        }
+    }
+}
+
+// nu sums of one row part: Z[b] = sum over the part's columns of A^T[b][nu] * M[nu], for the column block pair H (two 16-channel blocks) -> LDS slot SLOT
+template <int NU0, int NUN, int PL0, int SLOT>
+__device__ __forceinline__ void f4_nu_sums(const f32x4 (&acc)[9][4], float* Zs, int h, int lane) {
+    constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+    const int n16 = lane & 15, tg = lane >> 4;
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+        f32x4 z[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            z[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NUN; ++q) {
+                const float c = AT[b][NU0 + q];
+                if (c == 1.f) z[b] += acc[PL0 + q][2 * h + nn];
+                else if (c == -1.f) z[b] -= acc[PL0 + q][2 * h + nn];
+                else if (c != 0.f) z[b] += c * acc[PL0 + q][2 * h + nn];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) Zs[(SLOT * 16 + 4 * tg + e) * F4_ZT + b * 36 + nn * 16 + n16] = z[b][e];
+    }
+}
+
+template <int WV>
+__device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_tile, int n_tile) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+
+    // ---- staging geometry: DMA instruction px (= patch pixel (px / 6, px % 6)) of a stage writes the 1 KB row px of the stage buffer; its lane L delivers slot L of
+    // that row = (tile L / 4, channel quad (L % 4 - tile / 4) & 3): the rotation spreads the 16 tiles of a fragment read over the 16 bank groups.  Per lane that is ONE
+    // base offset (patch pixel (0, 0) of its tile, its quad) + a wave-uniform pixel offset, and a 6 + 6 bit row / column mask of the pixels inside the image ----
+    unsigned tile_base, inside;
+    {
+        const int tl = lane >> 2, qd = ((lane & 3) - (tl >> 2)) & 3;
+        const int T = m_tile * F4_TB + tl;
+        const int img = fdiv(T, p.d_tpi), rem = T - img * p.tpi;
+        const int ty = fdiv(rem, p.d_TW), tx = rem - ty * p.TW;
+        tile_base = (unsigned)((((img * p.H + 4 * ty - 1) * p.W + 4 * tx - 1) * p.Cin + qd * 4) * 4);     // (may wrap below zero for the first tile: its row / column -1 is masked)
+        inside = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int iy = 4 * ty - 1 + i, ix = 4 * tx - 1 + i;
+            inside |= (T < p.Mtiles && iy >= 0 && iy < p.H ? 1u : 0u) << i;
+            inside |= (ix >= 0 && ix < p.W ? 1u : 0u) << (6 + i);
+        }
+    }
+    const unsigned row_bytes = (unsigned)(p.W * p.Cin * 4), px_bytes = (unsigned)(p.Cin * 4);
+    auto request = [&](int stage, float* buf) {
+        unsigned tb = tile_base, in = inside;
+        asm volatile("" : "+v"(tb), "+v"(in));             // (the nine offsets are formed HERE, every stage: hoisted out of the stage loop they cost nine registers next to 144 accumulators)
+#pragma unroll
+        for (int k = 0; k < F4_KDMA; ++k) {
+            const int px = WV + 4 * k, i = px / 6, jx = px - 6 * i;                     // compile-time
+            const bool ok = ((in >> i) & (in >> (6 + jx)) & 1u) != 0;
+            const unsigned off = ok ? tb + (unsigned)i * row_bytes + (unsigned)jx * px_bytes : F4_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (f4_lds_void*)(buf + px * 256), 16, off, (unsigned)stage * 64u, 0, 0);
+        }
+    };
+
+    // ---- operands ----
+    const int t16 = lane & 15, quad = lane >> 4;
+    const int lane_floats = (t16 * 4 + ((quad + (t16 >> 2)) & 3)) * 4;     // this lane's slot in every pixel row of a stage buffer
+    const unsigned nbg = (unsigned)(p.Cout >> 4);
+    const unsigned pos_bytes = nbg * 1024u;                // bytes between consecutive positions of U
+    const unsigned stage_bytes = 36u * pos_bytes;
+    const unsigned ublock = ((unsigned)n_tile * 4u * 64u + (unsigned)lane) * 16u;
+    // the wave's two row parts, the half row first (its reads are done a third into the stage: the next stage's requests go out behind the SECOND part's reads)
+    constexpr int XA = WV == 0 ? 1 : (WV == 1 ? 1 : 4), NA0 = (WV == 0 || WV == 2) ? 0 : 3;          // half row: 3 positions
+    constexpr int XB = WV == 0 ? 0 : (WV == 1 ? 2 : (WV == 2 ? 3 : 5));                               // full row: 6 positions
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[q][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    request(0, smem);
+    f32x4 bcur[4];
+    {
+        const unsigned first = ublock + (unsigned)(XA * 6 + NA0) * pos_bytes;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bcur[n] = f4_buf_load4(ur, first + n * 1024u);
+    }
+    for (int s = 0; s < p.stages; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage s have landed (and the first filter fragments)
+        __builtin_amdgcn_s_barrier();                      // ... everyone's; and every wave is done reading the other buffer (stage s - 1)
+        asm volatile("" ::: "memory");
+        float* cur = smem + (s & 1) * F4_STAGE;
+        float* nxt = smem + ((s + 1) & 1) * F4_STAGE;
+        const float* Pl = cur + lane_floats;
+        const unsigned ub = ublock + (unsigned)s * stage_bytes;
+        const bool more = s + 1 < p.stages;
+        f4_part<XA, NA0, 3, 0>(Pl, acc, ur, ub, pos_bytes, bcur, [] {}, true, ub + (unsigned)(XB * 6) * pos_bytes);
+        f4_part<XB, 0, 6, 3>(Pl, acc, ur, ub, pos_bytes, bcur, [&] { if (more) request(s + 1, nxt); }, more,
+                             ub + stage_bytes + (unsigned)(XA * 6 + NA0) * pos_bytes);
+    }
+
+    // ---- output transform ----
+    lds_barrier();                                         // every wave is done with the stage buffers
+    float* Zs = smem;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), 0, p.res ? p.y_bytes : 0u, 0x00020000);
+    const float lo = p.relu ? 0.f : -INFINITY;
+    const int c4 = tid & 7;                                // this thread's 16-byte channel group of the 32-channel half (the same for both of its items)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f4_nu_sums<NA0, 3, 0, 2 * WV>(acc, Zs, h, lane);
+        f4_nu_sums<0, 6, 3, 2 * WV + 1>(acc, Zs, h, lane);
+        lds_barrier();
+        const int n = n_tile * 64 + h * 32 + c4 * 4;
+        const f32x4 one = {1.f, 1.f, 1.f, 1.f}, nul = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : one;
+        const f32x4 bi = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : nul;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int id = tid + 256 * r;                  // (tile, b, c4)
+            const int b = (id >> 3) & 3, tl = id >> 5;
+            const int T = m_tile * F4_TB + tl;
+            const int img = fdiv(T, p.d_tpi), rem = T - img * p.tpi;
+            const int ty = fdiv(rem, p.d_TW), tx = rem - ty * p.TW;
+            const bool ok = T < p.Mtiles;
+            const unsigned base = ok ? (unsigned)((((img * p.H + 4 * ty) * p.W + 4 * tx + b) * p.Cout + n) * 4) : 0xFFFFFFF0u;
+            const unsigned rowb = (unsigned)(p.W * p.Cout * 4);
+            f32x4 rs[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) rs[a] = f4_buf_load4(rr, ok ? base + a * rowb : 0xFFFFFFF0u);
+            f32x4 S[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) S[k] = *reinterpret_cast<const f32x4*>(Zs + (k * 16 + tl) * F4_ZT + b * 36 + c4 * 4);
+            // slots: 0 = row 1 (nu 0-2), 1 = row 0, 2 = row 1 (nu 3-5), 3 = row 2, 4 = row 4 (nu 0-2), 5 = row 3, 6 = row 4 (nu 3-5), 7 = row 5
+            const f32x4 z0 = S[1], z1 = S[0] + S[2], z2 = S[3], z3 = S[5], z4 = S[4] + S[6], z5 = S[7];
+            const f32x4 d12 = z1 - z2, s12 = z1 + z2, d34 = z3 - z4, s34 = z3 + z4;
+            f32x4 o[4];
+            o[0] = z0 + s12 + s34;
+            o[1] = d12 + 2.f * d34;
+            o[2] = s12 + 4.f * s34;
+            o[3] = d12 + 8.f * d34 + z5;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                f32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(fmaf(o[a][c], sc[c], bi[c]) + rs[a][c], lo);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), yr, ok ? base + a * rowb : 0xFFFFFFF0u, 0, 0);
+            }
+        }
+        if (h == 0) lds_barrier();                         // the second half overwrites the exchange area
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void winograd_f4_kernel(F4Params p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    int m_tile, n_tile;
+    if (p.xper > 0) {                                      // block b runs on XCD b % 8: every XCD keeps ONE 64-channel slice of U in its L2
+        const int xcd = bid & 7, s = bid >> 3;
+        n_tile = xcd % p.n_tiles;
+        m_tile = s * p.xper + xcd / p.n_tiles;
+    } else {
+        n_tile = bid % p.n_tiles;
+        m_tile = bid / p.n_tiles;
+    }
+    if (m_tile >= p.m_tiles) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (wave) {                                        // the position split is per wave and compile-time: four instantiations of the body
+        case 0: f4_body<0>(p, smem, m_tile, n_tile); break;
+        case 1: f4_body<1>(p, smem, m_tile, n_tile); break;
+        case 2: f4_body<2>(p, smem, m_tile, n_tile); break;
+        default: f4_body<3>(p, smem, m_tile, n_tile); break;
+    }
+}
+
+// (Cout, Cin, 3, 3) -> U = G g G^T (float64 arithmetic) in fragment order [stage][position][column block][lane][k-step]: channel 16 stage + 4 (lane / 16) + k-step,
+// output channel 16 block + lane % 16
+__global__ __launch_bounds__(256) void winograd_f4_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin) {
+    const long long id = blockIdx.x * 256LL + threadIdx.x;
+    const int nbg = Cout >> 4;
+    const long long total = (long long)(Cin >> 4) * 36 * nbg * 64;
+    if (id >= total) return;
+    const int lane = (int)(id & 63);
+    const int blk = (int)((id >> 6) % nbg);
+    const int pos = (int)((id >> 6) / nbg % 36);
+    const int stage = (int)((id >> 6) / nbg / 36);
+    const int xi = pos / 6, nu = pos - 6 * xi;
+    const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int n = 16 * blk + (lane & 15);
+    f32x4 o;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = 16 * stage + 4 * (lane >> 4) + s;
+        const float* g = w + ((long long)n * Cin + c) * 9;
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v += G[xi][i] * (double)g[i * 3 + j] * G[nu][j];
+        o[s] = (float)v;
+    }
+    *reinterpret_cast<f32x4*>(u + id * 4) = o;
+}
+
+}  // namespace vatl
+
+using namespace vatl;
+
+extern "C" int64_t vatl_winograd_f4_weight_floats(int Cout, int Cin) { return 36LL * Cout * Cin; }
+
+extern "C" int vatl_conv3x3_winograd_f4_supported(int N, int H, int W, int Cin, int Cout) {
+    if (N <= 0 || H < 4 || W < 4 || (H & 3) || (W & 3) || Cin < 64 || (Cin & 15) || Cout < 64 || (Cout & 63)) return 0;
+    const long long xe = (long long)N * H * W * Cin, ye = (long long)N * H * W * Cout;
+    return xe * 4 <= (long long)F4_OOB && ye < (1LL << 30) && 36LL * Cin * Cout < (1LL << 28) ? 1 : 0;
+}
+
+extern "C" int vatl_pack_winograd_f4_weight(const float* w, float* u, int Cout, int Cin, void* stream) {
+    if (!w || !u || Cout <= 0 || Cin <= 0 || (Cout & 15) || (Cin & 15)) return fail(VATL_EINVAL, "pack_winograd_f4_weight: needs channel counts that are multiples of 16");
+    const long long total = (long long)(Cin >> 4) * 36 * (Cout >> 4) * 64;
+    hipLaunchKernelGGL(winograd_f4_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, u, Cout, Cin);
+    return check_launch("winograd_f4_pack");
+}
+
+extern "C" int vatl_conv3x3_winograd_f4_fwd(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, int N, int H, int W,
+                                            int Cin, int Cout, int relu, void* stream) {
+    if (!x || !u || !y) return fail(VATL_EINVAL, "conv3x3_winograd_f4_fwd: null pointer");
+    if (!vatl_conv3x3_winograd_f4_supported(N, H, W, Cin, Cout))
+        return fail(VATL_EINVAL, "conv3x3_winograd_f4_fwd: serves H, W multiples of 4, Cin >= 64 a multiple of 16, Cout a multiple of 64 (got %d x %d, %d -> %d)", H, W, Cin, Cout);
+    F4Params p{};
+    p.x = x; p.u = u; p.scale = scale; p.bias = bias; p.res = residual; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
+    p.TH = H / 4; p.TW = W / 4; p.tpi = p.TH * p.TW;
+    const long long mt = (long long)N * p.tpi;
+    if (mt >= (1LL << 30)) return fail(VATL_EINVAL, "conv3x3_winograd_f4_fwd: too many tiles");
+    p.Mtiles = (int)mt;
+    p.m_tiles = cdiv(mt, F4_TB);
+    p.n_tiles = Cout / 64;
+    p.stages = Cin / 16;
+    p.x_bytes = (unsigned)((long long)N * H * W * Cin * 4); p.y_bytes = (unsigned)((long long)N * H * W * Cout * 4);
+    p.u_bytes = (unsigned)(36LL * Cin * Cout * 4);
+    p.d_tpi = make_fastdiv((unsigned)p.tpi); p.d_TW = make_fastdiv((unsigned)p.TW);
+    long long grid;
+    if (p.n_tiles == 1 || p.n_tiles == 2 || p.n_tiles == 4 || p.n_tiles == 8) {
+        p.xper = 8 / p.n_tiles;
+        grid = 8LL * cdiv(p.m_tiles, p.xper);
+    } else {
+        p.xper = 0;
+        grid = (long long)p.m_tiles * p.n_tiles;
+    }
+    if (grid >= (1LL << 31)) return fail(VATL_EINVAL, "conv3x3_winograd_f4_fwd: too many blocks");
+    const int smem = F4_LDS_FLOATS * (int)sizeof(float);
+    static std::atomic<unsigned> configured{0};
+    auto kern = winograd_f4_kernel;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, configured, "winograd_f4")) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
+    meter_add(1, 2.0 * ((double)p.m_tiles * F4_TB) * (double)Cout * (double)Cin * 36.0);
+    meter_route(kRouteWinoF4);
+    return check_launch("winograd_f4");
+}

@@ -39,6 +39,10 @@ SIGNATURES = {
     "vatl_pack_winograd_c32_weight": (_i, [_p, _p, _p]),
     "vatl_conv3x3_winograd_c32_supported": (_i, [_i, _i, _i, _i, _i]),
     "vatl_conv3x3_winograd_c32_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "vatl_winograd_f4_weight_floats": (_i64, [_i, _i]),
+    "vatl_pack_winograd_f4_weight": (_i, [_p, _p, _i, _i, _p]),
+    "vatl_conv3x3_winograd_f4_supported": (_i, [_i, _i, _i, _i, _i]),
+    "vatl_conv3x3_winograd_f4_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_conv1x1_rows_supported": (_i, [_i, _i, _i, _i64]),
     "vatl_conv1x1_rows_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p]),
     "vatl_bottleneck_chain_supported": (_i, [_i, _i, _i, _i64]),
@@ -231,7 +235,7 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
 
 
 ROUTE_NAMES = ("igemm", "igemm_bnbwd", "igemm_dma", "persistent_1x1", "streamk", "rows_1x1", "bottleneck_chain", "stem_pool", "halo_3x3", "winograd",
-               "winograd_2h", "winograd_bnbwd", "winograd_persist", "winograd_c32", "wgrad", "winograd_wgrad", "winograd_wgrad_2h", "winograd_wgrad_table")
+               "winograd_2h", "winograd_bnbwd", "winograd_persist", "winograd_c32", "wgrad", "winograd_wgrad", "winograd_wgrad_2h", "winograd_wgrad_table", "winograd_f4")
 
 
 class flop_meter:
@@ -525,6 +529,27 @@ def conv3x3_winograd_c32_fwd(x, u, scale, bias, relu: bool, residual=None, out=N
            "vatl_conv3x3_winograd_c32_fwd")
     return y
 
+
+
+def pack_winograd_f4_weight(w: torch.Tensor) -> torch.Tensor:
+    """(Cout,Cin,3,3) -> U = G g G^T of F(4x4,3x3) in the MFMA fragment order of csrc/winograd_f4.hip."""
+    cout, cin = w.shape[:2]
+    u = torch.empty(int(lib().vatl_winograd_f4_weight_floats(cout, cin)), device=w.device, dtype=torch.float32)
+    _check(lib().vatl_pack_winograd_f4_weight(_ptr(w.contiguous()), _ptr(u), cout, cin, _stream()), "vatl_pack_winograd_f4_weight")
+    return u
+
+
+def conv3x3_winograd_f4_supported(n: int, h: int, w: int, cin: int, cout: int) -> bool:
+    return bool(lib().vatl_conv3x3_winograd_f4_supported(n, h, w, cin, cout))
+
+
+def conv3x3_winograd_f4_fwd(x, u, scale, bias, cout: int, relu: bool, residual=None, out=None):
+    """3x3 / stride 1 / pad 1 conv as Winograd F(4x4,3x3): x NHWC (N,H,W,Cin), H and W multiples of 4 -> (N,H,W,Cout)."""
+    n, h, w, cin = x.shape
+    y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    _check(lib().vatl_conv3x3_winograd_f4_fwd(_ptr(x), _ptr(u), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(y), n, h, w, cin, cout, int(relu), _stream()),
+           "vatl_conv3x3_winograd_f4_fwd")
+    return y
 
 
 def conv1x1_rows_supported(k1: int, k2: int, n: int, m: int) -> bool:
