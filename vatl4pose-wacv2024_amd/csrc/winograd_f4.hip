@@ -18,8 +18,8 @@
 //   * A operand: lane (tile = lane % 16, quad = lane / 16) reads ITS tile's pixels, four consecutive channels per 16-byte read = the four MFMA k-steps
 //     (k-step s multiplies channels {4 quad + s}: the same permutation on both operands).  The raw pixels of the block's 16 tiles x 36 pixels x 16
 //     channels are staged by LDS-DMA (double buffer, one stage ahead; out-of-image pieces are requested out of range = the zero padding), one 1 KB
-//     request per patch pixel: lane = (tile, channel quad), the quad rotated by tile / 4 so that the 16 tiles of a fragment read fall on 16 different
-//     bank groups.  A lane's requests differ by wave-uniform pixel offsets only: one base register + a 12-bit inside-the-image mask.
+//     request per patch pixel: lane = (tile, channel quad), the quad rotated by 2 (tile / 8) so that the 16 lanes of a ds_read_b128 service group fall on
+//     16 different bank slots.  A lane's requests differ by wave-uniform pixel offsets only: one base register + a 12-bit inside-the-image mask.
 //   * B operand (U): packed in fragment order [stage][position][16-channel column block][lane][k-step]: a wave's read is 1 KB contiguous, the four column
 //     blocks of a position 4 KB; straight from L2 into registers one position ahead.  A block needs the 64-channel slice of U (36 x Cin x 256 bytes:
 //     2.4 MB at 256 channels); the block -> (tile group, slice) map gives every XCD ONE slice, so that it stays in that XCD's L2.
@@ -29,6 +29,7 @@
 #include "common.h"
 
 #include <atomic>
+#include <type_traits>
 
 namespace vatl {
 
@@ -74,69 +75,93 @@ template <int XI> __device__ __forceinline__ constexpr bool f4_uses(int i) {
 __device__ __forceinline__ f32x4 f4_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
-
+// F4_ABL (tools/f4_ablate.sh only; wrong results): 1 no filter loads, 2 no LDS reads / row combinations, 4 no staging DMA, 8 no stage barrier
+#ifndef F4_ABL
+#define F4_ABL 0
+#endif
+// Filter fragments and the staging DMA share the wave's IN-ORDER vector-memory counter, and hipcc does not count an LDS-DMA request (the builtin below) in the
+// bookkeeping behind its own waits: a fragment load issued after a DMA request completes after it, and the compiler's wait for an OLDER batch ("the four younger loads
+// may stay in flight": vmcnt(4)) in fact also waits for a request issued in between.  With one request behind every position's MFMAs every position waited for a
+// fresh L2 / HBM round trip (tools/f4_ablate.sh: the requests cost 21 % of the kernel, the fragment loads 16 %).  The requests of a stage therefore go out in ONE burst
+// at the point of the stage from which the next wait on a younger fragment batch is farthest away (f4_part, BURST).
+__device__ __forceinline__ f32x4 f4_filter_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    if constexpr ((F4_ABL & 1) != 0) { f32x4 v; asm volatile("" : "=v"(v)); return v; }
+    else return f4_buf_load4(r, off);
+}
+// compile-time loop index
+template <int I, int N, typename F>
+__device__ __forceinline__ void f4_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        f4_static_for<I + 1, N>(f);
+    }
+}
 // One row part of a wave: row XI of the transform domain, columns NU0 .. NU0 + NUN - 1, accumulators PL0 .. PL0 + NUN - 1.
 // Pl: this lane's slot in the current stage buffer (+ 256 floats per patch pixel); ub: byte offset of (stage, position 0, this block's first column block, this lane).
-template <int XI, int NU0, int NUN, int PL0, typename AFTER>
-__device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][4], __amdgpu_buffer_rsrc_t ur, unsigned ub, unsigned pos_bytes, f32x4 (&bcur)[4], AFTER after_reads,
+// BURST: the position of this part (local index, -1: none) behind whose first four MFMAs the next stage's DMA requests go out.
+template <int XI, int NU0, int NUN, int PL0, int BURST, typename DMA>
+__device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][4], __amdgpu_buffer_rsrc_t ur, unsigned ub, unsigned pos_bytes, f32x4 (&bcur)[4], DMA dma_burst,
                                         bool more, unsigned next_ub) {
-    // row combination XI of the six patch columns as a chain of multiply-adds over the rows it uses, the read of the next term issued one ahead: two 16-byte
-    // temporaries instead of the 3 - 4 a column needs at once (the compiler otherwise issues all 18 - 24 reads of the part first: ~100 registers, spilled next
-    // to the 144 accumulators).  One instruction more per column than the shared-subexpression form for rows 1 - 4.
+    // row combination XI of the six patch columns as a chain of multiply-adds over the rows it uses, term by term (18 - 24 terms: column-major), the reads a ring of
+    // DEPTH terms ahead: ~DEPTH x 16 cycles of vector work cover an LDS read (with the read one term ahead every term waited ~50 cycles for its operand: 30 % of the
+    // wave time at s_waitcnt), and four 16-byte temporaries are what the registers next to 144 accumulators allow (the compiler, left alone, issues all reads of the
+    // part first: ~100 registers).  One instruction more per column than the shared-subexpression form for rows 1 - 4.
     constexpr float CF[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0}, {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
     constexpr int NR = (XI == 0 || XI == 5) ? 3 : 4, R0 = XI == 0 ? 0 : 1, RS = (XI == 0 || XI == 5) ? 2 : 1;      // rows R0, R0 + RS, ...
+    constexpr int NT = 6 * NR, DEPTH = 4;
     f32x4 R[6];
-    f32x4 t = *reinterpret_cast<const f32x4*>(Pl + (R0 * 6 + 0) * 256);
+    f32x4 ring[DEPTH];
+    auto term_ptr = [&](int t) { return reinterpret_cast<const f32x4*>(Pl + ((F4_ABL & 2) ? 0 : ((R0 + (t % NR) * RS) * 6 + t / NR) * 256)); };
 #pragma unroll
-    for (int jj = 0; jj < 6; ++jj) {
+    for (int t = 0; t < DEPTH; ++t) ring[t] = *term_ptr(t);
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int i = R0 + k * RS;
-            const f32x4 cur = t;
-            if (k + 1 < NR) t = *reinterpret_cast<const f32x4*>(Pl + ((R0 + (k + 1) * RS) * 6 + jj) * 256);
-            else if (jj < 5) t = *reinterpret_cast<const f32x4*>(Pl + (R0 * 6 + jj + 1) * 256);
-            const float c = CF[XI][i];
-            if (k == 0) R[jj] = c == 1.f ? cur : c * cur;
-            else if (c == 1.f) R[jj] += cur;
-            else if (c == -1.f) R[jj] -= cur;
-            else R[jj] += c * cur;
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    for (int t = 0; t < NT; ++t) {
+        const int jj = t / NR, k = t % NR;
+        const f32x4 cur = ring[t % DEPTH];
+        if (t + DEPTH < NT) ring[t % DEPTH] = *term_ptr(t + DEPTH);
+        const float c = CF[XI][R0 + k * RS];
+        if (k == 0) R[jj] = c == 1.f ? cur : c * cur;
+        else if (c == 1.f) R[jj] += cur;
+        else if (c == -1.f) R[jj] -= cur;
+        else R[jj] += c * cur;
+        __builtin_amdgcn_sched_barrier(0);
     }
-    after_reads();                                         // (the second part of a stage: the next stage's DMA requests go out here, behind the stage's last LDS reads)
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < NUN; ++q) {
-        f32x4 V;
-        const int nu = NU0 + q;
-        // column combination nu of the row values (compile-time nu: the loop is unrolled)
-        switch (nu) {
-            case 0: V = f4_comb<0>(R[0], R[1], R[2], R[3], R[4], R[5]); break;
-            case 1: V = f4_comb<1>(R[0], R[1], R[2], R[3], R[4], R[5]); break;
-            case 2: V = f4_comb<2>(R[0], R[1], R[2], R[3], R[4], R[5]); break;
-            case 3: V = f4_comb<3>(R[0], R[1], R[2], R[3], R[4], R[5]); break;
-            case 4: V = f4_comb<4>(R[0], R[1], R[2], R[3], R[4], R[5]); break;
-            default: V = f4_comb<5>(R[0], R[1], R[2], R[3], R[4], R[5]); break;
-        }
-        // the filter fragments of the NEXT position (of this part, or the first one of what follows) are requested before this position's MFMAs
+    f4_static_for<0, NUN>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, nu = NU0 + q;
+        const f32x4 V = f4_comb<nu>(R[0], R[1], R[2], R[3], R[4], R[5]);        // column combination nu of the row values
+        constexpr int pl = PL0 + q;
+        constexpr bool last = q == NUN - 1;
         f32x4 bnext[4];
-        const bool last = q == NUN - 1;
-        if (!last || more) {
-            const unsigned nb = last ? next_ub : ub + (unsigned)(XI * 6 + nu + 1) * pos_bytes;
+        auto prefetch = [&] {                              // the filter fragments of the NEXT position (of this part, or the first one of what follows)
+            if (!last || more) {
+                const unsigned nb = last ? next_ub : ub + (unsigned)(XI * 6 + nu + 1) * pos_bytes;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) bnext[n] = f4_buf_load4(ur, nb + n * 1024u);
-        }
+                for (int n = 0; n < 4; ++n) bnext[n] = f4_filter_load(ur, nb + n * 1024u);
+            }
+        };
+        if constexpr (q != BURST) prefetch();              // ... requested before this position's MFMAs
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int n = 0; n < 4; ++n) acc[pl][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[0], bcur[n][0], acc[pl][n], 0, 0, 0);
+        if constexpr (q == BURST) {
+            // the burst position: its own fragments have been waited for by the four MFMAs above (nothing younger in flight), so the requests and the prefetch
+            // behind them delay nothing here; the next wait on a younger batch is 12 MFMAs + the next part's row combinations away
+            __builtin_amdgcn_sched_barrier(0);
+            dma_burst();
+            prefetch();
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[PL0 + q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[s], bcur[n][s], acc[PL0 + q][n], 0, 0, 0);
+        for (int s = 1; s < 4; ++s)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[pl][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[s], bcur[n][s], acc[pl][n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (!last || more) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) bcur[n] = bnext[n];
         }
-    }
+    });
 }
 
 // nu sums of one row part: Z[b] = sum over the part's columns of A^T[b][nu] * M[nu], for the column block pair H (two 16-channel blocks) -> LDS slot SLOT
@@ -172,11 +197,13 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
 
     // ---- staging geometry: DMA instruction px (= patch pixel (px / 6, px % 6)) of a stage writes the 1 KB row px of the stage buffer; its lane L delivers slot L of
-    // that row = (tile L / 4, channel quad (L % 4 - tile / 4) & 3): the rotation spreads the 16 tiles of a fragment read over the 16 bank groups.  Per lane that is ONE
+    // that row = (tile L / 4, channel quad (L % 4 - 2 (tile / 8)) & 3): with that rotation the 16 lanes of every ds_read_b128 service group ({0-3, 12-15, 20-27}, ...:
+    // tiles 0-3 / 12-15 of one quad and tiles 4-11 of the next) hit 16 different 16-byte bank slots (a rotation by tile / 4 left every read a 2-way conflict:
+    // SQ_LDS_BANK_CONFLICT 48 % of the LDS cycles).  Per lane that is ONE
     // base offset (patch pixel (0, 0) of its tile, its quad) + a wave-uniform pixel offset, and a 6 + 6 bit row / column mask of the pixels inside the image ----
     unsigned tile_base, inside;
     {
-        const int tl = lane >> 2, qd = ((lane & 3) - (tl >> 2)) & 3;
+        const int tl = lane >> 2, qd = ((lane & 3) - 2 * (tl >> 3)) & 3;
         const int T = m_tile * F4_TB + tl;
         const int img = fdiv(T, p.d_tpi), rem = T - img * p.tpi;
         const int ty = fdiv(rem, p.d_TW), tx = rem - ty * p.TW;
@@ -190,21 +217,18 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
         }
     }
     const unsigned row_bytes = (unsigned)(p.W * p.Cin * 4), px_bytes = (unsigned)(p.Cin * 4);
-    auto request = [&](int stage, float* buf) {
+    auto request_piece = [&](int stage, float* buf, int k) {                            // k: compile-time at every call site
         unsigned tb = tile_base, in = inside;
-        asm volatile("" : "+v"(tb), "+v"(in));             // (the nine offsets are formed HERE, every stage: hoisted out of the stage loop they cost nine registers next to 144 accumulators)
-#pragma unroll
-        for (int k = 0; k < F4_KDMA; ++k) {
-            const int px = WV + 4 * k, i = px / 6, jx = px - 6 * i;                     // compile-time
-            const bool ok = ((in >> i) & (in >> (6 + jx)) & 1u) != 0;
-            const unsigned off = ok ? tb + (unsigned)i * row_bytes + (unsigned)jx * px_bytes : F4_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (f4_lds_void*)(buf + px * 256), 16, off, (unsigned)stage * 64u, 0, 0);
-        }
+        asm volatile("" : "+v"(tb), "+v"(in));             // (the offset is formed HERE: hoisted out of the stage loop the nine of them cost nine registers next to 144 accumulators)
+        const int px = WV + 4 * k, i = px / 6, jx = px - 6 * i;
+        const bool ok = ((in >> i) & (in >> (6 + jx)) & 1u) != 0;
+        const unsigned off = ok ? tb + (unsigned)i * row_bytes + (unsigned)jx * px_bytes : F4_OOB;
+        if constexpr ((F4_ABL & 4) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (f4_lds_void*)(buf + px * 256), 16, off, (unsigned)stage * 64u, 0, 0);
     };
 
     // ---- operands ----
     const int t16 = lane & 15, quad = lane >> 4;
-    const int lane_floats = (t16 * 4 + ((quad + (t16 >> 2)) & 3)) * 4;     // this lane's slot in every pixel row of a stage buffer
+    const int lane_floats = (t16 * 4 + ((quad + 2 * (t16 >> 3)) & 3)) * 4;     // this lane's slot in every pixel row of a stage buffer
     const unsigned nbg = (unsigned)(p.Cout >> 4);
     const unsigned pos_bytes = nbg * 1024u;                // bytes between consecutive positions of U
     const unsigned stage_bytes = 36u * pos_bytes;
@@ -218,25 +242,31 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[q][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    request(0, smem);
+#pragma unroll
+    for (int k = 0; k < F4_KDMA; ++k) request_piece(0, smem, k);
     f32x4 bcur[4];
     {
         const unsigned first = ublock + (unsigned)(XA * 6 + NA0) * pos_bytes;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) bcur[n] = f4_buf_load4(ur, first + n * 1024u);
+        for (int n = 0; n < 4; ++n) bcur[n] = f4_filter_load(ur, first + n * 1024u);
     }
     for (int s = 0; s < p.stages; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage s have landed (and the first filter fragments)
-        __builtin_amdgcn_s_barrier();                      // ... everyone's; and every wave is done reading the other buffer (stage s - 1)
+        if constexpr ((F4_ABL & 8) == 0) __builtin_amdgcn_s_barrier();                      // ... everyone's; and every wave is done reading the other buffer (stage s - 1)
         asm volatile("" ::: "memory");
         float* cur = smem + (s & 1) * F4_STAGE;
         float* nxt = smem + ((s + 1) & 1) * F4_STAGE;
         const float* Pl = cur + lane_floats;
         const unsigned ub = ublock + (unsigned)s * stage_bytes;
         const bool more = s + 1 < p.stages;
-        f4_part<XA, NA0, 3, 0>(Pl, acc, ur, ub, pos_bytes, bcur, [] {}, true, ub + (unsigned)(XB * 6) * pos_bytes);
-        f4_part<XB, 0, 6, 3>(Pl, acc, ur, ub, pos_bytes, bcur, [&] { if (more) request(s + 1, nxt); }, more,
-                             ub + stage_bytes + (unsigned)(XA * 6 + NA0) * pos_bytes);
+        auto burst = [&] {                                 // (the other buffer: every wave is past this stage's barrier, i.e. done with it)
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < F4_KDMA; ++k) request_piece(s + 1, nxt, k);
+            }
+        };
+        f4_part<XA, NA0, 3, 0, 2>(Pl, acc, ur, ub, pos_bytes, bcur, burst, true, ub + (unsigned)(XB * 6) * pos_bytes);
+        f4_part<XB, 0, 6, 3, -1>(Pl, acc, ur, ub, pos_bytes, bcur, burst, more, ub + stage_bytes + (unsigned)(XA * 6 + NA0) * pos_bytes);
     }
 
     // ---- output transform ----
