@@ -98,10 +98,12 @@ __device__ __forceinline__ void f4_static_for(F&& f) {
 }
 // One row part of a wave: row XI of the transform domain, columns NU0 .. NU0 + NUN - 1, accumulators PL0 .. PL0 + NUN - 1.
 // Pl: this lane's slot in the current stage buffer (+ 256 floats per patch pixel); ub: byte offset of (stage, position 0, this block's first column block, this lane).
-// BURST: the position of this part (local index, -1: none) behind whose first four MFMAs the next stage's DMA requests go out.
-template <int XI, int NU0, int NUN, int PL0, int BURST, typename DMA>
-__device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][4], __amdgpu_buffer_rsrc_t ur, unsigned ub, unsigned pos_bytes, f32x4 (&bcur)[4], DMA dma_burst,
-                                        bool more, unsigned next_ub) {
+// BURST: the position of the STAGE (0 .. 8, -1: none in this part) behind whose first four MFMAs the next stage's DMA requests go out.
+// B: ring of three fragment sets: position pl of a stage multiplies with B[pl % 3]; the set of position pl + 2 is requested at position pl (nine positions per stage:
+// the ring index carries over from stage to stage).  POS(k): transform-domain position (xi * 6 + nu) of the wave's k-th position of a stage.
+template <int XI, int NU0, int NUN, int PL0, int BURST, typename DMA, typename POS>
+__device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][4], __amdgpu_buffer_rsrc_t ur, unsigned ub, unsigned pos_bytes, unsigned stage_bytes, f32x4 (&B)[3][4],
+                                        DMA dma_burst, bool more, POS pos_of) {
     // row combination XI of the six patch columns as a chain of multiply-adds over the rows it uses, term by term (18 - 24 terms: column-major), the reads a ring of
     // DEPTH terms ahead: ~DEPTH x 16 cycles of vector work cover an LDS read (with the read one term ahead every term waited ~50 cycles for its operand: 30 % of the
     // wave time at s_waitcnt), and four 16-byte temporaries are what the registers next to 144 accumulators allow (the compiler, left alone, issues all reads of the
@@ -131,22 +133,22 @@ __device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][4], __a
         constexpr int q = decltype(qc)::value, nu = NU0 + q;
         const f32x4 V = f4_comb<nu>(R[0], R[1], R[2], R[3], R[4], R[5]);        // column combination nu of the row values
         constexpr int pl = PL0 + q;
-        constexpr bool last = q == NUN - 1;
-        f32x4 bnext[4];
-        auto prefetch = [&] {                              // the filter fragments of the NEXT position (of this part, or the first one of what follows)
-            if (!last || more) {
-                const unsigned nb = last ? next_ub : ub + (unsigned)(XI * 6 + nu + 1) * pos_bytes;
+        f32x4 (&bcur)[4] = B[pl % 3];
+        auto prefetch = [&] {                              // the filter fragments of the position after next (of this stage, or the first / second one of the next stage)
+            constexpr int t = pl + 2;
+            if (t < 9 || more) {
+                const unsigned nb = t < 9 ? ub + (unsigned)pos_of(t) * pos_bytes : ub + stage_bytes + (unsigned)pos_of(t - 9) * pos_bytes;
 #pragma unroll
-                for (int n = 0; n < 4; ++n) bnext[n] = f4_filter_load(ur, nb + n * 1024u);
+                for (int n = 0; n < 4; ++n) B[t % 3][n] = f4_filter_load(ur, nb + n * 1024u);
             }
         };
-        if constexpr (q != BURST) prefetch();              // ... requested before this position's MFMAs
+        if constexpr (pl != BURST) prefetch();             // ... requested before this position's MFMAs
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[pl][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[0], bcur[n][0], acc[pl][n], 0, 0, 0);
-        if constexpr (q == BURST) {
-            // the burst position: its own fragments have been waited for by the four MFMAs above (nothing younger in flight), so the requests and the prefetch
-            // behind them delay nothing here; the next wait on a younger batch is 12 MFMAs + the next part's row combinations away
+        if constexpr (pl == BURST) {
+            // the burst position: its own fragments and the next position's are older than the requests, so nothing here waits for them; the first younger batch
+            // (position pl + 2) is waited for 12 MFMAs + the next part's row combinations + one whole position later
             __builtin_amdgcn_sched_barrier(0);
             dma_burst();
             prefetch();
@@ -157,10 +159,6 @@ __device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][4], __a
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[pl][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[s], bcur[n][s], acc[pl][n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (!last || more) {
-#pragma unroll
-            for (int n = 0; n < 4; ++n) bcur[n] = bnext[n];
-        }
     });
 }
 
@@ -244,12 +242,12 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
 
 #pragma unroll
     for (int k = 0; k < F4_KDMA; ++k) request_piece(0, smem, k);
-    f32x4 bcur[4];
-    {
-        const unsigned first = ublock + (unsigned)(XA * 6 + NA0) * pos_bytes;
+    auto pos_of = [](int k) { return k < 3 ? XA * 6 + NA0 + k : XB * 6 + (k - 3); };     // the wave's k-th position of a stage
+    f32x4 B[3][4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) bcur[n] = f4_filter_load(ur, first + n * 1024u);
-    }
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) B[k][n] = f4_filter_load(ur, ublock + (unsigned)pos_of(k) * pos_bytes + n * 1024u);
     for (int s = 0; s < p.stages; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage s have landed (and the first filter fragments)
         if constexpr ((F4_ABL & 8) == 0) __builtin_amdgcn_s_barrier();                      // ... everyone's; and every wave is done reading the other buffer (stage s - 1)
@@ -265,8 +263,8 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
                 for (int k = 0; k < F4_KDMA; ++k) request_piece(s + 1, nxt, k);
             }
         };
-        f4_part<XA, NA0, 3, 0, 2>(Pl, acc, ur, ub, pos_bytes, bcur, burst, true, ub + (unsigned)(XB * 6) * pos_bytes);
-        f4_part<XB, 0, 6, 3, -1>(Pl, acc, ur, ub, pos_bytes, bcur, burst, more, ub + stage_bytes + (unsigned)(XA * 6 + NA0) * pos_bytes);
+        f4_part<XA, NA0, 3, 0, 2>(Pl, acc, ur, ub, pos_bytes, stage_bytes, B, burst, more, pos_of);
+        f4_part<XB, 0, 6, 3, -1>(Pl, acc, ur, ub, pos_bytes, stage_bytes, B, burst, more, pos_of);
     }
 
     // ---- output transform ----
