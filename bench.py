@@ -145,7 +145,8 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
                    "stem_pool_fwd": 0,               # the fused stem: conv1 + bn1 + relu + maxpool in one launch — its pooling is inside the timed launch
                    "bottleneck_chain_fwd": 0,        # conv3 + skip of one bottleneck and conv1 of the next in one launch
                    "conv1x1_rows_fwd": 0,            # K = 128 1x1 layers as a row-streaming GEMM
-                   "conv3x3_winograd_c32_fwd": 9}    # 32 -> 32 channel 3x3 layers (HRNet): wave-private Winograd
+                   "conv3x3_winograd_c32_fwd": 9,    # 32 -> 32 channel 3x3 layers (HRNet): wave-private Winograd
+                   "conv3x3_winograd_f4_fwd": 9}     # 3x3 layers on grids of whole 4x4 tiles: Winograd F(4x4,3x3)
     originals = {n: getattr(vh, n) for n in timed_names}
 
     inside = [0]                                           # metered launches made inside timed entry-point calls
@@ -195,7 +196,7 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": (traffic / len(events)) if traffic else None,
-            "metered_launches": metered, "timed_calls": len(events), "kernel": "stem_pool_kernel + conv_igemm_kernel + gemm1x1_persistent2_kernel + conv1x1_rows_kernel + bottleneck_chain_kernel + winograd_kernel / winograd_persist_kernel (all conv/deconv launches of one step; the stem launch includes bn1 + relu + maxpool; 4 launches fuse a projection shortcut with the block's last conv, 1 chains a block's last conv with the next block's first; the 13 3x3 stride-1 layers run as Winograd F(2x2,3x3), the 3 transposed convs as F(3x3,2x2) on their four phases)", "launches": len(events),
+            "metered_launches": metered, "timed_calls": len(events), "kernel": "stem_pool_kernel + conv_igemm_kernel + gemm1x1_persistent2_kernel + conv1x1_rows_kernel + bottleneck_chain_kernel + winograd_kernel / winograd_persist_kernel (all conv/deconv launches of one step; the stem launch includes bn1 + relu + maxpool; 4 launches fuse a projection shortcut with the block's last conv, 1 chains a block's last conv with the next block's first; of the 13 3x3 stride-1 layers the 11 on grids of whole 4x4 tiles run as Winograd F(4x4,3x3) (winograd_f4_kernel), the 2 at 8x6 as F(2x2,3x3), the 3 transposed convs as F(3x3,2x2) on their four phases)", "launches": len(events),
             # `achieved` / `frac`: MFMA FLOPs the launches EXECUTE (counted per launch by libvatl_hip.so: 2 x padded M x padded N x padded K; the
             # Winograd launches their 16 transform-domain GEMMs) / event-timed duration / peak = how busy the matrix pipe is.
             # `algorithmic_*`: the step's direct-sum FLOPs (10.853 GFLOP x frames) over the same time; the Winograd launches deliver

@@ -692,12 +692,18 @@ def test_streamk_route_matches_the_whole_tile_kernels(vh):
 # ---------------------------------------------------------------------------------------------------------------------
 
 def _count_winograd(vh, monkeypatch):
-    calls = {"conv": 0, "deconv": 0, "splitk": 0}
+    calls = {"conv": 0, "deconv": 0, "splitk": 0, "f4": 0}
     oc, od = vh.conv3x3_winograd_fwd, vh.deconv4x4s2_winograd_fwd
     monkeypatch.setattr(vh, "conv3x3_winograd_fwd", lambda *a, **k: (calls.__setitem__("conv", calls["conv"] + 1), oc(*a, **k))[1])
     o32 = vh.conv3x3_winograd_c32_fwd                      # (the 32 -> 32 channel layers' own Winograd kernel counts as a Winograd launch)
     monkeypatch.setattr(vh, "conv3x3_winograd_c32_fwd", lambda *a, **k: (calls.__setitem__("conv", calls["conv"] + 1), o32(*a, **k))[1])
     monkeypatch.setattr(vh, "deconv4x4s2_winograd_fwd", lambda *a, **k: (calls.__setitem__("deconv", calls["deconv"] + 1), od(*a, **k))[1])
+    o4 = vh.conv3x3_winograd_f4_fwd                        # (F(4x4,3x3) launches: Winograd launches too, counted on their own as well)
+
+    def f4(*a, **k):
+        calls["conv"] += 1; calls["f4"] += 1
+        return o4(*a, **k)
+    monkeypatch.setattr(vh, "conv3x3_winograd_f4_fwd", f4)
     return calls
 
 
@@ -710,7 +716,9 @@ def _eligible(m, head):
     return c, d
 
 
-STREAM_CASES = [("simplepose_r50", (13, 3)), ("fastpose_r50", (15, 0)), ("hrnet_w32", (213, 0)), ("fastpose_r152_384", (49, 0))]
+# (3x3 Winograd launches, transposed-conv Winograd launches, how many of the former are F(4x4,3x3): R50 = stages 1 - 3 (3 + 3 + 5; stage 4 is 8x6); FastPose-R50 adds the
+#  two DUC convs; HRNet-W32 = the 64- and 128-channel branch convs; R152 at 384x288 = stage 1 (3) + stage 2 (7: 48x36) + duc2 (48x36) — 24x18 and 12x9 are not whole tiles)
+STREAM_CASES = [("simplepose_r50", (13, 3, 11)), ("fastpose_r50", (15, 0, 13)), ("hrnet_w32", (213, 0, None)), ("fastpose_r152_384", (49, 0, None))]
 
 
 @pytest.mark.parametrize("case", STREAM_CASES, ids=[c[0] for c in STREAM_CASES])
@@ -724,7 +732,7 @@ def test_stream_route_vs_reference_golden(vh, monkeypatch, case):
     from alphapose.models import builder, hip_engine
     from alphapose.utils.config import edict
     from oracle import scorers
-    name, (want_conv, want_deconv) = case
+    name, (want_conv, want_deconv, want_f4) = case
     gdir = os.path.join(os.path.dirname(__file__), "golden")
     hw = (256, 192)
     if name == "simplepose_r50":
@@ -754,9 +762,10 @@ def test_stream_route_vs_reference_golden(vh, monkeypatch, case):
         s = score_batch(out, to_dev(bb), ip, inx, thc_norm="L1")
     torch.cuda.synchronize()
     assert (calls["conv"], calls["deconv"]) == (want_conv, want_deconv), calls
+    assert calls["f4"] == want_f4 if want_f4 is not None else calls["f4"] >= 8, calls
     hm = out.cpu().numpy()
     e = rel_err(hm, ref)
-    record(f"stream_route_{name}", rel=e, winograd_conv=calls["conv"], winograd_deconv=calls["deconv"])
+    record(f"stream_route_{name}", rel=e, winograd_conv=calls["conv"], winograd_deconv=calls["deconv"], winograd_f4=calls["f4"])
     assert e < 1e-4                                                                   # north_star: heat-maps within 1e-4 rel fp32
     ref_idx = ref.reshape(n, 17, -1).argmax(2)
     assert np.array_equal(hm.reshape(n, 17, -1).argmax(2), ref_idx)                   # integer peak indices bit-exact

@@ -49,10 +49,14 @@ ROWS_GEMM = True
 # 32 -> 32 channel 3x3 layers (HRNet's highest-resolution branch) through the wave-private Winograd kernel (csrc/winograd_c32.hip: a wave owns 16 tiles with all 16
 # transform positions, no cross-wave exchange).  False = the general Winograd kernel (same values to fp32 rounding, not the same bits).
 WINO_C32 = True
+# 3x3 / stride 1 / pad 1 layers with >= 64 input channels, a multiple of 64 output channels and a grid of whole 4x4 tiles (ResNet stages 1 - 3 at 256x192, HRNet's 64- and
+# 128-channel branches, the DUC convs) as Winograd F(4x4,3x3) (csrc/winograd_f4.hip: 0.5625x the multiplies of F(2x2); measured 1.17 - 1.47x at 1024 crops, tools/f4_bench.py).
+# Geometry-only choice like WINOGRAD: a crop's bits do not depend on its batch.  False = the F(2x2) route (same values to fp32 rounding, not the same bits).
+WINO_F4 = True
 
 
 class _Conv:
-    __slots__ = ("w", "u", "u32", "scale", "bias", "cout", "r", "s", "stride", "pad")
+    __slots__ = ("w", "u", "u32", "u4", "scale", "bias", "cout", "r", "s", "stride", "pad")
 
     def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d | None):
         assert conv.groups == 1 and conv.dilation == (1, 1)
@@ -66,6 +70,9 @@ class _Conv:
         self.u32 = None
         if self.u is not None and WINO_C32 and conv.in_channels == 32 and self.cout == 32:
             self.u32 = vh.pack_winograd_c32_weight(conv.weight.detach())
+        self.u4 = None
+        if self.u is not None and WINO_F4 and conv.in_channels >= 64 and conv.in_channels % 16 == 0 and self.cout % 64 == 0:
+            self.u4 = vh.pack_winograd_f4_weight(conv.weight.detach())
         cb = conv.bias.detach() if conv.bias is not None else None
         if bn is not None:
             self.scale, self.bias = vh.bn_fold(_d(bn.weight), _d(bn.bias), bn.running_mean, bn.running_var, bn.eps, cb)
@@ -78,6 +85,8 @@ class _Conv:
         if self.u is not None and not out_nchw and not vh.latency_mode():
             if self.u32 is not None and vh.conv3x3_winograd_c32_supported(x.shape[0], x.shape[1], x.shape[2], 32, 32):
                 return vh.conv3x3_winograd_c32_fwd(x, self.u32, self.scale, self.bias, relu, residual=residual, out=out)
+            if self.u4 is not None and vh.conv3x3_winograd_f4_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.cout):
+                return vh.conv3x3_winograd_f4_fwd(x, self.u4, self.scale, self.bias, self.cout, relu, residual=residual, out=out)
             return vh.conv3x3_winograd_fwd(x, self.u, self.scale, self.bias, self.cout, relu, residual=residual, out=out)
         if (ROWS_GEMM and self.r == 1 and self.stride == 1 and not out_nchw and not vh.latency_mode() and x.shape[-1] == 128
                 and vh.conv1x1_rows_supported(128, 0, self.cout, x.shape[0] * x.shape[1] * x.shape[2])):
