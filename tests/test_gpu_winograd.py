@@ -142,27 +142,44 @@ def test_winograd_data_gradient_filter(vh):
 
 
 def test_inference_plans_route_3x3_layers_through_winograd(vh, monkeypatch):
-    """SimplePose-R50: the 13 stride-1 3x3 layers of the trunk take the Winograd route; the heat-maps agree with the
-    all-implicit-GEMM plan to the layer tolerance."""
+    """SimplePose-R50: the 13 stride-1 3x3 layers of the trunk take the Winograd routes — F(4x4,3x3) for the 11 on grids of whole 4x4 tiles (stages 1 - 3),
+    F(2x2,3x3) for the two at 8x6; with WINO_F4 off all 13 take F(2x2) and the heat-maps agree to fp32 rounding; both agree with the all-implicit-GEMM plan
+    to the layer tolerance."""
     from alphapose.models import hip_engine
     from oracle import synth
     from tests.test_gpu_conv import _build_simplepose
     m = _build_simplepose()
     x = to_dev(synth.crops(3))
-    calls = []
-    orig = vh.conv3x3_winograd_fwd
+    calls, calls4 = [], []
+    orig, orig4 = vh.conv3x3_winograd_fwd, vh.conv3x3_winograd_f4_fwd
     monkeypatch.setattr(vh, "conv3x3_winograd_fwd", lambda *a, **k: (calls.append(a[0].shape), orig(*a, **k))[1])
+    monkeypatch.setattr(vh, "conv3x3_winograd_f4_fwd", lambda *a, **k: (calls4.append(a[0].shape), orig4(*a, **k))[1])
     out = torch.empty((3, 17, 64, 48), device=dev())
     with torch.no_grad():
         hip_engine.forward_into(m, x, out)
-    assert len(calls) == 13
+    assert (len(calls), len(calls4)) == (2, 11) and all(s[1] % 4 == 0 and s[2] % 4 == 0 for s in calls4) and all(tuple(s[1:3]) == (8, 6) for s in calls)
+    monkeypatch.setattr(hip_engine, "WINO_F4", False)
+    m.__dict__.pop("_vatl_plan", None)
+    f2 = torch.empty_like(out)
+    with torch.no_grad():
+        hip_engine.forward_into(m, x, f2)
+    assert (len(calls), len(calls4)) == (15, 11)
+    e42 = rel_err(out.cpu().numpy(), f2.cpu().numpy())
+    record("winograd_f4_vs_f2_simplepose_r50", rel=e42)
+    assert e42 < 2e-5 and torch.equal(out.flatten(2).argmax(-1), f2.flatten(2).argmax(-1))
+    del calls[:]
+    del calls4[:]
+    monkeypatch.setattr(hip_engine, "WINO_F4", True)
+    m.__dict__.pop("_vatl_plan", None)
+    with torch.no_grad():
+        hip_engine.forward_into(m, x, out)
     monkeypatch.setattr(hip_engine, "WINOGRAD", False)
     m.__dict__.pop("_vatl_plan", None)
     direct = torch.empty_like(out)
     with torch.no_grad():
         hip_engine.forward_into(m, x, direct)
     m.__dict__.pop("_vatl_plan", None)
-    assert len(calls) == 13
+    assert (len(calls), len(calls4)) == (2, 11)            # the all-implicit-GEMM plan made no Winograd launch
     e = rel_err(out.cpu().numpy(), direct.cpu().numpy())
     record("winograd_vs_direct_simplepose_r50", rel=e)
     assert e < 1e-4
@@ -299,7 +316,7 @@ def test_small_batch_module_calls_stay_on_the_implicit_gemm(vh, monkeypatch):
     m = _build_simplepose()
     x = to_dev(synth.crops(4))
     calls = []
-    for name in ("conv3x3_winograd_fwd", "deconv4x4s2_winograd_fwd"):
+    for name in ("conv3x3_winograd_fwd", "conv3x3_winograd_f4_fwd", "deconv4x4s2_winograd_fwd"):
         orig = getattr(vh, name)
         monkeypatch.setattr(vh, name, (lambda o: lambda *a, **k: (calls.append(1), o(*a, **k))[1])(orig))
     with torch.no_grad():

@@ -11,7 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "vatl4pose-wacv2024_amd")):
 import torch  # noqa: E402
 import vatl_hip as vh  # noqa: E402
 
-NAMES = ["conv2d_fwd", "conv3x3_winograd_fwd", "conv3x3_winograd_c32_fwd", "conv1x1_dual_fwd", "conv1x1_rows_fwd", "fuse_upsample_add", "bottleneck_chain_fwd", "stem3_fwd", "stem_pool_fwd", "deconv4x4s2_winograd_fwd", "deconv4x4s2_fwd",
+NAMES = ["conv2d_fwd", "conv3x3_winograd_fwd", "conv3x3_winograd_f4_fwd", "conv3x3_winograd_c32_fwd", "conv1x1_dual_fwd", "conv1x1_rows_fwd", "fuse_upsample_add", "bottleneck_chain_fwd", "stem3_fwd", "stem_pool_fwd", "deconv4x4s2_winograd_fwd", "deconv4x4s2_fwd",
          "fuse_up", "maxpool3x3s2_fwd", "nchw_to_nhwc", "pixelshuffle2_fwd", "se_scale_add_relu", "gap_fwd"]
 
 
@@ -50,7 +50,7 @@ def main():
             extra = ""
             if name == "conv2d_fwd":
                 extra = f" k{a[5]} s{a[7]}" + (" +res" if k.get("residual") is not None else "")
-            elif name == "conv3x3_winograd_fwd":
+            elif name in ("conv3x3_winograd_fwd", "conv3x3_winograd_f4_fwd"):
                 extra = " +res" if k.get("residual") is not None else ""
             events.append((name + extra, tuple(t0.shape[1:]), tuple(ro.shape[1:]), e0, e1))
             return r
