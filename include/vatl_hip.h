@@ -50,7 +50,7 @@ int vatl_flop_meter_end(double* direct_flops, double* winograd_flops, int64_t* d
  * BatchNorm-backward epilogue, ...) instead of trusting the dispatch rules. */
 #define VATL_ROUTE_NAMES "igemm,igemm_bnbwd,igemm_dma,persistent_1x1,streamk,rows_1x1,bottleneck_chain,stem_pool,halo_3x3," \
                          "winograd,winograd_2h,winograd_bnbwd,winograd_persist,winograd_c32,wgrad,winograd_wgrad,winograd_wgrad_2h," \
-                         "winograd_wgrad_table,winograd_f4"
+                         "winograd_wgrad_table,winograd_f4,winograd_f4_bnbwd"
 int vatl_flop_meter_routes(int64_t* counts, int n);
 
 /* ------------------------------------------------------------------------ *
@@ -136,10 +136,20 @@ int vatl_conv3x3_winograd_c32_fwd(const float* x, const float* u, const float* s
  * multiples of 4, Cin >= 64 a multiple of 16, Cout a multiple of 64.  Exact fp32 products and sums like the F(2x2) route; the rounding differs in the last bits (tests hold both
  * routes to the same float64 bound), and a crop's bits do not depend on its batch position. */
 int64_t vatl_winograd_f4_weight_floats(int Cout, int Cin);
-int vatl_pack_winograd_f4_weight(const float* w, float* u, int Cout, int Cin, void* stream);
+/* (Cout, Cin) describe the PACKED filter; data_gradient: w is the forward filter (O = Cin, I = Cout, 3, 3) and u the filter of dX = conv(dY, rot180(w)^T). */
+int vatl_pack_winograd_f4_weight(const float* w, float* u, int Cout, int Cin, int data_gradient, void* stream);
 int vatl_conv3x3_winograd_f4_supported(int N, int H, int W, int Cin, int Cout);
 int vatl_conv3x3_winograd_f4_fwd(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, int N, int H, int W,
                                  int Cin, int Cout, int relu, void* stream);
+/* The same launch under `model.train()` (ActiveLearning.py:658-673), F(4x4,3x3) counterparts of vatl_conv3x3_winograd_fwd_stats / _fwd_bnbwd: _stats: y = conv(x) and the
+ * per-(16-tile row block, channel) double (sum, sum of squares) partials of y in the layout vatl_bn_train_finalize reduces; _bnbwd (u packed with data_gradient = 1):
+ * y = (conv(x) + residual) * [consumer layer's ReLU mask], `stats` the (sum g, sum g * xhat) partials.  Capacity vatl_winograd_f4_stats_row_blocks(N, H, W) * Cout * 2 doubles. */
+int64_t vatl_winograd_f4_stats_row_blocks(int64_t N, int H, int W);
+int vatl_conv3x3_winograd_f4_fwd_stats(const float* x, const float* u, float* y, double* stats, int64_t* row_blocks_used, int N, int H, int W, int Cin, int Cout,
+                                       void* stream);
+int vatl_conv3x3_winograd_f4_fwd_bnbwd(const float* x, const float* u, const float* residual, float* y, int N, int H, int W, int Cin, int Cout, const float* bn_z,
+                                       const float* bn_mask_y, const float* bn_scale, const float* bn_bias, const float* bn_mean, const float* bn_invstd,
+                                       double* stats, int64_t* row_blocks_used, void* stream);
 
 /* 1x1 convolution with K = 128 input channels as a row-streaming GEMM (csrc/conv1x1_rows.hip): y = act(scale * (A W^T) + bias + residual) for the short-K /
  * wide-N layers the tiled implicit GEMM runs far from both roofs (Bottleneck.conv3 of ResNet stage 2, Resnet.py:120-128; with x2: conv3 + projection
@@ -440,6 +450,8 @@ int vatl_bn_train_bwd_relu_pool(const float* dpool, const uint8_t* idx, const fl
  * kind 5: Winograd F(3x3,2x2) phase filters of ConvTranspose2d(4,2,1) (vatl_pack_winograd_deconv_weight): src (Cin,Cout,4,4), a / b as
  *   for kinds 3 / 4, c = Cout;  kind 6: the filters of its data gradient (vatl_pack_winograd_deconv_dgrad_weight): (Cout, Cin) fields =
  *   (layer Cin, layer Cout), c = layer Cout;
+ * kind 7 / 8: Winograd F(4x4,3x3) filter transform, forward / data gradient (vatl_pack_winograd_f4_weight): (Cout, Cin) of the PACKED filter, c = inner dimension
+ *   of src; ceil(elements / 1024) blocks.
  * kind 3 / 4: Winograd F(2x2,3x3) filter transform, forward / data gradient (vatl_pack_winograd_weight): (Cout, Cin) of the PACKED
  *   filter, a = its padded Cout, b = 32-channel groups per tile (a / 32 <= 1 ? 1 : 2), c = Cin (kind 3) or Cout (kind 4) = the inner
  *   dimension of src. */

@@ -578,3 +578,69 @@ def test_winograd_f4_vs_float64_and_the_f2_route(vh):
             assert torch.equal(vh.conv3x3_winograd_f4_fwd(xd, u4, to_dev(sc), to_dev(bi), cout, True, residual=rd), full)      # same bits again
     with pytest.raises(vh.VatlError):
         vh.conv3x3_winograd_f4_fwd(to_dev(r.standard_normal((1, 6, 8, 64)).astype(np.float32)), u4, None, None, 64, False)
+
+
+def test_winograd_f4_training_epilogues(vh):
+    """The F(4x4,3x3) kernel under `model.train()`: (1) statistics epilogue: z bit-identical to the plain launch, the (sum, sum^2) row-block partials equal to the
+    sums of the stored tensor, and the finalized mean / inverse deviation equal to float64 statistics of z; (2) the data-gradient packing against autograd in
+    float64; (3) the BatchNorm-backward epilogue (mask recomputed from z / taken from a saved output / none; with and without a residual): g = (conv + residual) *
+    mask with the plain launch's bits, (sum g, sum g * xhat) against float64 sums of the stored g, bit-reproducible; (4) the step's one re-pack launch refreshes
+    the F(4x4) filters with the bits of the pack kernel."""
+    g = torch.Generator(device="cpu").manual_seed(29)
+    for n, h, w, cin, cout in ((5, 16, 12, 64, 64), (3, 8, 12, 128, 256), (17, 4, 4, 64, 128)):
+        x = torch.randn((n, h, w, cin), generator=g).to(dev())
+        wt = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev())
+        u = vh.pack_winograd_f4_weight(wt)
+        plain = vh.conv3x3_winograd_f4_fwd(x, u, None, None, cout, False)
+        gamma, beta = (torch.rand(cout, generator=g) + 0.5).to(dev()), torch.randn(cout, generator=g).to(dev())
+        rm, rv = torch.zeros(cout, device=dev()), torch.ones(cout, device=dev())
+        z, mean, invstd, scale, bias = vh.conv3x3_winograd_f4_fwd_bnstats(x, u, cout, gamma, beta, rm, rv, 0.1, 1e-5)
+        assert torch.equal(z, plain)
+        z64 = z.double().reshape(-1, cout)
+        assert torch.allclose(mean.double(), z64.mean(0), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(invstd.double(), 1.0 / (z64.var(0, unbiased=False) + 1e-5).sqrt(), rtol=1e-5)
+        assert torch.allclose(rm.double(), 0.1 * z64.mean(0), rtol=1e-5, atol=1e-6)
+        # (2) data gradient: a 3x3 conv of dz with cout input and cin output channels (cin % 64 == 0 in every case here)
+        dy = torch.randn((n, h, w, cout), generator=g).to(dev())
+        xr = x.double().permute(0, 3, 1, 2).cpu().requires_grad_(True)
+        F.conv2d(xr, wt.double().cpu(), None, 1, 1).backward(dy.double().permute(0, 3, 1, 2).cpu())
+        ud = vh.pack_winograd_f4_weight(wt, data_gradient=True)
+        dx = vh.conv3x3_winograd_f4_fwd(dy, ud, None, None, cin, False)
+        e = rel_err(dx.permute(0, 3, 1, 2).cpu().numpy(), xr.grad.numpy())
+        record(f"winograd_f4_dgrad_{cin}_{cout}", rel=e)
+        assert e < 2e-5, e
+        # (3) BatchNorm-backward epilogue of that data gradient; the consumer layer's conv output zc has the data gradient's shape (n, h, w, cin)
+        zc = torch.randn((n, h, w, cin), generator=g).to(dev())
+        yc = torch.randn((n, h, w, cin), generator=g).to(dev())
+        mu, isd = zc.reshape(-1, cin).mean(0), 1.0 / (zc.reshape(-1, cin).var(0, unbiased=False) + 1e-5).sqrt()
+        s2, b2 = (torch.rand(cin, generator=g) + 0.5).to(dev()), (torch.randn(cin, generator=g) * 0.3).to(dev())
+        res = torch.randn((n, h, w, cin), generator=g).to(dev())
+        for kind, use_res in (("recompute", False), ("saved", True), ("none", True)):
+            def run():
+                spec = vh.BnBwdSpec(zc, mu, isd, scale=s2, bias=b2) if kind == "recompute" else (vh.BnBwdSpec(zc, mu, isd, mask_y=yc) if kind == "saved" else vh.BnBwdSpec(zc, mu, isd))
+                gq = vh.conv3x3_winograd_f4_fwd_bnbwd(dy, ud, cin, spec, residual=res if use_res else None)
+                return gq, spec.stats[:spec.blocks * cin * 2].clone(), spec.blocks
+            (ga, ta, blocks), (gb, tb, _) = run(), run()
+            assert torch.equal(ga, gb) and torch.equal(ta, tb)
+            d = vh.conv3x3_winograd_f4_fwd(dy, ud, None, None, cin, False, residual=res if use_res else None)
+            mask = (zc * s2 + b2 > 0) if kind == "recompute" else ((yc > 0) if kind == "saved" else torch.ones_like(zc, dtype=torch.bool))
+            assert torch.equal(ga, torch.where(mask, d, torch.zeros_like(d))), kind
+            sums = ta.view(blocks, cin, 2).sum(0)
+            g64, xhat = ga.double().reshape(-1, cin), ((zc - mu) * isd).double().reshape(-1, cin)
+            assert torch.allclose(sums[:, 0], g64.sum(0), rtol=1e-5, atol=1e-3) and torch.allclose(sums[:, 1], (g64 * xhat).sum(0), rtol=1e-5, atol=1e-3), kind
+        # (4) the pack plan
+        plan = vh.PackPlan()
+        prev = vh.set_pack_plan(plan)
+        try:
+            plan.begin()
+            first = (vh.pack_winograd_f4_weight(wt), vh.pack_winograd_f4_weight(wt, data_gradient=True), vh.pack_conv_weight(wt))
+            plan.seal()
+            want = [t.clone() for t in first]
+            for t in first:
+                t.zero_()
+            plan.begin()                                           # the one launch re-packs all three
+            again = (vh.pack_winograd_f4_weight(wt), vh.pack_winograd_f4_weight(wt, data_gradient=True), vh.pack_conv_weight(wt))
+            assert all(a.data_ptr() == b.data_ptr() for a, b in zip(first, again)) and all(torch.equal(a, b) for a, b in zip(again, want))
+        finally:
+            vh.set_pack_plan(prev)
+        assert torch.equal(want[0], u) and torch.equal(want[1], ud)

@@ -14,6 +14,7 @@ removed at the Python level (the results are then WRONG — only the step time i
   bn_minc64       BatchNorm-backward epilogue also for the 64-channel layers (hip_train._FUSE_BN_MIN_C = 64)
   wwg_minc64/256  Winograd weight gradients from 64 / 256 channels on (hip_train._WINOGRAD_WGRAD_MIN_C)
   one_stream      weight gradients on the main stream
+  f4_off / f4_on  F(4x4,3x3) for the 3x3 layers' forward + data gradient off / on (NOT an ablation: both are correct; hip_train._WINOGRAD_F4)
 """
 import json
 import os
@@ -128,6 +129,8 @@ VARIANTS = [
     ("wwg_minc64", lambda: patch(hip_train, "_WINOGRAD_WGRAD_MIN_C", 64)),
     ("wwg_minc256", lambda: patch(hip_train, "_WINOGRAD_WGRAD_MIN_C", 256)),
     ("one_stream", lambda: patch(hip_train._side, "enabled", False)),
+    ("f4_off", lambda: patch(hip_train, "_WINOGRAD_F4", False)),
+    ("f4_on", lambda: patch(hip_train, "_WINOGRAD_F4", True)),
     ("base", lambda: None),
 ]
 for name, setup in VARIANTS:

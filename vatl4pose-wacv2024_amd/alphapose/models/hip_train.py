@@ -129,6 +129,13 @@ def _gout(grads, p):
 # stand-alone reduction pass (same values up to the summation order of the per-channel sums)
 _FUSE_BN_BWD = True
 _WINOGRAD = True    # 3x3 / stride-1 layers: forward + data gradient as Winograd F(2x2,3x3)
+# ... or as F(4x4,3x3) (csrc/winograd_f4.hip: 0.5625x the multiplies of F(2x2); statistics and BatchNorm-backward epilogues built and tested,
+# tests/test_gpu_winograd.py::test_winograd_f4_training_epilogues) where the grid is whole 4x4 tiles and the channel counts fit its 64-channel blocks (ResNet stages 1 - 3 at
+# 256x192, stages 1 - 2 at 384x288).  OFF for the fine-tune step, on measurement (profiles/r05_notes.md): at B = 120 / 32 the step gains 0.8 % / 1.5 % (36.8 -> 36.5 ms,
+# 55.1 -> 54.3 ms: 22 of ~500 launches, one more re-pack each), while F(4x4)'s larger transform constants cost ~4 bits per layer — invisible in the heat-maps, but in the
+# ill-conditioned default-initialisation gradient fixture (tests/test_gpu_train.py::test_b16_default_init_step_vs_reference_and_float64) the trunk gradients land 1.5 - 1.7x
+# as far from float64 as torch's own fp32 step (3.4e-2 against 2.1e-2), over that test's "as close to float64 as the reference is" bound.  Not worth it for < 2 %.
+_WINOGRAD_F4 = False
 # ... and the weight gradient from this many channels on (measured at B = 120, tools/wino_wgrad_bench.py: 128 channels 1.30x, 256 1.35x, 512 1.44x
 # over the implicit GEMM; 64 channels 1.0x, 32 channels slower — both operands are transformed per tile pair, 2.5x the vector work of the forward)
 _WINOGRAD_WGRAD_MIN_C = 128
@@ -222,12 +229,21 @@ class _ConvBN:
         # 3x3 / stride 1 / pad 1: forward and data gradient on the Winograd route (csrc/conv_winograd.hip; geometry-only choice)
         self.wino = (_WINOGRAD and (self.r, self.s, self.stride, self.pad) == (3, 3, 1, 1) and self.cin % 16 == 0 and self.cout % 16 == 0)
 
+    @staticmethod
+    def _f4(shape, cin, cout):
+        """F(4x4,3x3) serves this launch: whole 4x4 tiles, >= 64 input channels (a multiple of 16), output channels a multiple of 64."""
+        return _WINOGRAD_F4 and cin >= 64 and cin % 16 == 0 and cout % 64 == 0 and vh.conv3x3_winograd_f4_supported(int(shape[0]), int(shape[1]), int(shape[2]), cin, cout)
+
     # ---- forward -------------------------------------------------------------
     def forward(self, x, skip=None, relu=None):
         relu = self.relu if relu is None else relu
         bn = self.bn
         # z = conv(x); the batch statistics come out of the conv epilogue (no extra pass over z)
-        if self.wino:
+        if self.wino and self._f4(x.shape, self.cin, self.cout):
+            z, mean, invstd, scale, bias = vh.conv3x3_winograd_f4_fwd_bnstats(x, vh.pack_winograd_f4_weight(self.conv.weight.detach()), self.cout,
+                                                                              bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                                                              bn.momentum, bn.eps)
+        elif self.wino:
             z, mean, invstd, scale, bias = vh.conv3x3_winograd_fwd_bnstats(x, vh.pack_winograd_weight(self.conv.weight.detach()), self.cout,
                                                                            bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                                            bn.momentum, bn.eps)
@@ -319,6 +335,11 @@ class _ConvBN:
 
         def conv(*a, **k):                                # with a consumer spec: mask + BatchNorm-backward reduction in the epilogue
             return vh.conv2d_fwd_ex_bnbwd(*a, spec, **k) if spec is not None else vh.conv2d_fwd_ex(*a, **k)
+        if self.wino and self._f4(dz.shape, self.cout, cin):           # the data gradient is a 3x3 conv of dz with cout input and cin output channels
+            ud = vh.pack_winograd_f4_weight(wt, data_gradient=True)
+            if spec is not None:
+                return vh.conv3x3_winograd_f4_fwd_bnbwd(dz, ud, cin, spec, residual=residual)
+            return vh.conv3x3_winograd_f4_fwd(dz, ud, None, None, cin, False, residual=residual)
         if self.wino:
             ud = vh.pack_winograd_weight(wt, data_gradient=True)
             if spec is not None:

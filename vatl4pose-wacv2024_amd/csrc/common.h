@@ -24,7 +24,7 @@ void meter_add(int kind, double flops);
 enum MeterRoute {
     kRouteIgemm = 0, kRouteIgemmBnBwd, kRouteIgemmDma, kRoutePersistent1x1, kRouteStreamK, kRouteRows, kRouteChain, kRouteStemPool, kRouteHalo,
     kRouteWino, kRouteWino2H, kRouteWinoBnBwd, kRouteWinoPersist, kRouteWinoC32, kRouteWgrad, kRouteWinoWgrad, kRouteWinoWgrad2H,
-    kRouteWinoWgradTable, kRouteWinoF4, kRouteCount
+    kRouteWinoWgradTable, kRouteWinoF4, kRouteWinoF4BnBwd, kRouteCount
 };
 void meter_route(int route);
 

@@ -399,6 +399,10 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const VatlPackJob* __re
     const float* __restrict__ w = J->src;
     float* __restrict__ out = J->dst;
     const int kind = J->kind, Cout = J->Cout, Cin = J->Cin, R = J->R, S = J->S, pa = J->a, pb = J->b, pc = J->c;
+    if (kind >= 7) {                                               // 7 / 8: F(4x4,3x3) filter transform, forward / data gradient; c = inner dimension of src; 256 items per block
+        f4_pack_item(w, out, kind - 7, pc, Cout, Cin, ((long long)blockIdx.x - J->first_block) * 256 + threadIdx.x);
+        return;
+    }
     if (kind >= 3) {                                               // 3 / 4 / 5: Winograd filter transforms (forward, data gradient, transposed conv); b = NH, c = w_i
         wino_pack_block(w, out, kind - 3, pc, Cout, Cin, pb, (long long)blockIdx.x - J->first_block, threadIdx.x);   // 4096 elements per block
         return;

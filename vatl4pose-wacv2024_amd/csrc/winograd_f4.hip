@@ -27,6 +27,7 @@
 //     row tiles per block, every thread then combines them for whole 16-byte channel groups and stores NHWC channel runs with scale / bias / residual / ReLU.
 // The per-output arithmetic depends only on the tile's own pixels: results do not depend on the batch position.
 #include "common.h"
+#include "winograd_pack.h"
 
 #include <atomic>
 #include <type_traits>
@@ -40,6 +41,16 @@ struct F4Params {
     const float* bias;
     const float* res;
     float* y;
+    // training epilogues (MODE 1: BatchNorm batch statistics of the raw output; MODE 2: BatchNorm-backward fusion of a data-gradient launch, semantics of
+    // ConvParams::bz .. in conv_igemm.hip): (sum, sum^2) / (sum g, sum g * xhat) per (16-tile row block, channel) as doubles, the layout vatl_bn_train_finalize /
+    // vatl_bn_bwd_from_stats reduce in a fixed order
+    double* stats;
+    const float* bz;
+    const float* bmy;
+    const float* bsc;
+    const float* bbi;
+    const float* bmu;
+    const float* bis;
     int N, H, W, Cin, Cout;
     int TH, TW, tpi, Mtiles, m_tiles, n_tiles, stages, relu;
     int xper;                          // XCDs per 64-channel slice (8 / n_tiles), 0: plain order
@@ -188,7 +199,8 @@ __device__ __forceinline__ void f4_nu_sums(const f32x4 (&acc)[9][4], float* Zs, 
     }
 }
 
-template <int WV>
+// MODE 0: y = act(scale * conv + bias + residual) (inference); 1: y = conv, batch statistics; 2: y = (conv + residual) * [consumer's ReLU mask], BatchNorm-backward sums
+template <int WV, int MODE>
 __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_tile, int n_tile) {
     const int tid = threadIdx.x, lane = tid & 63;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
@@ -281,8 +293,17 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
         lds_barrier();
         const int n = n_tile * 64 + h * 32 + c4 * 4;
         const f32x4 one = {1.f, 1.f, 1.f, 1.f}, nul = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + n) : one;
-        const f32x4 bi = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : nul;
+        const f32x4 sc = (MODE == 0 && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + n) : one;
+        const f32x4 bi = (MODE == 0 && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + n) : nul;
+        f32x4 mu = nul, is = nul, msc = nul, mbi = one;    // MODE 2 (no mask given: 0 * z + 1 > 0)
+        __amdgpu_buffer_rsrc_t zr = yr, mr = yr;
+        if constexpr (MODE == 2) {
+            mu = *reinterpret_cast<const f32x4*>(p.bmu + n); is = *reinterpret_cast<const f32x4*>(p.bis + n);
+            if (p.bsc) { msc = *reinterpret_cast<const f32x4*>(p.bsc + n); mbi = *reinterpret_cast<const f32x4*>(p.bbi + n); }
+            zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bz), 0, p.y_bytes, 0x00020000);
+            mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bmy ? p.bmy : p.bz), 0, p.bmy ? p.y_bytes : 0u, 0x00020000);
+        }
+        f32x4 s1 = nul, s2 = nul;                          // this thread's share of the two per-channel sums (MODE 1 / 2)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int id = tid + 256 * r;                  // (tile, b, c4)
@@ -293,9 +314,13 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
             const bool ok = T < p.Mtiles;
             const unsigned base = ok ? (unsigned)((((img * p.H + 4 * ty) * p.W + 4 * tx + b) * p.Cout + n) * 4) : 0xFFFFFFF0u;
             const unsigned rowb = (unsigned)(p.W * p.Cout * 4);
-            f32x4 rs[4];
+            f32x4 rs[4], zt[4], yt[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) rs[a] = f4_buf_load4(rr, ok ? base + a * rowb : 0xFFFFFFF0u);
+            for (int a = 0; a < 4; ++a) {
+                const unsigned off = ok ? base + a * rowb : 0xFFFFFFF0u;
+                rs[a] = MODE == 1 ? nul : f4_buf_load4(rr, off);
+                if constexpr (MODE == 2) { zt[a] = f4_buf_load4(zr, off); yt[a] = f4_buf_load4(mr, off); }
+            }
             f32x4 S[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) S[k] = *reinterpret_cast<const f32x4*>(Zs + (k * 16 + tl) * F4_ZT + b * 36 + c4 * 4);
@@ -311,14 +336,47 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
             for (int a = 0; a < 4; ++a) {
                 f32x4 v;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = fmaxf(fmaf(o[a][c], sc[c], bi[c]) + rs[a][c], lo);
+                for (int c = 0; c < 4; ++c) {
+                    if constexpr (MODE == 0) v[c] = fmaxf(fmaf(o[a][c], sc[c], bi[c]) + rs[a][c], lo);
+                    else if constexpr (MODE == 1) { v[c] = o[a][c]; s1[c] += v[c]; s2[c] += v[c] * v[c]; }       // tiles past the end: exact zeros
+                    else {
+                        const float d = o[a][c] + rs[a][c];
+                        const bool on = p.bmy ? yt[a][c] > 0.f : fmaf(zt[a][c], msc[c], mbi[c]) > 0.f;
+                        v[c] = on ? d : 0.f;
+                        s1[c] += v[c];
+                        s2[c] += v[c] * ((zt[a][c] - mu[c]) * is[c]);
+                    }
+                }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), yr, ok ? base + a * rowb : 0xFFFFFFF0u, 0, 0);
+            }
+        }
+        if constexpr (MODE != 0) {
+            // per-channel sums of this block's 16 tiles x 16 pixels: the 8 lanes of a wave that share c4 (lane bits 3 .. 5) by shuffles in fp32 (64 values each), the four
+            // waves through LDS and in double, one (row block = m_tile, channel) pair per channel of the half: fixed order, no atomics
+#pragma unroll
+            for (int sh = 8; sh < 64; sh <<= 1)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { s1[c] += __shfl_xor(s1[c], sh, 64); s2[c] += __shfl_xor(s2[c], sh, 64); }
+            lds_barrier();                                 // every thread is done reading the exchange area
+            if (lane < 8) {
+                *reinterpret_cast<f32x4*>(Zs + (WV * 8 + lane) * 8) = s1;
+                *reinterpret_cast<f32x4*>(Zs + (WV * 8 + lane) * 8 + 4) = s2;
+            }
+            lds_barrier();
+            if (tid < 32) {
+                double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { a1 += (double)Zs[(w * 8 + (tid >> 2)) * 8 + (tid & 3)]; a2 += (double)Zs[(w * 8 + (tid >> 2)) * 8 + 4 + (tid & 3)]; }
+                const long long ch = (long long)m_tile * p.Cout + n_tile * 64 + h * 32 + tid;
+                p.stats[ch * 2 + 0] = a1;
+                p.stats[ch * 2 + 1] = a2;
             }
         }
         if (h == 0) lds_barrier();                         // the second half overwrites the exchange area
     }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void winograd_f4_kernel(F4Params p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
@@ -334,40 +392,16 @@ __global__ __launch_bounds__(256, 2) void winograd_f4_kernel(F4Params p) {
     if (m_tile >= p.m_tiles) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wave) {                                        // the position split is per wave and compile-time: four instantiations of the body
-        case 0: f4_body<0>(p, smem, m_tile, n_tile); break;
-        case 1: f4_body<1>(p, smem, m_tile, n_tile); break;
-        case 2: f4_body<2>(p, smem, m_tile, n_tile); break;
-        default: f4_body<3>(p, smem, m_tile, n_tile); break;
+        case 0: f4_body<0, MODE>(p, smem, m_tile, n_tile); break;
+        case 1: f4_body<1, MODE>(p, smem, m_tile, n_tile); break;
+        case 2: f4_body<2, MODE>(p, smem, m_tile, n_tile); break;
+        default: f4_body<3, MODE>(p, smem, m_tile, n_tile); break;
     }
 }
 
-// (Cout, Cin, 3, 3) -> U = G g G^T (float64 arithmetic) in fragment order [stage][position][column block][lane][k-step]: channel 16 stage + 4 (lane / 16) + k-step,
-// output channel 16 block + lane % 16
-__global__ __launch_bounds__(256) void winograd_f4_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin) {
-    const long long id = blockIdx.x * 256LL + threadIdx.x;
-    const int nbg = Cout >> 4;
-    const long long total = (long long)(Cin >> 4) * 36 * nbg * 64;
-    if (id >= total) return;
-    const int lane = (int)(id & 63);
-    const int blk = (int)((id >> 6) % nbg);
-    const int pos = (int)((id >> 6) / nbg % 36);
-    const int stage = (int)((id >> 6) / nbg / 36);
-    const int xi = pos / 6, nu = pos - 6 * xi;
-    const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-    const int n = 16 * blk + (lane & 15);
-    f32x4 o;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int c = 16 * stage + 4 * (lane >> 4) + s;
-        const float* g = w + ((long long)n * Cin + c) * 9;
-        double v = 0.0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) v += G[xi][i] * (double)g[i * 3 + j] * G[nu][j];
-        o[s] = (float)v;
-    }
-    *reinterpret_cast<f32x4*>(u + id * 4) = o;
+// (Cout, Cin, 3, 3) -> U = G g G^T (float64 arithmetic) in fragment order (winograd_pack.h: f4_pack_item)
+__global__ __launch_bounds__(256) void winograd_f4_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int dgrad) {
+    f4_pack_item(w, u, dgrad, dgrad ? Cout : Cin, Cout, Cin, blockIdx.x * 256LL + threadIdx.x);
 }
 
 }  // namespace vatl
@@ -382,24 +416,35 @@ extern "C" int vatl_conv3x3_winograd_f4_supported(int N, int H, int W, int Cin, 
     return xe * 4 <= (long long)F4_OOB && ye < (1LL << 30) && 36LL * Cin * Cout < (1LL << 28) ? 1 : 0;
 }
 
-extern "C" int vatl_pack_winograd_f4_weight(const float* w, float* u, int Cout, int Cin, void* stream) {
+extern "C" int64_t vatl_winograd_f4_stats_row_blocks(int64_t N, int H, int W) { return (N * (H / 4) * (W / 4) + F4_TB - 1) / F4_TB; }
+
+// (Cout, Cin) of the PACKED filter: with data_gradient the source is the forward filter (O = Cin, I = Cout, 3, 3) and the result the filter of dX = conv(dY, rot180(w)^T)
+extern "C" int vatl_pack_winograd_f4_weight(const float* w, float* u, int Cout, int Cin, int data_gradient, void* stream) {
     if (!w || !u || Cout <= 0 || Cin <= 0 || (Cout & 15) || (Cin & 15)) return fail(VATL_EINVAL, "pack_winograd_f4_weight: needs channel counts that are multiples of 16");
     const long long total = (long long)(Cin >> 4) * 36 * (Cout >> 4) * 64;
-    hipLaunchKernelGGL(winograd_f4_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, u, Cout, Cin);
+    hipLaunchKernelGGL(winograd_f4_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, u, Cout, Cin, data_gradient ? 1 : 0);
     return check_launch("winograd_f4_pack");
 }
 
-extern "C" int vatl_conv3x3_winograd_f4_fwd(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, int N, int H, int W,
-                                            int Cin, int Cout, int relu, void* stream) {
-    if (!x || !u || !y) return fail(VATL_EINVAL, "conv3x3_winograd_f4_fwd: null pointer");
+struct F4Fuse {
+    const float *z, *mask_y, *scale, *bias, *mean, *invstd;
+};
+
+static int f4_impl(int mode, const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, double* stats, int64_t* row_blocks_used,
+                   const F4Fuse* fuse, int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
+    if (!x || !u || !y) return fail(VATL_EINVAL, "conv3x3_winograd_f4: null pointer");
     if (!vatl_conv3x3_winograd_f4_supported(N, H, W, Cin, Cout))
-        return fail(VATL_EINVAL, "conv3x3_winograd_f4_fwd: serves H, W multiples of 4, Cin >= 64 a multiple of 16, Cout a multiple of 64 (got %d x %d, %d -> %d)", H, W, Cin, Cout);
+        return fail(VATL_EINVAL, "conv3x3_winograd_f4: serves H, W multiples of 4, Cin >= 64 a multiple of 16, Cout a multiple of 64 (got %d x %d, %d -> %d)", H, W, Cin, Cout);
+    if (mode != 0 && !stats) return fail(VATL_EINVAL, "conv3x3_winograd_f4: the training epilogues need a statistics buffer");
+    if (mode == 2 && (!fuse || !fuse->z || !fuse->mean || !fuse->invstd || (!fuse->scale != !fuse->bias)))
+        return fail(VATL_EINVAL, "conv3x3_winograd_f4_fwd_bnbwd: needs the consumer layer's conv output and saved statistics (and scale WITH bias, or neither)");
     F4Params p{};
-    p.x = x; p.u = u; p.scale = scale; p.bias = bias; p.res = residual; p.y = y;
+    p.x = x; p.u = u; p.scale = scale; p.bias = bias; p.res = residual; p.y = y; p.stats = stats;
+    if (fuse) { p.bz = fuse->z; p.bmy = fuse->mask_y; p.bsc = fuse->scale; p.bbi = fuse->bias; p.bmu = fuse->mean; p.bis = fuse->invstd; }
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
     p.TH = H / 4; p.TW = W / 4; p.tpi = p.TH * p.TW;
     const long long mt = (long long)N * p.tpi;
-    if (mt >= (1LL << 30)) return fail(VATL_EINVAL, "conv3x3_winograd_f4_fwd: too many tiles");
+    if (mt >= (1LL << 30)) return fail(VATL_EINVAL, "conv3x3_winograd_f4: too many tiles");
     p.Mtiles = (int)mt;
     p.m_tiles = cdiv(mt, F4_TB);
     p.n_tiles = Cout / 64;
@@ -407,6 +452,7 @@ extern "C" int vatl_conv3x3_winograd_f4_fwd(const float* x, const float* u, cons
     p.x_bytes = (unsigned)((long long)N * H * W * Cin * 4); p.y_bytes = (unsigned)((long long)N * H * W * Cout * 4);
     p.u_bytes = (unsigned)(36LL * Cin * Cout * 4);
     p.d_tpi = make_fastdiv((unsigned)p.tpi); p.d_TW = make_fastdiv((unsigned)p.TW);
+    if (row_blocks_used) *row_blocks_used = p.m_tiles;
     long long grid;
     if (p.n_tiles == 1 || p.n_tiles == 2 || p.n_tiles == 4 || p.n_tiles == 8) {
         p.xper = 8 / p.n_tiles;
@@ -415,13 +461,32 @@ extern "C" int vatl_conv3x3_winograd_f4_fwd(const float* x, const float* u, cons
         p.xper = 0;
         grid = (long long)p.m_tiles * p.n_tiles;
     }
-    if (grid >= (1LL << 31)) return fail(VATL_EINVAL, "conv3x3_winograd_f4_fwd: too many blocks");
+    if (grid >= (1LL << 31)) return fail(VATL_EINVAL, "conv3x3_winograd_f4: too many blocks");
     const int smem = F4_LDS_FLOATS * (int)sizeof(float);
-    static std::atomic<unsigned> configured{0};
-    auto kern = winograd_f4_kernel;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, configured, "winograd_f4")) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
+    static std::atomic<unsigned> configured[3] = {{0}, {0}, {0}};
+    const void* kern = mode == 0 ? (const void*)winograd_f4_kernel<0> : (mode == 1 ? (const void*)winograd_f4_kernel<1> : (const void*)winograd_f4_kernel<2>);
+    if (int rc = ensure_dynamic_lds(kern, smem, configured[mode], "winograd_f4")) return rc;
+    if (mode == 0) hipLaunchKernelGGL(winograd_f4_kernel<0>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
+    else if (mode == 1) hipLaunchKernelGGL(winograd_f4_kernel<1>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(winograd_f4_kernel<2>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
     meter_add(1, 2.0 * ((double)p.m_tiles * F4_TB) * (double)Cout * (double)Cin * 36.0);
-    meter_route(kRouteWinoF4);
+    meter_route(mode == 2 ? kRouteWinoF4BnBwd : kRouteWinoF4);
     return check_launch("winograd_f4");
+}
+
+extern "C" int vatl_conv3x3_winograd_f4_fwd(const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, int N, int H, int W,
+                                            int Cin, int Cout, int relu, void* stream) {
+    return f4_impl(0, x, u, scale, bias, residual, y, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, relu, stream);
+}
+
+extern "C" int vatl_conv3x3_winograd_f4_fwd_stats(const float* x, const float* u, float* y, double* stats, int64_t* row_blocks_used, int N, int H, int W, int Cin, int Cout,
+                                                  void* stream) {
+    return f4_impl(1, x, u, nullptr, nullptr, nullptr, y, stats, row_blocks_used, nullptr, N, H, W, Cin, Cout, 0, stream);
+}
+
+extern "C" int vatl_conv3x3_winograd_f4_fwd_bnbwd(const float* x, const float* u, const float* residual, float* y, int N, int H, int W, int Cin, int Cout, const float* bn_z,
+                                                  const float* bn_mask_y, const float* bn_scale, const float* bn_bias, const float* bn_mean, const float* bn_invstd,
+                                                  double* stats, int64_t* row_blocks_used, void* stream) {
+    const F4Fuse f{bn_z, bn_mask_y, bn_scale, bn_bias, bn_mean, bn_invstd};
+    return f4_impl(2, x, u, nullptr, nullptr, residual, y, stats, row_blocks_used, &f, N, H, W, Cin, Cout, 0, stream);
 }

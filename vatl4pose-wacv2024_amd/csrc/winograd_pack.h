@@ -79,4 +79,35 @@ __device__ __forceinline__ void wino_pack_block(const float* __restrict__ w, flo
     }
 }
 
+// One 16-byte item of the F(4x4,3x3) filter transform U = G g G^T (csrc/winograd_f4.hip), shared by its pack kernel and the table-driven multi-pack launch.
+// Fragment order [stage = c / 16][position xi * 6 + nu][column block = n / 16][lane = (c % 16 / 4) * 16 + n % 16][k-step = c % 4]; item = (stage, position, block, lane).
+// dgrad = 0: g = w[n][c] of the (Cout, Cin, 3, 3) filter (w_i = Cin); 1: the data gradient's filter g = rot180(w[o = c][i = n]) of the forward (O, I, 3, 3) filter
+// (w_i = I = the packed Cout).  Float64 arithmetic, rounded once.
+__device__ __forceinline__ void f4_pack_item(const float* __restrict__ w, float* __restrict__ u, int dgrad, int w_i, int Cout, int Cin, long long id) {
+    const int nbg = Cout >> 4;
+    const long long total = (long long)(Cin >> 4) * 36 * nbg * 64;
+    if (id >= total) return;
+    const int lane = (int)(id & 63);
+    const int blk = (int)((id >> 6) % nbg);
+    const int pos = (int)((id >> 6) / nbg % 36);
+    const int stage = (int)((id >> 6) / nbg / 36);
+    const int xi = pos / 6, nu = pos - 6 * xi;
+    const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6}, {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int n = 16 * blk + (lane & 15);
+    float o[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = 16 * stage + 4 * (lane >> 4) + s;
+        const float* g = dgrad ? w + ((long long)c * w_i + n) * 9 : w + ((long long)n * w_i + c) * 9;
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v += G[xi][i] * (double)(dgrad ? g[(2 - i) * 3 + (2 - j)] : g[i * 3 + j]) * G[nu][j];
+        o[s] = (float)v;
+    }
+    float* dst = u + id * 4;
+    dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+}
+
 }  // namespace vatl

@@ -40,7 +40,10 @@ SIGNATURES = {
     "vatl_conv3x3_winograd_c32_supported": (_i, [_i, _i, _i, _i, _i]),
     "vatl_conv3x3_winograd_c32_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_winograd_f4_weight_floats": (_i64, [_i, _i]),
-    "vatl_pack_winograd_f4_weight": (_i, [_p, _p, _i, _i, _p]),
+    "vatl_pack_winograd_f4_weight": (_i, [_p, _p, _i, _i, _i, _p]),
+    "vatl_winograd_f4_stats_row_blocks": (_i64, [_i64, _i, _i]),
+    "vatl_conv3x3_winograd_f4_fwd_stats": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "vatl_conv3x3_winograd_f4_fwd_bnbwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vatl_conv3x3_winograd_f4_supported": (_i, [_i, _i, _i, _i, _i]),
     "vatl_conv3x3_winograd_f4_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "vatl_conv1x1_rows_supported": (_i, [_i, _i, _i, _i64]),
@@ -235,7 +238,7 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
 
 
 ROUTE_NAMES = ("igemm", "igemm_bnbwd", "igemm_dma", "persistent_1x1", "streamk", "rows_1x1", "bottleneck_chain", "stem_pool", "halo_3x3", "winograd",
-               "winograd_2h", "winograd_bnbwd", "winograd_persist", "winograd_c32", "wgrad", "winograd_wgrad", "winograd_wgrad_2h", "winograd_wgrad_table", "winograd_f4")
+               "winograd_2h", "winograd_bnbwd", "winograd_persist", "winograd_c32", "wgrad", "winograd_wgrad", "winograd_wgrad_2h", "winograd_wgrad_table", "winograd_f4", "winograd_f4_bnbwd")
 
 
 class flop_meter:
@@ -408,8 +411,8 @@ class PackPlan:
                 jb.tap_r[t], jb.tap_s[t] = tr, ts
             if f[0] == 1:                                    # data-gradient layout [a = CinPad][c = taps][b = CoutK]: 32 x 32 tiles of one tap
                 blocks += ((f[5] + 31) // 32) * f[7] * ((f[6] + 31) // 32)
-            else:
-                blocks += (dst.numel() + 1023) // 1024 if f[0] < 3 else dst.numel() // 4096     # Winograd filters: 4096 elements per block
+            else:                                            # F(2x2) / F(3x3,2x2) Winograd filters (kinds 3 .. 6): 4096 elements per block; everything else 1024
+                blocks += (dst.numel() + 1023) // 1024 if (f[0] < 3 or f[0] >= 7) else dst.numel() // 4096
         dev = next(iter(self.jobs.values()))[1].device
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.table = host.to(dev)
@@ -531,11 +534,21 @@ def conv3x3_winograd_c32_fwd(x, u, scale, bias, relu: bool, residual=None, out=N
 
 
 
-def pack_winograd_f4_weight(w: torch.Tensor) -> torch.Tensor:
-    """(Cout,Cin,3,3) -> U = G g G^T of F(4x4,3x3) in the MFMA fragment order of csrc/winograd_f4.hip."""
-    cout, cin = w.shape[:2]
+def pack_winograd_f4_weight(w: torch.Tensor, data_gradient: bool = False) -> torch.Tensor:
+    """(Cout,Cin,3,3) -> U = G g G^T of F(4x4,3x3) in the MFMA fragment order of csrc/winograd_f4.hip.  With ``data_gradient`` the result is the filter of
+    dX = conv(dY, rot180(w)^T): its output channels are the forward Cin.  Inside a PackPlan (the trainers' forward / backward) the buffer is kept and refreshed by
+    the step's one re-pack launch."""
+    co, ci = w.shape[:2]
+    cout, cin = (ci, co) if data_gradient else (co, ci)
+    plan, key = getattr(_tls, "pack_plan", None), ("winograd_f4", w.data_ptr(), tuple(w.shape), bool(data_gradient))
+    if plan is not None and w.is_contiguous():
+        kept = plan.lookup(key, w)
+        if kept is not None:
+            return kept
     u = torch.empty(int(lib().vatl_winograd_f4_weight_floats(cout, cin)), device=w.device, dtype=torch.float32)
-    _check(lib().vatl_pack_winograd_f4_weight(_ptr(w.contiguous()), _ptr(u), cout, cin, _stream()), "vatl_pack_winograd_f4_weight")
+    _check(lib().vatl_pack_winograd_f4_weight(_ptr(w.contiguous()), _ptr(u), cout, cin, int(data_gradient), _stream()), "vatl_pack_winograd_f4_weight")
+    if plan is not None and w.is_contiguous():
+        plan.record(key, w, u, (8 if data_gradient else 7, cout, cin, 3, 3, 0, 0, ci, ()))
     return u
 
 
@@ -549,6 +562,36 @@ def conv3x3_winograd_f4_fwd(x, u, scale, bias, cout: int, relu: bool, residual=N
     y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
     _check(lib().vatl_conv3x3_winograd_f4_fwd(_ptr(x), _ptr(u), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(y), n, h, w, cin, cout, int(relu), _stream()),
            "vatl_conv3x3_winograd_f4_fwd")
+    return y
+
+
+def conv3x3_winograd_f4_fwd_bnstats(x, u, cout: int, gamma, beta, running_mean, running_var, momentum: float, eps: float):
+    """conv3x3_winograd_fwd_bnstats on the F(4x4,3x3) route: -> z, save_mean, save_invstd, scale, bias; running stats updated in place."""
+    n, h, w, cin = x.shape
+    z = torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    stats = torch.empty(int(lib().vatl_winograd_f4_stats_row_blocks(n, h, w)) * cout * 2, device=x.device, dtype=torch.float64)
+    used = C.c_int64(0)
+    _check(lib().vatl_conv3x3_winograd_f4_fwd_stats(_ptr(x), _ptr(u), _ptr(z), _ptr(stats, torch.float64), C.addressof(used), n, h, w, cin, cout, _stream()),
+           "vatl_conv3x3_winograd_f4_fwd_stats")
+    return [z] + _bn_finalize(stats, used.value, z.numel() // cout, cout, (gamma, beta, running_mean, running_var, momentum, eps), x.device)
+
+
+def conv3x3_winograd_f4_fwd_bnbwd(x, u, cout: int, spec: "BnBwdSpec", out=None, residual=None):
+    """conv3x3_winograd_fwd_bnbwd on the F(4x4,3x3) route (u: data-gradient packing)."""
+    n, h, w, cin = x.shape
+    y = out if out is not None else torch.empty((n, h, w, cout), device=x.device, dtype=torch.float32)
+    if y.shape != spec.z.shape:
+        raise VatlError("conv3x3_winograd_f4_fwd_bnbwd: the BatchNorm tensors must have the layout of the output")
+    used = C.c_int64(0)
+    c = spec.z.shape[-1]
+    need = int(lib().vatl_winograd_f4_stats_row_blocks(n, h, w))
+    if (spec.blocks + need) * c * 2 > spec.stats.numel():
+        raise VatlError("conv3x3_winograd_f4_fwd_bnbwd: statistics buffer too small")
+    stats_ptr = spec.stats.data_ptr() + spec.blocks * c * 2 * 8
+    _check(lib().vatl_conv3x3_winograd_f4_fwd_bnbwd(_ptr(x), _ptr(u), _ptr(residual), _ptr(y), n, h, w, cin, cout, _ptr(spec.z), _ptr(spec.mask_y), _ptr(spec.scale),
+                                                    _ptr(spec.bias), _ptr(spec.mean), _ptr(spec.invstd), stats_ptr, C.addressof(used), _stream()),
+           "vatl_conv3x3_winograd_f4_fwd_bnbwd")
+    spec.blocks += used.value
     return y
 
 
