@@ -11,7 +11,7 @@ import torch
 import vatl_hip as vh
 
 SHAPES = {"l3.c2": (16, 12, 256, 256, False), "l2.c2": (32, 24, 128, 128, False), "l1.c2": (64, 48, 64, 64, False), "hr.b128": (16, 12, 128, 128, True),
-          "hr.b64": (32, 24, 64, 64, True), "r152.l2.c2": (48, 36, 128, 128, False), "duc1": (24, 18, 512, 1024, False)}
+          "hr.b64": (32, 24, 64, 64, True), "hr.b32": (64, 48, 32, 32, True), "r152.l2.c2": (48, 36, 128, 128, False), "duc1": (24, 18, 512, 1024, False)}
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=10)
@@ -49,6 +49,10 @@ for name in (a.layers.split(",") if a.layers else SHAPES):
     u4, u2 = vh.pack_winograd_f4_weight(wt), vh.pack_winograd_weight(wt)
     y4 = vh.conv3x3_winograd_f4_fwd(x, u4, sc, bi, cout, True, residual=res)
     y2 = vh.conv3x3_winograd_fwd(x, u2, sc, bi, cout, True, residual=res)
+    if cin == 32 and cout == 32:                           # the wave-private F(2x2) kernel is what these layers run on today
+        u32 = vh.pack_winograd_c32_weight(wt)
+        t32 = timed(lambda: vh.conv3x3_winograd_c32_fwd(x, u32, sc, bi, True, residual=res), a.iters)
+        print(f"{name:11s} winograd_c32 {t32:8.1f} us", flush=True)
     k = min(4, b)
     ref = torch.nn.functional.conv2d(x[:k].permute(0, 3, 1, 2).double(), wt.double(), padding=1).permute(0, 2, 3, 1) * sc.double() + bi.double()
     if skip:

@@ -54,7 +54,7 @@ def layers(B, fused=False, chained=False):
 def main():
     path = sys.argv[1]
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "gemm1x1_persistent" in r["Kernel_Name"] or "winograd_kernel" in r["Kernel_Name"] or "winograd_persist_kernel" in r["Kernel_Name"] or "stem_pool_kernel" in r["Kernel_Name"] or "bottleneck_chain_kernel" in r["Kernel_Name"] or "conv1x1_rows_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "gemm1x1_persistent" in r["Kernel_Name"] or "winograd_kernel" in r["Kernel_Name"] or "winograd_persist_kernel" in r["Kernel_Name"] or "winograd_f4_kernel" in r["Kernel_Name"] or "stem_pool_kernel" in r["Kernel_Name"] or "bottleneck_chain_kernel" in r["Kernel_Name"] or "conv1x1_rows_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     import re
     is_stem = lambda name: bool(re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, true", name)) or "stem_pool_kernel" in name   # (the fused stem launch includes bn1 + relu + maxpool)
@@ -68,16 +68,16 @@ def main():
         du = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         a = agg.setdefault((name, M, N, K), [0, 0, 0, 0, False])
         a[0] += fl; a[1] += du; a[2] += 1; a[3] += by
-        a[4] = "winograd" in r["Kernel_Name"]
+        a[4] = 4 if "winograd_f4" in r["Kernel_Name"] else (2 if "winograd" in r["Kernel_Name"] else 0)
     tot = sum(a[1] for a in agg.values())
     totf = sum(a[0] for a in agg.values())
     print(f"{'layer':12s} {'M':>8s} {'N':>5s} {'K':>5s}  cnt   us/launch   TF/s   share%  mfma_ms   hbm_ms  (ideal at 157.3 TFLOP/s / compulsory bytes at 8 TB/s)")
     bound = 0.0
     for (name, M, N, K), (fl, du, c, by, wino) in agg.items():
-        # Winograd launches (W): TF/s counts the direct-sum FLOPs; the MFMA floor counts the 16 / 36 multiplies they execute
-        t_m, t_h = fl / 157.3e12 * 1e3 * (4 / 9 if wino else 1), by / 8e12 * 1e3
+        # Winograd launches (W: F(2x2,3x3) / F(3x3,2x2); W4: F(4x4,3x3)): TF/s counts the direct-sum FLOPs; the MFMA floor counts the 16 / 36 (36 / 144) multiplies they execute
+        t_m, t_h = fl / 157.3e12 * 1e3 * (0.25 if wino == 4 else (4 / 9 if wino else 1)), by / 8e12 * 1e3
         bound += max(t_m, t_h)
-        print(f"{name:12s} {M:8d} {N:5d} {K:5d}  x{c:<2d} {du / c / 1e3:10.1f} {fl / du / 1e3:7.1f} {100 * du / tot:7.2f} {t_m:8.3f} {t_h:8.3f}{'  W' if wino else ''}{'  <- HBM-bound' if t_h > t_m else ''}")
+        print(f"{name:12s} {M:8d} {N:5d} {K:5d}  x{c:<2d} {du / c / 1e3:10.1f} {fl / du / 1e3:7.1f} {100 * du / tot:7.2f} {t_m:8.3f} {t_h:8.3f}{'  W4' if wino == 4 else ('  W' if wino else '')}{'  <- HBM-bound' if t_h > t_m else ''}")
     print(f"total {tot / 1e6:.2f} ms for {B} frames -> {totf / tot / 1e3:.1f} TF/s, {B / (tot / 1e9):.0f} frames/s (conv only)")
     print(f"layer-by-layer roofline (each launch at max(MFMA, HBM) time): {bound:.2f} ms -> {B / bound * 1e3:.0f} frames/s; "
           f"measured / that bound = {bound / (tot / 1e6):.3f}")

@@ -112,8 +112,8 @@ __device__ __forceinline__ void f4_static_for(F&& f) {
 // BURST: the position of the STAGE (0 .. 8, -1: none in this part) behind whose first four MFMAs the next stage's DMA requests go out.
 // B: ring of three fragment sets: position pl of a stage multiplies with B[pl % 3]; the set of position pl + 2 is requested at position pl (nine positions per stage:
 // the ring index carries over from stage to stage).  POS(k): transform-domain position (xi * 6 + nu) of the wave's k-th position of a stage.
-template <int XI, int NU0, int NUN, int PL0, int BURST, typename DMA, typename POS>
-__device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][4], __amdgpu_buffer_rsrc_t ur, unsigned ub, unsigned pos_bytes, unsigned stage_bytes, f32x4 (&B)[3][4],
+template <int XI, int NU0, int NUN, int PL0, int BURST, int NB, typename DMA, typename POS>
+__device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][NB], __amdgpu_buffer_rsrc_t ur, unsigned ub, unsigned pos_bytes, unsigned stage_bytes, f32x4 (&B)[3][NB],
                                         DMA dma_burst, bool more, POS pos_of) {
     // row combination XI of the six patch columns as a chain of multiply-adds over the rows it uses, term by term (18 - 24 terms: column-major), the reads a ring of
     // DEPTH terms ahead: ~DEPTH x 16 cycles of vector work cover an LDS read (with the read one term ahead every term waited ~50 cycles for its operand: 30 % of the
@@ -144,19 +144,19 @@ __device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][4], __a
         constexpr int q = decltype(qc)::value, nu = NU0 + q;
         const f32x4 V = f4_comb<nu>(R[0], R[1], R[2], R[3], R[4], R[5]);        // column combination nu of the row values
         constexpr int pl = PL0 + q;
-        f32x4 (&bcur)[4] = B[pl % 3];
+        f32x4 (&bcur)[NB] = B[pl % 3];
         auto prefetch = [&] {                              // the filter fragments of the position after next (of this stage, or the first / second one of the next stage)
             constexpr int t = pl + 2;
             if (t < 9 || more) {
                 const unsigned nb = t < 9 ? ub + (unsigned)pos_of(t) * pos_bytes : ub + stage_bytes + (unsigned)pos_of(t - 9) * pos_bytes;
 #pragma unroll
-                for (int n = 0; n < 4; ++n) B[t % 3][n] = f4_filter_load(ur, nb + n * 1024u);
+                for (int n = 0; n < NB; ++n) B[t % 3][n] = f4_filter_load(ur, nb + n * 1024u);
             }
         };
         if constexpr (pl != BURST) prefetch();             // ... requested before this position's MFMAs
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[pl][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[0], bcur[n][0], acc[pl][n], 0, 0, 0);
+        for (int n = 0; n < NB; ++n) acc[pl][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[0], bcur[n][0], acc[pl][n], 0, 0, 0);
         if constexpr (pl == BURST) {
             // the burst position: its own fragments and the next position's are older than the requests, so nothing here waits for them; the first younger batch
             // (position pl + 2) is waited for 12 MFMAs + the next part's row combinations + one whole position later
@@ -168,14 +168,14 @@ __device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][4], __a
 #pragma unroll
         for (int s = 1; s < 4; ++s)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[pl][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[s], bcur[n][s], acc[pl][n], 0, 0, 0);
+            for (int n = 0; n < NB; ++n) acc[pl][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[s], bcur[n][s], acc[pl][n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     });
 }
 
 // nu sums of one row part: Z[b] = sum over the part's columns of A^T[b][nu] * M[nu], for the column block pair H (two 16-channel blocks) -> LDS slot SLOT
-template <int NU0, int NUN, int PL0, int SLOT>
-__device__ __forceinline__ void f4_nu_sums(const f32x4 (&acc)[9][4], float* Zs, int h, int lane) {
+template <int NU0, int NUN, int PL0, int SLOT, int NB>
+__device__ __forceinline__ void f4_nu_sums(const f32x4 (&acc)[9][NB], float* Zs, int h, int lane) {
     constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
     const int n16 = lane & 15, tg = lane >> 4;
 #pragma unroll
@@ -200,7 +200,8 @@ __device__ __forceinline__ void f4_nu_sums(const f32x4 (&acc)[9][4], float* Zs, 
 }
 
 // MODE 0: y = act(scale * conv + bias + residual) (inference); 1: y = conv, batch statistics; 2: y = (conv + residual) * [consumer's ReLU mask], BatchNorm-backward sums
-template <int WV, int MODE>
+// NB: 16-channel column blocks per block: 4 (64 output channels) or 2 (32: the 32-channel layers of HRNet's first branch; half the MFMAs per transformed value)
+template <int WV, int MODE, int NB>
 __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_tile, int n_tile) {
     const int tid = threadIdx.x, lane = tid & 63;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
@@ -242,24 +243,24 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
     const unsigned nbg = (unsigned)(p.Cout >> 4);
     const unsigned pos_bytes = nbg * 1024u;                // bytes between consecutive positions of U
     const unsigned stage_bytes = 36u * pos_bytes;
-    const unsigned ublock = ((unsigned)n_tile * 4u * 64u + (unsigned)lane) * 16u;
+    const unsigned ublock = ((unsigned)n_tile * (unsigned)NB * 64u + (unsigned)lane) * 16u;
     // the wave's two row parts, the half row first (its reads are done a third into the stage: the next stage's requests go out behind the SECOND part's reads)
     constexpr int XA = WV == 0 ? 1 : (WV == 1 ? 1 : 4), NA0 = (WV == 0 || WV == 2) ? 0 : 3;          // half row: 3 positions
     constexpr int XB = WV == 0 ? 0 : (WV == 1 ? 2 : (WV == 2 ? 3 : 5));                               // full row: 6 positions
-    f32x4 acc[9][4];
+    f32x4 acc[9][NB];
 #pragma unroll
     for (int q = 0; q < 9; ++q)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[q][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NB; ++n) acc[q][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int k = 0; k < F4_KDMA; ++k) request_piece(0, smem, k);
     auto pos_of = [](int k) { return k < 3 ? XA * 6 + NA0 + k : XB * 6 + (k - 3); };     // the wave's k-th position of a stage
-    f32x4 B[3][4];
+    f32x4 B[3][NB];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) B[k][n] = f4_filter_load(ur, ublock + (unsigned)pos_of(k) * pos_bytes + n * 1024u);
+        for (int n = 0; n < NB; ++n) B[k][n] = f4_filter_load(ur, ublock + (unsigned)pos_of(k) * pos_bytes + n * 1024u);
     for (int s = 0; s < p.stages; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage s have landed (and the first filter fragments)
         if constexpr ((F4_ABL & 8) == 0) __builtin_amdgcn_s_barrier();                      // ... everyone's; and every wave is done reading the other buffer (stage s - 1)
@@ -275,8 +276,8 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
                 for (int k = 0; k < F4_KDMA; ++k) request_piece(s + 1, nxt, k);
             }
         };
-        f4_part<XA, NA0, 3, 0, 2>(Pl, acc, ur, ub, pos_bytes, stage_bytes, B, burst, more, pos_of);
-        f4_part<XB, 0, 6, 3, -1>(Pl, acc, ur, ub, pos_bytes, stage_bytes, B, burst, more, pos_of);
+        f4_part<XA, NA0, 3, 0, 2, NB>(Pl, acc, ur, ub, pos_bytes, stage_bytes, B, burst, more, pos_of);
+        f4_part<XB, 0, 6, 3, -1, NB>(Pl, acc, ur, ub, pos_bytes, stage_bytes, B, burst, more, pos_of);
     }
 
     // ---- output transform ----
@@ -287,11 +288,11 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
     const float lo = p.relu ? 0.f : -INFINITY;
     const int c4 = tid & 7;                                // this thread's 16-byte channel group of the 32-channel half (the same for both of its items)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        f4_nu_sums<NA0, 3, 0, 2 * WV>(acc, Zs, h, lane);
-        f4_nu_sums<0, 6, 3, 2 * WV + 1>(acc, Zs, h, lane);
+    for (int h = 0; h < NB / 2; ++h) {
+        f4_nu_sums<NA0, 3, 0, 2 * WV, NB>(acc, Zs, h, lane);
+        f4_nu_sums<0, 6, 3, 2 * WV + 1, NB>(acc, Zs, h, lane);
         lds_barrier();
-        const int n = n_tile * 64 + h * 32 + c4 * 4;
+        const int n = n_tile * (16 * NB) + h * 32 + c4 * 4;
         const f32x4 one = {1.f, 1.f, 1.f, 1.f}, nul = {0.f, 0.f, 0.f, 0.f};
         const f32x4 sc = (MODE == 0 && p.scale) ? *reinterpret_cast<const f32x4*>(p.scale + n) : one;
         const f32x4 bi = (MODE == 0 && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + n) : nul;
@@ -367,16 +368,16 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
                 double a1 = 0.0, a2 = 0.0;
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { a1 += (double)Zs[(w * 8 + (tid >> 2)) * 8 + (tid & 3)]; a2 += (double)Zs[(w * 8 + (tid >> 2)) * 8 + 4 + (tid & 3)]; }
-                const long long ch = (long long)m_tile * p.Cout + n_tile * 64 + h * 32 + tid;
+                const long long ch = (long long)m_tile * p.Cout + n_tile * (16 * NB) + h * 32 + tid;
                 p.stats[ch * 2 + 0] = a1;
                 p.stats[ch * 2 + 1] = a2;
             }
         }
-        if (h == 0) lds_barrier();                         // the second half overwrites the exchange area
+        if (h + 1 < NB / 2) lds_barrier();                 // the second half overwrites the exchange area
     }
 }
 
-template <int MODE>
+template <int MODE, int NB>
 __global__ __launch_bounds__(256, 2) void winograd_f4_kernel(F4Params p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
@@ -392,10 +393,10 @@ __global__ __launch_bounds__(256, 2) void winograd_f4_kernel(F4Params p) {
     if (m_tile >= p.m_tiles) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wave) {                                        // the position split is per wave and compile-time: four instantiations of the body
-        case 0: f4_body<0, MODE>(p, smem, m_tile, n_tile); break;
-        case 1: f4_body<1, MODE>(p, smem, m_tile, n_tile); break;
-        case 2: f4_body<2, MODE>(p, smem, m_tile, n_tile); break;
-        default: f4_body<3, MODE>(p, smem, m_tile, n_tile); break;
+        case 0: f4_body<0, MODE, NB>(p, smem, m_tile, n_tile); break;
+        case 1: f4_body<1, MODE, NB>(p, smem, m_tile, n_tile); break;
+        case 2: f4_body<2, MODE, NB>(p, smem, m_tile, n_tile); break;
+        default: f4_body<3, MODE, NB>(p, smem, m_tile, n_tile); break;
     }
 }
 
@@ -411,7 +412,9 @@ using namespace vatl;
 extern "C" int64_t vatl_winograd_f4_weight_floats(int Cout, int Cin) { return 36LL * Cout * Cin; }
 
 extern "C" int vatl_conv3x3_winograd_f4_supported(int N, int H, int W, int Cin, int Cout) {
-    if (N <= 0 || H < 4 || W < 4 || (H & 3) || (W & 3) || Cin < 64 || (Cin & 15) || Cout < 64 || (Cout & 63)) return 0;
+    // 64-channel blocks (Cout a multiple of 64, Cin >= 64); 32 -> 32 channels with 32-channel blocks (the inference launch only: two stages per block)
+    const bool c64 = Cin >= 64 && (Cin & 15) == 0 && Cout >= 64 && (Cout & 63) == 0, c32 = Cin == 32 && Cout == 32;
+    if (N <= 0 || H < 4 || W < 4 || (H & 3) || (W & 3) || !(c64 || c32)) return 0;
     const long long xe = (long long)N * H * W * Cin, ye = (long long)N * H * W * Cout;
     return xe * 4 <= (long long)F4_OOB && ye < (1LL << 30) && 36LL * Cin * Cout < (1LL << 28) ? 1 : 0;
 }
@@ -433,8 +436,9 @@ struct F4Fuse {
 static int f4_impl(int mode, const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, double* stats, int64_t* row_blocks_used,
                    const F4Fuse* fuse, int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
     if (!x || !u || !y) return fail(VATL_EINVAL, "conv3x3_winograd_f4: null pointer");
-    if (!vatl_conv3x3_winograd_f4_supported(N, H, W, Cin, Cout))
-        return fail(VATL_EINVAL, "conv3x3_winograd_f4: serves H, W multiples of 4, Cin >= 64 a multiple of 16, Cout a multiple of 64 (got %d x %d, %d -> %d)", H, W, Cin, Cout);
+    if (!vatl_conv3x3_winograd_f4_supported(N, H, W, Cin, Cout) || (mode != 0 && Cout == 32))
+        return fail(VATL_EINVAL, "conv3x3_winograd_f4: serves H, W multiples of 4 with Cin >= 64 a multiple of 16 and Cout a multiple of 64, or 32 -> 32 channels (inference) "
+                    "(got %d x %d, %d -> %d)", H, W, Cin, Cout);
     if (mode != 0 && !stats) return fail(VATL_EINVAL, "conv3x3_winograd_f4: the training epilogues need a statistics buffer");
     if (mode == 2 && (!fuse || !fuse->z || !fuse->mean || !fuse->invstd || (!fuse->scale != !fuse->bias)))
         return fail(VATL_EINVAL, "conv3x3_winograd_f4_fwd_bnbwd: needs the consumer layer's conv output and saved statistics (and scale WITH bias, or neither)");
@@ -447,7 +451,8 @@ static int f4_impl(int mode, const float* x, const float* u, const float* scale,
     if (mt >= (1LL << 30)) return fail(VATL_EINVAL, "conv3x3_winograd_f4: too many tiles");
     p.Mtiles = (int)mt;
     p.m_tiles = cdiv(mt, F4_TB);
-    p.n_tiles = Cout / 64;
+    const bool nb2 = Cout == 32;
+    p.n_tiles = nb2 ? 1 : Cout / 64;
     p.stages = Cin / 16;
     p.x_bytes = (unsigned)((long long)N * H * W * Cin * 4); p.y_bytes = (unsigned)((long long)N * H * W * Cout * 4);
     p.u_bytes = (unsigned)(36LL * Cin * Cout * 4);
@@ -463,12 +468,15 @@ static int f4_impl(int mode, const float* x, const float* u, const float* scale,
     }
     if (grid >= (1LL << 31)) return fail(VATL_EINVAL, "conv3x3_winograd_f4: too many blocks");
     const int smem = F4_LDS_FLOATS * (int)sizeof(float);
-    static std::atomic<unsigned> configured[3] = {{0}, {0}, {0}};
-    const void* kern = mode == 0 ? (const void*)winograd_f4_kernel<0> : (mode == 1 ? (const void*)winograd_f4_kernel<1> : (const void*)winograd_f4_kernel<2>);
-    if (int rc = ensure_dynamic_lds(kern, smem, configured[mode], "winograd_f4")) return rc;
-    if (mode == 0) hipLaunchKernelGGL(winograd_f4_kernel<0>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
-    else if (mode == 1) hipLaunchKernelGGL(winograd_f4_kernel<1>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(winograd_f4_kernel<2>, dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
+    static std::atomic<unsigned> configured[4] = {{0}, {0}, {0}, {0}};
+    const int slot = nb2 ? 3 : mode;
+    const void* kern = nb2 ? (const void*)winograd_f4_kernel<0, 2>
+                           : (mode == 0 ? (const void*)winograd_f4_kernel<0, 4> : (mode == 1 ? (const void*)winograd_f4_kernel<1, 4> : (const void*)winograd_f4_kernel<2, 4>));
+    if (int rc = ensure_dynamic_lds(kern, smem, configured[slot], "winograd_f4")) return rc;
+    if (nb2) hipLaunchKernelGGL((winograd_f4_kernel<0, 2>), dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
+    else if (mode == 0) hipLaunchKernelGGL((winograd_f4_kernel<0, 4>), dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
+    else if (mode == 1) hipLaunchKernelGGL((winograd_f4_kernel<1, 4>), dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((winograd_f4_kernel<2, 4>), dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
     meter_add(1, 2.0 * ((double)p.m_tiles * F4_TB) * (double)Cout * (double)Cin * 36.0);
     meter_route(mode == 2 ? kRouteWinoF4BnBwd : kRouteWinoF4);
     return check_launch("winograd_f4");
