@@ -11,7 +11,7 @@ import torch
 import vatl_hip as vh
 
 SHAPES = {"l3.c2": (16, 12, 256, 256, False), "l2.c2": (32, 24, 128, 128, False), "l1.c2": (64, 48, 64, 64, False), "hr.b128": (16, 12, 128, 128, True),
-          "hr.b64": (32, 24, 64, 64, True), "hr.b32": (64, 48, 32, 32, True), "r152.l2.c2": (48, 36, 128, 128, False), "duc1": (24, 18, 512, 1024, False)}
+          "hr.b64": (32, 24, 64, 64, True), "r152.l2.c2": (48, 36, 128, 128, False), "duc1": (24, 18, 512, 1024, False)}
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--iters", type=int, default=10)

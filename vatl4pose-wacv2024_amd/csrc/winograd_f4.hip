@@ -200,7 +200,7 @@ __device__ __forceinline__ void f4_nu_sums(const f32x4 (&acc)[9][NB], float* Zs,
 }
 
 // MODE 0: y = act(scale * conv + bias + residual) (inference); 1: y = conv, batch statistics; 2: y = (conv + residual) * [consumer's ReLU mask], BatchNorm-backward sums
-// NB: 16-channel column blocks per block: 4 (64 output channels) or 2 (32: the 32-channel layers of HRNet's first branch; half the MFMAs per transformed value)
+// NB: 16-channel column blocks per block (4 = 64 output channels; 2 was measured for HRNet's 32-channel branch and is not instantiated: see _supported)
 template <int WV, int MODE, int NB>
 __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_tile, int n_tile) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -412,9 +412,9 @@ using namespace vatl;
 extern "C" int64_t vatl_winograd_f4_weight_floats(int Cout, int Cin) { return 36LL * Cout * Cin; }
 
 extern "C" int vatl_conv3x3_winograd_f4_supported(int N, int H, int W, int Cin, int Cout) {
-    // 64-channel blocks (Cout a multiple of 64, Cin >= 64); 32 -> 32 channels with 32-channel blocks (the inference launch only: two stages per block)
-    const bool c64 = Cin >= 64 && (Cin & 15) == 0 && Cout >= 64 && (Cout & 63) == 0, c32 = Cin == 32 && Cout == 32;
-    if (N <= 0 || H < 4 || W < 4 || (H & 3) || (W & 3) || !(c64 || c32)) return 0;
+    // (32 -> 32 channels with 32-channel blocks, NB = 2, was built and measured: 384 us against 405 us for winograd_c32 on HRNet's first branch at 1024 crops — two stages
+    //  per block leave the transforms and the write-out unamortised; not served)
+    if (N <= 0 || H < 4 || W < 4 || (H & 3) || (W & 3) || Cin < 64 || (Cin & 15) || Cout < 64 || (Cout & 63)) return 0;
     const long long xe = (long long)N * H * W * Cin, ye = (long long)N * H * W * Cout;
     return xe * 4 <= (long long)F4_OOB && ye < (1LL << 30) && 36LL * Cin * Cout < (1LL << 28) ? 1 : 0;
 }
@@ -436,9 +436,8 @@ struct F4Fuse {
 static int f4_impl(int mode, const float* x, const float* u, const float* scale, const float* bias, const float* residual, float* y, double* stats, int64_t* row_blocks_used,
                    const F4Fuse* fuse, int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
     if (!x || !u || !y) return fail(VATL_EINVAL, "conv3x3_winograd_f4: null pointer");
-    if (!vatl_conv3x3_winograd_f4_supported(N, H, W, Cin, Cout) || (mode != 0 && Cout == 32))
-        return fail(VATL_EINVAL, "conv3x3_winograd_f4: serves H, W multiples of 4 with Cin >= 64 a multiple of 16 and Cout a multiple of 64, or 32 -> 32 channels (inference) "
-                    "(got %d x %d, %d -> %d)", H, W, Cin, Cout);
+    if (!vatl_conv3x3_winograd_f4_supported(N, H, W, Cin, Cout))
+        return fail(VATL_EINVAL, "conv3x3_winograd_f4: serves H, W multiples of 4, Cin >= 64 a multiple of 16, Cout a multiple of 64 (got %d x %d, %d -> %d)", H, W, Cin, Cout);
     if (mode != 0 && !stats) return fail(VATL_EINVAL, "conv3x3_winograd_f4: the training epilogues need a statistics buffer");
     if (mode == 2 && (!fuse || !fuse->z || !fuse->mean || !fuse->invstd || (!fuse->scale != !fuse->bias)))
         return fail(VATL_EINVAL, "conv3x3_winograd_f4_fwd_bnbwd: needs the consumer layer's conv output and saved statistics (and scale WITH bias, or neither)");
@@ -451,8 +450,7 @@ static int f4_impl(int mode, const float* x, const float* u, const float* scale,
     if (mt >= (1LL << 30)) return fail(VATL_EINVAL, "conv3x3_winograd_f4: too many tiles");
     p.Mtiles = (int)mt;
     p.m_tiles = cdiv(mt, F4_TB);
-    const bool nb2 = Cout == 32;
-    p.n_tiles = nb2 ? 1 : Cout / 64;
+    p.n_tiles = Cout / 64;
     p.stages = Cin / 16;
     p.x_bytes = (unsigned)((long long)N * H * W * Cin * 4); p.y_bytes = (unsigned)((long long)N * H * W * Cout * 4);
     p.u_bytes = (unsigned)(36LL * Cin * Cout * 4);
@@ -468,13 +466,10 @@ static int f4_impl(int mode, const float* x, const float* u, const float* scale,
     }
     if (grid >= (1LL << 31)) return fail(VATL_EINVAL, "conv3x3_winograd_f4: too many blocks");
     const int smem = F4_LDS_FLOATS * (int)sizeof(float);
-    static std::atomic<unsigned> configured[4] = {{0}, {0}, {0}, {0}};
-    const int slot = nb2 ? 3 : mode;
-    const void* kern = nb2 ? (const void*)winograd_f4_kernel<0, 2>
-                           : (mode == 0 ? (const void*)winograd_f4_kernel<0, 4> : (mode == 1 ? (const void*)winograd_f4_kernel<1, 4> : (const void*)winograd_f4_kernel<2, 4>));
-    if (int rc = ensure_dynamic_lds(kern, smem, configured[slot], "winograd_f4")) return rc;
-    if (nb2) hipLaunchKernelGGL((winograd_f4_kernel<0, 2>), dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
-    else if (mode == 0) hipLaunchKernelGGL((winograd_f4_kernel<0, 4>), dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
+    static std::atomic<unsigned> configured[3] = {{0}, {0}, {0}};
+    const void* kern = mode == 0 ? (const void*)winograd_f4_kernel<0, 4> : (mode == 1 ? (const void*)winograd_f4_kernel<1, 4> : (const void*)winograd_f4_kernel<2, 4>);
+    if (int rc = ensure_dynamic_lds(kern, smem, configured[mode], "winograd_f4")) return rc;
+    if (mode == 0) hipLaunchKernelGGL((winograd_f4_kernel<0, 4>), dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
     else if (mode == 1) hipLaunchKernelGGL((winograd_f4_kernel<1, 4>), dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((winograd_f4_kernel<2, 4>), dim3((unsigned)grid), dim3(256), smem, (hipStream_t)stream, p);
     meter_add(1, 2.0 * ((double)p.m_tiles * F4_TB) * (double)Cout * (double)Cin * 36.0);
