@@ -371,3 +371,41 @@ def test_host_augmentation_arithmetic_matches_reference_fixture():
     for nj in (17, 136, 133, 68):
         t, w = st._integral_target_generator(g[f"int{nj}_joints"], nj, 256, 192)
         assert np.array_equal(t, g[f"int{nj}_target"]) and np.array_equal(w, g[f"int{nj}_weight"]) and t.dtype == w.dtype == np.float32
+
+
+def test_plan_key_sees_every_way_a_model_can_change():
+    """`hip_engine._version_key` (what decides whether the packed weights of a plan are still the model's) re-validates a cached walk of
+    the module tree instead of walking it on every call: it must still change for an in-place update, a re-assigned parameter, a replaced
+    layer at any depth, an added and a removed sub-module, a buffer update — and must not change when nothing did."""
+    from alphapose.models import builder, hip_engine
+    cfg, preset = _cfgs()
+    m = builder.build_sppe(cfg, preset_cfg=preset)
+    ref = []
+    for t in list(m.parameters()) + list(m.buffers()):
+        ref += [t.data_ptr(), t._version]
+    k0 = hip_engine._version_key(m, "cpu")
+    assert sorted(k0[1:]) == sorted(ref) and hip_engine._version_key(m, "cpu") == k0
+    keys = [k0]
+
+    def changed():
+        k = hip_engine._version_key(m, "cpu")
+        assert k not in keys and hip_engine._version_key(m, "cpu") == k
+        keys.append(k)
+    with torch.no_grad():
+        m.final_layer.weight.add_(1.0)
+    changed()
+    m.preact.bn1.running_mean.add_(1.0)                                  # a buffer
+    changed()
+    m.final_layer.bias = torch.nn.Parameter(torch.zeros(17))             # re-assigned parameter
+    changed()
+    m.final_layer = torch.nn.Conv2d(256, 17, 1)                          # replaced layer
+    changed()
+    m.preact.layer1[0].conv1 = torch.nn.Conv2d(64, 64, 1, bias=False)    # ... three levels down
+    changed()
+    before = keys[-1]
+    m.extra = torch.nn.Linear(2, 2)                                      # added
+    changed()
+    del m.extra                                                          # removed: the previous state again
+    assert hip_engine._version_key(m, "cpu") == before
+    m.double()                                                           # new storage for every tensor
+    changed()

@@ -234,6 +234,15 @@ def test_frame_video_items_follow_the_reference_item_contract():
     for k in range(5):
         assert torch.equal(batch[1][k], ds[k][1]) and torch.equal(batch[2][k], ds[k][2])
     assert batch[9] == [False, True, True, True, True]
+    direct = ds.collated(range(5))                                   # what ActiveLearning's scoring loop takes: the same 11 columns, no per-item objects
+    assert len(direct) == 11
+    for a, b in zip(batch, direct):
+        assert (torch.equal(a, b) and a.dtype == b.dtype) if torch.is_tensor(a) else list(a) == list(b)
+    ds.emit_neighbour_crops = False                                  # (the id-sorted stream mode: current crops only)
+    lean = ds.collated([3, 1, 4])
+    assert lean[1].shape == (3, 1, 3, 256, 192) and torch.equal(lean[1][:, 0], torch.stack([ds[3][1][0], ds[1][1][0], ds[4][1][0]]))
+    assert lean[0] == [3, 1, 4] and torch.equal(lean[4][1], ds[1][4]) and lean[5] == [ds[3][5], ds[1][5], ds[4][5]]
+    ds.emit_neighbour_crops = True
 
 
 def test_active_learning_round_on_decoded_frames(tmp_path):

@@ -30,15 +30,16 @@ def main():
     ap.add_argument("--retrain", action="store_true", help="also time one fine-tune epoch over all items")
     ap.add_argument("--representativeness", default="None")
     ap.add_argument("--filter", default="None")
+    ap.add_argument("--loader", action="store_true", help="evaluation batches through torch's DataLoader + the data set's collate function instead of FrameVideo.collated")
     ap.add_argument("--trace", action="store_true", help="print the wall-clock check-points of every eval_and_query round (ms since its start)")
     ap.add_argument("--cprofile", action="store_true", help="cProfile the rounds after the first and print the 30 most expensive functions (own time)")
     a = ap.parse_args()
     from active_learning import ActiveLearning
     from alphapose.datasets import FrameVideo
     from alphapose.utils.config import edict
-    from oracle import synth
+    import bench
     tracks = 16
-    frames, anns = synth.frame_video(a.items // tracks, tracks, hw=(480, 640))
+    frames, anns = bench._synthetic_frame_video(a.items // tracks, tracks, hw=(480, 640))      # (the bench line's own generator: tools do not use oracle/)
     preset = {"IMAGE_SIZE": [256, 192], "HEATMAP_SIZE": [64, 48], "SIGMA": 2}
     ev = FrameVideo(frames, anns, train=False, get_prenext=True, PRESET=preset)
     tr = FrameVideo(frames, anns, train=True, get_prenext=False, PRESET=preset, AUG={"SCALE_FACTOR": 0.25, "ROT_FACTOR": 30, "NUM_JOINTS_HALF_BODY": 8, "PROB_HALF_BODY": 0.3})
@@ -51,7 +52,8 @@ def main():
         "VAL": {"BATCH_SIZE": a.batch, "W_UNC": 0.01, "UNC_LAMBDA": 0.01, "QUERY_RATIO": [0.05, 0.1, 1.0]}})
     with tempfile.TemporaryDirectory() as wd:
         opt = types.SimpleNamespace(work_dir=wd, uncertainty=a.uncertainty, representativeness=a.representativeness, filter=a.filter, strategy=a.uncertainty, video_id="syn",
-                                    get_prenext=True, from_scratch=True, continual=True, num_gpu=1, onebyone=False, retrain_thresh=1, THCvsWPU="const")
+                                    get_prenext=True, from_scratch=True, continual=True, num_gpu=1, onebyone=False, retrain_thresh=1, THCvsWPU="const",
+                                    device_batches=not a.loader)
         torch.manual_seed(0); np.random.seed(0)
         al = ActiveLearning(cfg, opt, eval_dataset=ev, train_dataset=tr)
         times = []

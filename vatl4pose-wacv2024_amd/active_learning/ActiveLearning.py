@@ -259,9 +259,16 @@ class ActiveLearning:
         ids_all = np.zeros((n, 2), np.float64)                            # image id, annotation id (exact in float64)
         emb_all = torch.empty((n, self.emb_dim), device=self.device) if self.need_embedding else None
         thc_norm = "L1" if self.unc_kind in ("THC", "THC+WPU") else None          # `norm_type = 'L1'` for every THC* (:346)
-        loader = self.eval_loader if (lo == 0 and hi == self.eval_len) else DataLoader(
-            Subset(self.eval_dataset, list(range(lo, hi))), batch_size=self.eval_loader.batch_size, shuffle=False, num_workers=0,
-            collate_fn=self.collate_fn)
+        if getattr(self.eval_dataset, "DEVICE_ITEMS", False) and callable(getattr(self.eval_dataset, "collated", None)) and \
+                getattr(self.opt, "device_batches", True):
+            # items made on the device by this process: the data set hands over whole batches (same columns as its collate function makes
+            # from `__getitems__`, without 11 Python objects per item — the first batch's host time is the one the device cannot hide)
+            bs = self.eval_loader.batch_size
+            loader = (self.eval_dataset.collated(range(a, min(a + bs, hi))) for a in range(lo, hi, bs))
+        else:
+            loader = self.eval_loader if (lo == 0 and hi == self.eval_len) else DataLoader(
+                Subset(self.eval_dataset, list(range(lo, hi))), batch_size=self.eval_loader.batch_size, shuffle=False, num_workers=0,
+                collate_fn=self.collate_fn)
         for (idxs, inps, labels, label_masks, GTkpts, img_ids, ann_ids, bboxes_crop, bboxes_ann, isPrev, isNext) in loader:
             loc = np.asarray(idxs) - lo
             a0, b0 = int(loc[0]), int(loc[0]) + len(loc)
@@ -352,6 +359,7 @@ class ActiveLearning:
         side = D.sharded_rows(n, side_rows, 2 + 4 + 3 * self.cfg.DATA_PRESET.NUM_JOINTS, self.device, halo=1 if self.dedup else 0)
         self._host_critical(False)                     # everything is enqueued: while the main thread waits for the device, the record thread runs
         side = side.cpu().numpy()
+        self._mark("eval: side rows on the host")
         self._side = None
         rows = rows_dev[:, :55].cpu().numpy()
         self._check_wpu(self.__dict__.pop("_wpu_status", None))      # compute_hybrid's two asserts (hybrid_feature.py:25,31), for this rank's shard
@@ -540,6 +548,7 @@ class ActiveLearning:
             def pause(self):
                 if self.gated and not gate.wait(0.25):
                     self.gated = False                             # no window in sight: run to completion beside whatever the main thread does
+                    al._mark("records: ungated")
                 time.sleep(0)                                      # hand the interpreter lock to a main thread that is waiting for it
 
             def run(self):
@@ -566,10 +575,12 @@ class ActiveLearning:
                 "category_id": [1] * len(kp32)}
         self.__dict__["_records_cols"], self.__dict__["_records_labeled"] = cols, labeled
         self.__dict__["_records_lists"] = None
+        self._mark("records: columns")
         if work_dir:
             import os
             os.makedirs(work_dir, exist_ok=True)
             texts = self._records_text(cols, labeled, pause)
+            self._mark("records: text")
             pause()
             for name, text in zip(("predicted_kpt.json", "predicted_kpt_ann.json", "GT_kpt.json"), texts):
                 with open(os.path.join(work_dir, name), "w") as f:

@@ -193,6 +193,8 @@ class _CocoImages(_CocoVideo):
             out.append({"bbox": (-1.0, -1.0, 0.0, 0.0), "width": width, "height": height, "joints_3d": np.zeros((self.num_joints, 3, 2), np.float32)})
         return out
 
+    collated = None                                          # (5-tuple items: no video columns; loaders go through __getitems__)
+
     def __getitems__(self, idxs):
         idxs = [int(i) for i in idxs]
         labels = [dict(self._labels[i]) for i in idxs]

@@ -77,22 +77,50 @@ class FrameVideo(Dataset):
         j = i + step
         return 0 <= j < len(self._labels) and self._labels[j]["track_id"] == self._labels[i]["track_id"]
 
-    def __getitems__(self, idxs):
-        idxs = [int(i) for i in idxs]
-        labels = [dict(self._labels[i]) for i in idxs]          # shallow: the transform copies the joints it moves, nothing else is written
-        is_prev = [self.get_prenext and self._neighbour(i, -1) for i in idxs]
-        is_next = [self.get_prenext and self._neighbour(i, +1) for i in idxs]
-        keys = [lb["frame"] for lb in labels]
+    def _columns(self):
+        """The annotation fields of every item as arrays (built once: the labels do not change after construction) — what an evaluation
+        batch slices instead of touching 256 dicts: boxes xyxy float64, joints (N,J,3,2), GT key-points and annotation boxes as float32,
+        image / annotation ids, frame keys, same-track flags of the id-neighbours.  numpy arrays, sliced by numpy: a torch CPU indexing op
+        here starts torch's intra-op thread pool (one thread per host core, 256 on the MI355X boxes), whose spinning workers delayed the HIP
+        runtime's own threads — launches of the scoring loop then blocked for a whole device backlog (rounds of 90 - 300 ms instead of 71)."""
+        c = self.__dict__.get("_cols")
+        if c is None:
+            lb = self._labels
+            n = len(lb)
+            track = [a["track_id"] for a in lb]
+            same = np.array([track[i] == track[i + 1] for i in range(n - 1)], bool) if n > 1 else np.zeros(0, bool)
+            c = self._cols = {
+                "bbox": np.array([a["bbox"] for a in lb], np.float64).reshape(n, 4),
+                "joints": np.stack([a["joints_3d"] for a in lb]).astype(np.float32) if n else np.zeros((0, 17, 3, 2), np.float32),
+                "kp": np.array([a["keypoint"] for a in lb], np.float64).astype(np.float32).reshape(n, -1),
+                "bbox_ann": np.array([a["bbox"] for a in lb], np.float64).astype(np.float32).reshape(n, 4),
+                "img_id": [a["img_id"] for a in lb], "ann_id": [a["ann_id"] for a in lb], "frame": [a["frame"] for a in lb],
+                "prev": np.concatenate([[False], same]), "next": np.concatenate([same, [False]])}
+        return c
+
+    def collated(self, idxs):
+        """The batch `my_collate_fn(__getitems__(idxs))` makes, without the per-item detour: the 11 columns directly.  In evaluation mode
+        nothing is done per item on the host (array slices of `_columns`, one warp launch, one target launch)."""
+        idxs = np.asarray([int(i) for i in idxs], np.int64)
+        n = len(idxs)
+        c = self._columns()
+        is_prev = (c["prev"][idxs] if self.get_prenext else np.zeros(n, bool)).tolist()
+        is_next = (c["next"][idxs] if self.get_prenext else np.zeros(n, bool)).tolist()
+        frames = [c["frame"][i] for i in idxs]
+        keys = list(frames)
         if self.emit_neighbour_crops:
-            keys += [self._labels[i - 1]["frame"] for i, f in zip(idxs, is_prev) if f] + [self._labels[i + 1]["frame"] for i, f in zip(idxs, is_next) if f]
+            keys += [c["frame"][i - 1] for i, f in zip(idxs, is_prev) if f] + [c["frame"][i + 1] for i, f in zip(idxs, is_next) if f]
         arena, where = self._frames_for(keys)
         at = (lambda k: k) if where is None else (lambda k: where[k])
-        for lb in labels:
-            h, w = arena.hw[at(lb["frame"])]
-            lb.setdefault("width", int(w)); lb.setdefault("height", int(h))
         st = self.transformation
-        cur, target, weight, boxes = st.call_batch(arena, [at(lb["frame"]) for lb in labels], labels)
-        n = len(idxs)
+        if self._train:
+            labels = [dict(self._labels[i]) for i in idxs]      # shallow: the transform copies the joints it moves, nothing else is written
+            for lb in labels:
+                h, w = arena.hw[at(lb["frame"])]
+                lb.setdefault("width", int(w)); lb.setdefault("height", int(h))
+            cur, target, weight, boxes = st.call_batch(arena, [at(f) for f in frames], labels)
+        else:
+            cur, target, weight, boxes = st.eval_batch(arena, [at(f) for f in frames], c["bbox"][idxs], c["joints"][idxs])
         slots = 3 if self.emit_neighbour_crops else 1
         stacked = torch.zeros((n, slots) + tuple(cur.shape[1:]), device=cur.device) if slots == 3 else cur[:, None]
         if slots == 3:
@@ -100,14 +128,15 @@ class FrameVideo(Dataset):
         for slot, flags, step in ((1, is_prev, -1), (2, is_next, +1)):               # test_transform of the neighbour (:154-178)
             rows = [k for k in range(n) if flags[k]] if slots == 3 else []
             if rows:
-                nb = [self._labels[idxs[k] + step] for k in rows]
-                crops, _ = st.test_transform_batch(arena, [at(a["frame"]) for a in nb], np.array([a["bbox"] for a in nb], np.float64))
+                nb = idxs[rows] + step
+                crops, _ = st.test_transform_batch(arena, [at(c["frame"][j]) for j in nb], c["bbox"][nb])
                 stacked[vh.upload(np.asarray(rows, np.int64), cur.device), slot] = crops
-        out = []
-        for k, (i, lb) in enumerate(zip(idxs, labels)):
-            out.append((i, stacked[k], target[k], weight[k], torch.tensor(lb["keypoint"], dtype=torch.float32), lb["img_id"], lb["ann_id"],
-                        boxes[k], torch.Tensor(list(lb["bbox"])), bool(is_prev[k]), bool(is_next[k])))
-        return out
+        return (idxs.tolist(), stacked, target, weight, torch.from_numpy(c["kp"][idxs]), [c["img_id"][i] for i in idxs], [c["ann_id"][i] for i in idxs],
+                boxes, torch.from_numpy(c["bbox_ann"][idxs]), is_prev, is_next)
+
+    def __getitems__(self, idxs):
+        cols = self.collated(idxs)
+        return [tuple(col[k] for col in cols) for k in range(len(cols[0]))]
 
     def __getitem__(self, i):
         return self.__getitems__([i])[0]

@@ -417,14 +417,47 @@ def _chunks(n: int, hw=(256, 192)):
     return [(i, min(i + size, n)) for i in range(0, n, size)]
 
 
+def _walk(m: nn.Module):
+    """One traversal of the module tree, kept so that the next call only has to CHECK it: (parent, name, child) of every sub-module,
+    (owner, dict, name, tensor) of every parameter / buffer in `parameters()` + `buffers()` order (shared tensors once), and the
+    sizes of every module's three dicts."""
+    mods, links, seen = [m], [], {id(m)}
+    k = 0
+    while k < len(mods):                                     # breadth first; the ORDER of the signature only has to be stable
+        for name, child in mods[k]._modules.items():
+            links.append((mods[k], name, child))
+            if child is not None and id(child) not in seen:
+                seen.add(id(child)); mods.append(child)
+        k += 1
+    tensors, seen_t = [], set()
+    for mod in mods:
+        for d in (mod._parameters, mod._buffers):
+            for name, t in d.items():
+                if t is not None and id(t) not in seen_t:
+                    seen_t.add(id(t)); tensors.append((d, name, t))
+    sizes = [(mod, len(mod._modules), len(mod._parameters), len(mod._buffers)) for mod in mods]
+    return links, tensors, sizes
+
+
 def _version_key(m: nn.Module, device):
     """Exact signature of everything a plan bakes in (packed weights, folded BatchNorm): storage address and version counter of
     every parameter and buffer — compared as a tuple, so two different states can never share a key.  Writers that go through
-    the C ABI bump the counters themselves (optimizers: active_learning/optim.py; BatchNorm running statistics: hip_train.py)."""
+    the C ABI bump the counters themselves (optimizers: active_learning/optim.py; BatchNorm running statistics: hip_train.py).
+    `m.parameters()` walks the module tree through Python generators (0.4 ms for ResNet-50, 2 ms for HRNet-W32: a third of a
+    single-crop call); the walk is cached and re-validated by identity instead — every (parent, name) still holds the same child,
+    every dict the same tensor objects and the same number of entries — which catches replaced layers, re-assigned parameters and
+    additions alike; anything that does not check out is walked again."""
+    walk = m.__dict__.get("_vatl_walk")
+    if walk is not None:
+        links, tensors, sizes = walk
+        ok = all(p._modules.get(n) is c for p, n, c in links) and all(d.get(n) is t for d, n, t in tensors) and \
+            all(len(mod._modules) == a and len(mod._parameters) == b and len(mod._buffers) == c for mod, a, b, c in sizes)
+        if not ok:
+            walk = None
+    if walk is None:
+        walk = m.__dict__["_vatl_walk"] = _walk(m)
     sig = [str(device)]
-    for t in m.parameters():
-        sig.append(t.data_ptr()); sig.append(t._version)
-    for t in m.buffers():
+    for _, _, t in walk[1]:
         sig.append(t.data_ptr()); sig.append(t._version)
     return tuple(sig)
 

@@ -156,13 +156,30 @@ class SimpleTransform(object):
     def call_batch(self, arena: FrameArena, frame_index, labels):
         """``__call__`` (:179-251) for a batch: per-item draws on the host, then ONE warp launch and ONE target launch.
         -> crops (B,3,H,W), targets, target weights, boxes (B,4) float32 (host tensor)."""
-        inp_h, inp_w = self._input_size
+        if not self._train:                                                             # no draws: the arithmetic of `_draw` on arrays
+            return self.eval_batch(arena, frame_index, np.array([lb["bbox"] for lb in labels], np.float64).reshape(-1, 4),
+                                   np.stack([lb["joints_3d"] for lb in labels]))
         draws = [self._draw(lb) for lb in labels]
         centers = np.stack([d[0] for d in draws]).astype(np.float32).reshape(-1, 2)
         scales = np.stack([d[1] for d in draws]).astype(np.float32).reshape(-1, 2)
         rots = np.array([d[2] for d in draws], np.float64)
         crops, trans = self.crop_batch(arena, frame_index, centers, scales, rots, mirror=[d[3] for d in draws])
         joints = np.stack([d[4] for d in draws]).astype(np.float32)                     # (B,J,3,2), a copy
+        return self._finish_batch(crops, trans, joints, centers, scales)
+
+    def eval_batch(self, arena: FrameArena, frame_index, boxes_xyxy, joints_3d):
+        """``call_batch`` of an evaluation-mode transform from ARRAYS (boxes (B,4) xyxy float64, joints (B,J,3,2)): without augmentation
+        `_draw` is the box -> centre / scale arithmetic alone (:179-229 with `train` off), so a batch needs no per-item host work."""
+        if self._train:
+            raise ValueError("eval_batch: this transform draws augmentations (train mode); use call_batch")
+        centers, scales = box_to_center_scale_batch(boxes_xyxy, self._aspect_ratio)
+        crops, trans = self.crop_batch(arena, frame_index, centers, scales, 0.0)
+        self.num_joints = int(np.shape(joints_3d)[1])
+        return self._finish_batch(crops, trans, np.array(joints_3d, np.float32), centers, scales)
+
+    def _finish_batch(self, crops, trans, joints, centers, scales):
+        """Joints through the crop's affine map, targets / weights on the device, the corrected boxes (:231-251)."""
+        inp_h, inp_w = self._input_size
         xy1 = np.concatenate([joints[:, :, 0:2, 0].astype(np.float64), np.ones(joints.shape[:2] + (1,))], 2)
         moved = np.einsum("bik,bjk->bji", trans, xy1)                                   # affine_transform (:789-792) per joint
         vis = joints[:, :, 0, 1] > 0.0
