@@ -86,7 +86,8 @@ template <int XI> __device__ __forceinline__ constexpr bool f4_uses(int i) {
 __device__ __forceinline__ f32x4 f4_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
-// F4_ABL (tools/f4_ablate.sh only; wrong results): 1 no filter loads, 2 no LDS reads / row combinations, 4 no staging DMA, 8 no stage barrier
+// F4_ABL (tools/f4_ablate.sh only; wrong results): 1 no filter loads, 2 no LDS reads / row combinations, 4 no staging DMA, 8 no stage barrier,
+// 16 no output transform / write-out (the accumulators stay alive), 32 no wait for the block's first stage and first filter fragments
 #ifndef F4_ABL
 #define F4_ABL 0
 #endif
@@ -262,7 +263,7 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
 #pragma unroll
         for (int n = 0; n < NB; ++n) B[k][n] = f4_filter_load(ur, ublock + (unsigned)pos_of(k) * pos_bytes + n * 1024u);
     for (int s = 0; s < p.stages; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage s have landed (and the first filter fragments)
+        if ((F4_ABL & 32) == 0 || s > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage s have landed (and the first filter fragments)
         if constexpr ((F4_ABL & 8) == 0) __builtin_amdgcn_s_barrier();                      // ... everyone's; and every wave is done reading the other buffer (stage s - 1)
         asm volatile("" ::: "memory");
         float* cur = smem + (s & 1) * F4_STAGE;
@@ -281,6 +282,15 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
     }
 
     // ---- output transform ----
+    if constexpr ((F4_ABL & 16) != 0) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) t += acc[q][n];
+        if (t[0] + t[1] + t[2] + t[3] == 12345.678f) p.y[0] = t[0];
+        return;
+    }
     lds_barrier();                                         // every wave is done with the stage buffers
     float* Zs = smem;
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
