@@ -84,7 +84,7 @@ class FrameVideo(Dataset):
         here starts torch's intra-op thread pool (one thread per host core, 256 on the MI355X boxes), whose spinning workers delayed the HIP
         runtime's own threads — launches of the scoring loop then blocked for a whole device backlog (rounds of 90 - 300 ms instead of 71)."""
         c = self.__dict__.get("_cols")
-        if c is None:
+        if c is None or len(c["frame"]) != len(self._labels):
             lb = self._labels
             n = len(lb)
             track = [a["track_id"] for a in lb]
