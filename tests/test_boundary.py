@@ -409,3 +409,9 @@ def test_plan_key_sees_every_way_a_model_can_change():
     assert hip_engine._version_key(m, "cpu") == before
     m.double()                                                           # new storage for every tensor
     changed()
+    import copy
+    r = copy.copy(m)                                                     # what DataParallel's replicate() does: the original's attribute dict, copied ...
+    r.__dict__ = dict(m.__dict__)
+    r._parameters, r._buffers, r._modules = dict(m._parameters), dict(m._buffers), {k: copy.deepcopy(v) for k, v in m._modules.items()}   # ... its own tensors
+    kr = hip_engine._version_key(r, "cpu")
+    assert kr != keys[-1] and hip_engine._version_key(m, "cpu") == keys[-1]       # the original's cached walk is not taken for the replica's

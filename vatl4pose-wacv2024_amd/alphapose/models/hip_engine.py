@@ -446,16 +446,19 @@ def _version_key(m: nn.Module, device):
     `m.parameters()` walks the module tree through Python generators (0.4 ms for ResNet-50, 2 ms for HRNet-W32: a third of a
     single-crop call); the walk is cached and re-validated by identity instead — every (parent, name) still holds the same child,
     every dict the same tensor objects and the same number of entries — which catches replaced layers, re-assigned parameters and
-    additions alike; anything that does not check out is walked again."""
+    additions alike; anything that does not check out is walked again (a walk that was recorded for another module object — replicas copy
+    the attribute dict of their original — included)."""
     walk = m.__dict__.get("_vatl_walk")
+    if walk is not None and walk[3] is not m:               # a copy of another module's attribute dict (DataParallel replicas are made that way)
+        walk = None
     if walk is not None:
-        links, tensors, sizes = walk
+        links, tensors, sizes = walk[:3]
         ok = all(p._modules.get(n) is c for p, n, c in links) and all(d.get(n) is t for d, n, t in tensors) and \
             all(len(mod._modules) == a and len(mod._parameters) == b and len(mod._buffers) == c for mod, a, b, c in sizes)
         if not ok:
             walk = None
     if walk is None:
-        walk = m.__dict__["_vatl_walk"] = _walk(m)
+        walk = m.__dict__["_vatl_walk"] = _walk(m) + (m,)
     sig = [str(device)]
     for _, _, t in walk[1]:
         sig.append(t.data_ptr()); sig.append(t._version)
