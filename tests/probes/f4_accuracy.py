@@ -1,5 +1,10 @@
-import sys, numpy as np, torch, torch.nn as nn, torch.nn.functional as F
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/vatl4pose-wacv2024_amd')
+"""Accuracy gate of the F(4x4,3x3) route, checked before the kernel existed (CPU, minutes): the ORACLE network of SimplePose-R50 with its stage-2 / 3 3x3 layers replaced by an
+fp32 emulation of F(4x4,3x3) against the float64 network.  A checker script, not a collected test (it lives under tests/ because only tests may run the oracle).
+
+    python tests/probes/f4_accuracy.py"""
+import os, sys, numpy as np, torch, torch.nn as nn, torch.nn.functional as F
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vatl4pose-wacv2024_amd"))
 from oracle import nets, synth
 torch.set_num_threads(8)
 BT=torch.tensor([[4,0,-5,0,1,0],[0,-4,-4,1,1,0],[0,4,-4,-1,1,0],[0,-2,-1,2,1,0],[0,2,-1,-2,1,0],[0,4,0,-5,0,1]],dtype=torch.float64)

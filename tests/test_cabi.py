@@ -163,3 +163,26 @@ def test_no_undocumented_environment_switch():
         if name.startswith("VATL_"):
             assert f"`{name}`" in doc, f"{name} is read by the package but INTEGRATION.md does not document it"
     assert "VATL_HIP_LIB" in seen
+
+
+def test_the_oracle_is_test_infrastructure_only():
+    """Nothing that ships or measures the product reaches into oracle/: the package never mentions it, the tools do not import it (tools/make_golden.py, the
+    script that made the committed fixtures, is the one exception), bench.py imports it inside `cpu_baseline` only and __graft_entry__.py inside `smoke` only."""
+    import ast
+    imp = re.compile(r"^\s*(?:from\s+oracle\b|import\s+oracle\b)", re.M)
+    for base, dirs, files in os.walk(os.path.join(ROOT, "vatl4pose-wacv2024_amd")):
+        dirs[:] = [d for d in dirs if d not in ("build", "build_ablation", "__pycache__")]
+        for f in files:
+            if f.endswith(".py"):
+                assert not imp.search(open(os.path.join(base, f)).read()), f"{base}/{f} imports the oracle"
+    for base, dirs, files in os.walk(os.path.join(ROOT, "tools")):
+        for f in files:
+            if f.endswith(".py") and f != "make_golden.py":
+                assert not imp.search(open(os.path.join(base, f)).read()), f"tools/{f} imports the oracle"
+    for script, allowed in (("bench.py", "cpu_baseline"), ("__graft_entry__.py", "smoke")):
+        tree = ast.parse(open(os.path.join(ROOT, script)).read())
+        for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+            for node in (ast.walk(fn) if isinstance(fn, ast.FunctionDef) else fn.body):
+                names = [a.name for a in node.names] if isinstance(node, ast.Import) else ([node.module or ""] if isinstance(node, ast.ImportFrom) else [])
+                if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                    assert isinstance(fn, ast.FunctionDef) and fn.name == allowed, f"{script}: oracle imported outside {allowed}()"
