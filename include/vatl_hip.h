@@ -635,6 +635,17 @@ int vatl_conv3x3_winograd_fwd_bnbwd(const float* x, const float* u, const float*
                                     const float* bn_z, const float* bn_mask_y, const float* bn_scale, const float* bn_bias,
                                     const float* bn_mean, const float* bn_invstd, double* stats, int64_t* row_blocks_used, void* stream);
 
+/* Parameter guard of the inference plans (csrc/checksum.hip): one launch folds n_tensors device tensors into one 64-bit checksum each.
+ * A plan (packed filters, folded BatchNorm) is keyed on tensor addresses and torch version counters; an in-place write through `.data`
+ * (`p.data.copy_(w)`: alphapose/models/layers/dcn/deform_conv.py:232,255; hand-written loaders beside ActiveLearning.py:217's
+ * load_state_dict) bumps no counter — the checksums taken in front of every plan call, compared with those taken when the plan was
+ * built, are what notices it.  table_dev: n_tensors rows of {pointer, 32-bit words, first block} (int64, resident on the device),
+ * first block = the running sum of ceil(words / vatl_checksum_block_words()) over the preceding rows, total_blocks = that sum over all
+ * rows.  out: n_tensors uint64 (zeroed and written by the call): sum_i ((w_i ^ (uint32) (i * 0x9E3779B1)) + 1) * 0x9E3779B97F4A7C15 mod 2^64
+ * over the tensor's words w_i — independent of the order in which blocks finish. */
+int64_t vatl_checksum_block_words(void);
+int vatl_checksum_multi(const int64_t* table_dev, int n_tensors, int64_t total_blocks, uint64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

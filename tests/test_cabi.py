@@ -48,6 +48,18 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert lib.vatl_version() == 100
 
 
+def test_library_exports_nothing_the_header_does_not_declare(built_lib):
+    """`nm -D`: the dynamic symbol table's C-named `vatl_*` functions are EXACTLY the header's declarations — no undeclared tuning hook
+    (round 5 shipped `vatl_tune_wgrad_blocks`, a summation-order knob, and `vatl_crop_tune_px` that way: they are internal C++ symbols
+    with hidden visibility now, reachable only through vatl_tune_set of the profiling variant)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TW" and ln.split()[-1].startswith("vatl_")}
+    assert exported == set(_prototypes()), exported ^ set(_prototypes())
+    hooks = [ln for ln in out.splitlines() if "tune_wgrad_blocks" in ln or "crop_tune_px" in ln]
+    assert not hooks, hooks
+
+
 def _ctype_of(decl: str):
     decl = decl.strip()
     if "*" in decl:

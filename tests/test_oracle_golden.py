@@ -183,6 +183,35 @@ def test_fastpose_hrnet_restatements_match_reference(golden_nets2, name, ctor):
             np.testing.assert_allclose(m.get_embedding(x).numpy(), g["fastpose_embedding"], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("name,ctor", [("simplepose_r50", nets.SimplePoseRef), ("fastpose_r50", nets.FastPoseRef), ("hrnet_w32", nets.HRNetRef)])
+def test_restatements_reproduce_the_wide_index_pin(name, ctor):
+    """tests/golden/widepin.npz (64 crops per network from the reference, tools/make_golden.py::gen_widepin): the oracle graphs give the
+    reference's arg-max indices, peak values and (through oracle.scorers.decode_heatmaps) its decoded key-points on the first 8 crops, and
+    the kept heat-maps to 1e-5."""
+    import os
+    from oracle import scorers
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "widepin.npz"))
+    n = 8
+    assert int(g[f"{name}_n"]) >= 64 and g[f"{name}_idx"].shape == (64, 17)
+    m = ctor()
+    m.load_state_dict(synth.state_dict_for(m), strict=True)
+    m.eval()
+    x = torch.from_numpy(synth.crops(64, seed=int(g["seed"]))[:n])
+    bb = synth.bboxes(64, seed=int(g["seed"]))
+    with torch.no_grad():
+        hm = m(x).numpy()
+    keep = g[f"{name}_heatmaps"]
+    assert np.abs(hm[:keep.shape[0]] - keep).max() <= 1e-5 * np.abs(keep).max()
+    assert np.array_equal(hm.reshape(n, 17, -1).argmax(2), g[f"{name}_idx"][:n])
+    np.testing.assert_allclose(hm.reshape(n, 17, -1).max(2), g[f"{name}_maxval"][:n], rtol=0, atol=1e-5 * float(g[f"{name}_absmax"]))
+    for i in range(keep.shape[0]):                                 # the reference's decode of ITS maps == the oracle's decode of the same maps
+        d = scorers.decode_heatmaps(keep[i], bb[i])
+        assert np.array_equal(d["idx"], g[f"{name}_idx"][i])
+        np.testing.assert_allclose(d["coords"], g[f"{name}_keypoints"][i], rtol=1e-6, atol=1e-4)
+    assert np.array_equal(g[f"{name}_idx_f64"], g[f"{name}_idx"])   # on this fixture the reference's fp32 and float64 runs pick the same pixels
+    assert float(g[f"{name}_gap"].min()) > 0.0
+
+
 def test_fastpose_r152_384_restatement_matches_reference():
     """BASELINE.json config 5: FastPose-R152 at 384x288 (96x72 heat-maps)."""
     import os

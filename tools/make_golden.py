@@ -763,6 +763,78 @@ def gen_peaks(ref: str, out: str):
           f"cases tied: {[n for n in names if res['tied_' + n]]})")
 
 
+# ----------------------------------------------------------------------------
+# wide arg-max pin of the timed (Winograd F(4x4)) route: >= 64 crops per network
+# ----------------------------------------------------------------------------
+
+WIDE_HRNET = {"TYPE": "PoseHighResolutionNet", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50, "FINAL_CONV_KERNEL": 1,
+              "PRETRAINED_LAYERS": ["*"],
+              "STAGE2": {"NUM_MODULES": 1, "NUM_BRANCHES": 2, "NUM_BLOCKS": [4, 4], "NUM_CHANNELS": [32, 64], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"},
+              "STAGE3": {"NUM_MODULES": 4, "NUM_BRANCHES": 3, "NUM_BLOCKS": [4, 4, 4], "NUM_CHANNELS": [32, 64, 128], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"},
+              "STAGE4": {"NUM_MODULES": 3, "NUM_BRANCHES": 4, "NUM_BLOCKS": [4, 4, 4, 4], "NUM_CHANNELS": [32, 64, 128, 256], "BLOCK": "BASIC", "FUSE_METHOD": "SUM"}}
+
+WIDE_CASES = {   # name -> (MODEL cfg, input size, heat-map size, crops, crops whose full heat-maps are kept)
+    "simplepose_r50": ({"TYPE": "SimplePose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_DECONV_FILTERS": [256, 256, 256], "NUM_LAYERS": 50}, (256, 192), (64, 48), 64, 4),
+    "fastpose_r50": ({"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 50}, (256, 192), (64, 48), 64, 4),
+    "hrnet_w32": (WIDE_HRNET, (256, 192), (64, 48), 64, 4),
+    "fastpose_r152_384": ({"TYPE": "FastPose", "PRETRAINED": "", "TRY_LOAD": "", "NUM_LAYERS": 152}, (384, 288), (96, 72), 8, 1),
+}
+WIDE_SEED = 2024     # crops = synth.crops(n, seed=WIDE_SEED, hw=...), boxes = synth.bboxes(n, seed=WIDE_SEED): not the seed of any other fixture
+
+
+def gen_widepin(EasyDict, out: str):
+    """The reference's own decode inputs on MANY crops: per network the arg-max index of every joint plane (get_max_pred,
+    transforms.py:710-727), its value, the gap to the plane's second largest value (how close each index is to moving), the decoded
+    key-points (heatmap_to_coord_simple, transforms.py:550-583), the same indices from the reference modules run in float64 (what
+    exact arithmetic would pick), and full heat-maps for a few crops only (the fixture stays small)."""
+    from alphapose.models import builder                         # the reference's
+    from alphapose.utils import transforms as T
+    res = {}
+    for name, (c, in_hw, hm_hw, n, keep) in WIDE_CASES.items():
+        preset = EasyDict({"TYPE": "simple", "SIGMA": 2, "NUM_JOINTS": 17, "IMAGE_SIZE": list(in_hw), "HEATMAP_SIZE": list(hm_hw)})
+        torch.manual_seed(synth.SEED)
+        m = builder.build_sppe(EasyDict(c), preset_cfg=preset)
+        m.load_state_dict(synth.state_dict_for(m), strict=True)
+        m.eval()
+        x = torch.from_numpy(synth.crops(n, seed=WIDE_SEED, hw=in_hw))
+        bb = synth.bboxes(n, seed=WIDE_SEED)
+        hm = np.empty((n, 17) + hm_hw, np.float32)
+        with torch.no_grad():
+            for i in range(0, n, 8):
+                hm[i:i + 8] = m(x[i:i + 8]).numpy()
+        flat = hm.reshape(n, 17, -1)
+        idx = flat.argmax(2)
+        part = np.partition(flat, -2, axis=2)
+        top1, top2 = part[..., -1], part[..., -2]
+        kp = np.zeros((n, 17, 2), np.float32); mv = np.zeros((n, 17), np.float32)
+        for i in range(n):
+            cds, mx = T.heatmap_to_coord_simple(torch.from_numpy(hm[i]), bb[i].tolist(), hm_shape=hm_hw, norm_type=None)
+            kp[i], mv[i] = cds, mx.reshape(-1)
+        assert np.array_equal(mv, top1)
+        m64 = m.double()
+        idx64 = np.empty((n, 17), np.int64); gap64 = np.empty((n, 17), np.float64); d32 = 0.0; amax = 0.0
+        with torch.no_grad():
+            for i in range(0, n, 4):
+                h64 = m64(x[i:i + 4].double()).numpy().reshape(-1, 17, hm_hw[0] * hm_hw[1])
+                idx64[i:i + 4] = h64.argmax(2)
+                p64 = np.partition(h64, -2, axis=2)
+                gap64[i:i + 4] = p64[..., -1] - p64[..., -2]
+                d32 = max(d32, float(np.abs(h64 - flat[i:i + 4]).max())); amax = max(amax, float(np.abs(h64).max()))
+        res[f"{name}_n"] = np.int64(n)
+        res[f"{name}_idx"] = idx.astype(np.int16)
+        res[f"{name}_maxval"] = top1.astype(np.float32)
+        res[f"{name}_gap"] = (top1.astype(np.float64) - top2.astype(np.float64)).astype(np.float32)
+        res[f"{name}_keypoints"] = kp
+        res[f"{name}_idx_f64"] = idx64.astype(np.int16)
+        res[f"{name}_gap_f64"] = gap64.astype(np.float32)
+        res[f"{name}_absmax"] = np.float64(np.abs(hm).max())
+        res[f"{name}_ref_fp32_vs_f64"] = np.float64(d32 / amax)
+        res[f"{name}_heatmaps"] = hm[:keep].copy()
+        print(name, hm.shape, "absmax", float(np.abs(hm).max()), "min gap", float(res[f"{name}_gap"].min()),
+              "fp32 != f64 indices", int((idx != idx64).sum()), "of", idx.size, "fp32 vs f64", d32 / amax, flush=True)
+    np.savez_compressed(os.path.join(out, "widepin.npz"), seed=np.int64(WIDE_SEED), **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -793,6 +865,8 @@ def main():
         gen_peaks(a.ref, a.out)
     if a.only in ("", "r152"):
         gen_fastpose_r152(EasyDict, a.out)
+    if a.only in ("", "widepin"):
+        gen_widepin(EasyDict, a.out)
 
 
 if __name__ == "__main__":

@@ -19,6 +19,8 @@ There is no fallback: without the library or on CPU tensors this raises.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -419,56 +421,146 @@ def _chunks(n: int, hw=(256, 192)):
 
 def _walk(m: nn.Module):
     """One traversal of the module tree, kept so that the next call only has to CHECK it: (parent, name, child) of every sub-module,
-    (owner, dict, name, tensor) of every parameter / buffer in `parameters()` + `buffers()` order (shared tensors once), and the
-    sizes of every module's three dicts."""
+    (owner, kind, name, tensor) of every parameter (kind 0) / buffer (kind 1) in `parameters()` + `buffers()` order (shared tensors once),
+    and the sizes of every module's three dicts.  The ROOT module appears as ``None`` everywhere (resolved to the module the walk is
+    checked for): the walk is stored in the root's own attribute dict, and a strong reference back to it would be a reference cycle —
+    which a host program that calls gc.freeze() never gets rid of (the packed plans and the weights of every model it ever built would
+    stay on the device)."""
     mods, links, seen = [m], [], {id(m)}
     k = 0
     while k < len(mods):                                     # breadth first; the ORDER of the signature only has to be stable
         for name, child in mods[k]._modules.items():
-            links.append((mods[k], name, child))
+            links.append((mods[k] if k else None, name, child))
             if child is not None and id(child) not in seen:
                 seen.add(id(child)); mods.append(child)
         k += 1
     tensors, seen_t = [], set()
-    for mod in mods:
-        for d in (mod._parameters, mod._buffers):
+    for i, mod in enumerate(mods):
+        for kind, d in enumerate((mod._parameters, mod._buffers)):
             for name, t in d.items():
                 if t is not None and id(t) not in seen_t:
-                    seen_t.add(id(t)); tensors.append((d, name, t))
-    sizes = [(mod, len(mod._modules), len(mod._parameters), len(mod._buffers)) for mod in mods]
+                    seen_t.add(id(t)); tensors.append((mod if i else None, kind, name, t))
+    sizes = [(mod if i else None, len(mod._modules), len(mod._parameters), len(mod._buffers)) for i, mod in enumerate(mods)]
     return links, tensors, sizes
 
 
-def _version_key(m: nn.Module, device):
-    """Exact signature of everything a plan bakes in (packed weights, folded BatchNorm): storage address and version counter of
-    every parameter and buffer — compared as a tuple, so two different states can never share a key.  Writers that go through
-    the C ABI bump the counters themselves (optimizers: active_learning/optim.py; BatchNorm running statistics: hip_train.py).
-    `m.parameters()` walks the module tree through Python generators (0.4 ms for ResNet-50, 2 ms for HRNet-W32: a third of a
-    single-crop call); the walk is cached and re-validated by identity instead — every (parent, name) still holds the same child,
-    every dict the same tensor objects and the same number of entries — which catches replaced layers, re-assigned parameters and
-    additions alike; anything that does not check out is walked again (a walk that was recorded for another module object — replicas copy
-    the attribute dict of their original — included)."""
+def _checked_walk(m: nn.Module):
+    """The cached walk of ``m`` if every (parent, name) still holds the same child, every module's CURRENT `_parameters` / `_buffers` dict
+    (read from the module now, not remembered) the same tensor objects under the same names and the same number of entries; a fresh walk
+    otherwise (a walk recorded for another module object — replicas copy the attribute dict of their original — included)."""
     walk = m.__dict__.get("_vatl_walk")
-    if walk is not None and walk[3] is not m:               # a copy of another module's attribute dict (DataParallel replicas are made that way)
+    if walk is not None and walk[3]() is not m:             # a copy of another module's attribute dict (DataParallel replicas are made that way)
         walk = None
     if walk is not None:
         links, tensors, sizes = walk[:3]
-        ok = all(p._modules.get(n) is c for p, n, c in links) and all(d.get(n) is t for d, n, t in tensors) and \
-            all(len(mod._modules) == a and len(mod._parameters) == b and len(mod._buffers) == c for mod, a, b, c in sizes)
+        ok = all((p or m)._modules.get(n) is c for p, n, c in links) and \
+            all(((o or m)._buffers if kind else (o or m)._parameters).get(n) is t for o, kind, n, t in tensors) and \
+            all(len((mod or m)._modules) == a and len((mod or m)._parameters) == b and len((mod or m)._buffers) == c for mod, a, b, c in sizes)
         if not ok:
             walk = None
     if walk is None:
-        walk = m.__dict__["_vatl_walk"] = _walk(m) + (m,)
+        walk = m.__dict__["_vatl_walk"] = _walk(m) + (weakref.ref(m),)
+    return walk
+
+
+def _version_key(m: nn.Module, device):
+    """Signature of everything a plan bakes in (packed weights, folded BatchNorm): storage address and version counter of
+    every parameter and buffer — compared as a tuple, so two different states can never share a key.  Writers that go through
+    the C ABI bump the counters themselves (optimizers: active_learning/optim.py; BatchNorm running statistics: hip_train.py).
+    `m.parameters()` walks the module tree through Python generators (0.4 ms for ResNet-50, 2 ms for HRNet-W32: a third of a
+    single-crop call); the walk is cached and re-validated by identity instead (`_checked_walk`), which catches replaced layers,
+    re-assigned parameters and additions alike.  What the key CANNOT see is a write that bumps no counter — `p.data.copy_(w)`,
+    `bn.running_var.data.fill_(1)`: `_ParamGuard` below covers those."""
     sig = [str(device)]
-    for _, _, t in walk[1]:
+    for _, _, _, t in _checked_walk(m)[1]:
         sig.append(t.data_ptr()); sig.append(t._version)
     return tuple(sig)
 
 
+# PARAMETER GUARD.  True: every plan call is preceded by ONE launch that checksums all parameters and buffers (vatl_checksum_multi: 136 MB
+# for SimplePose-R50, ~30 us, mostly from the Infinity Cache), read back asynchronously and compared with the checksums taken when the plan
+# was built; a difference — an in-place write that bumped no version counter — raises StalePlanError naming the tensor at the NEXT call
+# into this module (or at `verify(model)`), and the plan is dropped so that the call after the error runs the new values.
+# `invalidate(model)` after such a write avoids the error altogether.  False: no guard launches (what round 5 shipped).
+PARAM_GUARD = True
+# At most this many read-backs in flight per plan: an enqueue-only loop (ActiveLearning.eval_and_query) runs many calls ahead of the
+# device; the oldest read-back is waited for once the ring is full.
+_GUARD_RING = 8
+
+
+class StalePlanError(RuntimeError):
+    """A parameter or buffer was overwritten in place without torch noticing (`.data` writes bump no version counter) and at least one
+    inference call ran on the values packed BEFORE the write.  The plan has been dropped: calls from now on use the new values."""
+
+
+class _ParamGuard:
+    def __init__(self, m: nn.Module, device):
+        names = {id(t): n for n, t in list(m.named_parameters()) + list(m.named_buffers())}
+        ts = [t for _, _, _, t in _checked_walk(m)[1] if t.device == device and t.numel()]
+        self.names = [names.get(id(t), f"<tensor {i}>") for i, t in enumerate(ts)]
+        self.table = vh.ChecksumTable(ts)
+        self.ref = self.table.launch().cpu()                 # plan build is the slow path: a synchronous read-back here is fine
+        self.pending = []                                    # [(event, pinned host copy)] in launch order
+        self.model = weakref.ref(m)
+
+    def launch(self):
+        dev = self.table.launch()
+        if not dev.is_cuda:                                  # (a host-side stand-in table: tests/test_boundary.py drives this class without a GPU)
+            self.pending.append((None, dev))
+            return
+        host = torch.empty((self.table.n,), dtype=torch.int64, pin_memory=True)
+        host.copy_(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, host))
+
+    def check(self, wait: bool = False):
+        """Compare every finished read-back (all of them with ``wait``; the oldest ones beyond the ring in any case)."""
+        while self.pending and (wait or len(self.pending) > _GUARD_RING or self.pending[0][0] is None or self.pending[0][0].query()):
+            ev, host = self.pending.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            if not torch.equal(host, self.ref):
+                bad = [self.names[i] for i in torch.nonzero(host != self.ref).flatten().tolist()]
+                self.pending.clear()
+                m = self.model()
+                if m is not None:
+                    invalidate(m)
+                raise StalePlanError(
+                    f"{len(bad)} parameter / buffer tensor(s) were overwritten in place without a version bump (`.data` write?) after the "
+                    f"inference plan was built: {', '.join(bad[:6])}{' ...' if len(bad) > 6 else ''}.  At least one earlier call ran on the OLD "
+                    "values; the plan has been dropped and the next call packs the current ones.  Call "
+                    "alphapose.models.hip_engine.invalidate(model) after writing through `.data` to avoid this error.")
+
+
+def invalidate(m: nn.Module) -> None:
+    """Forget everything cached for ``m`` (packed filters, folded BatchNorm, the module walk): the next call re-packs from the
+    tensors' current values.  The thing to call after writing parameters or buffers in a way torch does not track —
+    `p.data.copy_(w)`, `bn.running_mean.data.zero_()`, a raw pointer write — and harmless otherwise."""
+    for mod in m.modules():
+        mod.__dict__.pop("_vatl_plan", None)
+        mod.__dict__.pop("_vatl_walk", None)
+
+
+def verify(m: nn.Module) -> None:
+    """Synchronous form of the parameter guard: waits for every outstanding read-back of ``m``'s plan, checksums the tensors once more NOW
+    and raises StalePlanError if anything differs from the plan's packed state.  (No-op for a model without a plan.)"""
+    cached = m.__dict__.get("_vatl_plan")
+    if cached is None or cached[2] is None:
+        return
+    cached[2].check(wait=True)
+    cached[2].launch()
+    cached[2].check(wait=True)
+
+
 def _plan_for(m: nn.Module, device):
     key = _version_key(m, device)
+    x_is_cuda = torch.device(device).type == "cuda"
     cached = m.__dict__.get("_vatl_plan")
     if cached is not None and cached[0] == key:
+        if cached[2] is not None and not (x_is_cuda and torch.cuda.is_current_stream_capturing()):
+            cached[2].check()                                # read-backs of earlier calls that have arrived
+            cached[2].launch()                               # this call's checksums, in front of its launches
         return cached[1]
     from .fastpose import FastPose
     from .hrnet import PoseHighResolutionNet
@@ -490,7 +582,8 @@ def _plan_for(m: nn.Module, device):
             plan = _NchwAdapter(_BottleneckPlan(m))
         else:
             raise TypeError(f"no HIP plan for {type(m).__name__}")
-    m.__dict__["_vatl_plan"] = (key, plan)
+        guard = _ParamGuard(m, torch.device(device)) if PARAM_GUARD else None      # AFTER packing: reference = what the packers read
+    m.__dict__["_vatl_plan"] = (key, plan, guard)
     return plan
 
 

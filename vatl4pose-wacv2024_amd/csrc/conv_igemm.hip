@@ -1594,8 +1594,10 @@ int wino_wgrad_set_blocks(int v);                              // winograd_wgrad
 
 using namespace vatl;
 
-extern "C" int vatl_tune_wgrad_blocks(int blocks);
-extern "C" int vatl_crop_tune_px(int px);
+namespace vatl {                                              // internal hooks behind vatl_tune_set (not part of the C ABI: hidden, C++ linkage)
+__attribute__((visibility("hidden"))) int tune_wgrad_blocks(int blocks);   // conv_wgrad.hip
+__attribute__((visibility("hidden"))) int crop_tune_px(int px);            // crop.hip
+}
 
 extern "C" int vatl_tune_set(int knob, int value) {
     // PRODUCT KNOBS — process-global route selectors (relaxed atomics; set them before launching from several threads).  Every accepted
@@ -1625,12 +1627,12 @@ extern "C" int vatl_tune_set(int knob, int value) {
     }
     if (knob == 0 && value >= 10 && value <= 13) { g_var.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 2 && value >= 0 && value <= 200) { g_stagger.store(value, std::memory_order_relaxed); return 0; }
-    if (knob == 3 && vatl_tune_wgrad_blocks(value) == 0) return 0;
-    if (knob == 4 && value >= 0 && value <= 3) return vatl_tune_wgrad_blocks(-value - 1);
+    if (knob == 3 && tune_wgrad_blocks(value) == 0) return 0;
+    if (knob == 4 && value >= 0 && value <= 3) return tune_wgrad_blocks(-value - 1);
     if (knob == 6 && value >= 0 && value <= 15) { g_ablate.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 9 && (value == 0 || value == 1)) { g_splitk_policy.store(value, std::memory_order_relaxed); return 0; }
     if (knob == 12 && (value == 0 || value == 1)) { g_streamk.store(value, std::memory_order_relaxed); return 0; }
-    if (knob == 16 && vatl_crop_tune_px(value) == 0) return 0;
+    if (knob == 16 && crop_tune_px(value) == 0) return 0;
     if (knob == 17 && value >= 0 && value <= 63) return wino_set_ablate(value);
     if (knob == 19 && value >= 1 && value <= (1 << 20)) return wino_wgrad_set_blocks(value);
     if (knob == 23 && value >= 1 && value <= 2) return wino_wgrad_set_halves(value);

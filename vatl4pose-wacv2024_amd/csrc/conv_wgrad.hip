@@ -344,12 +344,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 using namespace vatl;
 
-extern "C" int vatl_tune_wgrad_blocks(int blocks) {       // reached through vatl_tune_set(3, blocks) / (4, bits)
+namespace vatl {
+__attribute__((visibility("hidden"))) int tune_wgrad_blocks(int blocks) {       // reached through vatl_tune_set(3, blocks) / (4, bits) of the profiling variant only
     if (blocks < 0) { g_wgrad_ablate.store(-blocks - 1, std::memory_order_relaxed); return 0; }
     if (blocks < 64 || blocks > 65536) return -1;
     g_wgrad_blocks.store(blocks, std::memory_order_relaxed);
     return 0;
 }
+}  // namespace vatl
 
 static int64_t conv_packed_floats(int Cout, int Cin, int R, int S) { return Cin == 3 ? (int64_t)Cout * R * 8 * 4 : (int64_t)Cout * R * S * Cin; }
 

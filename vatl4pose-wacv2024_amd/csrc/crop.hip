@@ -170,8 +170,10 @@ __global__ __launch_bounds__(256) void crop_warp_kernel(CropParams p) {
 
 using namespace vatl;
 
-static std::atomic<int> g_crop_px{8};          // pixels per thread of the warp kernel (vatl_crop_tune_px: 4 or 8; identical results)
-extern "C" int vatl_crop_tune_px(int px) { if (px != 4 && px != 8) return -1; g_crop_px.store(px, std::memory_order_relaxed); return 0; }
+static std::atomic<int> g_crop_px{8};          // pixels per thread of the warp kernel (vatl::crop_tune_px, profiling variant only: 4 or 8; identical results)
+namespace vatl {
+__attribute__((visibility("hidden"))) int crop_tune_px(int px) { if (px != 4 && px != 8) return -1; g_crop_px.store(px, std::memory_order_relaxed); return 0; }
+}
 
 extern "C" int vatl_crop_warp_affine(const uint8_t* arena, const int64_t* src_off, const int32_t* src_hwf, const double* minv, float* out,
                                      int32_t* crop_max, int B, int out_h, int out_w, float mean0, float mean1, float mean2, void* stream) {

@@ -128,6 +128,8 @@ SIGNATURES = {
     "vatl_maxpool3x3s2_fwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_pack_weights_multi": (_i, [_p, _i, _i64, _p]),
     "vatl_adamw_multi_block_elems": (_i64, []),
+    "vatl_checksum_block_words": (_i64, []),
+    "vatl_checksum_multi": (_i, [_p, _i, _i64, _p, _p]),
     "vatl_maxpool3x3s2_fwd_idx_affine": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "vatl_bn_train_bwd_relu_pool": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "vatl_maxpool3x3s2_bwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
@@ -1487,6 +1489,33 @@ def unpack_ae(flat: torch.Tensor, module) -> None:
                 for t in (half[i].weight, half[i].bias):
                     t.copy_(flat[off:off + t.numel()].view_as(t))
                     off += t.numel()
+
+
+class ChecksumTable:
+    """Device table for vatl_checksum_multi over a fixed list of tensors (built once: their storage does not move while a plan lives)."""
+
+    def __init__(self, tensors):
+        bw = int(lib().vatl_checksum_block_words())
+        rows, blocks = [], 0
+        for t in tensors:
+            if not (t.is_cuda and t.is_contiguous()):
+                raise VatlError("checksum: contiguous device tensors only")
+            nbytes = t.numel() * t.element_size()
+            if nbytes % 4 or t.data_ptr() % 4:
+                raise VatlError(f"checksum: a tensor of {nbytes} bytes at {t.data_ptr():#x} is not made of aligned 32-bit words")
+            rows.append((t.data_ptr(), nbytes // 4, blocks))
+            blocks += max(1, (nbytes // 4 + bw - 1) // bw)
+        self.n, self.blocks = len(rows), blocks
+        self.device = tensors[0].device if tensors else None
+        self.table = upload(torch.tensor(rows, dtype=torch.int64), self.device) if rows else None
+
+    def launch(self, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Enqueue the checksums of the tensors' CURRENT contents on the current stream -> (n,) int64 device tensor (the bits of the uint64 sums)."""
+        if out is None:
+            out = torch.empty((self.n,), dtype=torch.int64, device=self.device)
+        if self.n:
+            _check(lib().vatl_checksum_multi(_ptr(self.table, torch.int64), self.n, self.blocks, _ptr(out, torch.int64), _stream()), "vatl_checksum_multi")
+        return out
 
 
 _adamw_tables = {}                                   # (device, pointers...) -> (device table, total blocks): the pointers of a group do not change
