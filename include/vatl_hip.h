@@ -269,8 +269,9 @@ int vatl_decode_argmax_affine(const float* hm, const float* bbox, float* coords,
 /* The same decode writing the reference's key-point rows directly — kpts (N,J,3) fp32 = (x, y, score) per joint, the
  * np.concatenate((pose_coords, pose_scores), axis=1) of ActiveLearning.py:304-306 — plus the two per-item scores made from
  * them: hp (N) = -np.sum(pose_scores) (the 'HP' uncertainty, :329-330; NumPy's float32 pairwise order, bit-identical) and
- * pose_score (N) = np.mean + 1.25 np.max (the json "score", :314).  idx, hp, pose_score may be NULL. */
-int vatl_decode_pose(const float* hm, const float* bbox, float* kpts, int32_t* idx, float* hp, float* pose_score,
+ * pose_score (N doubles) = float(np.mean(s) + 1.25 * np.max(s)) (the json "score", :314) with the promotion of the reference's pinned
+ * numpy 1.23.5: float32 mean, float64 product and sum (python float x NumPy scalar -> float64).  idx, hp, pose_score may be NULL. */
+int vatl_decode_pose(const float* hm, const float* bbox, float* kpts, int32_t* idx, float* hp, double* pose_score,
                      int N, int J, int H, int W, void* stream);
 
 /* compute_thc (ActiveLearning.py:747-760) for P pairs: out[i] = sum|a_i-b_i|/J
@@ -641,8 +642,8 @@ int vatl_conv3x3_winograd_fwd_bnbwd(const float* x, const float* u, const float*
  * load_state_dict) bumps no counter — the checksums taken in front of every plan call, compared with those taken when the plan was
  * built, are what notices it.  table_dev: n_tensors rows of {pointer, 32-bit words, first block} (int64, resident on the device),
  * first block = the running sum of ceil(words / vatl_checksum_block_words()) over the preceding rows, total_blocks = that sum over all
- * rows.  out: n_tensors uint64 (zeroed and written by the call): sum_i ((w_i ^ (uint32) (i * 0x9E3779B1)) + 1) * 0x9E3779B97F4A7C15 mod 2^64
- * over the tensor's words w_i — independent of the order in which blocks finish. */
+ * rows.  out: n_tensors uint64 (zeroed and written by the call): sum_i (w_i + 1) * (0x9E3779B97F4A7C15 + 2 i) mod 2^64
+ * over the tensor's words w_i (every word has its own odd multiplier: any single changed word, and any two swapped words, change the sum) — independent of the order in which blocks finish. */
 int64_t vatl_checksum_block_words(void);
 int vatl_checksum_multi(const int64_t* table_dev, int n_tensors, int64_t total_blocks, uint64_t* out, void* stream);
 

@@ -10,16 +10,14 @@ from __future__ import annotations
 import numpy as np
 
 K = np.uint64(0x9E3779B97F4A7C15)
-SALT = np.uint32(0x9E3779B1)
 
 
 def checksum_words(words: np.ndarray) -> int:
-    """sum_i ((w_i ^ (uint32)(i * SALT)) + 1) * K  mod 2^64 over the 32-bit words of a tensor."""
+    """sum_i (w_i + 1) * (K + 2 i)  mod 2^64 over the 32-bit words of a tensor."""
     w = np.ascontiguousarray(words).view(np.uint32).reshape(-1)
     i = np.arange(w.size, dtype=np.uint64)
-    salt = ((i * np.uint64(SALT)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     with np.errstate(over="ignore"):
-        terms = ((w ^ salt).astype(np.uint64) + np.uint64(1)) * K
+        terms = (w.astype(np.uint64) + np.uint64(1)) * (K + np.uint64(2) * i)
         return int(terms.sum(dtype=np.uint64))
 
 

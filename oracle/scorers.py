@@ -128,8 +128,11 @@ def keypoints_51(coords: np.ndarray, maxvals: np.ndarray) -> np.ndarray:
 
 
 def pose_score(maxvals: np.ndarray) -> float:
-    """mean + 1.25 max of joint scores, ActiveLearning.py:314."""
-    return float(np.mean(maxvals) + 1.25 * np.max(maxvals))
+    """float(np.mean(s) + 1.25 * np.max(s)), ActiveLearning.py:314, as the reference's pinned numpy==1.23.5 evaluates it: np.mean of the float32
+    scores is a float32 scalar; `1.25 * np.float32` (python float x NumPy scalar) is float64 there, so product and sum are float64.  (Written with
+    explicit casts because NumPy >= 2, installed here, would keep the expression in float32.)"""
+    s = np.asarray(maxvals, np.float32)
+    return float(np.float64(np.mean(s)) + 1.25 * np.float64(np.max(s)))
 
 
 # --------------------------------------------------------------------------

@@ -415,3 +415,64 @@ def test_plan_key_sees_every_way_a_model_can_change():
     r._parameters, r._buffers, r._modules = dict(m._parameters), dict(m._buffers), {k: copy.deepcopy(v) for k, v in m._modules.items()}   # ... its own tensors
     kr = hip_engine._version_key(r, "cpu")
     assert kr != keys[-1] and hip_engine._version_key(m, "cpu") == keys[-1]       # the original's cached walk is not taken for the replica's
+
+
+def test_parameter_guard_notices_writes_that_bump_no_version_counter(monkeypatch):
+    """`p.data.add_(1)` / `bn.running_mean.data.zero_()` bump no torch version counter, so `_version_key` cannot see them (asserted: that
+    is the hole) — the checksum guard of a plan must.  Driven here without a GPU: `vh.ChecksumTable` is replaced by a host table that
+    evaluates the published formula (oracle/checksum.py, the one the GPU test pins the kernel to), `_ParamGuard` itself is the product's."""
+    import weakref
+    from alphapose.models import builder, hip_engine
+    from oracle import checksum as oc
+    import vatl_hip as vh
+
+    class HostTable:
+        def __init__(self, tensors):
+            self.ts, self.n = list(tensors), len(tensors)
+
+        def launch(self, out=None):
+            return torch.tensor([np.int64(np.uint64(oc.checksum_tensor(t)).view(np.int64)) for t in self.ts], dtype=torch.int64)
+    monkeypatch.setattr(vh, "ChecksumTable", HostTable)
+    cfg, preset = _cfgs()
+    m = builder.build_sppe(cfg, preset_cfg=preset)
+    dev = torch.device("cpu")
+    k0 = hip_engine._version_key(m, dev)
+    g = hip_engine._ParamGuard(m, dev)
+    assert len(g.names) == len(list(m.parameters())) + len(list(m.buffers())) and "preact.bn1.running_mean" in g.names
+    m.__dict__["_vatl_plan"] = (k0, object(), g)
+    g.launch(); g.check(wait=True)                                        # untouched: fine
+    m.final_layer.weight.data.add_(1.0)
+    assert hip_engine._version_key(m, dev) == k0                          # the version key is blind to it ...
+    g.launch()
+    with pytest.raises(hip_engine.StalePlanError, match="final_layer.weight"):
+        g.check(wait=True)                                                # ... the guard is not, and names the tensor
+    assert "_vatl_plan" not in m.__dict__ and "_vatl_walk" not in m.__dict__        # the stale plan is gone
+    g = hip_engine._ParamGuard(m, dev)                                    # what the next call builds
+    m.preact.bn1.running_mean.data.add_(0.25)                           # (default-initialised running means ARE zero: .zero_() would change nothing)
+    m.preact.layer1[0].bn2.running_var.data.fill_(2.0)
+    g.launch()
+    with pytest.raises(hip_engine.StalePlanError) as ei:
+        g.check()
+    assert "preact.bn1.running_mean" in str(ei.value) and "preact.layer1.0.bn2.running_var" in str(ei.value) and "2 parameter" in str(ei.value)
+    # a single changed bit anywhere, and two swapped elements, change the sum
+    t = torch.arange(1000, dtype=torch.float32)
+    base = oc.checksum_tensor(t)
+    u = t.clone(); u[[10, 20]] = u[[20, 10]]
+    v = t.clone(); v.view(torch.int32)[999] ^= 1
+    assert len({base, oc.checksum_tensor(u), oc.checksum_tensor(v)}) == 3
+    # invalidate(): the public way out after a `.data` write — drops plan and walk of the model and of every sub-module
+    m.__dict__["_vatl_plan"] = (k0, object(), None)
+    m.preact.__dict__["_vatl_plan"] = (k0, object(), None)
+    hip_engine._version_key(m, dev)
+    hip_engine.invalidate(m)
+    assert "_vatl_plan" not in m.__dict__ and "_vatl_walk" not in m.__dict__ and "_vatl_plan" not in m.preact.__dict__
+    # the cached walk holds no strong reference to its root: a model is freed by reference counting alone once the caller lets go
+    hip_engine._version_key(m, dev)
+    import gc
+    gc.collect(); gc.disable()
+    try:
+        r = weakref.ref(m)
+        del m, g, ei
+        assert r() is None, "the model is kept alive by a reference cycle through its cached walk"
+    finally:
+        gc.enable()

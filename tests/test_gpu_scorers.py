@@ -36,7 +36,7 @@ def test_decode_golden(vh, golden_scorers):
 def test_decode_pose_rows_and_item_scores(vh, golden_scorers):
     """vatl_decode_pose: the interleaved (x, y, score) rows equal the separate decode bit for bit; HP = -np.sum(scores) is BIT-identical to
     NumPy's float32 pairwise sum (17 joints, and 5 / 8 / 136 / 300 joints for the other branches of the summation order); the json score
-    = mean + 1.25 max BIT-equal to NumPy's float32 arithmetic on the float32 scores (ActiveLearning.py:304-314, 329-330)."""
+    = mean + 1.25 max BIT-equal to what the reference's pinned numpy 1.23.5 computes (float32 mean, float64 product and sum; ActiveLearning.py:304-314, 329-330)."""
     g = golden_scorers
     hm, bb = to_dev(g["hm"]), to_dev(g["bbox"])
     coords, maxv, idx = vh.decode(hm, bb)
@@ -46,11 +46,11 @@ def test_decode_pose_rows_and_item_scores(vh, golden_scorers):
     mv = g["maxvals"][..., 0].astype(np.float32)
     want_hp = np.array([-np.sum(mv[i]) for i in range(mv.shape[0])], np.float32)
     assert np.array_equal(hp.cpu().numpy(), want_hp)
-    f32_score = lambda v: np.float32(np.mean(v.astype(np.float32))) + np.float32(1.25) * np.max(v.astype(np.float32))     # float32 arithmetic, three roundings
+    np123 = lambda v: float(np.float64(np.mean(v.astype(np.float32))) + 1.25 * np.float64(np.max(v.astype(np.float32))))   # numpy 1.23.5: float32 mean, float64 product + sum
     got_ps = ps.cpu().numpy()
+    assert got_ps.dtype == np.float64
     for i in range(mv.shape[0]):
-        assert got_ps[i] == f32_score(mv[i]) and type(f32_score(mv[i])) is np.float32                # bit-equal to NumPy's float32 arithmetic
-        np.testing.assert_allclose(float(ps[i]), scorers.pose_score(g["maxvals"][i]), rtol=1e-6)     # ... and the oracle's expression, whatever its promotion
+        assert got_ps[i] == np123(mv[i]) == scorers.pose_score(g["maxvals"][i])                      # bit-equal doubles
     r = np.random.RandomState(9)
     for j in (5, 8, 136, 300):
         h = r.standard_normal((3, j, 8, 12)).astype(np.float32) * 3
@@ -58,7 +58,7 @@ def test_decode_pose_rows_and_item_scores(vh, golden_scorers):
         sc = h.reshape(3, j, -1).max(2)
         assert np.array_equal(k[..., 2].cpu().numpy(), sc)
         assert np.array_equal(hp.cpu().numpy(), np.array([-np.sum(sc[i]) for i in range(3)], np.float32)), j
-        assert np.array_equal(ps.cpu().numpy(), np.array([f32_score(sc[i]) for i in range(3)], np.float32)), j
+        assert np.array_equal(ps.cpu().numpy(), np.array([np123(sc[i]) for i in range(3)], np.float64)), j
 
 
 def test_decode_random_vs_oracle(vh):

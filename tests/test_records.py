@@ -26,7 +26,7 @@ def test_record_files_are_json_dumps_of_the_record_lists():
     assert pred == json.dumps(al.kpt_json) and ann == json.dumps(al.kpt_json_ann) and gt == json.dumps(al._gt_dict())
     for i in (0, 3, 4, 256):
         rec, k = al.kpt_json[i], kp[i]
-        assert rec["score"] == float(np.mean(k[2::3]) + 1.25 * np.max(k[2::3])) and rec["keypoints"] == [float(x) for x in k] or i == 5
+        assert rec["score"] == float(np.float64(np.mean(k[2::3])) + 1.25 * np.float64(np.max(k[2::3]))) and rec["keypoints"] == [float(x) for x in k] or i == 5
         assert rec["image_id"] == i // 4 and rec["id"] == 1000 + i and rec["bbox"] == side[i, 2:6].tolist() and rec["OKS"] == float(oks[i])
         assert al.GT_json[i]["keypoints"] == side[i, 6:].tolist()
         assert al.kpt_json_ann[i]["keypoints"] == (side[i, 6:].tolist() if i % 3 == 0 else rec["keypoints"])

@@ -164,14 +164,26 @@ class ActiveLearning:
         if D.mirrored():                           # every worker has built its replica: the pickled datasets can go
             D.barrier()
             D.release_payloads()
-        if getattr(opt, "gc_freeze", True):
-            # The model, the data sets (one annotation dict per item) and the loaders built above live as long as this object.  A full pass of the
-            # cyclic collector over them costs 50 - 100 ms and — triggered by the allocation count, i.e. every few evaluation rounds — lands inside
-            # one (tools/al_eval_bench.py --trace: single rounds of 120 - 200 ms among rounds of 79).  gc.freeze() moves what exists NOW to the
-            # permanent generation: later passes only look at what the rounds allocate.  Reference counting is unaffected; opt.gc_freeze = False skips it.
+        if getattr(opt, "gc_freeze", False):
+            # OPT-IN (round 6; it was the default in round 5).  The model, the data sets (one annotation dict per item) and the loaders built above live as long
+            # as this object.  A full pass of the cyclic collector over them costs 50 - 100 ms and — triggered by the allocation count, i.e. every few evaluation
+            # rounds — lands inside one (tools/al_eval_bench.py --trace: single rounds of 120 - 200 ms among rounds of 79).  gc.freeze() moves what exists NOW to
+            # the permanent generation: later passes only look at what the rounds allocate.  It is a change to the HOST PROGRAM's collector — every object alive
+            # at this point, the host's own included, is exempt from cycle collection until gc.unfreeze() — so a library constructor must not make it on its
+            # own: the host asks for it (opt.gc_freeze = True) and `close()` undoes it.  Reference counting is unaffected.
             import gc
             gc.collect()
             gc.freeze()
+            self.__dict__["_gc_frozen"] = True
+
+    def close(self):
+        """Finish what runs in the background (the record thread) and undo the process-global change an opt-in made (`opt.gc_freeze`: gc.unfreeze(), so
+        that this object, its model and its device memory can be collected like anything else).  Safe to call more than once; the reference has no
+        counterpart (its objects hold no threads and change no global state)."""
+        self.flush_records()
+        if self.__dict__.pop("_gc_frozen", False):
+            import gc
+            gc.unfreeze()
 
     # ------------------------------------------------------------------ estimator
     def initialize_estimator(self):
@@ -376,6 +388,8 @@ class ActiveLearning:
         work_dir = getattr(self.opt, "work_dir", None)
         tp = self._third_party_scores(work_dir) if (work_dir and not evaluate and D.is_main()) else {}
         fallback = {"AP": None, "mOKS": float(oks.mean())}         # device OKS of every item: always available
+        if evaluate and work_dir:
+            self.flush_records()                                   # a user evaluator may read predicted_kpt.json / GT_kpt.json of THIS round
         res = evaluate(kp_all, self) if evaluate else (dict(tp["res"], mOKS=fallback["mOKS"]) if tp.get("res") else fallback)
         res_ann = res if (evaluate or not tp.get("res_ann")) else dict(tp["res_ann"], mOKS=fallback["mOKS"])
         self.percentage.append(len(self.labeled_id) / n * 100)
@@ -568,8 +582,9 @@ class ActiveLearning:
         trigger every few rounds (50 - 100 ms each over a process that holds a model and a data set) landed inside evaluation rounds."""
         pause()
         conf = kp32[:, 2::3]
-        # whole columns converted once (a numpy call per item costs more than the record itself); float32 arithmetic like the per-item form
-        cols = {"score": (conf.mean(1) + np.float32(1.25) * conf.max(1)).astype(np.float64).tolist() if len(kp32) else [],
+        # whole columns converted once (a numpy call per item costs more than the record itself).  score = float(np.mean(s) + 1.25 * np.max(s))
+        # (ActiveLearning.py:314) with the promotion of the reference's pinned numpy 1.23.5: float32 mean, then float64 product and sum
+        cols = {"score": (conf.mean(1).astype(np.float64) + 1.25 * conf.max(1).astype(np.float64)).tolist() if len(kp32) else [],
                 "keypoints": kp32.astype(np.float64).tolist(), "GT_keypoints": side[:, 6:].tolist(), "bbox": side[:, 2:6].tolist(),
                 "image_id": side[:, 0].astype(np.int64).tolist(), "id": side[:, 1].astype(np.int64).tolist(), "OKS": oks.tolist(),
                 "category_id": [1] * len(kp32)}
@@ -583,8 +598,10 @@ class ActiveLearning:
             self._mark("records: text")
             pause()
             for name, text in zip(("predicted_kpt.json", "predicted_kpt_ann.json", "GT_kpt.json"), texts):
-                with open(os.path.join(work_dir, name), "w") as f:
+                tmp = os.path.join(work_dir, f".{name}.{os.getpid()}.tmp")         # a reader never sees a half-written file: the previous round's or this one's
+                with open(tmp, "w") as f:
                     f.write(text)
+                os.replace(tmp, os.path.join(work_dir, name))
 
     def _record_lists(self):
         """(kpt_json, kpt_json_ann, GT_json) of the last evaluated round: one dict per item (ActiveLearning.py:310-327), built on first use."""

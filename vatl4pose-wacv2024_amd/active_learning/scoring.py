@@ -28,7 +28,7 @@ class Scores:
     keypoints: torch.Tensor          # (N,17,3) x, y, score  — fp32, image pixels
     argmax: torch.Tensor             # (N,17) int32 flat arg-max indices
     hp: torch.Tensor                 # (N,) -sum of joint scores ("HP" uncertainty)
-    pose_score: torch.Tensor         # (N,) mean + 1.25 max of joint scores (json "score")
+    pose_score: torch.Tensor         # (N,) float64: mean + 1.25 max of joint scores (json "score", numpy 1.23 promotion)
     localpeak: torch.Tensor          # (N,) mean of kept local peaks (nan when none)
     thc: torch.Tensor | None = None  # (N,)
     wpu: torch.Tensor | None = None  # (N,)

@@ -98,6 +98,12 @@ class FrameVideo(Dataset):
                 "prev": np.concatenate([[False], same]), "next": np.concatenate([same, [False]])}
         return c
 
+    def invalidate_columns(self):
+        """Call after editing an annotation dict of ``_labels`` IN PLACE (a corrected box, a pseudo-label): evaluation batches read the
+        cached columns, training batches and `annotation_of` read the dicts — without this call the two would disagree.  (The reference's
+        datasets build their labels once and never edit them, posetrack21.py:40-129; appending / removing items is noticed by itself.)"""
+        self.__dict__.pop("_cols", None)
+
     def collated(self, idxs):
         """The batch `my_collate_fn(__getitems__(idxs))` makes, without the per-item detour: the 11 columns directly.  In evaluation mode
         nothing is done per item on the host (array slices of `_columns`, one warp launch, one target launch)."""

@@ -58,7 +58,7 @@ WINO_F4 = True
 
 
 class _Conv:
-    __slots__ = ("w", "u", "u32", "u4", "scale", "bias", "cout", "r", "s", "stride", "pad")
+    __slots__ = ("w", "u", "u32", "u4", "wsrc", "wino", "c32", "f4", "scale", "bias", "cout", "r", "s", "stride", "pad")
 
     def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d | None):
         assert conv.groups == 1 and conv.dilation == (1, 1)
@@ -66,15 +66,15 @@ class _Conv:
         self.w = vh.pack_conv_weight(conv.weight.detach())
         self.cout, _, self.r, self.s = conv.weight.shape
         self.stride, self.pad = conv.stride[0], conv.padding[0]
-        self.u = None
-        if WINOGRAD and (self.r, self.s, self.stride, self.pad) == (3, 3, 1, 1) and conv.in_channels % 16 == 0 and self.cout % 4 == 0:
-            self.u = vh.pack_winograd_weight(conv.weight.detach())
-        self.u32 = None
-        if self.u is not None and WINO_C32 and conv.in_channels == 32 and self.cout == 32:
-            self.u32 = vh.pack_winograd_c32_weight(conv.weight.detach())
-        self.u4 = None
-        if self.u is not None and WINO_F4 and conv.in_channels >= 64 and conv.in_channels % 16 == 0 and self.cout % 64 == 0:
-            self.u4 = vh.pack_winograd_f4_weight(conv.weight.detach())
+        # Winograd filters are packed on the FIRST call that takes their route (the grid — whole 4x4 tiles or not — is only known then): a layer
+        # that never runs F(4x4) (ResNet stage 4 at 8x6; stages 3 - 4 of R152 at 384x288) does not keep 36 floats per channel pair for it, a layer
+        # that always does keeps no F(2x2) filter (113 MB per SimplePose-R50 plan, 450 MB for R152, per replica; and the pack time after every
+        # fine-tune).  `wsrc` is the module's own weight tensor (no copy); the plan is rebuilt — or the parameter guard raises — when it changes.
+        self.u = self.u32 = self.u4 = None
+        self.wino = WINOGRAD and (self.r, self.s, self.stride, self.pad) == (3, 3, 1, 1) and conv.in_channels % 16 == 0 and self.cout % 4 == 0
+        self.c32 = self.wino and WINO_C32 and conv.in_channels == 32 and self.cout == 32
+        self.f4 = self.wino and WINO_F4 and conv.in_channels >= 64 and conv.in_channels % 16 == 0 and self.cout % 64 == 0
+        self.wsrc = conv.weight.detach() if self.wino else None
         cb = conv.bias.detach() if conv.bias is not None else None
         if bn is not None:
             self.scale, self.bias = vh.bn_fold(_d(bn.weight), _d(bn.bias), bn.running_mean, bn.running_var, bn.eps, cb)
@@ -84,11 +84,17 @@ class _Conv:
             self.scale = self.bias = None
 
     def __call__(self, x, relu, residual=None, out_nchw=False, out=None):
-        if self.u is not None and not out_nchw and not vh.latency_mode():
-            if self.u32 is not None and vh.conv3x3_winograd_c32_supported(x.shape[0], x.shape[1], x.shape[2], 32, 32):
+        if self.wino and not out_nchw and not vh.latency_mode():
+            if self.c32 and vh.conv3x3_winograd_c32_supported(x.shape[0], x.shape[1], x.shape[2], 32, 32):
+                if self.u32 is None:
+                    self.u32 = vh.pack_winograd_c32_weight(self.wsrc)
                 return vh.conv3x3_winograd_c32_fwd(x, self.u32, self.scale, self.bias, relu, residual=residual, out=out)
-            if self.u4 is not None and vh.conv3x3_winograd_f4_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.cout):
+            if self.f4 and vh.conv3x3_winograd_f4_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.cout):
+                if self.u4 is None:
+                    self.u4 = vh.pack_winograd_f4_weight(self.wsrc)
                 return vh.conv3x3_winograd_f4_fwd(x, self.u4, self.scale, self.bias, self.cout, relu, residual=residual, out=out)
+            if self.u is None:
+                self.u = vh.pack_winograd_weight(self.wsrc)
             return vh.conv3x3_winograd_fwd(x, self.u, self.scale, self.bias, self.cout, relu, residual=residual, out=out)
         if (ROWS_GEMM and self.r == 1 and self.stride == 1 and not out_nchw and not vh.latency_mode() and x.shape[-1] == 128
                 and vh.conv1x1_rows_supported(128, 0, self.cout, x.shape[0] * x.shape[1] * x.shape[2])):

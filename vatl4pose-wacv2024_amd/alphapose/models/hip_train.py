@@ -469,7 +469,6 @@ class SimplePoseTrainer:
 
     def __init__(self, m):
         t = m.preact
-        self.m = m
         self.stem = _ConvBN(t.conv1, t.bn1, True, need_dx=False)   # the input gradient is never read
         self.blocks = [_BottleneckT(b) for stage in t.stages() for b in stage]
         d = m.deconv_layers

@@ -5,9 +5,10 @@
 // counter.  The checksums, launched in front of every plan call and compared with the ones taken when the plan was built, catch it.
 //
 // HBM-bound: every 32-bit word is read once (136 MB for SimplePose-R50, mostly resident in the Infinity Cache between calls).
-// sum_i ((w_i ^ salt(i)) + 1) * K over the ring of 64-bit integers, K odd: a change of any single word changes the sum with certainty
-// (an odd multiplier is a bijection), position salt makes swaps visible, and integer addition commutes, so blocks add their partial
-// sums with one atomic each and the result does not depend on the order.
+// sum_i (w_i + 1) * (K + 2 i) over the ring of 64-bit integers, K odd: every word has its own ODD multiplier, so a change of any single
+// word changes the sum with certainty (an odd multiplier is a bijection of the ring), two swapped words a, b at i, j move it by
+// 2 (a - b)(i - j) != 0, and integer addition commutes, so blocks add their partial sums with one atomic each and the result does not
+// depend on the order in which they finish.
 #include "common.h"
 
 namespace vatl {
@@ -15,8 +16,7 @@ namespace vatl {
 constexpr long long kSumBlockWords = 16384;                   // 64 KB per block
 
 __device__ __forceinline__ unsigned long long fold_word(unsigned w, long long i) {
-    const unsigned salt = (unsigned)i * 0x9E3779B1u;
-    return ((unsigned long long)(w ^ salt) + 1ull) * 0x9E3779B97F4A7C15ull;
+    return ((unsigned long long)w + 1ull) * (0x9E3779B97F4A7C15ull + 2ull * (unsigned long long)i);
 }
 
 // table rows: {pointer, 32-bit words, first block} (int64 each); out: one 64-bit sum per row, zeroed by the caller

@@ -145,7 +145,7 @@ __device__ float np_pairwise_sum(const float* a, int n, int stride) {
     return np_pairwise_sum(a, n2, stride) + np_pairwise_sum(a + (long long)n2 * stride, n - n2, stride);
 }
 
-__global__ void pose_scores_kernel(const float* __restrict__ kpts, float* __restrict__ hp, float* __restrict__ pose_score, int N, int J) {
+__global__ void pose_scores_kernel(const float* __restrict__ kpts, float* __restrict__ hp, double* __restrict__ pose_score, int N, int J) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const float* sc = kpts + (long long)i * J * 3 + 2;
@@ -156,17 +156,12 @@ __global__ void pose_scores_kernel(const float* __restrict__ kpts, float* __rest
         if (v > mx || v != v) mx = (mx != mx) ? mx : v;
     }
     if (hp) hp[i] = -sum;
-    // float(np.mean(s) + 1.25 * np.max(s)) on float32 scores: float32 mean (pairwise sum / J, correctly rounded), float32 product, float32 sum —
-    // three roundings, no fused multiply-add: what NumPy >= 2 computes (python float x np.float32 stays float32; the oracle, the golden vectors
-    // and ActiveLearning._write_records run on that).  NumPy 1.x's value-based promotion made the product float64: <= 1 ulp of float32 away.
-    // (HIP's __fmul_rn / __fadd_rn are plain operators: without the pragma hipcc's default -ffp-contract=fast fuses them into one v_fma_f32 — one rounding
-    //  fewer than NumPy, 1 ulp off on one item in three)
-    if (pose_score) {
-#pragma clang fp contract(off)
-        const float mean = sum / (float)J;
-        const float scaled = 1.25f * mx;
-        pose_score[i] = mean + scaled;
-    }
+    // float(np.mean(s) + 1.25 * np.max(s)) under the reference's pinned numpy==1.23.5 (pyproject.toml:35): np.mean of float32 scores is a float32
+    // scalar (pairwise sum / J, correctly rounded); `1.25 * np.float32` is a python float times a NumPy SCALAR, which numpy 1.x promotes to float64,
+    // so the product (exact in float64) and the sum (one rounding, in float64) are doubles and the json "score" is that double.  (NumPy >= 2 keeps the
+    // whole expression in float32; round 5 followed that and was up to 1 ulp of float32 away from the reference's file.  alphapose/utils/bbox.py
+    // follows the same 1.23 promotion for _center_scale_to_box.)
+    if (pose_score) pose_score[i] = (double)(sum / (float)J) + 1.25 * (double)mx;
 }
 
 // --------------------------------------------------------------------------
@@ -537,7 +532,7 @@ extern "C" int vatl_decode_argmax_affine(const float* hm, const float* bbox, flo
     return decode_launch(hm, bbox, coords, maxvals, idx, N, J, H, W, 2, 1, 0, (hipStream_t)stream);
 }
 
-extern "C" int vatl_decode_pose(const float* hm, const float* bbox, float* kpts, int32_t* idx, float* hp, float* pose_score, int N, int J, int H, int W,
+extern "C" int vatl_decode_pose(const float* hm, const float* bbox, float* kpts, int32_t* idx, float* hp, double* pose_score, int N, int J, int H, int W,
                                 void* stream) {
     if (N <= 0) return 0;
     if (!hm || !bbox || !kpts) return fail(VATL_EINVAL, "decode_pose: null pointer");

@@ -945,14 +945,14 @@ def decode(hm: torch.Tensor, bbox: torch.Tensor):
 
 
 def decode_pose(hm: torch.Tensor, bbox: torch.Tensor):
-    """-> kpts (N,J,3) f32 rows (x, y, score), idx (N,J) i32, hp (N) = -sum of scores, pose_score (N) = mean + 1.25 max: the decode and the
+    """-> kpts (N,J,3) f32 rows (x, y, score), idx (N,J) i32, hp (N) = -sum of scores, pose_score (N) f64 = float32 mean + 1.25 max in float64 (numpy 1.23 promotion): the decode and the
     per-item scores of ActiveLearning.py:304-314, 329-330 in two launches (no cat / neg / sum / max / mean kernels around them)."""
     n, j, h, w = hm.shape
     kpts = torch.empty((n, j, 3), device=hm.device, dtype=torch.float32)
     idx = torch.empty((n, j), device=hm.device, dtype=torch.int32)
     hp = torch.empty((n,), device=hm.device, dtype=torch.float32)
-    ps = torch.empty((n,), device=hm.device, dtype=torch.float32)
-    _check(lib().vatl_decode_pose(_ptr(hm), _ptr(bbox), _ptr(kpts), _ptr(idx, torch.int32), _ptr(hp), _ptr(ps), n, j, h, w, _stream()), "vatl_decode_pose")
+    ps = torch.empty((n,), device=hm.device, dtype=torch.float64)
+    _check(lib().vatl_decode_pose(_ptr(hm), _ptr(bbox), _ptr(kpts), _ptr(idx, torch.int32), _ptr(hp), _ptr(ps, torch.float64), n, j, h, w, _stream()), "vatl_decode_pose")
     return kpts, idx, hp, ps
 
 
