@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--filter", default="None")
     ap.add_argument("--loader", action="store_true", help="evaluation batches through torch's DataLoader + the data set's collate function instead of FrameVideo.collated")
     ap.add_argument("--trace", action="store_true", help="print the wall-clock check-points of every eval_and_query round (ms since its start)")
+    ap.add_argument("--b2b", action="store_true", help="bench.py's loop: rounds back to back with NO synchronize between them (the host runs ahead), one flush at the end")
+    ap.add_argument("--gc-freeze", action="store_true", help="opt.gc_freeze = True (the constructor freezes what it built; round 5's default)")
+    ap.add_argument("--gc-log", action="store_true", help="print every pass of the cyclic collector (generation, ms, collected) with the round it fell into")
     ap.add_argument("--cprofile", action="store_true", help="cProfile the rounds after the first and print the 30 most expensive functions (own time)")
     a = ap.parse_args()
     from active_learning import ActiveLearning
@@ -53,25 +56,43 @@ def main():
     with tempfile.TemporaryDirectory() as wd:
         opt = types.SimpleNamespace(work_dir=wd, uncertainty=a.uncertainty, representativeness=a.representativeness, filter=a.filter, strategy=a.uncertainty, video_id="syn",
                                     get_prenext=True, from_scratch=True, continual=True, num_gpu=1, onebyone=False, retrain_thresh=1, THCvsWPU="const",
-                                    device_batches=not a.loader)
+                                    device_batches=not a.loader, gc_freeze=a.gc_freeze)
         torch.manual_seed(0); np.random.seed(0)
         al = ActiveLearning(cfg, opt, eval_dataset=ev, train_dataset=tr)
         times = []
+        gc_log, cur = [], [None]
+        if a.gc_log:
+            import gc
+
+            def on_gc(phase, info):
+                if phase == "start":
+                    cur[0] = time.perf_counter()
+                else:
+                    gc_log.append((len(times), info["generation"], 1e3 * (time.perf_counter() - cur[0]), info["collected"]))
+            gc.callbacks.append(on_gc)
         prof = None
         for r in range(a.rounds):
             al.unlabeled_id = list(range(len(ev))); al.labeled_id = []
             if a.cprofile and r == 1:
                 import cProfile
                 prof = cProfile.Profile(); prof.enable()
-            torch.cuda.synchronize(); t0 = time.perf_counter()
+            if not a.b2b or r == 0:
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
             if a.trace:
                 al._trace = []
             al.eval_and_query()
             if r == a.rounds - 1:
                 al.flush_records()                               # the last round's record files inside its time; earlier rounds' were written during the next round's device waits
-            torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+            if not a.b2b or r == a.rounds - 1:
+                torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
             if a.trace:
                 print(f"round {r}: " + " | ".join(f"{lb} {1e3 * (t - t0):.1f}" for lb, t in list(al._trace)) + f" | end {1e3 * times[-1]:.1f}", flush=True)
+        if a.gc_log:
+            gc.callbacks.remove(on_gc)
+            print("collector passes (round, generation, ms, collected): " + ", ".join(f"({r}, {g}, {ms:.1f}, {c})" for r, g, ms, c in gc_log if g > 0 or ms > 1.0)
+                  + f"; {sum(1 for x in gc_log if x[1] == 0)} gen-0 passes, {sum(x[2] for x in gc_log if x[1] == 0):.1f} ms in total", flush=True)
         if prof is not None:
             import pstats
             prof.disable()
