@@ -3,7 +3,7 @@
 
     python tools/f4_bench.py [--batch 1024] [--iters 10]
 """
-import argparse, os, sys
+import argparse, hashlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "vatl4pose-wacv2024_amd")):
     sys.path.insert(0, p)
@@ -63,4 +63,4 @@ for name in (a.layers.split(",") if a.layers else SHAPES):
     t2 = timed(lambda: vh.conv3x3_winograd_fwd(x, u2, sc, bi, cout, True, residual=res), a.iters)
     fl = 2.0 * b * h * w * cout * cin * 9
     print(f"{name:11s} B={b:5d}  F(2x2) {t2:8.1f} us {fl / t2 / 1e6:6.1f} TF/s err {e2:.2e} | F(4x4) {t4:8.1f} us {fl / t4 / 1e6:6.1f} TF/s err {e4:.2e} | executed pipe share "
-          f"{fl / 4 / t4 / 1e6 / 157.3:.2f} | speed-up {t2 / t4:.2f}x", flush=True)
+          f"{fl / 4 / t4 / 1e6 / 157.3:.2f} | speed-up {t2 / t4:.2f}x | bits {hashlib.sha1(y4.cpu().numpy().tobytes()).hexdigest()[:12]}", flush=True)

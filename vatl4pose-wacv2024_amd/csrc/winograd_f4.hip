@@ -54,6 +54,7 @@ struct F4Params {
     int N, H, W, Cin, Cout;
     int TH, TW, tpi, Mtiles, m_tiles, n_tiles, stages, relu;
     int xper;                          // XCDs per 64-channel slice (8 / n_tiles), 0: plain order
+    int chunk;                         // tile groups per XCD of a slice: ceil(m_tiles / xper)
     unsigned x_bytes, y_bytes, u_bytes;
     FastDivU d_tpi, d_TW;
 };
@@ -113,7 +114,7 @@ __device__ __forceinline__ void f4_static_for(F&& f) {
 // BURST: the position of the STAGE (0 .. 8, -1: none in this part) behind whose first four MFMAs the next stage's DMA requests go out.
 // B: ring of three fragment sets: position pl of a stage multiplies with B[pl % 3]; the set of position pl + 2 is requested at position pl (nine positions per stage:
 // the ring index carries over from stage to stage).  POS(k): transform-domain position (xi * 6 + nu) of the wave's k-th position of a stage.
-template <int XI, int NU0, int NUN, int PL0, int BURST, int NB, typename DMA, typename POS>
+template <int XI, int NU0, int NUN, int PL0, int BURST, int NB, bool FIRST, typename DMA, typename POS>
 __device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][NB], __amdgpu_buffer_rsrc_t ur, unsigned ub, unsigned pos_bytes, unsigned stage_bytes, f32x4 (&B)[3][NB],
                                         DMA dma_burst, bool more, POS pos_of) {
     // row combination XI of the six patch columns as a chain of multiply-adds over the rows it uses, term by term (18 - 24 terms: column-major), the reads a ring of
@@ -157,7 +158,7 @@ __device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][NB], __
         if constexpr (pl != BURST) prefetch();             // ... requested before this position's MFMAs
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int n = 0; n < NB; ++n) acc[pl][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[0], bcur[n][0], acc[pl][n], 0, 0, 0);
+        for (int n = 0; n < NB; ++n) acc[pl][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[n][0], V[0], FIRST ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[pl][n], 0, 0, 0);   // FIRST: the C operand is the inline constant 0 (no 144 v_mov to clear the accumulators)
         if constexpr (pl == BURST) {
             // the burst position: its own fragments and the next position's are older than the requests, so nothing here waits for them; the first younger batch
             // (position pl + 2) is waited for 12 MFMAs + the next part's row combinations + one whole position later
@@ -169,34 +170,43 @@ __device__ __forceinline__ void f4_part(const float* Pl, f32x4 (&acc)[9][NB], __
 #pragma unroll
         for (int s = 1; s < 4; ++s)
 #pragma unroll
-            for (int n = 0; n < NB; ++n) acc[pl][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[s], bcur[n][s], acc[pl][n], 0, 0, 0);
+            for (int n = 0; n < NB; ++n) acc[pl][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[n][s], V[s], acc[pl][n], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     });
 }
 
-// nu sums of one row part: Z[b] = sum over the part's columns of A^T[b][nu] * M[nu], for the column block pair H (two 16-channel blocks) -> LDS slot SLOT
+// nu sums of one row part: Z[b] = sum over the part's columns of A^T[b][nu] * M[nu], for the column block pair H (two 16-channel blocks) -> LDS slot SLOT.
+// The MFMAs run with the FILTER fragment as their A operand (rows = output channels) and the transformed input as B (columns = tiles), so a lane's accumulator
+// quad is four CONSECUTIVE CHANNELS (16 n + 4 (lane / 16) + e) of one tile (lane % 16): each z[b] goes to the exchange area as ONE 16-byte write — the layout the
+// readers and the NHWC stores want.  (Round 5 had the operands the other way round — a quad = four tiles of one channel — and scattered every value with a 4-byte
+// write: 16 ds_write_b32 + the register shuffles around them per z[b] quad.  Same products, same order of the four k-steps: bit-identical.)
 template <int NU0, int NUN, int PL0, int SLOT, int NB>
 __device__ __forceinline__ void f4_nu_sums(const f32x4 (&acc)[9][NB], float* Zs, int h, int lane) {
-    constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
-    const int n16 = lane & 15, tg = lane >> 4;
+    // A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1] through the sums and differences of the column pairs (1, 2) and (3, 4) — the form the readers
+    // use along the other axis: 10 vector operations for a full row instead of 18, 3 / 5 for the two kinds of half row (round 6; round 5 summed term by term from
+    // zero, so the two agree to fp32 rounding, not bit for bit)
+    static_assert((NU0 == 0 && (NUN == 3 || NUN == 6)) || (NU0 == 3 && NUN == 3), "row parts: columns 0-2, 3-5 or 0-5");
+    const int tl = lane & 15, cg = lane >> 4;
+    float* dst = Zs + (SLOT * 16 + tl) * F4_ZT + cg * 4;
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
-        f32x4 z[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            z[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < NUN; ++q) {
-                const float c = AT[b][NU0 + q];
-                if (c == 1.f) z[b] += acc[PL0 + q][2 * h + nn];
-                else if (c == -1.f) z[b] -= acc[PL0 + q][2 * h + nn];
-                else if (c != 0.f) z[b] += c * acc[PL0 + q][2 * h + nn];
+        const int n = 2 * h + nn;
+        f32x4 z0, z1, z2, z3;
+        if constexpr (NU0 == 0) {
+            const f32x4 s12 = acc[PL0 + 1][n] + acc[PL0 + 2][n], d12 = acc[PL0 + 1][n] - acc[PL0 + 2][n];
+            z0 = acc[PL0][n] + s12; z1 = d12; z2 = s12; z3 = d12;
+            if constexpr (NUN == 6) {
+                const f32x4 s34 = acc[PL0 + 3][n] + acc[PL0 + 4][n], d34 = acc[PL0 + 3][n] - acc[PL0 + 4][n];
+                z0 += s34; z1 += 2.f * d34; z2 += 4.f * s34; z3 += 8.f * d34 + acc[PL0 + 5][n];
             }
+        } else {
+            const f32x4 s34 = acc[PL0][n] + acc[PL0 + 1][n], d34 = acc[PL0][n] - acc[PL0 + 1][n];
+            z0 = s34; z1 = 2.f * d34; z2 = 4.f * s34; z3 = 8.f * d34 + acc[PL0 + 2][n];
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) Zs[(SLOT * 16 + 4 * tg + e) * F4_ZT + b * 36 + nn * 16 + n16] = z[b][e];
+        *reinterpret_cast<f32x4*>(dst + 0 * 36 + nn * 16) = z0;
+        *reinterpret_cast<f32x4*>(dst + 1 * 36 + nn * 16) = z1;
+        *reinterpret_cast<f32x4*>(dst + 2 * 36 + nn * 16) = z2;
+        *reinterpret_cast<f32x4*>(dst + 3 * 36 + nn * 16) = z3;
     }
 }
 
@@ -249,10 +259,6 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
     constexpr int XA = WV == 0 ? 1 : (WV == 1 ? 1 : 4), NA0 = (WV == 0 || WV == 2) ? 0 : 3;          // half row: 3 positions
     constexpr int XB = WV == 0 ? 0 : (WV == 1 ? 2 : (WV == 2 ? 3 : 5));                               // full row: 6 positions
     f32x4 acc[9][NB];
-#pragma unroll
-    for (int q = 0; q < 9; ++q)
-#pragma unroll
-        for (int n = 0; n < NB; ++n) acc[q][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int k = 0; k < F4_KDMA; ++k) request_piece(0, smem, k);
@@ -262,8 +268,16 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
     for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int n = 0; n < NB; ++n) B[k][n] = f4_filter_load(ur, ublock + (unsigned)pos_of(k) * pos_bytes + n * 1024u);
-    for (int s = 0; s < p.stages; ++s) {
-        if ((F4_ABL & 32) == 0 || s > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage s have landed (and the first filter fragments)
+    auto stage = [&](int s, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
+        // This wave's pieces of stage s have landed.  The vector-memory counter retires IN ORDER, and the 2 NB youngest operations at this point are the filter
+        // fragments of the stage's first two positions (requested behind the last two positions of the stage before, or in the prologue) — the staging requests are
+        // all older.  Waiting for everything BUT those 2 NB leaves the fragments in flight across the barrier; the MFMAs that use them wait for them on their own
+        // (hipcc tracks buffer loads into registers).  Round 5 waited with vmcnt(0): every stage began with a full L2 round trip for fragments requested ~0.5 us earlier.
+        if ((F4_ABL & 32) == 0 || s > 0) {
+            if constexpr ((F4_ABL & 1) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else { static_assert(NB == 4, "the wait count below is 2 * NB"); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+        }
         if constexpr ((F4_ABL & 8) == 0) __builtin_amdgcn_s_barrier();                      // ... everyone's; and every wave is done reading the other buffer (stage s - 1)
         asm volatile("" ::: "memory");
         float* cur = smem + (s & 1) * F4_STAGE;
@@ -277,9 +291,11 @@ __device__ __forceinline__ void f4_body(const F4Params& p, float* smem, int m_ti
                 for (int k = 0; k < F4_KDMA; ++k) request_piece(s + 1, nxt, k);
             }
         };
-        f4_part<XA, NA0, 3, 0, 2, NB>(Pl, acc, ur, ub, pos_bytes, stage_bytes, B, burst, more, pos_of);
-        f4_part<XB, 0, 6, 3, -1, NB>(Pl, acc, ur, ub, pos_bytes, stage_bytes, B, burst, more, pos_of);
-    }
+        f4_part<XA, NA0, 3, 0, 2, NB, FIRST>(Pl, acc, ur, ub, pos_bytes, stage_bytes, B, burst, more, pos_of);
+        f4_part<XB, 0, 6, 3, -1, NB, FIRST>(Pl, acc, ur, ub, pos_bytes, stage_bytes, B, burst, more, pos_of);
+    };
+    stage(0, std::true_type{});                            // (Cin >= 64: at least four stages)
+    for (int s = 1; s < p.stages; ++s) stage(s, std::false_type{});
 
     // ---- output transform ----
     if constexpr ((F4_ABL & 16) != 0) {
@@ -395,7 +411,12 @@ __global__ __launch_bounds__(256, 2) void winograd_f4_kernel(F4Params p) {
     if (p.xper > 0) {                                      // block b runs on XCD b % 8: every XCD keeps ONE 64-channel slice of U in its L2
         const int xcd = bid & 7, s = bid >> 3;
         n_tile = xcd % p.n_tiles;
-        m_tile = s * p.xper + xcd / p.n_tiles;
+        // ... and a CONTIGUOUS run of tile groups: the blocks resident on an XCD at one time are then neighbours in the image (64 consecutive groups = 5 images at
+        // 64 x 48), so the two halo rows / columns a 6 x 6 patch shares with the tiles around it, and the second half of every 128-byte line that the next
+        // 16-channel stage reads, are found in THAT XCD's L2.  (Round 5 dealt the groups round-robin over the XCDs, m_tile = s * xper + xcd / n_tiles: vertical
+        // neighbours sat on different XCDs and the conv launches fetched 3.7x their input, profiles/r05_pmc_summary.json.)
+        m_tile = (xcd / p.n_tiles) * p.chunk + s;
+        if (s >= p.chunk) return;
     } else {
         n_tile = bid % p.n_tiles;
         m_tile = bid / p.n_tiles;
@@ -469,7 +490,8 @@ static int f4_impl(int mode, const float* x, const float* u, const float* scale,
     long long grid;
     if (p.n_tiles == 1 || p.n_tiles == 2 || p.n_tiles == 4 || p.n_tiles == 8) {
         p.xper = 8 / p.n_tiles;
-        grid = 8LL * cdiv(p.m_tiles, p.xper);
+        p.chunk = cdiv(p.m_tiles, p.xper);
+        grid = 8LL * p.chunk;
     } else {
         p.xper = 0;
         grid = (long long)p.m_tiles * p.n_tiles;
