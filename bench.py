@@ -281,7 +281,7 @@ def conv_roofline(model, x, bbox, is_prev, is_next, hm_buf):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA, 4), "traffic": (traffic / len(events)) if traffic else None,
-            "metered_launches": metered, "timed_calls": len(events), "kernel": "stem_pool_kernel + conv_igemm_kernel + gemm1x1_persistent2_kernel + conv1x1_rows_kernel + bottleneck_chain_kernel + winograd_kernel / winograd_persist_kernel (all conv/deconv launches of one step; the stem launch includes bn1 + relu + maxpool; 4 launches fuse a projection shortcut with the block's last conv, 1 chains a block's last conv with the next block's first; of the 13 3x3 stride-1 layers the 11 on grids of whole 4x4 tiles run as Winograd F(4x4,3x3) (winograd_f4_kernel), the 2 at 8x6 as F(2x2,3x3), the 3 transposed convs as F(3x3,2x2) on their four phases)", "launches": len(events),
+            "metered_launches": metered, "timed_calls": len(events), "kernel": "stem_pool_kernel + conv_igemm_kernel + gemm1x1_persistent2_kernel + conv1x1_rows_kernel / conv1x1_rows256_kernel + bottleneck_chain_kernel + winograd_kernel / winograd_persist_kernel (all conv/deconv launches of one step; the stem launch includes bn1 + relu + maxpool; 4 launches fuse a projection shortcut with the block's last conv, 1 chains a block's last conv with the next block's first; of the 13 3x3 stride-1 layers the 11 on grids of whole 4x4 tiles run as Winograd F(4x4,3x3) (winograd_f4_kernel), the 2 at 8x6 as F(2x2,3x3), the 3 transposed convs as F(3x3,2x2) on their four phases)", "launches": len(events),
             # `achieved` / `frac`: MFMA FLOPs the launches EXECUTE (counted per launch by libvatl_hip.so: 2 x padded M x padded N x padded K; the
             # Winograd launches their 16 transform-domain GEMMs) / event-timed duration / peak = how busy the matrix pipe is.
             # `algorithmic_*`: the step's direct-sum FLOPs (10.853 GFLOP x frames) over the same time; the Winograd launches deliver
@@ -632,6 +632,7 @@ def extra_product_entry_points(dev, items=1024, tracks=16, rounds=8):
         # showed a 107.7 ms generation-2 pass inside it); WHEN it lands depends on everything this process allocated before — the headline, configs 3 - 5 — not on
         # the rounds.  The passes that still fall into the rounds are reported below; `opt.gc_freeze` stays off (the product default).
         gc.collect()
+        evaluate()                                          # (untimed: the pass above left the device idle for ~0.1 s and its clocks down — r06_bench_c.json: 94 ms for the first round after it, 71 after)
         gc.callbacks.append(on_gc)
         t0 = time.perf_counter()
         for _ in range(rounds):                             # back to back: the record files of round r are written inside the device waits of round r + 1

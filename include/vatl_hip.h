@@ -151,12 +151,12 @@ int vatl_conv3x3_winograd_f4_fwd_bnbwd(const float* x, const float* u, const flo
                                        const float* bn_mask_y, const float* bn_scale, const float* bn_bias, const float* bn_mean, const float* bn_invstd,
                                        double* stats, int64_t* row_blocks_used, void* stream);
 
-/* 1x1 convolution with K = 128 input channels as a row-streaming GEMM (csrc/conv1x1_rows.hip): y = act(scale * (A W^T) + bias + residual) for the short-K /
+/* 1x1 convolution with K = 128 (or, since round 6, 256) input channels as a row-streaming GEMM (csrc/conv1x1_rows.hip): y = act(scale * (A W^T) + bias + residual) for the short-K /
  * wide-N layers the tiled implicit GEMM runs far from both roofs (Bottleneck.conv3 of ResNet stage 2, Resnet.py:120-128; with x2: conv3 + projection
  * shortcut of stage 1's first block as vatl_conv1x1_dual_fwd computes it, Resnet.py:104-128, 185-189).  a (M, K1), x2 (M, K2) or NULL: the K columns
- * K1 .. K1 + K2 - 1 come from x2; w [N][128] (vatl_pack_conv_weight layout of a 1x1 filter / vatl_pack_conv1x1_dual_weight); scale / bias / residual may
- * be NULL.  Bit-identical to vatl_conv2d_fwd / vatl_conv1x1_dual_fwd.  Served (vatl_conv1x1_rows_supported): K1 = 128, K2 = 0 or K1 = K2 = 64;
- * N a multiple of 128, <= 4096; (M + 32) * N < 2^30. */
+ * K1 .. K1 + K2 - 1 come from x2; w [N][K1 + K2] (vatl_pack_conv_weight layout of a 1x1 filter / vatl_pack_conv1x1_dual_weight); scale / bias / residual may
+ * be NULL.  Bit-identical to vatl_conv2d_fwd / vatl_conv1x1_dual_fwd.  Served (vatl_conv1x1_rows_supported): K1 = 128, K2 = 0; K1 = K2 = 64;
+ * K1 = 256, K2 = 0 (Bottleneck.conv3 of ResNet stage 3: 256 -> 1024); N a multiple of 128, <= 4096; (M + 32) * max(N, K) < 2^30. */
 int vatl_conv1x1_rows_supported(int K1, int K2, int N, int64_t M);
 int vatl_conv1x1_rows_fwd(const float* a, const float* x2, const float* w, const float* scale, const float* bias, const float* residual, float* y,
                           int64_t M, int K1, int K2, int N, int relu, void* stream);

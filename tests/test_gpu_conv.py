@@ -367,29 +367,30 @@ def test_bottleneck_chain_vs_two_launches_and_float64(vh):
 
 
 def test_conv1x1_rows_has_the_bits_of_the_tiled_kernels(vh):
-    """vatl_conv1x1_rows_fwd (csrc/conv1x1_rows.hip): K = 128 1x1 layers as a row-streaming GEMM — same k order as the tiled implicit GEMM, so the output must be
+    """vatl_conv1x1_rows_fwd (csrc/conv1x1_rows.hip): K = 128 (and K = 256) 1x1 layers as a row-streaming GEMM — same k order as the tiled implicit GEMM, so the output must be
     BIT-IDENTICAL to vatl_conv2d_fwd (with / without scale, bias, residual, ReLU; N = 128 .. 1024; ragged pixel counts, a single pixel, more tiles than one walk) and,
     in the two-source form, to vatl_conv1x1_dual_fwd; plus a float64 check and the batch independence of a crop's bits."""
     r = np.random.RandomState(91)
     assert vh.conv1x1_rows_supported(128, 0, 512, 1024 * 32 * 24) and vh.conv1x1_rows_supported(64, 64, 256, 1024 * 64 * 48)
-    assert not vh.conv1x1_rows_supported(256, 0, 512, 100) and not vh.conv1x1_rows_supported(128, 0, 192, 100) and not vh.conv1x1_rows_supported(128, 0, 512, 1 << 21)
-    for cout in (128, 512, 1024):
-        w = (r.standard_normal((cout, 128, 1, 1)) / 11).astype(np.float32)
+    assert vh.conv1x1_rows_supported(256, 0, 1024, 1024 * 16 * 12) and not vh.conv1x1_rows_supported(512, 0, 512, 100)
+    assert not vh.conv1x1_rows_supported(128, 0, 192, 100) and not vh.conv1x1_rows_supported(128, 0, 512, 1 << 21) and not vh.conv1x1_rows_supported(256, 64, 512, 100)
+    for cout, kin in ((128, 128), (512, 128), (1024, 128), (1024, 256), (256, 256), (512, 256)):
+        w = (r.standard_normal((cout, kin, 1, 1)) / 11).astype(np.float32)
         sc, bi = r.uniform(0.5, 1.5, cout).astype(np.float32), r.standard_normal(cout).astype(np.float32)
         wp, scd, bid = vh.pack_conv_weight(to_dev(w)), to_dev(sc), to_dev(bi)
         for n, h, wd in ((3, 32, 24), (1, 5, 7), (1, 1, 1), (70, 8, 6), (1, 1, 33), (40, 32, 24)):
-            a = r.standard_normal((n, h, wd, 128)).astype(np.float32)
+            a = r.standard_normal((n, h, wd, kin)).astype(np.float32)
             res = r.standard_normal((n, h, wd, cout)).astype(np.float32)
             ad, rd = to_dev(a), to_dev(res)
             for relu, use_res, use_sb in ((True, True, True), (False, False, True), (True, False, False)):
                 s_, b_ = (scd, bid) if use_sb else (None, None)
                 want = vh.conv2d_fwd(ad, wp, s_, b_, cout, 1, 1, 1, 0, relu, residual=rd if use_res else None)
                 got = vh.conv1x1_rows_fwd(ad, wp, s_, b_, cout, relu, residual=rd if use_res else None)
-                assert torch.equal(got, want), (cout, n, h, wd, relu, use_res, use_sb)
-            if cout == 512 and n == 3:
+                assert torch.equal(got, want), (cout, kin, n, h, wd, relu, use_res, use_sb)
+            if cout in (512, 1024) and n == 3:
                 ref = np.maximum((a.astype(np.float64) @ w[:, :, 0, 0].T.astype(np.float64)) * sc + bi + res, 0)
                 e = rel_err(vh.conv1x1_rows_fwd(ad, wp, scd, bid, cout, True, residual=rd).cpu().numpy(), ref)
-                record("conv1x1_rows_k128_n512", vs_fp64=e)
+                record(f"conv1x1_rows_k{kin}_n{cout}", vs_fp64=e)
                 assert e < 2e-6
                 solo = vh.conv1x1_rows_fwd(ad[1:2].contiguous(), wp, scd, bid, cout, True, residual=rd[1:2].contiguous())
                 assert torch.equal(solo, vh.conv1x1_rows_fwd(ad, wp, scd, bid, cout, True, residual=rd)[1:2])

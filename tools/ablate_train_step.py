@@ -14,6 +14,8 @@ removed at the Python level (the results are then WRONG — only the step time i
   bn_minc64       BatchNorm-backward epilogue also for the 64-channel layers (hip_train._FUSE_BN_MIN_C = 64)
   wwg_minc64/256  Winograd weight gradients from 64 / 256 channels on (hip_train._WINOGRAD_WGRAD_MIN_C)
   one_stream      weight gradients on the main stream
+  streamk         stream-K scheduling of the under-filled conv launches (vatl_hip.STREAMK_IN_TRAINING; correct, bit-identical)
+  bm64 / bm128    tile rows of the implicit-GEMM forward / data-gradient launches forced (vatl_tune_set(5, v); correct, bit-identical)
   f4_off / f4_on  F(4x4,3x3) for the 3x3 layers' forward + data gradient off / on (NOT an ablation: both are correct; hip_train._WINOGRAD_F4)
 """
 import json
@@ -79,6 +81,7 @@ def restore():
     for (obj, attr), v in saved.items():
         setattr(obj, attr, v)
     saved.clear()
+    vh.tune_set(5, 0)
 
 
 def no_mask_y():
@@ -129,6 +132,8 @@ VARIANTS = [
     ("wwg_minc64", lambda: patch(hip_train, "_WINOGRAD_WGRAD_MIN_C", 64)),
     ("wwg_minc256", lambda: patch(hip_train, "_WINOGRAD_WGRAD_MIN_C", 256)),
     ("one_stream", lambda: patch(hip_train._side, "enabled", False)),
+    ("streamk", lambda: patch(vh, "STREAMK_IN_TRAINING", True)),                  # stream-K scheduling of the under-filled conv launches (bit-identical; off in the product)
+    ("bm64", lambda: vh.tune_set(5, 64)), ("bm128", lambda: vh.tune_set(5, 128)),  # forward / data-gradient tile rows forced (product knob 5; 0 = the automatic choice)
     ("f4_off", lambda: patch(hip_train, "_WINOGRAD_F4", False)),
     ("f4_on", lambda: patch(hip_train, "_WINOGRAD_F4", True)),
     ("base", lambda: None),

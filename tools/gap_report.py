@@ -16,7 +16,7 @@ import sys
 def category(name: str) -> str:
     if "conv_wgrad" in name:
         return "wgrad"
-    if "conv_igemm" in name or "gemm1x1" in name or "conv3x3_halo" in name or "streamk" in name or "winograd_kernel" in name or "winograd_persist_kernel" in name or "stem_pool_kernel" in name or "bottleneck_chain_kernel" in name or "conv1x1_rows_kernel" in name or "winograd_c32_kernel" in name:
+    if "conv_igemm" in name or "gemm1x1" in name or "conv3x3_halo" in name or "streamk" in name or "winograd_kernel" in name or "winograd_persist_kernel" in name or "stem_pool_kernel" in name or "bottleneck_chain_kernel" in name or "conv1x1_rows_kernel" in name or "conv1x1_rows256_kernel" in name or "winograd_c32_kernel" in name or "winograd_f4_kernel" in name:
         return "conv_fwd_dgrad"
     if "adamw" in name or "adam_" in name or "sgd" in name:
         return "optimizer"

@@ -54,7 +54,7 @@ def layers(B, fused=False, chained=False):
 def main():
     path = sys.argv[1]
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "gemm1x1_persistent" in r["Kernel_Name"] or "winograd_kernel" in r["Kernel_Name"] or "winograd_persist_kernel" in r["Kernel_Name"] or "winograd_f4_kernel" in r["Kernel_Name"] or "stem_pool_kernel" in r["Kernel_Name"] or "bottleneck_chain_kernel" in r["Kernel_Name"] or "conv1x1_rows_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "gemm1x1_persistent" in r["Kernel_Name"] or "winograd_kernel" in r["Kernel_Name"] or "winograd_persist_kernel" in r["Kernel_Name"] or "winograd_f4_kernel" in r["Kernel_Name"] or "stem_pool_kernel" in r["Kernel_Name"] or "bottleneck_chain_kernel" in r["Kernel_Name"] or "conv1x1_rows_kernel" in r["Kernel_Name"] or "conv1x1_rows256_kernel" in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     import re
     is_stem = lambda name: bool(re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, true", name)) or "stem_pool_kernel" in name   # (the fused stem launch includes bn1 + relu + maxpool)

@@ -38,7 +38,7 @@ def main():
         kernels[k] = {"launches_per_step": n // steps,
                       "read_bytes_per_step": int(fetch[k][1] * 1024 * 2 / steps),      # x2: gfx950 FETCH_SIZE correction
                       "write_bytes_per_step": int(write[k][1] * 1024 / steps)}
-    conv = [v for k, v in kernels.items() if "conv_igemm" in k or "gemm1x1_persistent" in k or "winograd_kernel" in k or "winograd_persist_kernel" in k or "winograd_f4_kernel" in k or "stem_pool_kernel" in k or "bottleneck_chain_kernel" in k or "conv1x1_rows_kernel" in k or "winograd_c32_kernel" in k]   # all conv launches
+    conv = [v for k, v in kernels.items() if "conv_igemm" in k or "gemm1x1_persistent" in k or "winograd_kernel" in k or "winograd_persist_kernel" in k or "winograd_f4_kernel" in k or "stem_pool_kernel" in k or "bottleneck_chain_kernel" in k or "conv1x1_rows_kernel" in k or "conv1x1_rows256_kernel" in k or "winograd_c32_kernel" in k]   # all conv launches
     cal, cal_name = kernels.get("vatl::nchw_to_nhwc_kernel"), "nchw_to_nhwc_kernel"
     if cal is None:                     # round 4: the fused stem reads the NCHW crops itself (same known read volume; it writes the pooled 64-channel rows: N x 64 x 48 x 64 x 4 bytes)
         for k, v in kernels.items():

@@ -28,17 +28,19 @@ def main():
     for _ in range(100):
         warm @ warm
     g = torch.Generator(device=dev); g.manual_seed(3)
-    for name, (h, w, cout, res) in {"l2.n.c3 (128 -> 512 + skip)": (32, 24, 512, True), "se.l2.c3 (128 -> 512)": (32, 24, 512, False), "r152@384 l2.n.c3": (48, 36, 512, True)}.items():
-        nn = n if h == 32 else max(n // 4, 1)
-        a = torch.randn((nn, h, w, 128), device=dev, generator=g)
+    for name, (h, w, cout, res, kin) in {"l2.n.c3 (128 -> 512 + skip)": (32, 24, 512, True, 128), "se.l2.c3 (128 -> 512)": (32, 24, 512, False, 128), "r152@384 l2.n.c3": (48, 36, 512, True, 128),
+                                        "l3.n.c3 (256 -> 1024 + skip)": (16, 12, 1024, True, 256), "se.l3.c3 (256 -> 1024)": (16, 12, 1024, False, 256),
+                                        "r152@384 l3.n.c3": (24, 18, 1024, True, 256), "hr.layer1-like (256 -> 256)": (64, 48, 256, False, 256)}.items():
+        nn = n if h in (32, 16) else max(n // 4, 1)
+        a = torch.randn((nn, h, w, kin), device=dev, generator=g)
         r = torch.randn((nn, h, w, cout), device=dev, generator=g) if res else None
-        wt = vh.pack_conv_weight(torch.randn((cout, 128, 1, 1), device=dev, generator=g) / 11)
+        wt = vh.pack_conv_weight(torch.randn((cout, kin, 1, 1), device=dev, generator=g) / 11)
         sc = torch.rand(cout, device=dev, generator=g) + 0.5; bi = torch.randn(cout, device=dev, generator=g)
         y = torch.empty((nn, h, w, cout), device=dev)
         for rep in range(2):
             t0 = timed(lambda: vh.conv2d_fwd(a, wt, sc, bi, cout, 1, 1, 1, 0, True, residual=r, out=y))
             t1 = timed(lambda: vh.conv1x1_rows_fwd(a, wt, sc, bi, cout, True, residual=r, out=y))
-            fl = 2.0 * nn * h * w * 128 * cout
+            fl = 2.0 * nn * h * w * kin * cout
             print(f"{name:30s} B={nn}: tiled {t0:7.1f} us ({fl / t0 / 1e6:5.1f} TF/s)  rows {t1:7.1f} us ({fl / t1 / 1e6:5.1f} TF/s)  {t0 / t1:.2f}x", flush=True)
     h, w, cout = 64, 48, 256
     a, x = torch.randn((n, h, w, 64), device=dev, generator=g), torch.randn((n, h, w, 64), device=dev, generator=g)

@@ -48,6 +48,8 @@ WINOGRAD = True
 # 1x1 layers with K = 128 and N a multiple of 128 (Bottleneck.conv3 of stage 2; conv3 + projection of stage 1's first block) through the row-streaming GEMM
 # (csrc/conv1x1_rows.hip: filter slice in registers, 32-pixel tiles; bit-identical to the tiled kernels, which ROWS_GEMM = False selects).
 ROWS_GEMM = True
+# ... and, since round 6, K = 256 with N >= 512 (Bottleneck.conv3 of ResNet stage 3: 256 -> 1024 + skip; `conv1x1_rows256_kernel`, bit-identical as well).
+ROWS_GEMM_K = (128, 256)
 # 32 -> 32 channel 3x3 layers (HRNet's highest-resolution branch) through the wave-private Winograd kernel (csrc/winograd_c32.hip: a wave owns 16 tiles with all 16
 # transform positions, no cross-wave exchange).  False = the general Winograd kernel (same values to fp32 rounding, not the same bits).
 WINO_C32 = True
@@ -96,9 +98,9 @@ class _Conv:
             if self.u is None:
                 self.u = vh.pack_winograd_weight(self.wsrc)
             return vh.conv3x3_winograd_fwd(x, self.u, self.scale, self.bias, self.cout, relu, residual=residual, out=out)
-        if (ROWS_GEMM and self.r == 1 and self.stride == 1 and not out_nchw and not vh.latency_mode() and x.shape[-1] == 128
-                and vh.conv1x1_rows_supported(128, 0, self.cout, x.shape[0] * x.shape[1] * x.shape[2])):
-            return vh.conv1x1_rows_fwd(x, self.w, self.scale, self.bias, self.cout, relu, residual=residual, out=out)     # K = 128, wide N: row-streaming GEMM
+        if (ROWS_GEMM and self.r == 1 and self.stride == 1 and not out_nchw and not vh.latency_mode() and x.shape[-1] in ROWS_GEMM_K
+                and vh.conv1x1_rows_supported(x.shape[-1], 0, self.cout, x.shape[0] * x.shape[1] * x.shape[2])):
+            return vh.conv1x1_rows_fwd(x, self.w, self.scale, self.bias, self.cout, relu, residual=residual, out=out)     # K = 128 / 256, wide N: row-streaming GEMM
         return vh.conv2d_fwd(x, self.w, self.scale, self.bias, self.cout, self.r, self.s, self.stride, self.pad, relu,
                              residual=residual, out_nchw=out_nchw, out=out)
 

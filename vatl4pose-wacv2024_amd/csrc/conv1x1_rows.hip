@@ -124,12 +124,89 @@ __global__ __launch_bounds__(256, 3) void conv1x1_rows_kernel(RowsParams p) {
     }
 }
 
+// K = 256 (round 6: Bottleneck.conv3 of ResNet stage 3, 256 -> 1024 + skip, five launches of the headline step at 0.74 of their MFMA time on the tiled kernel, whose
+// 128 x 128 tile has one write-out per eight k-tiles).  Same scheme with the numbers doubled: 128 filter values per lane, A stages of 32 rows x 256 floats (two of them =
+// 64 KB: two blocks per CU), eight DMA instructions per wave and tile, 128 MFMAs per wave and tile.  The output tile does NOT go through LDS (no room for it next to a
+// second block, and the K = 128 kernel measured the two forms equal): a lane's 16 accumulator values are 16 rows of ONE channel, the 32 lanes of a half wave store a
+// 128-byte run per row; the skip values are read the same way before the MFMAs.  One barrier per tile.  Same k order as the tiled kernels: bit-identical.
+constexpr int RW2_K = 256;
+constexpr int RW2_AS = 32 * RW2_K;
+constexpr int RW2_FLOATS = 2 * RW2_AS;
+
+__global__ __launch_bounds__(256, 2) void conv1x1_rows256_kernel(RowsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                             // [2][32][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, h = lane >> 5;
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int slice = loc % p.nslices, seq = loc / p.nslices;
+    const int tstep = (gridDim.x >> 3) / p.nslices * 8;
+    const int n0 = slice * 128;
+
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), 0, p.res ? p.y_bytes : 0u, 0x00020000);
+
+    f32x4 wf[32];                                 // lane (channel fr of the wave's 32, k half h): W[n][8 g + 4 h .. + 3], g = 0 .. 31
+    const int nw = n0 + wave * 32 + fr;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) wf[g] = rbuf_load4(wr, (unsigned)((nw * RW2_K + 8 * g + 4 * h) * 4));
+    const float sc = p.scale ? p.scale[nw] : 1.f, bi = p.bias ? p.bias[nw] : 0.f;
+    const float lo = p.relu ? 0.f : -INFINITY;
+
+    // A stage: 2048 16-byte pieces per tile = 8 wave instructions per wave; LDS piece q = (row q >> 6, position q & 63) receives the row's chunk (q & 63) ^ (row & 7)
+    auto a_dma = [&](int buf, int mt) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = (wave * 8 + u) * 64 + lane;
+            const int row = q >> 6, chunk = (q & 63) ^ (row & 7);
+            rlds_void* dst = (rlds_void*)(As + buf * RW2_AS + (wave * 8 + u) * 256);
+            const unsigned off = (unsigned)mt * (32u * RW2_K * 4u) + (unsigned)(row * RW2_K + chunk * 4) * 4u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, dst, 16, off, 0, 0, 0);
+        }
+    };
+
+    const unsigned nrow = (unsigned)p.N * 4u;     // bytes of an output row
+    const unsigned ylane = (unsigned)((4 * h) * p.N + nw) * 4u;       // accumulator element e: row (e & 3) + 8 (e >> 2) + 4 h, channel nw
+    int mt = seq * 8 + xcd, buf = 0;
+    if (mt < p.m_tiles) a_dma(0, mt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (; mt < p.m_tiles; mt += tstep, buf ^= 1) {
+        __syncthreads();                          // this tile's A rows have landed (waited for at the end of the pass before); every wave is done reading the other buffer
+        const unsigned ybase = (unsigned)mt * (32u * nrow) + ylane;
+        float rs[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            rs[e] = p.res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, ybase + (unsigned)((e & 3) + 8 * (e >> 2)) * nrow, 0, 0)) : 0.f;
+        if (mt + tstep < p.m_tiles) a_dma(buf ^ 1, mt + tstep);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(As + buf * RW2_AS + fr * RW2_K + (((2 * g + h) ^ (fr & 7)) << 2));
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tt], wf[g][tt], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = fmaxf(acc[e] * sc + bi + rs[e], lo);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, ybase + (unsigned)((e & 3) + 8 * (e >> 2)) * nrow, 0, 0);
+        }
+        // the next tile's A rows were requested before this pass's 16 stores: wait for them only, the stores stay in flight across the barrier
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    }
+}
+
 }  // namespace vatl
 
 using namespace vatl;
 
 static bool rows_shape_ok(int K1, int K2, int N, long long M) {
-    return ((K1 == 128 && K2 == 0) || (K1 == 64 && K2 == 64)) && N >= 128 && N % 128 == 0 && N <= 4096 && M > 0 && (M + 32) * (long long)N < (1LL << 30);
+    return ((K1 == 128 && K2 == 0) || (K1 == 64 && K2 == 64) || (K1 == 256 && K2 == 0)) && N >= 128 && N % 128 == 0 && N <= 4096 && M > 0 && (M + 32) * (long long)N < (1LL << 30)
+        && (M + 32) * (long long)(K1 + K2) < (1LL << 30);
 }
 
 extern "C" int vatl_conv1x1_rows_supported(int K1, int K2, int N, int64_t M) { return rows_shape_ok(K1, K2, N, M) ? 1 : 0; }
@@ -138,11 +215,25 @@ extern "C" int vatl_conv1x1_rows_fwd(const float* a, const float* x2, const floa
                                      int64_t M, int K1, int K2, int N, int relu, void* stream) {
     if (!a || !w || !y || (K2 != 0) != (x2 != nullptr)) return fail(VATL_EINVAL, "conv1x1_rows_fwd: bad arguments");
     if (!rows_shape_ok(K1, K2, N, M))
-        return fail(VATL_EINVAL, "conv1x1_rows_fwd: serves K = 128 (or 64 + 64 from two tensors), N a multiple of 128 up to 4096, (M + 32) * N < 2^30");
+        return fail(VATL_EINVAL, "conv1x1_rows_fwd: serves K = 128 (or 64 + 64 from two tensors) and K = 256, N a multiple of 128 up to 4096, (M + 32) * N < 2^30");
     RowsParams p{};
     p.a = a; p.x2 = x2; p.w = w; p.scale = scale; p.bias = bias; p.res = residual; p.y = y;
     p.M = (int)M; p.N = N; p.relu = relu; p.m_tiles = (int)((M + 31) / 32); p.nslices = N / 128;
-    p.a_bytes = (unsigned)(M * K1 * 4); p.x2_bytes = (unsigned)(M * K2 * 4); p.y_bytes = (unsigned)(M * N * 4); p.w_bytes = (unsigned)((long long)N * 128 * 4);
+    p.a_bytes = (unsigned)(M * K1 * 4); p.x2_bytes = (unsigned)(M * K2 * 4); p.y_bytes = (unsigned)(M * N * 4); p.w_bytes = (unsigned)((long long)N * (K1 + K2) * 4);
+    if (K1 == 256) {                              // two blocks per CU; whole tile teams per XCD like below
+        int teams = 512 / (8 * p.nslices);
+        if (teams < 1) teams = 1;
+        const int need = (p.m_tiles + 7) / 8;
+        if (teams > need) teams = need;
+        const int grid = teams * 8 * p.nslices;
+        const int smem2 = RW2_FLOATS * (int)sizeof(float);
+        static std::atomic<unsigned> c2{0};
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_rows256_kernel), smem2, c2, "conv1x1_rows256")) return rc;
+        hipLaunchKernelGGL(conv1x1_rows256_kernel, dim3(grid), dim3(256), smem2, (hipStream_t)stream, p);
+        meter_add(0, 2.0 * ((double)p.m_tiles * 32.0) * (double)N * 256.0);
+        meter_route(kRouteRows);
+        return check_launch("conv1x1_rows256");
+    }
     const int smem = RW_FLOATS * (int)sizeof(float);
     // three blocks per CU; the grid is a multiple of 8 x nslices (whole tile teams per XCD), never more teams than tiles
     int teams = 768 / (8 * p.nslices);
