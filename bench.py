@@ -38,6 +38,29 @@ for p in (ROOT, os.path.join(ROOT, "vatl4pose-wacv2024_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+
+
+def granted_cpus():
+    """CPUs this process may USE: the affinity mask, cut down to the cgroup's CPU-time quota (the GPU boxes show 256 logical CPUs to a container that is
+    granted 16: /sys/fs/cgroup/cpu.max "1600000 100000")."""
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return (max(1, min(visible, int(quota + 0.5))) if quota else visible), visible, quota
+
+
+# Host thread pools sized to the GRANTED CPUs, before torch / numpy create them (setdefault: an explicit setting of the caller wins).  Left at their
+# default — one worker per VISIBLE core, 256 on the GPU boxes — a single parallel region of torch's intra-op pool or of numpy's BLAS spins 256 threads
+# against a 16-CPU quota; the kernel then throttles the whole process for the rest of the 100 ms period, main thread and HIP runtime threads included
+# (r06: single 85 - 109 ms rounds among 71 ms ones in `extra.product_entry_points` with no collector pass in them).
+for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+    os.environ.setdefault(_v, str(granted_cpus()[0]))
+
 import torch  # noqa: E402
 
 FRAMES = 1024
@@ -309,18 +332,10 @@ def cpu_baseline():
     m = nets.SimplePoseRef(50).eval()
     n = 32
     x = torch.from_numpy(synth.crops(n, seed=1))
-    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # The cores this process may actually USE: the GPU boxes show 256 logical CPUs to a container whose cgroup grants 16 CPUs of time
     # (cpu.max "1600000 100000") — 256 runnable threads against that quota are throttled to a crawl (measured: 36.8 s per 32-crop forward
     # against 0.9 s with 16 threads).  "All cores" therefore means all GRANTED cores.
-    quota = None
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            q, per = f.read().split()[:2]
-            quota = None if q == "max" else float(q) / float(per)
-    except (OSError, ValueError):
-        pass
-    avail = max(1, min(visible, int(quota + 0.5))) if quota else visible
+    avail, visible, quota = granted_cpus()
     cands = sorted({c for c in (4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512) if c < avail} | {avail})
     calib, budget = {}, time.perf_counter() + 45.0
     with torch.no_grad():
