@@ -92,6 +92,9 @@ __device__ __forceinline__ f32x4 f4_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned
 #ifndef F4_ABL
 #define F4_ABL 0
 #endif
+#ifndef F4_STAGGER
+#define F4_STAGGER 0
+#endif
 // Filter fragments and the staging DMA share the wave's IN-ORDER vector-memory counter, and hipcc does not count an LDS-DMA request (the builtin below) in the
 // bookkeeping behind its own waits: a fragment load issued after a DMA request completes after it, and the compiler's wait for an OLDER batch ("the four younger loads
 // may stay in flight": vmcnt(4)) in fact also waits for a request issued in between.  With one request behind every position's MFMAs every position waited for a
@@ -422,6 +425,14 @@ __global__ __launch_bounds__(256, 2) void winograd_f4_kernel(F4Params p) {
         m_tile = bid / p.n_tiles;
     }
     if (m_tile >= p.m_tiles) return;
+#if F4_STAGGER
+    // experiment (tools/f4_ablate.sh stagger): the blocks of a launch start together, take the same time and are replaced together, so the whole chip loads, computes and
+    // stores in phase; the SECOND block of every CU (ids 256 .. 511 of the first round) starts F4_STAGGER x 8128 cycles late, and the offset survives the rounds
+    if (bid >= 256 && bid < 512) {
+#pragma unroll 1
+        for (int i = 0; i < F4_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wave) {                                        // the position split is per wave and compile-time: four instantiations of the body
         case 0: f4_body<0, MODE, NB>(p, smem, m_tile, n_tile); break;
