@@ -45,9 +45,10 @@ def test_checksum_kernel_matches_the_published_formula(vh):
         vh.ChecksumTable([torch.zeros(3, dtype=torch.uint8, device=dev())])
 
 
-def test_data_writes_are_noticed_and_the_next_forward_equals_a_fresh_model(vh):
+def test_data_writes_are_noticed_and_the_next_forward_equals_a_fresh_model(vh, monkeypatch):
     from alphapose.models import hip_engine
-    assert hip_engine.PARAM_GUARD
+    assert hip_engine.PARAM_GUARD and 0 < hip_engine.GUARD_MIN_INTERVAL_S <= 0.05
+    monkeypatch.setattr(hip_engine, "GUARD_MIN_INTERVAL_S", 0.0)          # every call guarded: the sequence below is call-exact (the interval has its own test)
     m = _build_simplepose()
     x = to_dev(synth.crops(20, seed=4))
     out = torch.empty((20, 17, 64, 48), device=dev())
@@ -105,6 +106,35 @@ def test_data_writes_are_noticed_and_the_next_forward_equals_a_fresh_model(vh):
         m.final_layer.weight.mul_(0.5)
         y2 = m(x[:4]); m(x[:4]); hip_engine.verify(m)
     assert torch.allclose(y2, y0, rtol=1e-5, atol=1e-5)
+
+
+def test_guard_interval_bounds_how_long_a_write_can_go_unnoticed(vh, monkeypatch):
+    """With GUARD_MIN_INTERVAL_S = t a plan's checksums are launched at most once per t (latency loops of ~1 ms calls pay the guard's ~60 us of stream time on one call in
+    twenty): a write is noticed by the first call that is more than t after the last guarded one (+ one call for the read-back), and by `verify` at once."""
+    import time
+    from alphapose.models import hip_engine
+    monkeypatch.setattr(hip_engine, "GUARD_MIN_INTERVAL_S", 0.25)
+    m = _build_simplepose()
+    x = to_dev(synth.crops(4, seed=4))
+    with torch.no_grad():
+        m(x); m(x)                                                        # plan built (its own reference checksums), first guarded call
+        torch.cuda.synchronize()
+        g = m.__dict__["_vatl_plan"][2]
+        n0 = len(g.pending)
+        for _ in range(5):
+            m(x)
+        assert len(g.pending) <= n0 + 1                                   # calls inside the interval launch no checksums (arrived read-backs are consumed)
+        m.final_layer.weight.data.mul_(3.0)
+        m(x); m(x)                                                        # still inside the interval: nobody looked
+        with pytest.raises(hip_engine.StalePlanError, match="final_layer.weight"):
+            hip_engine.verify(m)                                          # ... but verify() looks at once
+        m(x); m(x)                                                        # new plan, new reference
+        m.final_layer.weight.data.mul_(0.5)
+        time.sleep(0.3)
+        m(x)                                                              # past the interval: guarded (stale values, as designed) ...
+        torch.cuda.synchronize()
+        with pytest.raises(hip_engine.StalePlanError):
+            m(x)                                                          # ... and reported by the next call
 
 
 def test_guard_cost_is_small_next_to_a_stream_call(vh):

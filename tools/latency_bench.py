@@ -18,7 +18,11 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--splitk", type=int, default=0, help="megabytes of split-K workspace (vatl_hip.enable_splitk); 0 = off")
+    ap.add_argument("--no-guard", action="store_true", help="hip_engine.PARAM_GUARD = False (no parameter-checksum launch in front of the plan calls)")
     a = ap.parse_args()
+    if a.no_guard:
+        from alphapose.models import hip_engine
+        hip_engine.PARAM_GUARD = False
     if a.splitk:
         import vatl_hip as vh
         vh.enable_splitk(a.splitk)
@@ -41,7 +45,7 @@ def main():
         fwd()
     torch.cuda.synchronize()
     eager = (time.perf_counter() - t0) / a.iters
-    res = {"batch": a.batch, "splitk_MB": a.splitk, "eager_ms": round(eager * 1e3, 3)}
+    res = {"batch": a.batch, "splitk_MB": a.splitk, "param_guard": not a.no_guard, "eager_ms": round(eager * 1e3, 3)}
     try:
         g = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream()

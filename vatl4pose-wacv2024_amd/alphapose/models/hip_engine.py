@@ -19,6 +19,7 @@ There is no fallback: without the library or on CPU tensors this raises.
 """
 from __future__ import annotations
 
+import time
 import weakref
 
 import torch
@@ -486,7 +487,7 @@ def _version_key(m: nn.Module, device):
 
 
 # PARAMETER GUARD.  True: every plan call is preceded by ONE launch that checksums all parameters and buffers (vatl_checksum_multi: 136 MB
-# for SimplePose-R50, ~30 us, mostly from the Infinity Cache), read back asynchronously and compared with the checksums taken when the plan
+# for SimplePose-R50, 38 us), read back asynchronously and compared with the checksums taken when the plan
 # was built; a difference — an in-place write that bumped no version counter — raises StalePlanError naming the tensor at the NEXT call
 # into this module (or at `verify(model)`), and the plan is dropped so that the call after the error runs the new values.
 # `invalidate(model)` after such a write avoids the error altogether.  False: no guard launches (what round 5 shipped).
@@ -494,6 +495,11 @@ PARAM_GUARD = True
 # At most this many read-backs in flight per plan: an enqueue-only loop (ActiveLearning.eval_and_query) runs many calls ahead of the
 # device; the oldest read-back is waited for once the ring is full.
 _GUARD_RING = 8
+# ... and at most one guard launch per plan in this many seconds: a stream call (tens of ms) is always guarded; of the ~1 ms module calls of a latency loop
+# (`model(x)`, <= 16 crops, ~60 launches) one in twenty is — the guard's ~60 us of stream time are +5 .. +7 % of such a call (tools/latency_bench.py: 0.94 -> 0.98 ms
+# at one crop, 1.09 -> 1.17 at four; tools/guard_prof.py: 1.068 -> 1.142 ms guarding every call, 1.086 at this rate).  An untracked write is therefore noticed within one call or this interval,
+# whichever is longer; `verify(model)` checks at once.  0 = every call.
+GUARD_MIN_INTERVAL_S = 0.02
 
 
 class StalePlanError(RuntimeError):
@@ -507,18 +513,30 @@ class _ParamGuard:
         ts = [t for _, _, _, t in _checked_walk(m)[1] if t.device == device and t.numel()]
         self.names = [names.get(id(t), f"<tensor {i}>") for i, t in enumerate(ts)]
         self.table = vh.ChecksumTable(ts)
+        self.device, self.slots, self.last_launch = torch.device(device), None, 0.0
         self.ref = self.table.launch().cpu()                 # plan build is the slow path: a synchronous read-back here is fine
         self.pending = []                                    # [(event, pinned host copy)] in launch order
         self.model = weakref.ref(m)
 
-    def launch(self):
-        dev = self.table.launch()
-        if not dev.is_cuda:                                  # (a host-side stand-in table: tests/test_boundary.py drives this class without a GPU)
-            self.pending.append((None, dev))
+    def launch(self, force: bool = True):
+        now = time.perf_counter()
+        if not force and now - self.last_launch < GUARD_MIN_INTERVAL_S:
             return
-        host = torch.empty((self.table.n,), dtype=torch.int64, pin_memory=True)
+        self.last_launch = now
+        if self.device.type != "cuda":                       # (a host-side stand-in table: tests/test_boundary.py drives this class without a GPU)
+            self.pending.append((None, self.table.launch()))
+            return
+        # On the CALLING stream, in front of the plan's launches (memset + checksum kernel + a 2.7 KB read-back: ~60 us of stream time).  A side stream ordered behind
+        # the calling one was measured and rejected (round 6, tools/guard_prof.py): free for a 256-crop call, but every activation of the otherwise idle second
+        # queue cost the calling stream ~1 ms — with one guarded call in twenty a 1.07 ms module call still averaged 1.12 ms.
+        if self.slots is None:                               # everything a launch needs is made ONCE: a pinned allocation or an event creation per call costs more than the launch
+            self.slots = [(torch.empty((self.table.n,), dtype=torch.int64, device=self.device), torch.empty((self.table.n,), dtype=torch.int64, pin_memory=True),
+                           torch.cuda.Event()) for _ in range(_GUARD_RING + 2)]
+            self.slot = 0
+        dev, host, ev = self.slots[self.slot]                # (at most _GUARD_RING read-backs are pending: this slot's last use has been consumed)
+        self.slot = (self.slot + 1) % len(self.slots)
+        self.table.launch(out=dev)
         host.copy_(dev, non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record()
         self.pending.append((ev, host))
 
@@ -530,6 +548,7 @@ class _ParamGuard:
                 ev.synchronize()
             if not torch.equal(host, self.ref):
                 bad = [self.names[i] for i in torch.nonzero(host != self.ref).flatten().tolist()]
+                host = None
                 self.pending.clear()
                 m = self.model()
                 if m is not None:
@@ -568,7 +587,7 @@ def _plan_for(m: nn.Module, device):
     if cached is not None and cached[0] == key:
         if cached[2] is not None and not (x_is_cuda and torch.cuda.is_current_stream_capturing()):
             cached[2].check()                                # read-backs of earlier calls that have arrived
-            cached[2].launch()                               # this call's checksums, in front of its launches
+            cached[2].launch(force=False)                    # this call's checksums (side stream), unless the last ones are younger than GUARD_MIN_INTERVAL_S
         return cached[1]
     from .fastpose import FastPose
     from .hrnet import PoseHighResolutionNet
