@@ -49,6 +49,14 @@ def test_bench_prints_one_contract_line():
     assert 0.2 < ex["cfg4_hrnet_w32_thc_wpu"]["executed_frac"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # round 6: the thread count is calibrated at the measured batch within the CPUs the container is GRANTED (cgroup quota), the all-granted-cores figure beside it
+    assert 1 <= c["cores"] <= c["cores_available"] <= c["cores_visible"] and str(c["cores"]) in c["calibration_forward_s"]
+    assert c["all_cores"]["cores"] == c["cores_available"] and 0 < c["all_cores"]["value"] <= c["value"] * 1.25
+    # round 6: the shader clock sampled over the timed region and the fractions against the peak at THAT clock (the hwmon files are readable on the GPU boxes)
+    assert r["sclk_samples"] >= 3 and 500 < r["sclk_mhz_min"] <= r["sclk_mhz_mean"] <= r["sclk_mhz_max"] <= 2600 and r["nominal_sclk_mhz"] == 2400.0
+    assert abs(r["peak_at_sclk"] - 157.3 * r["sclk_mhz_mean"] / 2400.0) < 0.02 and abs(r["frac_at_sclk"] - r["achieved"] / r["peak_at_sclk"]) < 1e-3
+    assert r["frac"] <= r["frac_at_sclk"] < 1.0
+    assert len(pe["eval_and_query_round_ms"]) == pe["eval_and_query_rounds"] and pe["gc_freeze"] is False and pe["eval_and_query_p90_round_ms"] >= pe["eval_and_query_median_round_ms"]
     # whole-job rate is consistent with the step time
     assert abs(d["value"] - 1024 * 1000.0 / d["ms_per_step"]) / d["value"] < 0.01
 
