@@ -766,7 +766,7 @@ def main():
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run bare and let --gpus start them)")
     dist = world > 1
     if dist:                                            # N ranks share the host: keep torch's CPU pools (model initialisation) from oversubscribing it
-        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
+        torch.set_num_threads(max(1, granted_cpus()[0] // world))
     ndev = torch.cuda.device_count()
     local = local % max(ndev, 1)                        # (a 1-GPU box can host a 2-rank smoke run: VATL_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
