@@ -816,6 +816,17 @@ def test_full_video_stream_spot_checks(vh):
             hip_engine.forward_into(m, x[i:i + 1], solo)
             assert torch.equal(solo[0], hm[i]), i
     hmc, bbc = hm.cpu().numpy(), bbox.cpu().numpy()
+    # ... and against the ORACLE graph (round 6: the spot frames inside the 1024-frame launch, not only their solo forwards): heat-maps within 1e-4, every arg-max index identical
+    from oracle import nets
+    ref = nets.SimplePoseRef(50)
+    ref.load_state_dict(synth.state_dict_for(ref), strict=True)
+    ref.eval()
+    with torch.no_grad():
+        want = ref(base.cpu()).numpy()
+    got = hmc[spots]
+    e = rel_err(got, want)
+    record("full_video_spot_frames_vs_oracle", rel=e)
+    assert e < 1e-4 and np.array_equal(got.reshape(8, 17, -1).argmax(2), want.reshape(8, 17, -1).argmax(2))
     for i in spots:
         d = scorers.decode_heatmaps(hmc[i], bbc[i])
         assert np.array_equal(s.argmax[i].cpu().numpy(), d["idx"])
