@@ -409,6 +409,12 @@ def test_plan_key_sees_every_way_a_model_can_change():
     assert hip_engine._version_key(m, "cpu") == before
     m.double()                                                           # new storage for every tensor
     changed()
+    fl = m.final_layer                                                   # a module's parameter DICT swapped for another of the same length (round-5 advisor): the walk reads
+    fl._parameters = {k: torch.nn.Parameter(v.detach().clone()) for k, v in fl._parameters.items()}   # the dict from the module at check time, not a remembered object
+    changed()
+    bn = m.preact.bn1
+    bn._buffers = {k: (None if v is None else v.clone()) for k, v in bn._buffers.items()}
+    changed()
     import copy
     r = copy.copy(m)                                                     # what DataParallel's replicate() does: the original's attribute dict, copied ...
     r.__dict__ = dict(m.__dict__)
