@@ -447,6 +447,11 @@ def test_parameter_guard_notices_writes_that_bump_no_version_counter(monkeypatch
     assert len(g.names) == len(list(m.parameters())) + len(list(m.buffers())) and "preact.bn1.running_mean" in g.names
     m.__dict__["_vatl_plan"] = (k0, object(), g)
     g.launch(); g.check(wait=True)                                        # untouched: fine
+    assert g.unguarded == []
+    m.register_buffer("flags", torch.zeros(3, dtype=torch.bool))          # 3 bytes: not made of 32-bit words — left out (and named), the plan does not fail
+    g2 = hip_engine._ParamGuard(m, dev)
+    assert g2.unguarded == ["flags"] and len(g2.names) == len(g.names)
+    del m._buffers["flags"]
     m.final_layer.weight.data.add_(1.0)
     assert hip_engine._version_key(m, dev) == k0                          # the version key is blind to it ...
     g.launch()

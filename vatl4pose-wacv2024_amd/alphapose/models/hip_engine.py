@@ -510,7 +510,12 @@ class StalePlanError(RuntimeError):
 class _ParamGuard:
     def __init__(self, m: nn.Module, device):
         names = {id(t): n for n, t in list(m.named_parameters()) + list(m.named_buffers())}
-        ts = [t for _, _, _, t in _checked_walk(m)[1] if t.device == device and t.numel()]
+        # (tensors the checksum kernel cannot read as aligned 32-bit words — a bool / uint8 buffer of a user's subclass; the three supported networks have none —
+        #  are left out rather than failing the plan: `unguarded` names them)
+        ok = lambda t: t.device == device and t.numel() and t.is_contiguous() and (t.numel() * t.element_size()) % 4 == 0 and t.data_ptr() % 4 == 0
+        walk = [t for _, _, _, t in _checked_walk(m)[1]]
+        ts = [t for t in walk if ok(t)]
+        self.unguarded = [names.get(id(t), "?") for t in walk if t.numel() and not ok(t)]
         self.names = [names.get(id(t), f"<tensor {i}>") for i, t in enumerate(ts)]
         self.table = vh.ChecksumTable(ts)
         self.device, self.slots, self.last_launch = torch.device(device), None, 0.0
